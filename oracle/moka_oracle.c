@@ -1,0 +1,338 @@
+/* moka_oracle.c -- TEST INFRASTRUCTURE ONLY (see moka_oracle.h).
+ *
+ * One C function per reference kernel, same loop nest, same operand order.  Citations are
+ * relative to the reference tree (jlk9/MPAS-Ocean.jl @ 2025-02-16).  Nothing here is derived
+ * from the HIP implementation; the HIP implementation is checked against this file.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -fPIC -shared   (oracle/Makefile)
+ */
+#include "moka_oracle.h"
+#include <string.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 1; /* KA CPU() under JULIA_NUM_THREADS=1 is single threaded */
+
+void oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int  oracle_get_threads(void) { return g_threads; }
+
+#define PFOR _Pragma("omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)")
+
+/* index helpers: Julia A[i,j] (1-based, column major, leading dim ld) -> C offset */
+#define IX(i, j, ld) ((int64_t)((j) - 1) * (ld) + ((i) - 1))
+
+/* ------------------------------------------------------------------------------------------
+ * K1 + K2  DivergenceOnCell_P1 / _P2                         src/ocn/Operators.jl:12-74
+ *   P1: temp[k,e] = VecEdge[k,e] * dvEdge[e]                 (:18)
+ *   P2: Div[k,c]  = 0; Div -= temp[k,eoc[i,c]] * sign[i,c]; Div /= areaCell[c]   (:34-42)
+ * ndrange (nEdges,K) / (nCells,K): all levels.
+ * ------------------------------------------------------------------------------------------ */
+void oracle_divergence_on_cell(const oracle_mesh *m, double *div, const double *vecEdge, double *temp)
+{
+    const int K = m->nVertLevels;
+    PFOR
+    for (int64_t e = 1; e <= m->nEdges; ++e)
+        for (int k = 1; k <= K; ++k)
+            temp[IX(k, e, K)] = vecEdge[IX(k, e, K)] * m->dvEdge[e - 1];
+    PFOR
+    for (int64_t c = 1; c <= m->nCells; ++c)
+        for (int k = 1; k <= K; ++k) {
+            double d = 0.0;
+            for (int i = 1; i <= m->nEdgesOnCell[c - 1]; ++i) {
+                int32_t e = m->edgesOnCell[IX(i, c, m->maxEdges)];
+                d -= temp[IX(k, e, K)] * (double)m->edgeSignOnCell[IX(i, c, m->maxEdges)];
+            }
+            div[IX(k, c, K)] = d / m->areaCell[c - 1];
+        }
+}
+
+/* K3  GradientOnEdge                                         src/ocn/Operators.jl:84-120
+ *   Grad[k,e] = (S[k,c2] - S[k,c1]) / dcEdge[e]              (:97) */
+void oracle_gradient_on_edge(const oracle_mesh *m, double *grad, const double *s)
+{
+    const int K = m->nVertLevels;
+    PFOR
+    for (int64_t e = 1; e <= m->nEdges; ++e) {
+        int32_t c1 = m->cellsOnEdge[IX(1, e, 2)], c2 = m->cellsOnEdge[IX(2, e, 2)];
+        for (int k = 1; k <= K; ++k)
+            grad[IX(k, e, K)] = (s[IX(k, c2, K)] - s[IX(k, c1, K)]) / m->dcEdge[e - 1];
+    }
+}
+
+/* K4  CurlOnVertex                                           src/ocn/Operators.jl:122-177
+ *   invA = 1/areaTriangle[v]; Curl[k,v] += dcEdge[e]*invA*Vec[k,e]*sign[j,v]     (:137-146)
+ * NOTE accumulates into the caller's array: the zeroing at :135 is commented out. */
+void oracle_curl_on_vertex(const oracle_mesh *m, double *curl, const double *vecEdge)
+{
+    const int K = m->nVertLevels;
+    PFOR
+    for (int64_t v = 1; v <= m->nVertices; ++v) {
+        double invA = 1.0 / m->areaTriangle[v - 1];
+        for (int k = 1; k <= K; ++k) {
+            double c = curl[IX(k, v, K)];
+            for (int j = 1; j <= m->vertexDegree; ++j) {
+                int32_t e = m->edgesOnVertex[IX(j, v, m->vertexDegree)];
+                c += m->dcEdge[e - 1] * invA * vecEdge[IX(k, e, K)] *
+                     (double)m->edgeSignOnVertex[IX(j, v, m->edgeSignOnVertexLD)];
+            }
+            curl[IX(k, v, K)] = c;
+        }
+    }
+}
+
+/* K5  interpolateCell2Edge                                   src/ocn/Operators.jl:179-222
+ *   edge[k,e] = 0.5 * (cell[k,c1] + cell[k,c2]), reference: k = 1 only (:207-208).
+ * nlev = 1 reproduces the reference; nlev = K is the N3 extension. */
+void oracle_interpolate_cell2edge(const oracle_mesh *m, double *edgeValue, const double *cellValue, int nlev)
+{
+    const int K = m->nVertLevels;
+    PFOR
+    for (int64_t e = 1; e <= m->nEdges; ++e) {
+        int32_t c1 = m->cellsOnEdge[IX(1, e, 2)], c2 = m->cellsOnEdge[IX(2, e, 2)];
+        for (int k = 1; k <= nlev; ++k)
+            edgeValue[IX(k, e, K)] = 0.5 * (cellValue[IX(k, c1, K)] + cellValue[IX(k, c2, K)]);
+    }
+}
+
+/* K6  ZeroOutVector!                                         src/ocn/Operators.jl:225-231
+ *   A[1,j] = 0  (level 1 only in the reference) */
+void oracle_zero_out(double *a, int64_t n, int K, int nlev)
+{
+    PFOR
+    for (int64_t j = 1; j <= n; ++j)
+        for (int k = 1; k <= nlev; ++k) a[IX(k, j, K)] = 0.0;
+}
+
+/* K7  compute_thicknessFlux!                                 src/ocn/DiagnosticVars.jl:158-173
+ *   F[1,e] = u[1,e] * hEdge[1,e] */
+void oracle_thickness_flux(const oracle_mesh *m, double *F, const double *u, const double *hEdge, int nlev)
+{
+    const int K = m->nVertLevels;
+    PFOR
+    for (int64_t e = 1; e <= m->nEdges; ++e)
+        for (int k = 1; k <= nlev; ++k) F[IX(k, e, K)] = u[IX(k, e, K)] * hEdge[IX(k, e, K)];
+}
+
+/* diagnostic_compute!                                        src/ocn/DiagnosticVars.jl:108-117
+ * fixed order: thicknessFlux (with the OLD hEdge) -> velocityDivCell (hEdge used as scratch,
+ * :185-190) -> relativeVorticity (accumulating) -> layerThicknessEdge. */
+void oracle_diagnostic_compute(const oracle_mesh *m, double *hEdge, double *F, double *div, double *vort,
+                               const double *u, const double *h, int nlev)
+{
+    oracle_thickness_flux(m, F, u, hEdge, nlev);
+    oracle_divergence_on_cell(m, div, u, hEdge);
+    oracle_curl_on_vertex(m, vort, u);
+    oracle_interpolate_cell2edge(m, hEdge, h, nlev);
+}
+
+/* K9  SSHGradOnEdge!            src/ocn/Tendencies/normalVelocity/pressure_gradient.jl:45-65
+ *   InvDc = 1/dcEdge[e]; for k in 1:maxLevelEdgeTop[e]: T[k,e] -= 9.80616*InvDc*(ssh[c2]-ssh[c1])
+ * K10 coriolis_force_tendency_kernel!   .../horizontal_advection_and_coriolis.jl:50-75
+ *   for i in 1:nEdgesOnEdge[e]: eoe = edgesOnEdge[i,e]; eoe == 0 && continue;
+ *       for k in 1:maxLevelEdgeTop[e]: T[k,e] += weightsOnEdge[i,e]*u[k,eoe]*fEdge[eoe]
+ * computeNormalVelocityTendency! (normalVelocity.jl:21-53): zero (K6), K9, K10. */
+void oracle_normal_velocity_tendency(const oracle_mesh *m, double *tendU, const double *ssh,
+                                     const double *u, int nlev)
+{
+    const int K = m->nVertLevels;
+    oracle_zero_out(tendU, m->nEdges, K, nlev);
+    PFOR
+    for (int64_t e = 1; e <= m->nEdges; ++e) {
+        int32_t c1 = m->cellsOnEdge[IX(1, e, 2)], c2 = m->cellsOnEdge[IX(2, e, 2)];
+        double invDc = 1. / m->dcEdge[e - 1];
+        for (int k = 1; k <= m->maxLevelEdgeTop[e - 1]; ++k)
+            tendU[IX(k, e, K)] -= 9.80616 * invDc * (ssh[c2 - 1] - ssh[c1 - 1]);
+    }
+    PFOR
+    for (int64_t e = 1; e <= m->nEdges; ++e) {
+        for (int i = 1; i <= m->nEdgesOnEdge[e - 1]; ++i) {
+            int32_t eoe = m->edgesOnEdge[IX(i, e, m->maxEdges2)];
+            if (eoe == 0) continue;
+            for (int k = 1; k <= m->maxLevelEdgeTop[e - 1]; ++k)
+                tendU[IX(k, e, K)] += m->weightsOnEdge[IX(i, e, m->maxEdges2)] * u[IX(k, eoe, K)] *
+                                      m->fEdge[eoe - 1];
+        }
+    }
+}
+
+/* K8  thicknessFluxDivOnCell!   src/ocn/Tendencies/layerThickness/horizontal_advection.jl:42-68
+ *   invArea = 1/areaCell[c]; for i: e = eoc[i,c]; for k in 1:maxLevelEdgeTop[e]:
+ *       T[k,c] += F[k,e]*dvEdge[e]*edgeSignOnCell[i,c]*invArea
+ * computeLayerThicknessTendency! (layerThickness.jl:14-28): zero (K6), K8. */
+void oracle_layer_thickness_tendency(const oracle_mesh *m, double *tendH, const double *F, int nlev)
+{
+    const int K = m->nVertLevels;
+    oracle_zero_out(tendH, m->nCells, K, nlev);
+    PFOR
+    for (int64_t c = 1; c <= m->nCells; ++c) {
+        double invArea = 1. / m->areaCell[c - 1];
+        for (int i = 1; i <= m->nEdgesOnCell[c - 1]; ++i) {
+            int32_t e = m->edgesOnCell[IX(i, c, m->maxEdges)];
+            for (int k = 1; k <= m->maxLevelEdgeTop[e - 1]; ++k)
+                tendH[IX(k, c, K)] += F[IX(k, e, K)] * m->dvEdge[e - 1] *
+                                      (double)m->edgeSignOnCell[IX(i, c, m->maxEdges)] * invArea;
+        }
+    }
+}
+
+/* Column sum used for ssh when K > 1 (a build decision, not a reference fact).
+ * K = 1 returns col[0] exactly, i.e. Update_ssh! (time_integration.jl:209).  For K > 1 the
+ * order is fixed as: 64 strided partial sums acc[l] = col[l] + col[l+64] + ..., then an XOR
+ * butterfly acc[l] += acc[l^s], s = 32,16,...,1 -- the order a 64-lane wavefront reduction
+ * produces, so the GPU can match it bit for bit.  (fp add is commutative, so every lane of the
+ * butterfly holds the same value; lane 0 is returned.) */
+double oracle_ksum(const double *col, int K)
+{
+    double acc[64];
+    for (int l = 0; l < 64; ++l) {
+        double a = 0.0;
+        int first = 1;
+        for (int k = l; k < K; k += 64) {
+            a = first ? col[k] : a + col[k];
+            first = 0;
+        }
+        acc[l] = a;
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        double t[64];
+        for (int l = 0; l < 64; ++l) t[l] = acc[l] + acc[l ^ s];
+        memcpy(acc, t, sizeof acc);
+    }
+    return acc[0];
+}
+
+/* K14 Update_ssh!                                            src/forward/time_integration.jl:205-211
+ *   ssh[j] = layerThickness[1,j] - restingThicknessSum[j]        (nlev = 1)
+ *   N3:      ssh[j] = ksum_k layerThickness[k,j] - restingThicknessSum[j]   (nlev = K) */
+void oracle_update_ssh(const oracle_mesh *m, double *ssh, const double *h, int nlev)
+{
+    const int K = m->nVertLevels;
+    PFOR
+    for (int64_t c = 1; c <= m->nCells; ++c)
+        ssh[c - 1] = oracle_ksum(&h[IX(1, c, K)], nlev) - m->restingThicknessSum[c - 1];
+}
+
+/* Tendency evaluation with diagnostics consistent with (u,h): SURVEY.md Appendix C. */
+void oracle_tendencies_clean(const oracle_mesh *m, double *tendU, double *tendH,
+                             const double *u, const double *h, double *ssh_out,
+                             double *hEdge, double *F)
+{
+    const int K = m->nVertLevels;
+    oracle_update_ssh(m, ssh_out, h, K);
+    oracle_interpolate_cell2edge(m, hEdge, h, K);
+    oracle_thickness_flux(m, F, u, hEdge, K);
+    oracle_normal_velocity_tendency(m, tendU, ssh_out, u, K);
+    oracle_layer_thickness_tendency(m, tendH, F, K);
+}
+
+/* K11/K12 advance_2d_array / advance_3d_array               src/forward/time_integration.jl:10-59
+ *   prev[j] = next[j];  prev[1,j] = next[1,j] (level 1 only) */
+static void advance_levels(double *prev, const double *next, int64_t n, int K, int nlev)
+{
+    PFOR
+    for (int64_t j = 1; j <= n; ++j)
+        for (int k = 1; k <= nlev; ++k) prev[IX(k, j, K)] = next[IX(k, j, K)];
+}
+
+/* K13 UpdateStateVariable!                                   src/forward/time_integration.jl:196-202
+ *   var[1,j] = var[1,j] + dt[1]*tend[1,j] */
+static void update_state(double *var, const double *tend, double dt, int64_t n, int K, int nlev)
+{
+    PFOR
+    for (int64_t j = 1; j <= n; ++j)
+        for (int k = 1; k <= nlev; ++k) var[IX(k, j, K)] = var[IX(k, j, K)] + dt * tend[IX(k, j, K)];
+}
+
+/* ocn_timestep(..., ForwardEuler)                            src/forward/time_integration.jl:150-193
+ * flags = ORACLE_FE_REFERENCE_COMPAT reproduces the live reference step.
+ * Clearing STALE_HEDGE refreshes layerThicknessEdge before the flux (and uses tendU as the
+ * divergence scratch); clearing ACCUM_VORT zeroes relativeVorticity first; clearing
+ * LEVEL1_ONLY applies the "[1,j]" kernels to all K levels (N3). */
+void oracle_step_fe(const oracle_mesh *m, oracle_state *s, double dt, int flags)
+{
+    const int K = m->nVertLevels;
+    const int nlev = (flags & ORACLE_FE_LEVEL1_ONLY) ? 1 : K;
+    /* advanceTimeLevels! (:163) */
+    advance_levels(s->ssh[0], s->ssh[1], m->nCells, 1, 1);
+    advance_levels(s->u[0], s->u[1], m->nEdges, K, nlev);
+    advance_levels(s->h[0], s->h[1], m->nCells, K, nlev);
+    /* diagnostic_compute! (:169) */
+    if (flags & ORACLE_FE_STALE_HEDGE) {
+        if (!(flags & ORACLE_FE_ACCUM_VORT)) memset(s->vort, 0, sizeof(double) * (size_t)K * m->nVertices);
+        oracle_diagnostic_compute(m, s->hEdge, s->F, s->div, s->vort, s->u[1], s->h[1], nlev);
+    } else {
+        oracle_interpolate_cell2edge(m, s->hEdge, s->h[1], nlev);
+        oracle_thickness_flux(m, s->F, s->u[1], s->hEdge, nlev);
+        oracle_divergence_on_cell(m, s->div, s->u[1], s->tendU);
+        if (!(flags & ORACLE_FE_ACCUM_VORT)) memset(s->vort, 0, sizeof(double) * (size_t)K * m->nVertices);
+        oracle_curl_on_vertex(m, s->vort, s->u[1]);
+    }
+    /* tendencies (:172-177) */
+    oracle_normal_velocity_tendency(m, s->tendU, s->ssh[1], s->u[1], nlev);
+    oracle_layer_thickness_tendency(m, s->tendH, s->F, nlev);
+    /* updates (:183-189) */
+    update_state(s->u[1], s->tendU, dt, m->nEdges, K, nlev);
+    update_state(s->h[1], s->tendH, dt, m->nCells, K, nlev);
+    oracle_update_ssh(m, s->ssh[1], s->h[1], nlev);
+}
+
+/* ocn_timestep(..., RungeKutta4)  -- dead code in the reference; algorithm specification only
+ *                                                            src/forward/time_integration.jl:61-148
+ *   a = [dt/2, dt/2, dt] (:77);  b = [dt/6, dt/3, dt/3, dt/6] (:78)
+ *   Curr = level end-1, Provis = level end, New = copy of Provis (:93-110)
+ *   for s in 1:4: tend = T(Provis); s<4: Provis = Curr + a[s]*tend, ssh from layerThickness (:124-127)
+ *                 New = New + b[s]*tend (:134-135)
+ *   state[end] = New (:140-141); diagnostics of the new state (:147)
+ * All K levels (N3).  Diagnostics at the end are the clean ones (vorticity zeroed first). */
+void oracle_step_rk4(const oracle_mesh *m, oracle_state *s, double dt, double *work)
+{
+    const int K = m->nVertLevels;
+    const int64_t nu = (int64_t)K * m->nEdges, nh = (int64_t)K * m->nCells;
+    double *newU = work, *newH = work + nu, *hEdge = s->hEdge, *F = s->F;
+    const double a[3] = {dt / 2., dt / 2., dt};
+    const double b[4] = {dt / 6., dt / 3., dt / 3., dt / 6.};
+    advance_levels(s->ssh[0], s->ssh[1], m->nCells, 1, 1);
+    advance_levels(s->u[0], s->u[1], m->nEdges, K, K);
+    advance_levels(s->h[0], s->h[1], m->nCells, K, K);
+    memcpy(newU, s->u[1], sizeof(double) * (size_t)nu);
+    memcpy(newH, s->h[1], sizeof(double) * (size_t)nh);
+    for (int st = 0; st < 4; ++st) {
+        oracle_tendencies_clean(m, s->tendU, s->tendH, s->u[1], s->h[1], s->ssh[1], hEdge, F);
+        if (st < 3) {
+            const double as = a[st];
+            double *pu = s->u[1], *ph = s->h[1];
+            const double *cu = s->u[0], *ch = s->h[0], *tu = s->tendU, *th = s->tendH;
+            PFOR
+            for (int64_t i = 0; i < nu; ++i) pu[i] = cu[i] + as * tu[i];
+            PFOR
+            for (int64_t i = 0; i < nh; ++i) ph[i] = ch[i] + as * th[i];
+        }
+        {
+            const double bs = b[st];
+            const double *tu = s->tendU, *th = s->tendH;
+            PFOR
+            for (int64_t i = 0; i < nu; ++i) newU[i] = newU[i] + bs * tu[i];
+            PFOR
+            for (int64_t i = 0; i < nh; ++i) newH[i] = newH[i] + bs * th[i];
+        }
+    }
+    memcpy(s->u[1], newU, sizeof(double) * (size_t)nu);
+    memcpy(s->h[1], newH, sizeof(double) * (size_t)nh);
+    oracle_update_ssh(m, s->ssh[1], s->h[1], K);
+    oracle_interpolate_cell2edge(m, s->hEdge, s->h[1], K);
+    oracle_thickness_flux(m, s->F, s->u[1], s->hEdge, K);
+    oracle_divergence_on_cell(m, s->div, s->u[1], newU); /* newU is free again: scratch */
+    memset(s->vort, 0, sizeof(double) * (size_t)K * m->nVertices);
+    oracle_curl_on_vertex(m, s->vort, s->u[1]);
+}
+
+/* K15 sumArray (serial, one work-item)                       src/forward/run_loop.jl:47-51
+ *   sum = sum + a[j]*a[j] */
+double oracle_sum_sq(const double *a, int64_t n)
+{
+    double sum = 0.0;
+    for (int64_t j = 0; j < n; ++j) sum = sum + a[j] * a[j];
+    return sum;
+}

@@ -1,0 +1,212 @@
+"""ctypes front-end of the CPU oracle (oracle/moka_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the
+product package (mpas-ocean.jl_amd/moka_hip) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmoka_oracle.so")
+
+FE_STALE_HEDGE, FE_ACCUM_VORT, FE_LEVEL1_ONLY = 1, 2, 4
+FE_REFERENCE_COMPAT = 7
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+class _OracleMesh(C.Structure):
+    _fields_ = [
+        ("nCells", C.c_int32), ("nEdges", C.c_int32), ("nVertices", C.c_int32),
+        ("maxEdges", C.c_int32), ("maxEdges2", C.c_int32), ("vertexDegree", C.c_int32),
+        ("nVertLevels", C.c_int32), ("edgeSignOnVertexLD", C.c_int32),
+        ("nEdgesOnCell", _i32p), ("edgesOnCell", _i32p), ("edgeSignOnCell", _i32p),
+        ("areaCell", _f64p),
+        ("cellsOnEdge", _i32p), ("nEdgesOnEdge", _i32p), ("edgesOnEdge", _i32p),
+        ("weightsOnEdge", _f64p), ("dvEdge", _f64p), ("dcEdge", _f64p), ("fEdge", _f64p),
+        ("edgesOnVertex", _i32p), ("edgeSignOnVertex", _i32p), ("areaTriangle", _f64p),
+        ("maxLevelEdgeTop", _i32p), ("restingThicknessSum", _f64p),
+    ]
+
+
+class _OracleState(C.Structure):
+    _fields_ = [
+        ("ssh", _f64p * 2), ("u", _f64p * 2), ("h", _f64p * 2),
+        ("hEdge", _f64p), ("F", _f64p), ("div", _f64p), ("vort", _f64p),
+        ("tendU", _f64p), ("tendH", _f64p),
+    ]
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(HERE, "moka_oracle.c"), os.path.join(HERE, "moka_oracle.h")]
+    if force or not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", HERE, "--no-print-directory"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        mp, sp = C.POINTER(_OracleMesh), C.POINTER(_OracleState)
+        L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_get_threads.restype = C.c_int
+        L.oracle_divergence_on_cell.argtypes = [mp, _f64p, _f64p, _f64p]
+        L.oracle_gradient_on_edge.argtypes = [mp, _f64p, _f64p]
+        L.oracle_curl_on_vertex.argtypes = [mp, _f64p, _f64p]
+        L.oracle_interpolate_cell2edge.argtypes = [mp, _f64p, _f64p, C.c_int]
+        L.oracle_thickness_flux.argtypes = [mp, _f64p, _f64p, _f64p, C.c_int]
+        L.oracle_normal_velocity_tendency.argtypes = [mp, _f64p, _f64p, _f64p, C.c_int]
+        L.oracle_layer_thickness_tendency.argtypes = [mp, _f64p, _f64p, C.c_int]
+        L.oracle_update_ssh.argtypes = [mp, _f64p, _f64p, C.c_int]
+        L.oracle_ksum.argtypes = [_f64p, C.c_int]
+        L.oracle_ksum.restype = C.c_double
+        L.oracle_tendencies_clean.argtypes = [mp] + [_f64p] * 7
+        L.oracle_step_fe.argtypes = [mp, sp, C.c_double, C.c_int]
+        L.oracle_step_rk4.argtypes = [mp, sp, C.c_double, _f64p]
+        L.oracle_sum_sq.argtypes = [_f64p, C.c_int64]
+        L.oracle_sum_sq.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_f64p if a.dtype == np.float64 else _i32p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class OracleMesh:
+    """Reference-convention mesh handed to the oracle.  `max_level_edge_top=None` gives the
+    reference's all-ones array (VertMesh.jl:32); pass K for the N3 multi-layer semantics."""
+
+    def __init__(self, mesh, K: int, resting_thickness_sum=None, max_level_edge_top=None):
+        self.mesh, self.K = mesh, int(K)
+        a = self.arrays = {}
+        for n in ("nEdgesOnCell", "edgesOnCell", "edgeSignOnCell", "cellsOnEdge", "nEdgesOnEdge",
+                  "edgesOnEdge", "edgesOnVertex", "edgeSignOnVertex"):
+            a[n] = _c(getattr(mesh, n), np.int32)
+        for n in ("areaCell", "weightsOnEdge", "dvEdge", "dcEdge", "fEdge", "areaTriangle"):
+            a[n] = _c(getattr(mesh, n), np.float64)
+        if max_level_edge_top is None:
+            mlt = np.ones(mesh.nEdges, dtype=np.int32)
+        elif np.isscalar(max_level_edge_top):
+            mlt = np.full(mesh.nEdges, int(max_level_edge_top), dtype=np.int32)
+        else:
+            mlt = _c(max_level_edge_top, np.int32)
+        a["maxLevelEdgeTop"] = mlt
+        if resting_thickness_sum is None:
+            resting_thickness_sum = np.ones(mesh.nCells)  # test ctor, VertMesh.jl:99-100
+        a["restingThicknessSum"] = _c(np.asarray(resting_thickness_sum).reshape(-1), np.float64)
+        s = self.c = _OracleMesh()
+        s.nCells, s.nEdges, s.nVertices = mesh.nCells, mesh.nEdges, mesh.nVertices
+        s.maxEdges, s.maxEdges2, s.vertexDegree = mesh.maxEdges, mesh.maxEdges2, mesh.vertexDegree
+        s.nVertLevels = self.K
+        s.edgeSignOnVertexLD = a["edgeSignOnVertex"].shape[1]
+        for n, arr in a.items():
+            setattr(s, n, _p(arr))
+
+    @property
+    def ref(self):
+        return C.byref(self.c)
+
+    # ---- operators --------------------------------------------------------------------
+    def divergence_on_cell(self, vecEdge, temp=None):
+        vecEdge = _c(vecEdge, np.float64)
+        div = np.zeros((self.mesh.nCells, self.K))
+        temp = np.zeros_like(vecEdge) if temp is None else temp
+        lib().oracle_divergence_on_cell(self.ref, _p(div), _p(vecEdge), _p(temp))
+        return div
+
+    def gradient_on_edge(self, scalarCell):
+        scalarCell = _c(scalarCell, np.float64)
+        g = np.zeros((self.mesh.nEdges, self.K))
+        lib().oracle_gradient_on_edge(self.ref, _p(g), _p(scalarCell))
+        return g
+
+    def curl_on_vertex(self, vecEdge, curl=None):
+        vecEdge = _c(vecEdge, np.float64)
+        curl = np.zeros((self.mesh.nVertices, self.K)) if curl is None else curl
+        lib().oracle_curl_on_vertex(self.ref, _p(curl), _p(vecEdge))
+        return curl
+
+    def interpolate_cell2edge(self, cellValue, nlev=None, out=None):
+        cellValue = _c(cellValue, np.float64)
+        out = np.zeros((self.mesh.nEdges, self.K)) if out is None else out
+        lib().oracle_interpolate_cell2edge(self.ref, _p(out), _p(cellValue), self.K if nlev is None else nlev)
+        return out
+
+    def update_ssh(self, h, nlev=None):
+        h = _c(h, np.float64)
+        ssh = np.zeros(self.mesh.nCells)
+        lib().oracle_update_ssh(self.ref, _p(ssh), _p(h), self.K if nlev is None else nlev)
+        return ssh
+
+    def tendencies_clean(self, u, h):
+        u, h = _c(u, np.float64), _c(h, np.float64)
+        tu, th = np.zeros_like(u), np.zeros_like(h)
+        ssh = np.zeros(self.mesh.nCells)
+        s1, s2 = np.zeros_like(u), np.zeros_like(u)
+        lib().oracle_tendencies_clean(self.ref, _p(tu), _p(th), _p(u), _p(h), _p(ssh), _p(s1), _p(s2))
+        return tu, th, ssh
+
+
+class OracleState:
+    """Two time levels of PrognosticVars + DiagnosticVars + TendencyVars, reference layout."""
+
+    def __init__(self, om: OracleMesh, ssh, u, h):
+        m, K = om.mesh, om.K
+        self.om = om
+        f = lambda a, shape: np.array(np.asarray(a, dtype=np.float64).reshape(shape), order="C", copy=True)
+        # nTimeLevels = 2 deep copies (PrognosticVars.jl:44-55)
+        self.ssh = [f(ssh, (m.nCells,)) for _ in range(2)]
+        self.u = [f(u, (m.nEdges, K)) for _ in range(2)]
+        self.h = [f(h, (m.nCells, K)) for _ in range(2)]
+        self.hEdge = np.zeros((m.nEdges, K))
+        self.F = np.zeros((m.nEdges, K))
+        self.div = np.zeros((m.nCells, K))
+        self.vort = np.zeros((m.nVertices, K))
+        self.tendU = np.zeros((m.nEdges, K))
+        self.tendH = np.zeros((m.nCells, K))
+        self._work = None
+        s = self.c = _OracleState()
+        for n in ("ssh", "u", "h"):
+            arr = getattr(self, n)
+            setattr(s, n, (_f64p * 2)(_p(arr[0]), _p(arr[1])))
+        for n in ("hEdge", "F", "div", "vort", "tendU", "tendH"):
+            setattr(s, n, _p(getattr(self, n)))
+
+    def step_fe(self, dt, flags=FE_REFERENCE_COMPAT):
+        lib().oracle_step_fe(self.om.ref, C.byref(self.c), float(dt), int(flags))
+
+    def step_rk4(self, dt):
+        if self._work is None:
+            m, K = self.om.mesh, self.om.K
+            self._work = np.zeros(2 * K * (m.nEdges + m.nCells) + m.nCells)
+        lib().oracle_step_rk4(self.om.ref, C.byref(self.c), float(dt), _p(self._work))
+
+    def sum_sq_ssh(self):
+        return lib().oracle_sum_sq(_p(self.ssh[1]), self.ssh[1].size)
+
+
+def set_threads(n: int):
+    lib().oracle_set_threads(int(n))
+
+
+def ksum(col):
+    col = _c(col, np.float64)
+    return lib().oracle_ksum(_p(col), col.size)

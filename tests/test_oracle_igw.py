@@ -1,0 +1,111 @@
+"""Step-loop checks of the CPU oracle on the reference's inertia-gravity-wave case
+(src/inertialGravityWave.jl; driver sequence src/driver/mpas_ocean.jl:20-53)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from moka_hip import meshgen as mg
+
+EXP = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "igw_expectations.json")))
+
+
+def run(res, scheme, nsteps=None):
+    mesh = mg.igw_mesh(res)
+    ssh, u, h, rest = mg.igw_initial_state(mesh)
+    dt = mg.igw_dt(mesh)
+    nsteps = int(EXP["run_hours"] * 3600 / dt) if nsteps is None else nsteps
+    om = orc.OracleMesh(mesh, 1, resting_thickness_sum=rest.sum(1))
+    st = orc.OracleState(om, ssh, u, h)
+    for _ in range(nsteps):
+        if scheme == "fe_compat":
+            st.step_fe(dt, orc.FE_REFERENCE_COMPAT)
+        elif scheme == "fe_clean":
+            st.step_fe(dt, 0)
+        else:
+            st.step_rk4(dt)
+    es, eu = mg.igw_exact(mesh, nsteps * dt)
+    rms = lambda a: float(np.sqrt(np.mean(a * a)))
+    return mesh, st, dt, rms(st.ssh[1] - es), rms(st.u[1][:, 0] - eu)
+
+
+def test_igw_sizing_and_dt():
+    """polaris sizing + dt rule of init.jl:118: 200 km -> 50x50, dt = 400 s; 100 km -> 100 s."""
+    m = mg.igw_mesh(200.0)
+    assert (m.nCells, m.nEdges, m.nVertices) == (2500, 7500, 5000)
+    assert mg.igw_dt(m) == 400 and mg.igw_dt(mg.igw_mesh(100.0)) == 100
+
+
+@pytest.mark.parametrize("scheme", ["fe_compat", "fe_clean", "rk4"])
+def test_igw_200km(scheme):
+    _, _, dt, e_ssh, e_u = run(200.0, scheme)
+    exp = EXP["cases"]["200km"][scheme]
+    assert math.isclose(e_ssh, exp["ssh"], rel_tol=EXP["rtol"])
+    assert math.isclose(e_u, exp["u"], rel_tol=EXP["rtol"])
+
+
+def test_igw_rk4_second_order_in_space():
+    _, _, _, e200, u200 = run(200.0, "rk4")
+    _, _, _, e100, u100 = run(100.0, "rk4")
+    exp = EXP["cases"]["100km"]["rk4"]
+    assert math.isclose(e100, exp["ssh"], rel_tol=EXP["rtol"])
+    assert 3.0 < e200 / e100 < 5.0 and 3.0 < u200 / u100 < 5.0
+
+
+def test_fe_compat_first_step_has_zero_thickness_tendency():
+    """Quirk 0.6(i): thicknessFlux uses the stale (zero-initialised) layerThicknessEdge on step 1
+    (DiagnosticVars.jl:90-93,113-116), so tendLayerThickness == 0 and h does not move."""
+    mesh, st, dt, _, _ = run(200.0, "fe_compat", nsteps=1)
+    assert np.all(st.tendH == 0.0)
+    assert np.array_equal(st.h[1], st.h[0])
+    assert not np.array_equal(st.u[1], st.u[0])
+    # hEdge has been refreshed at the end of diagnostic_compute!, F is still zero
+    assert np.all(st.F == 0.0) and np.all(st.hEdge > 0)
+
+
+def test_fe_compat_vorticity_accumulates():
+    mesh, st1, dt, _, _ = run(200.0, "fe_compat", nsteps=1)
+    _, st2, _, _, _ = run(200.0, "fe_compat", nsteps=2)
+    om = st1.om
+    z2 = om.curl_on_vertex(st1.u[1])            # curl of the state entering step 2
+    assert np.allclose(st2.vort, st1.vort + z2, rtol=1e-12, atol=1e-18)
+
+
+def test_time_levels_after_step():
+    """advanceTimeLevels!: level 1 (index 0) holds the pre-step state (time_integration.jl:10-40)."""
+    mesh = mg.igw_mesh(200.0)
+    ssh, u, h, rest = mg.igw_initial_state(mesh)
+    om = orc.OracleMesh(mesh, 1, resting_thickness_sum=rest.sum(1))
+    st = orc.OracleState(om, ssh, u, h)
+    st.step_rk4(400.0)
+    assert np.array_equal(st.u[0][:, 0], u[:, 0]) and np.array_equal(st.h[0], h)
+    assert np.allclose(st.ssh[1], st.h[1][:, 0] - rest[:, 0], rtol=0, atol=0)
+
+
+def test_mass_conservation_rk4():
+    mesh, st, dt, _, _ = run(200.0, "rk4", nsteps=20)
+    mass0 = (mesh.areaCell * st.om.arrays["restingThicknessSum"]).sum() + 0.0
+    ssh0, _ = mg.igw_exact(mesh, 0.0)
+    m0 = (mesh.areaCell * (1000.0 + ssh0)).sum()
+    m1 = (mesh.areaCell * st.h[1][:, 0]).sum()
+    assert abs(m1 - m0) / m0 < 1e-13
+
+
+def test_layer_split_invariance_N3():
+    """SURVEY N3 invariant: K identical layers with h_k = h/K, u_k = u reproduce the
+    single-layer ssh to round-off (clean RK4, maxLevelEdgeTop = K)."""
+    mesh = mg.igw_mesh(200.0)
+    ssh, u, h, rest = mg.igw_initial_state(mesh)
+    K = 4
+    om1 = orc.OracleMesh(mesh, 1, resting_thickness_sum=rest.sum(1), max_level_edge_top=1)
+    omK = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    s1 = orc.OracleState(om1, ssh, u, h)
+    sK = orc.OracleState(omK, ssh, np.repeat(u, K, axis=1), np.repeat(h / K, K, axis=1))
+    for _ in range(10):
+        s1.step_rk4(400.0)
+        sK.step_rk4(400.0)
+    assert np.abs(sK.ssh[1] - s1.ssh[1]).max() < 1e-9
+    assert np.abs(sK.u[1] - s1.u[1]).max() < 1e-12
