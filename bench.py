@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-updates/s per RK4 step + achieved HBM GB/s of the fused stage kernel.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one full 4-stage RK4 step of the shallow-water dycore over the whole synthetic mesh
+(BASELINE.json metric).  Default workload = BASELINE config 4: ~1 M-cell (1 024 002) icosahedral
+sphere x 60 layers, fp64, inputs resident in HBM before the timed region starts.
+For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU); the mesh is
+partitioned across ranks (strong scaling) and halos are exchanged over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import datetime as dt
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "mpas-ocean.jl_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # measured float4 copy ceiling, same guide
+
+WORKLOADS = {
+    # name: (icosahedral frequency m, layers)  -- SURVEY.md section 8 size table
+    "config4_1M_x60": (320, 60),
+    "config3_41k_x60": (64, 60),
+    "config2_41k_x1": (64, 1),
+    "small_10k_x60": (32, 60),
+}
+
+
+def algorithmic_bytes(nC, nE, K, S=8, I=4):
+    """the one formula for algorithmic bytes."""
+    nnzEE = 10 * nE - 60
+    nnzEC = 2 * nE
+    b_mesh = nE * (2 * I + 3 * 8 + 2 * I) + nnzEE * (I + 8) + nC * (I + 8 + 8) + nnzEC * 2 * I
+    b_tend = 2 * S * K * (nE + nC) + b_mesh
+    b_step = 18 * S * K * (nE + nC) + 4 * b_mesh
+    return b_mesh, b_tend, b_step
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def get_mesh(m):
+    from moka_hip import meshgen as mg
+    t0 = time.time()
+    mesh = mg.icosahedral_mesh(m)
+    log(f"[bench] mesh m={m}: {mesh.nCells} cells, {mesh.nEdges} edges built in {time.time() - t0:.1f}s")
+    return mesh
+
+
+def cpu_baseline(mesh, K, ssh, u, h, rest, dts, budget_s=25.0):
+    """Oracle (C restatement of the reference loop nests) timed on this box's host cores: clean RK4 step,
+    all cores (OpenMP), on the same mesh when one step fits the budget, else on a smaller sphere."""
+    import oracle as orc
+    cores = os.cpu_count() or 1
+    orc.set_threads(cores)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    t0 = time.time()
+    st.step_rk4(dts)                   # warm-up (page faults) and a size probe
+    t_probe = time.time() - t0
+    n = max(1, min(5, int(budget_s / max(t_probe, 1e-3)) - 1))
+    if t_probe > budget_s:
+        n = 0
+    t0 = time.time()
+    for _ in range(n):
+        st.step_rk4(dts)
+    t = (time.time() - t0) / n if n else t_probe
+    orc.set_threads(1)
+    return {"value": mesh.nCells * K / t, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "sample": f"{max(n, 1)} RK4 step(s) of the same workload ({mesh.nCells} cells x {K} layers), "
+                      f"oracle/moka_oracle.c with OpenMP on {cores} host threads",
+            "ms_per_step": t * 1e3}
+
+
+def cpu_baseline_1t(K, budget_s=12.0):
+    """Single-thread figure (what `julia mpas_ocean.jl` gives with JULIA_NUM_THREADS=1), small sphere."""
+    import oracle as orc
+    from moka_hip import meshgen as mg
+    mesh = mg.icosahedral_mesh(32)
+    ssh, u, h, rest, dts = mg.sphere_synthetic_state(mesh, K)
+    orc.set_threads(1)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    st.step_rk4(dts)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < budget_s and n < 20:
+        st.step_rk4(dts)
+        n += 1
+    t = (time.time() - t0) / n
+    return {"value": mesh.nCells * K / t, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{n} RK4 steps on a {mesh.nCells}-cell x {K}-layer sphere, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config4_1M_x60", choices=list(WORKLOADS))
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant: 0 auto, 1 direct, 2 LDS patch")
+    ap.add_argument("--patch-cells", type=int, default=0)
+    ap.add_argument("--ordering", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--tend-iters", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    import torch
+    import moka_hip as mk
+    from moka_hip import meshgen as mg
+
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    m, K = WORKLOADS[args.workload]
+    mesh = get_mesh(m)
+    ssh, u, h, rest, dts = mg.sphere_synthetic_state(mesh, K)
+    cfg = {"time_management": {"config_start_time": dt.datetime(1, 1, 1), "config_run_duration": dt.timedelta(hours=1)},
+           "time_integration": {"config_dt": dt.timedelta(seconds=dts), "config_number_of_time_levels": 2}}
+
+    backend = mk.MokaHIP(local_rank)
+    if args.variant:
+        backend.set_kernel_variant(args.variant)
+
+    if world > 1:
+        from moka_hip import parallel as mp
+        model = mp.DistributedModel(mesh, ssh, u, h, rest, dts, backend, rank, world,
+                                    ordering=args.ordering, patch_cells=args.patch_cells)
+        step = model.step_rk4
+        sync = backend.synchronize
+        info = model.info()
+    else:
+        t0 = time.time()
+        Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, cfg, backend, multilayer=True,
+                                                           ordering=args.ordering, patch_cells=args.patch_cells)
+        log(f"[bench] plan + upload: {time.time() - t0:.1f}s")
+        info = Setup.mesh.info()
+        step = lambda: mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)  # noqa: E731
+        sync = backend.synchronize
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync(); torch.cuda.synchronize(); barrier()
+    backend.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ev_ms = backend.timer_stop()
+    sync(); torch.cuda.synchronize(); barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed, ev_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, ev_ms = float(tt[0]), float(tt[1])
+    ms_per_step = elapsed / args.steps * 1e3
+    value = mesh.nCells * K / (elapsed / args.steps)
+
+    b_mesh, b_tend, b_step = algorithmic_bytes(mesh.nCells, mesh.nEdges, K)
+    # dominant kernel = the fused RK-stage kernel k_stage: 4 launches per step, average launch time from HIP
+    # events on the library's compute stream over the timed region; algorithmic bytes per launch = B_step / 4.
+    launches = 4 * args.steps
+    avg_launch_ms = ev_ms / launches
+    per_rank_bytes = b_step / 4 / world
+    achieved = per_rank_bytes / (avg_launch_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(args.workload, {}).get("stage_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_stage (fused TRiSK tendency + RK4 stage update)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": per_rank_bytes, "avg_launch_ms": avg_launch_ms,
+                "launches_timed": launches}
+
+    out = {"metric": "cell-updates/sec per RK4 step", "value": value, "unit": "cell-updates/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": args.workload, "mesh": f"icosahedral m={m}", "nCells": mesh.nCells,
+                      "nEdges": mesh.nEdges, "nVertLevels": K, "integrator": "RK4", "dt_s": dts,
+                      "ordering": info.get("ordering"), "patch_cells": info.get("patch_cells"),
+                      "kernel_variant": args.variant,
+                      "parallelism": "single GPU" if world == 1 else f"mesh partitioned over {world} GPUs, RCCL halo exchange"},
+           "roofline": roofline}
+
+    if world == 1:
+        # the pure tendency kernel (north_star's 40 % target is quoted on it): B_tend / t
+        for _ in range(3):
+            mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
+        backend.synchronize()
+        backend.timer_start()
+        for _ in range(args.tend_iters):
+            mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
+        tms = backend.timer_stop() / args.tend_iters
+        out["tendency_kernel"] = {"avg_launch_ms": tms, "algorithmic_bytes": b_tend,
+                                  "achieved_GBs": b_tend / (tms * 1e-3) / 1e9,
+                                  "frac_of_peak": b_tend / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if rank == 0 and not args.no_cpu:
+        t0 = time.time()
+        out["cpu_baseline"] = cpu_baseline(mesh, K, ssh, u, h, rest, dts)
+        out["cpu_baseline_1t"] = cpu_baseline_1t(K)
+        out["cpu_baseline"]["host"] = _cpu_model()
+        log(f"[bench] cpu baseline legs: {time.time() - t0:.1f}s")
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return f"{line.split(':', 1)[1].strip()} x{os.cpu_count()}"
+    except Exception:
+        pass
+    return f"unknown x{os.cpu_count()}"
+
+
+if __name__ == "__main__":
+    main()

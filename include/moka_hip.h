@@ -1,0 +1,207 @@
+/* moka_hip.h -- C ABI of libmoka_hip.so: the MI355X-native (gfx950, HIP) implementation of the
+ * MOKA.jl (jlk9/MPAS-Ocean.jl) shallow-water hot path: TRiSK tendency operators of src/ocn and
+ * the Forward-Euler / RK4 step loop of src/forward.
+ *
+ * This is the drop-in boundary.  The reference has no FFI; its seam is Julia dispatch on the
+ * `backend` keyword + `Adapt.adapt_structure` (src/Architectures.jl:12, MPASMesh.jl:26,
+ * HorzMesh.jl:53,357,373,388, VertMesh.jl:119,124, PrognosticVars.jl:108, DiagnosticVars.jl:101).
+ * A Julia shim (mpas-ocean.jl_amd/julia/MokaHIP.jl) overloads those methods for a `MokaHIP`
+ * backend tag and `ccall`s the functions below; INTEGRATION.md shows the binding.  Each entry
+ * point cites the reference method it replaces.
+ *
+ * Conventions
+ *   - Plain C types only.  All host arrays are exactly what Julia holds in memory: Float64 /
+ *     Int32, column-major, 1-based connectivity (0 = "no neighbour" in edgesOnEdge), the slot
+ *     index fastest for connectivity ((maxEdges,nCells)...), the level index fastest for fields
+ *     ((nVertLevels,n)).
+ *   - Host pointers are borrowed for the duration of a call only.  The library owns all device
+ *     memory, its reordered copies of the mesh and the permutations; uploads/downloads present
+ *     the caller's original numbering.
+ *   - Every function returns 0 (MOKA_OK) or a negative moka_status; the message is available from
+ *     moka_last_error().  Nothing aborts, nothing prints.
+ *   - One context = one device = one owning host thread (not thread-safe).
+ *   - Operator entry points are synchronous on return (the reference ends every operator with
+ *     KA.synchronize: Operators.jl:72,119,176,198).  moka_step_ / moka_run are asynchronous on the
+ *     context's compute stream; download, sum_sq, timer_stop and sync are completion points.
+ *   - There is no CPU fallback: without a usable HIP device moka_ctx_create fails.
+ */
+#ifndef MOKA_HIP_H
+#define MOKA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct moka_ctx   moka_ctx;
+typedef struct moka_plan  moka_plan;   /* host-side reordered mesh (no GPU needed) */
+typedef struct moka_mesh  moka_mesh;   /* plan resident on a device                */
+typedef struct moka_state moka_state;  /* Prog + Diag + Tend on a device           */
+
+typedef enum {
+    MOKA_OK = 0,
+    MOKA_ERR_ARG = -1,       /* bad argument / inconsistent mesh (Julia: error("..."))  */
+    MOKA_ERR_HIP = -2,       /* a HIP runtime call failed (message has hipGetErrorString) */
+    MOKA_ERR_NO_DEVICE = -3, /* no usable gfx950 device: there is no CPU fallback         */
+    MOKA_ERR_ALLOC = -4,
+    MOKA_ERR_UNSUPPORTED = -5,
+    MOKA_ERR_COMM = -6
+} moka_status;
+
+/* cell ordering applied at mesh upload (north_star: "re-laid out SoA and RCM-reordered") */
+typedef enum {
+    MOKA_ORDER_DEFAULT = 0,  /* RCB patches when coordinates are given, else RCM */
+    MOKA_ORDER_NONE = 1,     /* keep the caller's numbering                      */
+    MOKA_ORDER_RCM = 2,      /* reverse Cuthill-McKee on the cell graph          */
+    MOKA_ORDER_RCB = 3       /* recursive coordinate bisection into compact patches */
+} moka_ordering;
+
+/* Mesh as the reference holds it: Edges (HorzMesh.jl:64-95), PrimaryCells (:102-132),
+ * DualCells (:135-162), VerticalMesh (VertMesh.jl:3-26).  Pointers marked (opt) may be NULL. */
+typedef struct moka_mesh_desc {
+    int32_t nCells, nEdges, nVertices;
+    int32_t maxEdges, maxEdges2, vertexDegree;
+    int32_t nVertLevels;
+    int32_t edgeSignOnVertexLD;      /* leading dim of edgeSignOnVertex (= maxEdges, HorzMesh.jl:234); 0 -> vertexDegree */
+    /* PrimaryCells */
+    const double  *xCell, *yCell, *zCell;            /* (opt) only used to order cells          */
+    const int32_t *nEdgesOnCell;                     /* (nCells)                                */
+    const int32_t *edgesOnCell;                      /* (maxEdges, nCells)                      */
+    const int32_t *edgeSignOnCell;                   /* (maxEdges, nCells)  signIndexField! :292 */
+    const double  *areaCell;                         /* (nCells)                                */
+    /* Edges */
+    const int32_t *cellsOnEdge;                      /* (2, nEdges)                             */
+    const int32_t *verticesOnEdge;                   /* (opt) (2, nEdges)                       */
+    const int32_t *nEdgesOnEdge;                     /* (nEdges)                                */
+    const int32_t *edgesOnEdge;                      /* (maxEdges2, nEdges), 0 = none           */
+    const double  *weightsOnEdge;                    /* (maxEdges2, nEdges)                     */
+    const double  *dvEdge, *dcEdge, *fEdge;          /* (nEdges)                                */
+    /* DualCells */
+    const int32_t *edgesOnVertex;                    /* (vertexDegree, nVertices)               */
+    const int32_t *cellsOnVertex;                    /* (opt) (vertexDegree, nVertices)         */
+    const int32_t *edgeSignOnVertex;                 /* (edgeSignOnVertexLD, nVertices) :313    */
+    const double  *areaTriangle;                     /* (nVertices)                             */
+    /* VerticalMesh */
+    const int32_t *maxLevelEdgeTop;                  /* (opt) (nEdges); NULL -> all ones (VertMesh.jl:32) */
+    const double  *restingThicknessSum;              /* (nCells) (VertMesh.jl:73,100)           */
+    /* layout controls */
+    int32_t ordering;                                /* moka_ordering                            */
+    int32_t patch_cells;                             /* cells per patch (0 = library default)    */
+} moka_mesh_desc;
+
+typedef struct moka_mesh_info {
+    int32_t nCells, nEdges, nVertices, nVertLevels;
+    int32_t ordering, patch_cells, nPatches;
+    int32_t maxEdgesUsed, maxEdges2Used;             /* record widths after compaction           */
+    int32_t lanesPerColumn;                          /* wavefront lanes that span one k-column   */
+    int64_t meshBytesDevice;                         /* reordered mesh resident in HBM           */
+    int64_t cellBandwidth;                           /* max |new(c1)-new(c2)| over edges         */
+} moka_mesh_info;
+
+/* entity kinds for permutations */
+enum { MOKA_CELL = 0, MOKA_EDGE = 1, MOKA_VERTEX = 2 };
+
+/* state fields (PrognosticVars.jl:6-57, DiagnosticVars.jl:6-73, TendencyVars.jl:7-49) */
+typedef enum {
+    MOKA_F_SSH = 0,                  /* (nCells)            time levels 0,1 */
+    MOKA_F_NORMAL_VELOCITY = 1,      /* (K, nEdges)         time levels 0,1 */
+    MOKA_F_LAYER_THICKNESS = 2,      /* (K, nCells)         time levels 0,1 */
+    MOKA_F_LAYER_THICKNESS_EDGE = 3, /* (K, nEdges)                         */
+    MOKA_F_THICKNESS_FLUX = 4,       /* (K, nEdges)                         */
+    MOKA_F_VELOCITY_DIV_CELL = 5,    /* (K, nCells)                         */
+    MOKA_F_RELATIVE_VORTICITY = 6,   /* (K, nVertices)                      */
+    MOKA_F_TEND_NORMAL_VELOCITY = 7, /* (K, nEdges)                         */
+    MOKA_F_TEND_LAYER_THICKNESS = 8  /* (K, nCells)                         */
+} moka_field;
+
+/* Forward-Euler order-of-evaluation switches; all set = the live reference step */
+#define MOKA_FE_STALE_HEDGE      1  /* flux uses previous step's layerThicknessEdge (DiagnosticVars.jl:113-116) */
+#define MOKA_FE_ACCUM_VORT       2  /* relativeVorticity accumulates (Operators.jl:135,142)                      */
+#define MOKA_FE_LEVEL1_ONLY      4  /* "[1,j]" kernels touch level 1 only (Operators.jl:207,228 ...)             */
+#define MOKA_FE_REFERENCE_COMPAT 7
+
+typedef enum { MOKA_FORWARD_EULER = 0, MOKA_RUNGE_KUTTA_4 = 1 } moka_integrator;
+
+/* ---- library / context ---------------------------------------------------------------- */
+const char *moka_version(void);
+/* replaces the `backend = CUDABackend()` choice, src/driver/mpas_ocean.jl:28 */
+int  moka_ctx_create(int device, moka_ctx **out);
+void moka_ctx_destroy(moka_ctx *ctx);
+const char *moka_last_error(const moka_ctx *ctx);   /* ctx may be NULL: last error of the calling thread */
+int  moka_sync(moka_ctx *ctx);                      /* KA.synchronize(backend) */
+/* HIP-event timer on the compute stream (used by bench.py for the roofline figure) */
+int  moka_timer_start(moka_ctx *ctx);
+int  moka_timer_stop(moka_ctx *ctx, float *elapsed_ms);
+
+/* ---- mesh ------------------------------------------------------------------------------ */
+/* Host-only: validate, convert to 0-based, order cells (RCB patches / RCM), renumber edges and
+ * vertices by first-touching cell, build per-entity records.  Needs no GPU. */
+int  moka_plan_create(const moka_mesh_desc *desc, moka_plan **out);
+void moka_plan_destroy(moka_plan *plan);
+int  moka_plan_info(const moka_plan *plan, moka_mesh_info *info);
+/* new_to_old[new] = caller's 0-based index; kind = MOKA_CELL / MOKA_EDGE / MOKA_VERTEX */
+int  moka_plan_permutation(const moka_plan *plan, int kind, int32_t *new_to_old);
+/* first cell / edge / vertex of every patch, nPatches+1 entries each */
+int  moka_plan_patch_ranges(const moka_plan *plan, int32_t *cellStart, int32_t *edgeStart, int32_t *vertexStart);
+
+/* Read-only view of one of the plan's per-entity record arrays (device layout, new numbering):
+ * lets host tests check the reordered mesh without a GPU.  `data` stays valid until plan destroy. */
+enum {
+    MOKA_PA_EOC = 0, MOKA_PA_COC, MOKA_PA_MLTC, MOKA_PA_SDV, MOKA_PA_INVAREA, MOKA_PA_AREACELL, MOKA_PA_RSUM,
+    MOKA_PA_EHDR, MOKA_PA_EOE, MOKA_PA_WOE, MOKA_PA_GINVDC, MOKA_PA_DCEDGE, MOKA_PA_DVEDGE, MOKA_PA_FEDGE,
+    MOKA_PA_EOV, MOKA_PA_CV
+};
+int  moka_plan_array(const moka_plan *plan, int which, const void **data, int64_t *count);
+
+/* replaces Adapt.adapt_structure(backend, ::Mesh) (MPASMesh.jl:26; HorzMesh.jl:354) */
+int  moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out);
+void moka_mesh_destroy(moka_mesh *mesh);
+int  moka_mesh_info_get(const moka_mesh *mesh, moka_mesh_info *info);
+
+/* ---- operators on host arrays (synchronous) -------------------------------------------- */
+/* GradientOnEdge!(grad, h, Mesh)            src/ocn/Operators.jl:102-120 */
+int moka_gradient_on_edge(moka_mesh *mesh, const double *scalarCell, double *gradEdge);
+/* DivergenceOnCell!(div, V, temp, Mesh)     src/ocn/Operators.jl:46-74; temp (opt) receives V*dvEdge */
+int moka_divergence_on_cell(moka_mesh *mesh, const double *vecEdge, double *tempEdge, double *divCell);
+/* CurlOnVertex!(curl, V, Mesh)              src/ocn/Operators.jl:151-177; ACCUMULATES into curlVertex */
+int moka_curl_on_vertex(moka_mesh *mesh, const double *vecEdge, double *curlVertex);
+/* interpolateCell2Edge!(e, c, Mesh)         src/ocn/Operators.jl:179-222; nlev = 1 is the reference (level 1 only) */
+int moka_interpolate_cell2edge(moka_mesh *mesh, const double *cellValue, double *edgeValue, int nlev);
+
+/* ---- state ----------------------------------------------------------------------------- */
+/* PrognosticVars/DiagnosticVars/TendencyVars constructors with KA.zeros on the backend
+ * (PrognosticVars.jl:59-106, DiagnosticVars.jl:75-99, TendencyVars.jl:51-67); nTimeLevels = 2 */
+int  moka_state_create(moka_ctx *ctx, moka_mesh *mesh, moka_state **out);
+void moka_state_destroy(moka_state *st);
+/* Adapt.adapt(backend, array) / Adapt.adapt_structure(KA.CPU(), x) (OutPut.jl:122-124).
+ * time_level: 0 = previous, 1 = current (reference indices 1 and end); ignored for Diag/Tend. */
+int  moka_state_upload(moka_state *st, int field, int time_level, const double *host);
+int  moka_state_download(moka_state *st, int field, int time_level, double *host);
+
+/* advanceTimeLevels!(Prog)                  src/forward/time_integration.jl:10-40 */
+int moka_advance_time_levels(moka_state *st, int flags);
+/* diagnostic_compute!(Mesh, Diag, Prog)     src/ocn/DiagnosticVars.jl:108-117 (flags: MOKA_FE_*) */
+int moka_diagnostic_compute(moka_state *st, int flags);
+/* computeNormalVelocityTendency!            src/ocn/Tendencies/normalVelocity/normalVelocity.jl:21-53 */
+int moka_compute_normal_velocity_tendency(moka_state *st, int flags);
+/* computeLayerThicknessTendency!            src/ocn/Tendencies/layerThickness/layerThickness.jl:14-28 */
+int moka_compute_layer_thickness_tendency(moka_state *st, int flags);
+/* Fused tendency evaluation (u,h) -> (tendU,tendH) with consistent diagnostics:
+ * the kernel the roofline figure is quoted on. */
+int moka_tendencies(moka_state *st);
+/* ocn_timestep(timestep, Prog, Diag, Tend, S, ForwardEuler)   time_integration.jl:150-193 */
+int moka_step_fe(moka_state *st, double dt, int flags);
+/* ocn_timestep(Prog, Diag, Tend, S, RungeKutta4)              time_integration.jl:61-148 (spec) */
+int moka_step_rk4(moka_state *st, double dt);
+/* the body of ocn_run_loop                   src/forward/run_loop.jl:8-22 : nsteps x ocn_timestep */
+int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flags);
+/* sumArray                                   src/forward/run_loop.jl:39-51 : sum_j a[j]^2 */
+int moka_sum_sq(moka_state *st, int field, int time_level, double *out);
+
+/* kernel variant selection for measurement: 0 = auto, 1 = direct (L2-gather), 2 = LDS patch-tiled */
+int moka_set_kernel_variant(moka_ctx *ctx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOKA_HIP_H */

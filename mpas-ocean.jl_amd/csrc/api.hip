@@ -1,0 +1,604 @@
+// api.hip -- C ABI of libmoka_hip.so (include/moka_hip.h): context, device mesh, state, steps.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "kernels.hpp"
+#include "moka_internal.hpp"
+
+namespace moka { void fill_mesh_info(const Plan &p, moka_mesh_info *info); }
+
+struct moka_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int variant = 0;
+    std::string err;
+};
+
+struct moka_mesh {
+    moka_ctx *ctx = nullptr;
+    moka::Plan plan;          // host copy (permutations, sizes)
+    moka::MeshDev dev{};
+    std::vector<void *> allocs;
+    int lpc = 1;
+    double *opBuf[3] = {nullptr, nullptr, nullptr};   // operator / transfer scratch, lazily sized
+    size_t opBufElems = 0;
+};
+
+struct LevelBufs {
+    double *ssh = nullptr, *u = nullptr, *h = nullptr;
+};
+
+struct moka_state {
+    moka_ctx *ctx = nullptr;
+    moka_mesh *mesh = nullptr;
+    LevelBufs lev[2];                 // [0] previous, [1] current   (reference Vector index 1 / end)
+    double *hEdge[2] = {nullptr, nullptr};   // [0] is Diag.layerThicknessEdge, [1] the write target of the next step
+    double *F = nullptr, *div = nullptr, *vort = nullptr, *tendU = nullptr, *tendH = nullptr;
+    LevelBufs rk[2];                  // RK4 provisional states (lazily allocated)
+    double *scalar = nullptr;         // 1 double (sum_sq result)
+    bool sshConsistent = false;       // lev[1].ssh == ksum(lev[1].h) - restingThicknessSum
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+using namespace moka;
+
+int fail(moka_ctx *ctx, int code, const std::string &msg)
+{
+    set_error(msg);
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(ctx, MOKA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+int lanes_per_column(int K)
+{
+    int l = 1;
+    while (l < K && l < 64) l <<= 1;
+    return l;
+}
+
+template <class T>
+int upload_vec(moka_mesh *m, const std::vector<T> &v, const T **out)
+{
+    void *d = nullptr;
+    const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIPCHK(m->ctx, hipMalloc(&d, bytes));
+    m->allocs.push_back(d);
+    if (!v.empty()) HIPCHK(m->ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(d);
+    return MOKA_OK;
+}
+
+int ensure_op_bufs(moka_mesh *m)
+{
+    const Plan &p = m->plan;
+    const size_t need = (size_t)p.K * std::max(p.nE, std::max(p.nC, p.nV));
+    if (m->opBufElems >= need) return MOKA_OK;
+    for (auto &b : m->opBuf) {
+        if (b) HIPCHK(m->ctx, hipFree(b));
+        b = nullptr;
+    }
+    for (auto &b : m->opBuf) HIPCHK(m->ctx, hipMalloc((void **)&b, need * sizeof(double)));
+    m->opBufElems = need;
+    return MOKA_OK;
+}
+
+int alloc_field(moka_state *st, double **out, size_t elems)
+{
+    void *d = nullptr;
+    HIPCHK(st->ctx, hipMalloc(&d, std::max<size_t>(elems * sizeof(double), 16)));
+    st->allocs.push_back(d);
+    HIPCHK(st->ctx, hipMemsetAsync(d, 0, elems * sizeof(double), st->ctx->stream));   // KA.zeros
+    *out = static_cast<double *>(d);
+    return MOKA_OK;
+}
+
+int ensure_rk_bufs(moka_state *st)
+{
+    if (st->rk[0].u) return MOKA_OK;
+    const Plan &p = st->mesh->plan;
+    for (auto &r : st->rk) {
+        int rc;
+        if ((rc = alloc_field(st, &r.u, (size_t)p.K * p.nE))) return rc;
+        if ((rc = alloc_field(st, &r.h, (size_t)p.K * p.nC))) return rc;
+        if ((rc = alloc_field(st, &r.ssh, (size_t)p.nC))) return rc;
+    }
+    return MOKA_OK;
+}
+
+struct FieldRef {
+    double *ptr;
+    int kind;     // MOKA_CELL / EDGE / VERTEX
+    int64_t n;
+    int K;
+};
+
+int field_ref(moka_state *st, int field, int level, FieldRef *r)
+{
+    const Plan &p = st->mesh->plan;
+    if (level != 0 && level != 1) return fail(st->ctx, MOKA_ERR_ARG, "time_level must be 0 (previous) or 1 (current)");
+    switch (field) {
+        case MOKA_F_SSH: *r = {st->lev[level].ssh, MOKA_CELL, p.nC, 1}; break;
+        case MOKA_F_NORMAL_VELOCITY: *r = {st->lev[level].u, MOKA_EDGE, p.nE, p.K}; break;
+        case MOKA_F_LAYER_THICKNESS: *r = {st->lev[level].h, MOKA_CELL, p.nC, p.K}; break;
+        case MOKA_F_LAYER_THICKNESS_EDGE: *r = {st->hEdge[0], MOKA_EDGE, p.nE, p.K}; break;
+        case MOKA_F_THICKNESS_FLUX: *r = {st->F, MOKA_EDGE, p.nE, p.K}; break;
+        case MOKA_F_VELOCITY_DIV_CELL: *r = {st->div, MOKA_CELL, p.nC, p.K}; break;
+        case MOKA_F_RELATIVE_VORTICITY: *r = {st->vort, MOKA_VERTEX, p.nV, p.K}; break;
+        case MOKA_F_TEND_NORMAL_VELOCITY: *r = {st->tendU, MOKA_EDGE, p.nE, p.K}; break;
+        case MOKA_F_TEND_LAYER_THICKNESS: *r = {st->tendH, MOKA_CELL, p.nC, p.K}; break;
+        default: return fail(st->ctx, MOKA_ERR_ARG, "unknown field id");
+    }
+    return MOKA_OK;
+}
+
+const int32_t *perm_of(const moka_mesh *m, int kind)
+{
+    return kind == MOKA_CELL ? m->dev.cellN2O : kind == MOKA_EDGE ? m->dev.edgeN2O : m->dev.vertN2O;
+}
+
+// host (caller numbering) -> device field (device numbering)
+int put_rows(moka_mesh *m, double *dst, const double *host, int kind, int64_t n, int K)
+{
+    int rc = ensure_op_bufs(m);
+    if (rc) return rc;
+    hipStream_t s = m->ctx->stream;
+    HIPCHK(m->ctx, hipMemcpyAsync(m->opBuf[2], host, (size_t)n * K * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(m->ctx, launch_permute_rows(dst, m->opBuf[2], perm_of(m, kind), n, K, 1, s));
+    HIPCHK(m->ctx, hipStreamSynchronize(s));
+    return MOKA_OK;
+}
+
+int get_rows(moka_mesh *m, double *host, const double *src, int kind, int64_t n, int K)
+{
+    int rc = ensure_op_bufs(m);
+    if (rc) return rc;
+    hipStream_t s = m->ctx->stream;
+    HIPCHK(m->ctx, launch_permute_rows(m->opBuf[2], src, perm_of(m, kind), n, K, 0, s));
+    HIPCHK(m->ctx, hipMemcpyAsync(host, m->opBuf[2], (size_t)n * K * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(m->ctx, hipStreamSynchronize(s));
+    return MOKA_OK;
+}
+
+int nlev_of(const moka_state *st, int flags) { return (flags & MOKA_FE_LEVEL1_ONLY) ? 1 : st->mesh->plan.K; }
+
+FeArgs fe_args(moka_state *st, int ops, int flags, double dt)
+{
+    FeArgs a{};
+    a.ops = ops;
+    a.flags = flags;
+    a.nlev = nlev_of(st, flags);
+    a.dt = dt;
+    a.u = st->lev[1].u; a.h = st->lev[1].h; a.ssh = st->lev[1].ssh;
+    a.hEdgeOld = st->hEdge[0]; a.hEdgeNew = st->hEdge[1];
+    a.Fin = st->F; a.F = st->F; a.div = st->div; a.vort = st->vort;
+    a.tendU = st->tendU; a.tendH = st->tendH;
+    a.u_new = st->lev[0].u; a.h_new = st->lev[0].h; a.ssh_new = st->lev[0].ssh;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *moka_version(void) { return "moka-hip 0.1.0 (gfx950)"; }
+
+const char *moka_last_error(const moka_ctx *ctx) { return ctx ? ctx->err.c_str() : moka::get_error(); }
+
+int moka_ctx_create(int device, moka_ctx **out)
+{
+    if (!out) return fail(nullptr, MOKA_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, MOKA_ERR_NO_DEVICE,
+                    std::string("no HIP device available (libmoka_hip has no CPU fallback): ") +
+                        (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= ndev) return fail(nullptr, MOKA_ERR_ARG, "device index out of range");
+    HIPCHK(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MOKA_ERR_NO_DEVICE,
+                    std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code objects only");
+    moka_ctx *c = new (std::nothrow) moka_ctx();
+    if (!c) return fail(nullptr, MOKA_ERR_ALLOC, "out of host memory");
+    c->device = device;
+    hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e2 = hipEventCreate(&c->ev0);
+    hipError_t e3 = hipEventCreate(&c->ev1);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        delete c;
+        return fail(nullptr, MOKA_ERR_HIP, "failed to create stream/events");
+    }
+    *out = c;
+    return MOKA_OK;
+}
+
+void moka_ctx_destroy(moka_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int moka_sync(moka_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MOKA_OK;
+}
+
+int moka_timer_start(moka_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return MOKA_OK;
+}
+
+int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms) return fail(ctx, MOKA_ERR_ARG, "NULL argument");
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return MOKA_OK;
+}
+
+int moka_set_kernel_variant(moka_ctx *ctx, int variant)
+{
+    if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
+    if (variant < 0 || variant > 2) return fail(ctx, MOKA_ERR_ARG, "variant must be 0, 1 or 2");
+    ctx->variant = variant;
+    return MOKA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mesh
+// ---------------------------------------------------------------------------------------------
+int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
+{
+    if (!ctx || !out) return fail(ctx, MOKA_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    moka_mesh *m = new (std::nothrow) moka_mesh();
+    if (!m) return fail(ctx, MOKA_ERR_ALLOC, "out of host memory");
+    m->ctx = ctx;
+    int rc;
+    try {
+        rc = build_plan(desc, m->plan);
+    } catch (const std::bad_alloc &) {
+        rc = fail(ctx, MOKA_ERR_ALLOC, "out of host memory while building the mesh plan");
+    }
+    if (rc != MOKA_OK) {
+        ctx->err = moka::get_error();
+        delete m;
+        return rc;
+    }
+    const Plan &p = m->plan;
+    if (p.ME > 8 || p.ME2 > 14) {
+        delete m;
+        return fail(ctx, MOKA_ERR_UNSUPPORTED, "cells with more than 8 edges are not supported by the gfx950 kernels");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    MeshDev &d = m->dev;
+    d.nC = p.nC; d.nE = p.nE; d.nV = p.nV; d.K = p.K; d.ME = p.ME; d.ME2 = p.ME2; d.VD = p.VD; d.nPatches = p.nPatches;
+    m->lpc = lanes_per_column(p.K);
+#define UP(field)                                                \
+    if ((rc = upload_vec(m, p.field, &d.field)) != MOKA_OK) {    \
+        moka_mesh_destroy(m);                                    \
+        return rc;                                               \
+    }
+    UP(patchCellStart) UP(patchEdgeStart) UP(patchVertStart)
+    UP(eoc) UP(coc) UP(mltc) UP(sdv) UP(invArea) UP(areaCell) UP(rsum)
+    UP(ehdr) UP(eoe) UP(woe) UP(gInvDc) UP(dcEdge) UP(dvEdge) UP(fEdge)
+    UP(eov) UP(cv) UP(cellN2O) UP(edgeN2O) UP(vertN2O)
+#undef UP
+    *out = m;
+    return MOKA_OK;
+}
+
+void moka_mesh_destroy(moka_mesh *mesh)
+{
+    if (!mesh) return;
+    (void)hipSetDevice(mesh->ctx->device);
+    (void)hipStreamSynchronize(mesh->ctx->stream);
+    for (void *q : mesh->allocs) (void)hipFree(q);
+    for (auto b : mesh->opBuf)
+        if (b) (void)hipFree(b);
+    delete mesh;
+}
+
+int moka_mesh_info_get(const moka_mesh *mesh, moka_mesh_info *info)
+{
+    if (!mesh || !info) return fail(nullptr, MOKA_ERR_ARG, "NULL argument");
+    fill_mesh_info(mesh->plan, info);
+    return MOKA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// operators on host arrays
+// ---------------------------------------------------------------------------------------------
+static int run_operator(moka_mesh *m, int op, int nlev, const double *in, int inKind, double *out, int outKind,
+                        bool out_is_inout)
+{
+    if (!m || !in || !out) return fail(m ? m->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    const Plan &p = m->plan;
+    auto count = [&](int kind) -> int64_t { return kind == MOKA_CELL ? p.nC : kind == MOKA_EDGE ? p.nE : p.nV; };
+    int rc = ensure_op_bufs(m);
+    if (rc) return rc;
+    hipStream_t s = m->ctx->stream;
+    HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
+    if ((rc = put_rows(m, m->opBuf[0], in, inKind, count(inKind), p.K))) return rc;
+    if (out_is_inout) {
+        if ((rc = put_rows(m, m->opBuf[1], out, outKind, count(outKind), p.K))) return rc;
+    } else {
+        // untouched levels (interpolate, nlev < K) must come back as the caller had them
+        if (op == OP_INTERP && nlev < p.K) {
+            if ((rc = put_rows(m, m->opBuf[1], out, outKind, count(outKind), p.K))) return rc;
+        }
+    }
+    OpArgs a{op, nlev, m->opBuf[0], m->opBuf[1]};
+    HIPCHK(m->ctx, launch_operator(m->dev, a, m->lpc, s));
+    return get_rows(m, out, m->opBuf[1], outKind, count(outKind), p.K);
+}
+
+int moka_gradient_on_edge(moka_mesh *mesh, const double *scalarCell, double *gradEdge)
+{
+    return run_operator(mesh, OP_GRADIENT, 0, scalarCell, MOKA_CELL, gradEdge, MOKA_EDGE, false);
+}
+
+int moka_interpolate_cell2edge(moka_mesh *mesh, const double *cellValue, double *edgeValue, int nlev)
+{
+    if (mesh && (nlev < 1 || nlev > mesh->plan.K)) return fail(mesh->ctx, MOKA_ERR_ARG, "nlev out of range");
+    return run_operator(mesh, OP_INTERP, nlev, cellValue, MOKA_CELL, edgeValue, MOKA_EDGE, false);
+}
+
+int moka_curl_on_vertex(moka_mesh *mesh, const double *vecEdge, double *curlVertex)
+{
+    return run_operator(mesh, OP_CURL, 0, vecEdge, MOKA_EDGE, curlVertex, MOKA_VERTEX, true);
+}
+
+int moka_divergence_on_cell(moka_mesh *m, const double *vecEdge, double *tempEdge, double *divCell)
+{
+    if (!m || !vecEdge || !divCell) return fail(m ? m->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    const Plan &p = m->plan;
+    int rc = ensure_op_bufs(m);
+    if (rc) return rc;
+    hipStream_t s = m->ctx->stream;
+    HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
+    if ((rc = put_rows(m, m->opBuf[0], vecEdge, MOKA_EDGE, p.nE, p.K))) return rc;
+    OpArgs a1{OP_DIV_P1, 0, m->opBuf[0], m->opBuf[1]};      // temp = V*dvEdge (Operators.jl:60)
+    HIPCHK(m->ctx, launch_operator(m->dev, a1, m->lpc, s));
+    if (tempEdge && (rc = get_rows(m, tempEdge, m->opBuf[1], MOKA_EDGE, p.nE, p.K))) return rc;
+    OpArgs a2{OP_DIV_P2, 0, m->opBuf[0], m->opBuf[1]};      // second pass reads V, folds dvEdge*sign exactly
+    HIPCHK(m->ctx, launch_operator(m->dev, a2, m->lpc, s));
+    return get_rows(m, divCell, m->opBuf[1], MOKA_CELL, p.nC, p.K);
+}
+
+// ---------------------------------------------------------------------------------------------
+// state
+// ---------------------------------------------------------------------------------------------
+int moka_state_create(moka_ctx *ctx, moka_mesh *mesh, moka_state **out)
+{
+    if (!ctx || !mesh || !out) return fail(ctx, MOKA_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    moka_state *st = new (std::nothrow) moka_state();
+    if (!st) return fail(ctx, MOKA_ERR_ALLOC, "out of host memory");
+    st->ctx = ctx;
+    st->mesh = mesh;
+    const Plan &p = mesh->plan;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nEK = (size_t)p.K * p.nE, nCK = (size_t)p.K * p.nC, nVK = (size_t)p.K * p.nV;
+    int rc = MOKA_OK;
+    auto A = [&](double **q, size_t n) { if (rc == MOKA_OK) rc = alloc_field(st, q, n); };
+    for (auto &l : st->lev) { A(&l.ssh, p.nC); A(&l.u, nEK); A(&l.h, nCK); }
+    A(&st->hEdge[0], nEK); A(&st->hEdge[1], nEK);
+    A(&st->F, nEK); A(&st->div, nCK); A(&st->vort, nVK); A(&st->tendU, nEK); A(&st->tendH, nCK);
+    A(&st->scalar, 2);
+    if (rc != MOKA_OK) { moka_state_destroy(st); return rc; }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = st;
+    return MOKA_OK;
+}
+
+void moka_state_destroy(moka_state *st)
+{
+    if (!st) return;
+    (void)hipSetDevice(st->ctx->device);
+    (void)hipStreamSynchronize(st->ctx->stream);
+    for (void *q : st->allocs) (void)hipFree(q);
+    delete st;
+}
+
+int moka_state_upload(moka_state *st, int field, int time_level, const double *host)
+{
+    if (!st || !host) return fail(st ? st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    FieldRef r;
+    int rc = field_ref(st, field, time_level, &r);
+    if (rc) return rc;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (time_level == 1 && (field == MOKA_F_SSH || field == MOKA_F_LAYER_THICKNESS)) st->sshConsistent = false;
+    return put_rows(st->mesh, r.ptr, host, r.kind, r.n, r.K);
+}
+
+int moka_state_download(moka_state *st, int field, int time_level, double *host)
+{
+    if (!st || !host) return fail(st ? st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    FieldRef r;
+    int rc = field_ref(st, field, time_level, &r);
+    if (rc) return rc;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    return get_rows(st->mesh, host, r.ptr, r.kind, r.n, r.K);
+}
+
+int moka_advance_time_levels(moka_state *st, int flags)
+{
+    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    const Plan &p = st->mesh->plan;
+    hipStream_t s = st->ctx->stream;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    // advance_2d_array / advance_3d_array (time_integration.jl:42-59): prev <- next.
+    // Level-1-only copies (K > 1) go through the FE kernel's carry-over path instead.
+    if ((flags & MOKA_FE_LEVEL1_ONLY) && p.K > 1)
+        return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "level-1-only advanceTimeLevels! is only available inside moka_step_fe");
+    HIPCHK(st->ctx, launch_copy(st->lev[0].ssh, st->lev[1].ssh, p.nC, s));
+    HIPCHK(st->ctx, launch_copy(st->lev[0].u, st->lev[1].u, (int64_t)p.K * p.nE, s));
+    HIPCHK(st->ctx, launch_copy(st->lev[0].h, st->lev[1].h, (int64_t)p.K * p.nC, s));
+    return MOKA_OK;
+}
+
+int moka_diagnostic_compute(moka_state *st, int flags)
+{
+    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE, flags, 0.0);
+    HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
+    std::swap(st->hEdge[0], st->hEdge[1]);
+    return MOKA_OK;
+}
+
+int moka_compute_normal_velocity_tendency(moka_state *st, int flags)
+{
+    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    FeArgs a = fe_args(st, FE_TENDU, flags, 0.0);
+    HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
+    return MOKA_OK;
+}
+
+int moka_compute_layer_thickness_tendency(moka_state *st, int flags)
+{
+    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    FeArgs a = fe_args(st, FE_TENDH | FE_TENDH_FROM_F, flags, 0.0);
+    HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
+    return MOKA_OK;
+}
+
+static int make_ssh_consistent(moka_state *st, double *dst)
+{
+    const Plan &p = st->mesh->plan;
+    HIPCHK(st->ctx, launch_update_ssh(st->mesh->dev, st->lev[1].h, dst, p.K, st->mesh->lpc, st->ctx->stream));
+    return MOKA_OK;
+}
+
+int moka_tendencies(moka_state *st)
+{
+    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    int rc;
+    if (!st->sshConsistent) {
+        if ((rc = make_ssh_consistent(st, st->lev[1].ssh))) return rc;
+        st->sshConsistent = true;
+    }
+    StageArgs a{};
+    a.pu = st->lev[1].u; a.ph = st->lev[1].h; a.ssh = st->lev[1].ssh;
+    a.tendU = st->tendU; a.tendH = st->tendH;
+    HIPCHK(st->ctx, launch_stage(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
+    return MOKA_OK;
+}
+
+int moka_step_fe(moka_state *st, double dt, int flags)
+{
+    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    // advanceTimeLevels! + diagnostic_compute! + both tendencies + updates (time_integration.jl:163-189)
+    // in one launch: new values are written into the previous level's buffers, then the levels swap.
+    FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE | FE_TENDU | FE_TENDH | FE_UPDATE, flags, dt);
+    HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
+    std::swap(st->lev[0], st->lev[1]);
+    std::swap(st->hEdge[0], st->hEdge[1]);
+    st->sshConsistent = !(flags & MOKA_FE_LEVEL1_ONLY) || st->mesh->plan.K == 1;
+    return MOKA_OK;
+}
+
+int moka_step_rk4(moka_state *st, double dt)
+{
+    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    int rc = ensure_rk_bufs(st);
+    if (rc) return rc;
+    const MeshDev &m = st->mesh->dev;
+    const int lpc = st->mesh->lpc;
+    hipStream_t s = st->ctx->stream;
+    const double a[3] = {dt / 2., dt / 2., dt};                         // time_integration.jl:77
+    const double b[4] = {dt / 6., dt / 3., dt / 3., dt / 6.};           // :78
+    LevelBufs &A = st->lev[1];   // Curr (becomes the previous level)
+    LevelBufs &B = st->lev[0];   // New accumulator (becomes the current level)
+    LevelBufs &R1 = st->rk[0], &R2 = st->rk[1];
+    const double *ssh0 = A.ssh;
+    if (!st->sshConsistent) {    // the tendency of stage 1 uses ssh computed from layerThickness
+        if ((rc = make_ssh_consistent(st, R2.ssh))) return rc;
+        ssh0 = R2.ssh;
+    }
+    StageArgs g{};
+    // stage 1: Provis == Curr == A;  New = Curr + b1*k1 -> B;  Provis' = Curr + a1*k1 -> R1
+    g.pu = A.u; g.ph = A.h; g.ssh = ssh0; g.cu = nullptr; g.ch = nullptr; g.nu_in = nullptr; g.nh_in = nullptr;
+    g.nu_out = B.u; g.nh_out = B.h; g.pu_out = R1.u; g.ph_out = R1.h; g.ssh_out = R1.ssh; g.a = a[0]; g.b = b[0];
+    HIPCHK(st->ctx, launch_stage(m, g, lpc, s));
+    // stage 2: Provis = R1 -> R2
+    g.pu = R1.u; g.ph = R1.h; g.ssh = R1.ssh; g.cu = A.u; g.ch = A.h; g.nu_in = B.u; g.nh_in = B.h;
+    g.pu_out = R2.u; g.ph_out = R2.h; g.ssh_out = R2.ssh; g.a = a[1]; g.b = b[1];
+    HIPCHK(st->ctx, launch_stage(m, g, lpc, s));
+    // stage 3: Provis = R2 -> R1
+    g.pu = R2.u; g.ph = R2.h; g.ssh = R2.ssh; g.pu_out = R1.u; g.ph_out = R1.h; g.ssh_out = R1.ssh; g.a = a[2]; g.b = b[2];
+    HIPCHK(st->ctx, launch_stage(m, g, lpc, s));
+    // stage 4: Provis = R1; New += b4*k4; ssh of New
+    g.pu = R1.u; g.ph = R1.h; g.ssh = R1.ssh; g.pu_out = nullptr; g.ph_out = nullptr; g.ssh_out = B.ssh; g.a = 0.0; g.b = b[3];
+    HIPCHK(st->ctx, launch_stage(m, g, lpc, s));
+    std::swap(st->lev[0], st->lev[1]);
+    st->sshConsistent = true;
+    return MOKA_OK;
+}
+
+int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flags)
+{
+    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    if (nsteps < 0) return fail(st->ctx, MOKA_ERR_ARG, "nsteps must be >= 0");
+    for (int64_t i = 0; i < nsteps; ++i) {
+        int rc = integrator == MOKA_FORWARD_EULER ? moka_step_fe(st, dt, flags)
+               : integrator == MOKA_RUNGE_KUTTA_4 ? moka_step_rk4(st, dt)
+               : fail(st->ctx, MOKA_ERR_ARG, "unknown integrator");
+        if (rc) return rc;
+    }
+    return MOKA_OK;
+}
+
+int moka_sum_sq(moka_state *st, int field, int time_level, double *out)
+{
+    if (!st || !out) return fail(st ? st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    FieldRef r;
+    int rc = field_ref(st, field, time_level, &r);
+    if (rc) return rc;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if ((rc = ensure_op_bufs(st->mesh))) return rc;
+    hipStream_t s = st->ctx->stream;
+    // caller's numbering, then the strictly serial order of sumArray (run_loop.jl:47-51)
+    HIPCHK(st->ctx, launch_permute_rows(st->mesh->opBuf[2], r.ptr, perm_of(st->mesh, r.kind), r.n, r.K, 0, s));
+    HIPCHK(st->ctx, launch_sum_sq_serial(st->mesh->opBuf[2], r.n * r.K, st->scalar, s));
+    HIPCHK(st->ctx, hipMemcpyAsync(out, st->scalar, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(st->ctx, hipStreamSynchronize(s));
+    return MOKA_OK;
+}
+
+}  // extern "C"

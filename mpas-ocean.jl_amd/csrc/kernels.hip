@@ -1,0 +1,531 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of libmoka_hip.
+//
+// Execution shape ("column kernels").  Fields are (nVertLevels, n) with the level index fastest,
+// exactly the reference layout (PrognosticVars.jl:11-17).  A group of LPC lanes (LPC = smallest
+// power of two >= nVertLevels, capped at 64: one whole wavefront for the 60/80-layer configs)
+// owns one mesh entity at a time; lane l of the group owns levels l, l+LPC, ...  Every neighbour
+// gather is therefore one contiguous K*8-byte row read, and with LPC = 64 all connectivity of the
+// entity is wave-uniform (scalar loads).  One workgroup (256 threads) walks one *patch*: P
+// consecutive cells of the RCB/RCM ordering plus the edges and vertices those cells own, so the
+// rows a workgroup gathers are the rows its neighbours in the grid also touch; the blockIdx ->
+// patch map keeps consecutive patches on one XCD (blocks b, b+8, ... share an XCD's L2).
+//
+// Arithmetic.  Compiled with -ffp-contract=off and written in the reference's operand order
+// (each expression cites the reference line), so results are bit-identical to the CPU oracle.
+// Memory-bound indirect stencil: no MFMA by design.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace moka {
+
+constexpr int BLOCK = 256;
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+template <int LPC>
+__device__ __forceinline__ double group_sum(double v)
+{
+    // XOR butterfly over the LPC lanes of a group: the summation order fixed by the oracle
+    // (oracle_ksum).  fp add is commutative, so every lane ends with the same bits.
+#pragma unroll
+    for (int s = LPC / 2; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
+    return v;
+}
+
+template <int LPC>
+__device__ __forceinline__ int uniform_if_wave(int x)
+{
+    if constexpr (LPC == 64) return __builtin_amdgcn_readfirstlane(x);
+    else return x;
+}
+
+// blockIdx -> patch: XCD x (= blockIdx % 8 by the observed round-robin dispatch; speed only)
+// walks the contiguous patch range [x*chunk, (x+1)*chunk).
+__device__ __forceinline__ int patch_of_block(int nPatches)
+{
+    const int chunk = (nPatches + 7) >> 3;
+    return (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused tendency / RK-stage kernel.
+//   cells : hEdge (K5, Operators.jl:217) -> thicknessFlux (K7, DiagnosticVars.jl:165)
+//           -> flux divergence (K8, horizontal_advection.jl:60-66) [-> state update, ssh (K14)]
+//   edges : -g grad ssh (K9, pressure_gradient.jl:58-64) + Coriolis (K10,
+//           horizontal_advection_and_coriolis.jl:61-73)          [-> state update]
+// The stage update is the RK4 specification of time_integration.jl:112-137:
+//   Provis' = Curr + a*tend ; New = New + b*tend ; ssh from layerThickness.
+// ------------------------------------------------------------------------------------------------
+template <int LPC, int ME, int ME2>
+__global__ __launch_bounds__(BLOCK) void k_stage(const MeshDev m, const StageArgs a)
+{
+    const int p = patch_of_block(m.nPatches);
+    if (p >= m.nPatches) return;
+    constexpr int NG = BLOCK / LPC;
+    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC);
+    const int l = threadIdx.x % LPC;
+    const int K = m.K;
+    const int Kc = ((K + LPC - 1) / LPC) * LPC;
+
+    // ---------------- cells ----------------
+    const int c0 = m.patchCellStart[p], c1 = m.patchCellStart[p + 1];
+    for (int c = c0 + grp; c < c1; c += NG) {
+        const int32_t *re = m.eoc + (size_t)c * ME;
+        const int32_t *rc = m.coc + (size_t)c * ME;
+        const int32_t *rm = m.mltc + (size_t)c * ME;
+        const double *rs = m.sdv + (size_t)c * ME;
+        const double invA = m.invArea[c];
+        int ei[ME], ci[ME], mi[ME];
+        double si[ME];
+#pragma unroll
+        for (int i = 0; i < ME; ++i) {
+            ei[i] = re[i];
+            ci[i] = rc[i];
+            mi[i] = rm[i];
+            si[i] = rs[i];
+        }
+        double sshAcc = 0.0;
+        bool first = true;
+        for (int k = l; k < Kc; k += LPC) {
+            const bool act = k < K;
+            const size_t off = (size_t)c * K + k;
+            double hc = 0.0, uv[ME], hv[ME];
+            if (act) {
+                hc = a.ph[off];
+#pragma unroll
+                for (int i = 0; i < ME; ++i) {
+                    const int es = ei[i] >= 0 ? ei[i] : ei[0];
+                    const int cs = ci[i] >= 0 ? ci[i] : c;
+                    uv[i] = a.pu[(size_t)es * K + k];
+                    hv[i] = a.ph[(size_t)cs * K + k];
+                }
+            }
+            double t = 0.0;
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < ME; ++i) {
+                    if (ei[i] >= 0 && k < mi[i]) {
+                        const double hE = 0.5 * (hc + hv[i]);      // Operators.jl:217
+                        const double F = uv[i] * hE;               // DiagnosticVars.jl:165
+                        t += F * si[i] * invA;                     // horizontal_advection.jl:63-64
+                    }
+                }
+            }
+            double hs = 0.0;   // the thickness whose column sum gives ssh_out
+            if (act) {
+                if (a.tendH) a.tendH[off] = t;
+                const double hcur = a.ch ? a.ch[off] : hc;
+                if (a.ph_out) {
+                    const double hp = hcur + a.a * t;              // time_integration.jl:125
+                    a.ph_out[off] = hp;
+                    hs = hp;
+                }
+                if (a.nh_out) {
+                    const double hn = (a.nh_in ? a.nh_in[off] : hcur) + a.b * t;   // :135
+                    a.nh_out[off] = hn;
+                    if (!a.ph_out) hs = hn;
+                }
+            }
+            sshAcc = first ? hs : sshAcc + hs;                     // oracle_ksum strided partials
+            first = false;
+        }
+        if (a.ssh_out) {
+            const double s = group_sum<LPC>(sshAcc);
+            if (l == 0) a.ssh_out[c] = s - m.rsum[c];              // time_integration.jl:209 (+N3)
+        }
+    }
+
+    // ---------------- edges ----------------
+    const int e0 = m.patchEdgeStart[p], e1 = m.patchEdgeStart[p + 1];
+    for (int e = e0 + grp; e < e1; e += NG) {
+        const int4 hdr = *reinterpret_cast<const int4 *>(m.ehdr + (size_t)e * 4);
+        const int32_t *re = m.eoe + (size_t)e * ME2;
+        const double *rw = m.woe + (size_t)e * ME2;
+        int xi[ME2];
+        double wi[ME2], fi[ME2];
+#pragma unroll
+        for (int i = 0; i < ME2; ++i) {
+            xi[i] = re[i];
+            wi[i] = rw[i];
+        }
+#pragma unroll
+        for (int i = 0; i < ME2; ++i) fi[i] = m.fEdge[xi[i] >= 0 ? xi[i] : e];
+        const double g = m.gInvDc[e];
+        const double ds = a.ssh[hdr.y] - a.ssh[hdr.x];            // ssh[c2] - ssh[c1]
+        const int mlt = hdr.w;
+        for (int k = l; k < K; k += LPC) {
+            const size_t off = (size_t)e * K + k;
+            double uv[ME2];
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) uv[i] = a.pu[(size_t)(xi[i] >= 0 ? xi[i] : e) * K + k];
+            double t = 0.0;
+            if (k < mlt) {
+                t -= g * ds;                                       // pressure_gradient.jl:63
+#pragma unroll
+                for (int i = 0; i < ME2; ++i)
+                    if (xi[i] >= 0) t += wi[i] * uv[i] * fi[i];    // ...coriolis.jl:70-72
+            }
+            if (a.tendU) a.tendU[off] = t;
+            const double ucur = a.cu ? a.cu[off] : a.pu[off];
+            if (a.pu_out) a.pu_out[off] = ucur + a.a * t;          // time_integration.jl:124
+            if (a.nu_out) a.nu_out[off] = (a.nu_in ? a.nu_in[off] : ucur) + a.b * t;   // :134
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward-Euler step / reference-sequenced pieces (time_integration.jl:150-193) in one launch.
+// `ops` selects which reference calls are performed, `flags` the quirks of SURVEY.md 0.6.
+// All reads come from the current time level and the *old* layerThicknessEdge buffer, all writes
+// go to other buffers, so the single launch is race-free.
+// ------------------------------------------------------------------------------------------------
+template <int LPC, int ME, int ME2>
+__global__ __launch_bounds__(BLOCK) void k_fe(const MeshDev m, const FeArgs a)
+{
+    const int p = patch_of_block(m.nPatches);
+    if (p >= m.nPatches) return;
+    constexpr int NG = BLOCK / LPC;
+    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC);
+    const int l = threadIdx.x % LPC;
+    const int K = m.K;
+    const int Kc = ((K + LPC - 1) / LPC) * LPC;
+    const int nlev = a.nlev;
+    const bool stale = a.flags & MOKA_FE_STALE_HEDGE;
+
+    // ---------------- cells: velocityDivCell, tendLayerThickness, h update, ssh ----------------
+    if (a.ops & (FE_DIV | FE_TENDH | FE_UPDATE)) {
+        const int c0 = m.patchCellStart[p], c1 = m.patchCellStart[p + 1];
+        for (int c = c0 + grp; c < c1; c += NG) {
+            const int32_t *re = m.eoc + (size_t)c * ME;
+            const int32_t *rc = m.coc + (size_t)c * ME;
+            const int32_t *rm = m.mltc + (size_t)c * ME;
+            const double *rs = m.sdv + (size_t)c * ME;
+            const double invA = m.invArea[c];
+            const double area = m.areaCell[c];
+            double sshAcc = 0.0;
+            bool first = true;
+            for (int k = l; k < Kc; k += LPC) {
+                const bool act = k < K;
+                const size_t off = (size_t)c * K + k;
+                double hs = 0.0;
+                if (act) {
+                    const double hc = a.h[off];
+                    double d = 0.0, t = 0.0;
+#pragma unroll
+                    for (int i = 0; i < ME; ++i) {
+                        const int e = re[i];
+                        if (e < 0) continue;
+                        const double uv = a.u[(size_t)e * K + k];
+                        // DivergenceOnCell_P1/_P2 (Operators.jl:18,39): Div -= (V*dv)*sign
+                        d -= uv * rs[i];
+                        if ((a.ops & FE_TENDH) && k < nlev && k < rm[i]) {
+                            double F;
+                            if (a.ops & FE_TENDH_FROM_F) F = a.Fin[(size_t)e * K + k];
+                            else if (stale) F = uv * a.hEdgeOld[(size_t)e * K + k];
+                            else F = uv * (0.5 * (hc + a.h[(size_t)rc[i] * K + k]));
+                            t += F * rs[i] * invA;                 // horizontal_advection.jl:63-64
+                        }
+                    }
+                    if (a.ops & FE_DIV) a.div[off] = d / area;     // Operators.jl:41
+                    if ((a.ops & FE_TENDH) && k < nlev) a.tendH[off] = t;
+                    if (a.ops & FE_UPDATE) {
+                        // UpdateStateVariable! (time_integration.jl:199); untouched levels carried over
+                        const double hn = k < nlev ? hc + a.dt * t : hc;
+                        a.h_new[off] = hn;
+                        if (k < nlev) hs = hn;
+                    }
+                }
+                sshAcc = first ? hs : sshAcc + hs;
+                first = false;
+            }
+            if (a.ops & FE_UPDATE) {
+                const double s = group_sum<LPC>(sshAcc);
+                if (l == 0) a.ssh_new[c] = s - m.rsum[c];          // Update_ssh! (:209)
+            }
+        }
+    }
+
+    // ---------------- edges: thicknessFlux, layerThicknessEdge, tendNormalVelocity, u update ----
+    if (a.ops & (FE_FLUX | FE_HEDGE | FE_TENDU | FE_UPDATE)) {
+        const int e0 = m.patchEdgeStart[p], e1 = m.patchEdgeStart[p + 1];
+        for (int e = e0 + grp; e < e1; e += NG) {
+            const int4 hdr = *reinterpret_cast<const int4 *>(m.ehdr + (size_t)e * 4);
+            const int32_t *re = m.eoe + (size_t)e * ME2;
+            const double *rw = m.woe + (size_t)e * ME2;
+            const double g = m.gInvDc[e];
+            const double dv = m.dvEdge[e];
+            const int mlt = hdr.w;
+            double ds = 0.0;
+            if (a.ops & FE_TENDU) ds = a.ssh[hdr.y] - a.ssh[hdr.x];
+            for (int k = l; k < K; k += LPC) {
+                const size_t off = (size_t)e * K + k;
+                const double uk = a.u[off];
+                double hfresh = 0.0;
+                if (a.ops & (FE_FLUX | FE_HEDGE))
+                    hfresh = 0.5 * (a.h[(size_t)hdr.x * K + k] + a.h[(size_t)hdr.y * K + k]);   // Operators.jl:217
+                if ((a.ops & FE_FLUX) && k < nlev)
+                    a.F[off] = uk * (stale ? a.hEdgeOld[off] : hfresh);        // DiagnosticVars.jl:165
+                if (a.ops & FE_HEDGE) {
+                    // levels >= nlev keep what DivergenceOnCell_P1 left in the scratch (compat) or the old value
+                    a.hEdgeNew[off] = k < nlev ? hfresh : (stale ? uk * dv : a.hEdgeOld[off]);
+                }
+                double t = 0.0;
+                if ((a.ops & FE_TENDU) && k < nlev) {
+                    if (k < mlt) {
+                        t -= g * ds;                                           // pressure_gradient.jl:63
+#pragma unroll
+                        for (int i = 0; i < ME2; ++i) {
+                            const int x = re[i];
+                            if (x >= 0) t += rw[i] * a.u[(size_t)x * K + k] * m.fEdge[x];   // coriolis.jl:70-72
+                        }
+                    }
+                    a.tendU[off] = t;
+                }
+                if (a.ops & FE_UPDATE) a.u_new[off] = k < nlev ? uk + a.dt * t : uk;   // time_integration.jl:199
+            }
+        }
+    }
+
+    // ---------------- vertices: relativeVorticity (CurlOnVertex, Operators.jl:137-146) ----------
+    if (a.ops & FE_CURL) {
+        const int v0 = m.patchVertStart[p], v1 = m.patchVertStart[p + 1];
+        const bool accum = a.flags & MOKA_FE_ACCUM_VORT;
+        for (int v = v0 + grp; v < v1; v += NG) {
+            for (int k = l; k < K; k += LPC) {
+                const size_t off = (size_t)v * K + k;
+                double cacc = accum ? a.vort[off] : 0.0;
+                for (int j = 0; j < m.VD; ++j) {
+                    const int e = m.eov[(size_t)v * m.VD + j];
+                    cacc += m.cv[(size_t)v * m.VD + j] * a.u[(size_t)e * K + k];
+                }
+                a.vort[off] = cacc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone operators on arbitrary (K,n) arrays in the new numbering (Operators.jl).
+// ------------------------------------------------------------------------------------------------
+template <int LPC>
+__global__ __launch_bounds__(BLOCK) void k_operator(const MeshDev m, const OpArgs a)
+{
+    const int p = patch_of_block(m.nPatches);
+    if (p >= m.nPatches) return;
+    constexpr int NG = BLOCK / LPC;
+    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC);
+    const int l = threadIdx.x % LPC;
+    const int K = m.K;
+    if (a.op == OP_GRADIENT || a.op == OP_INTERP || a.op == OP_DIV_P1) {
+        const int e0 = m.patchEdgeStart[p], e1 = m.patchEdgeStart[p + 1];
+        for (int e = e0 + grp; e < e1; e += NG) {
+            const int c1 = m.ehdr[(size_t)e * 4], c2 = m.ehdr[(size_t)e * 4 + 1];
+            for (int k = l; k < K; k += LPC) {
+                const size_t off = (size_t)e * K + k;
+                if (a.op == OP_GRADIENT)       // (S[k,c2]-S[k,c1]) / dcEdge     Operators.jl:97
+                    a.out[off] = (a.in[(size_t)c2 * K + k] - a.in[(size_t)c1 * K + k]) / m.dcEdge[e];
+                else if (a.op == OP_INTERP) {  // 0.5*(C[k,c1]+C[k,c2])          Operators.jl:217
+                    if (k < a.nlev) a.out[off] = 0.5 * (a.in[(size_t)c1 * K + k] + a.in[(size_t)c2 * K + k]);
+                } else                         // temp = V*dvEdge                Operators.jl:18
+                    a.out[off] = a.in[off] * m.dvEdge[e];
+            }
+        }
+    } else if (a.op == OP_DIV_P2) {
+        const int c0 = m.patchCellStart[p], c1 = m.patchCellStart[p + 1];
+        for (int c = c0 + grp; c < c1; c += NG) {
+            for (int k = l; k < K; k += LPC) {
+                double d = 0.0;
+                for (int i = 0; i < m.ME; ++i) {
+                    const int e = m.eoc[(size_t)c * m.ME + i];
+                    if (e >= 0) d -= a.in[(size_t)e * K + k] * m.sdv[(size_t)c * m.ME + i];   // Operators.jl:18,39
+                }
+                a.out[(size_t)c * K + k] = d / m.areaCell[c];                                // :41
+            }
+        }
+    } else if (a.op == OP_CURL) {
+        const int v0 = m.patchVertStart[p], v1 = m.patchVertStart[p + 1];
+        for (int v = v0 + grp; v < v1; v += NG) {
+            for (int k = l; k < K; k += LPC) {
+                const size_t off = (size_t)v * K + k;
+                double cacc = a.out[off];                                                    // accumulates
+                for (int j = 0; j < m.VD; ++j)
+                    cacc += m.cv[(size_t)v * m.VD + j] * a.in[(size_t)m.eov[(size_t)v * m.VD + j] * K + k];
+                a.out[off] = cacc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ssh from layerThickness (Update_ssh!, time_integration.jl:205-211, N3 column sum)
+// ------------------------------------------------------------------------------------------------
+template <int LPC>
+__global__ __launch_bounds__(BLOCK) void k_update_ssh(const MeshDev m, const double *h, double *ssh, int nlev)
+{
+    constexpr int NG = BLOCK / LPC;
+    const int grp = threadIdx.x / LPC, l = threadIdx.x % LPC;
+    const int K = m.K;
+    const int Kc = ((nlev + LPC - 1) / LPC) * LPC;
+    for (int c = blockIdx.x * NG + grp; c < m.nC; c += gridDim.x * NG) {
+        double acc = 0.0;
+        bool first = true;
+        for (int k = l; k < Kc; k += LPC) {
+            const double v = k < nlev ? h[(size_t)c * K + k] : 0.0;
+            acc = first ? v : acc + v;
+            first = false;
+        }
+        const double s = group_sum<LPC>(acc);
+        if (l == 0) ssh[c] = s - m.rsum[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row permutation between the caller's numbering and the device numbering
+//   to_device: dev[n][k] = host_order[n2o[n]][k]     else: host_order[n2o[n]][k] = dev[n][k]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_permute_rows(double *dst, const double *src, const int32_t *n2o,
+                                                       int64_t n, int K, int to_device)
+{
+    const int64_t total = n * K;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+        const int64_t r = i / K;
+        const int k = (int)(i - r * K);
+        const int64_t o = (int64_t)n2o[r] * K + k;
+        if (to_device) dst[i] = src[o];
+        else dst[o] = src[i];
+    }
+}
+
+// sumArray (run_loop.jl:47-51): strictly serial sum_j a[j]^2 in the caller's numbering, one wave.
+__global__ __launch_bounds__(64) void k_sum_sq_serial(const double *a, int64_t n, double *out)
+{
+    const int lane = threadIdx.x;
+    double sum = 0.0;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t j = base + lane;
+        const double v = j < n ? a[j] : 0.0;
+        const int cnt = (int)((n - base) < 64 ? (n - base) : 64);
+        for (int t = 0; t < cnt; ++t) {
+            const double x = __shfl(v, t, 64);
+            sum = sum + x * x;
+        }
+    }
+    if (lane == 0) *out = sum;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_copy(double *dst, const double *src, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline int patch_grid(const MeshDev &m) { return 8 * ((m.nPatches + 7) / 8); }
+
+template <int LPC>
+static hipError_t launch_stage_lpc(const MeshDev &m, const StageArgs &a, hipStream_t s)
+{
+    const dim3 g(patch_grid(m)), b(BLOCK);
+    if (m.ME == 6 && m.ME2 == 10) hipLaunchKernelGGL((k_stage<LPC, 6, 10>), g, b, 0, s, m, a);
+    else if (m.ME == 8 && m.ME2 == 14) hipLaunchKernelGGL((k_stage<LPC, 8, 14>), g, b, 0, s, m, a);
+    else if (m.ME <= 6 && m.ME2 <= 14) hipLaunchKernelGGL((k_stage<LPC, 6, 14>), g, b, 0, s, m, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+template <int LPC>
+static hipError_t launch_fe_lpc(const MeshDev &m, const FeArgs &a, hipStream_t s)
+{
+    const dim3 g(patch_grid(m)), b(BLOCK);
+    if (m.ME == 6 && m.ME2 == 10) hipLaunchKernelGGL((k_fe<LPC, 6, 10>), g, b, 0, s, m, a);
+    else if (m.ME == 8 && m.ME2 == 14) hipLaunchKernelGGL((k_fe<LPC, 8, 14>), g, b, 0, s, m, a);
+    else if (m.ME <= 6 && m.ME2 <= 14) hipLaunchKernelGGL((k_fe<LPC, 6, 14>), g, b, 0, s, m, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+#define DISPATCH_LPC(lpc, CALL)                 \
+    switch (lpc) {                              \
+        case 1: return CALL(1);                 \
+        case 2: return CALL(2);                 \
+        case 4: return CALL(4);                 \
+        case 8: return CALL(8);                 \
+        case 16: return CALL(16);               \
+        case 32: return CALL(32);               \
+        default: return CALL(64);               \
+    }
+
+hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream_t s)
+{
+#define CALL(L) launch_stage_lpc<L>(m, a, s)
+    DISPATCH_LPC(lpc, CALL)
+#undef CALL
+}
+
+hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s)
+{
+#define CALL(L) launch_fe_lpc<L>(m, a, s)
+    DISPATCH_LPC(lpc, CALL)
+#undef CALL
+}
+
+template <int LPC>
+static hipError_t launch_operator_lpc(const MeshDev &m, const OpArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_operator<LPC>), dim3(patch_grid(m)), dim3(BLOCK), 0, s, m, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_operator(const MeshDev &m, const OpArgs &a, int lpc, hipStream_t s)
+{
+#define CALL(L) launch_operator_lpc<L>(m, a, s)
+    DISPATCH_LPC(lpc, CALL)
+#undef CALL
+}
+
+template <int LPC>
+static hipError_t launch_update_ssh_lpc(const MeshDev &m, const double *h, double *ssh, int nlev, hipStream_t s)
+{
+    const int ng = BLOCK / LPC;
+    int grid = (m.nC + ng - 1) / ng;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL((k_update_ssh<LPC>), dim3(grid), dim3(BLOCK), 0, s, m, h, ssh, nlev);
+    return hipGetLastError();
+}
+
+hipError_t launch_update_ssh(const MeshDev &m, const double *h, double *ssh, int nlev, int lpc, hipStream_t s)
+{
+#define CALL(L) launch_update_ssh_lpc<L>(m, h, ssh, nlev, s)
+    DISPATCH_LPC(lpc, CALL)
+#undef CALL
+}
+
+hipError_t launch_permute_rows(double *dst, const double *src, const int32_t *n2o, int64_t n, int K, int to_device,
+                               hipStream_t s)
+{
+    int64_t blocks = (n * K + BLOCK - 1) / BLOCK;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)blocks), dim3(BLOCK), 0, s, dst, src, n2o, n, K, to_device);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_sq_serial(const double *a, int64_t n, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sum_sq_serial, dim3(1), dim3(64), 0, s, a, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy(double *dst, const double *src, int64_t n, hipStream_t s)
+{
+    int64_t blocks = (n + BLOCK - 1) / BLOCK;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)blocks), dim3(BLOCK), 0, s, dst, src, n);
+    return hipGetLastError();
+}
+
+}  // namespace moka

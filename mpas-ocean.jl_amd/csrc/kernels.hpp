@@ -1,0 +1,54 @@
+// kernels.hpp -- argument blocks and launchers of the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "moka_internal.hpp"
+
+namespace moka {
+
+// Fused tendency / RK-stage kernel.  NULL pointers switch the corresponding read/write off.
+struct StageArgs {
+    const double *pu, *ph;        // provisional state: the gather source of the tendency
+    const double *ssh;            // ssh of the provisional state (nC)
+    const double *cu, *ch;        // Curr (NULL: Curr == Provis, e.g. RK stage 1 / Forward Euler)
+    const double *nu_in, *nh_in;  // New accumulator in (NULL: start from Curr)
+    double *nu_out, *nh_out;      // New accumulator out
+    double *pu_out, *ph_out;      // next provisional state  Curr + a*tend
+    double *ssh_out;              // ssh of ph_out (or of nh_out when ph_out == NULL)
+    double *tendU, *tendH;        // tendencies
+    double a, b;
+};
+
+enum : int {
+    FE_FLUX = 1, FE_DIV = 2, FE_CURL = 4, FE_HEDGE = 8, FE_TENDU = 16, FE_TENDH = 32, FE_UPDATE = 64,
+    FE_TENDH_FROM_F = 128
+};
+
+struct FeArgs {
+    int ops, flags, nlev;
+    double dt;
+    const double *u, *h, *ssh;    // current time level
+    const double *hEdgeOld;       // layerThicknessEdge as the previous step left it
+    const double *Fin;            // stored thicknessFlux (FE_TENDH_FROM_F)
+    double *hEdgeNew, *F, *div, *vort, *tendU, *tendH;
+    double *u_new, *h_new, *ssh_new;
+};
+
+enum : int { OP_GRADIENT = 0, OP_INTERP = 1, OP_DIV_P1 = 2, OP_DIV_P2 = 3, OP_CURL = 4 };
+
+struct OpArgs {
+    int op, nlev;
+    const double *in;
+    double *out;
+};
+
+hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream_t s);
+hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s);
+hipError_t launch_operator(const MeshDev &m, const OpArgs &a, int lpc, hipStream_t s);
+hipError_t launch_update_ssh(const MeshDev &m, const double *h, double *ssh, int nlev, int lpc, hipStream_t s);
+hipError_t launch_permute_rows(double *dst, const double *src, const int32_t *n2o, int64_t n, int K, int to_device,
+                               hipStream_t s);
+hipError_t launch_sum_sq_serial(const double *a, int64_t n, double *out, hipStream_t s);
+hipError_t launch_copy(double *dst, const double *src, int64_t n, hipStream_t s);
+
+}  // namespace moka

@@ -1,0 +1,71 @@
+// moka_internal.hpp -- shared declarations of libmoka_hip (host plan + device views).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/moka_hip.h"
+
+namespace moka {
+
+void set_error(const std::string &msg);   // thread-local last error
+const char *get_error();
+
+// ----------------------------------------------------------------------------------------------
+// Host-side reordered mesh.  All indices 0-based in the NEW numbering, -1 = none / padding.
+// Records are entity-major with the slot index fastest (one contiguous record per entity): the
+// column kernels give one wavefront (or one LPC-lane group) to an entity, so its record is read
+// with wave-uniform scalar loads.
+// ----------------------------------------------------------------------------------------------
+struct Plan {
+    int32_t nC = 0, nE = 0, nV = 0, K = 1;
+    int32_t ME = 0;    // record width for cells  (>= max nEdgesOnCell, 6 or 8 or generic)
+    int32_t ME2 = 0;   // record width for edges  (>= max nEdgesOnEdge)
+    int32_t VD = 3;
+    int32_t ordering = 0, P = 0, nPatches = 0;
+    int64_t cellBandwidth = 0;
+
+    std::vector<int32_t> cellN2O, cellO2N, edgeN2O, edgeO2N, vertN2O, vertO2N;
+    std::vector<int32_t> patchCellStart, patchEdgeStart, patchVertStart;   // nPatches + 1
+
+    // cells
+    std::vector<int32_t> eoc;      // nC*ME  edge of slot i                (edgesOnCell)
+    std::vector<int32_t> coc;      // nC*ME  the cell across that edge     (from cellsOnEdge)
+    std::vector<int32_t> mltc;     // nC*ME  maxLevelEdgeTop of that edge (0 for padding)
+    std::vector<double>  sdv;      // nC*ME  dvEdge[e]*edgeSignOnCell[i,c] (exact: sign = +-1)
+    std::vector<double>  invArea;  // nC     1/areaCell      (horizontal_advection.jl:53)
+    std::vector<double>  areaCell; // nC                    (Operators.jl:41 divides by it)
+    std::vector<double>  rsum;     // nC     restingThicknessSum
+    // edges
+    std::vector<int32_t> ehdr;     // nE*4   {c1, c2, nEdgesOnEdge, maxLevelEdgeTop}
+    std::vector<int32_t> eoe;      // nE*ME2 edgesOnEdge (-1: zero entry or beyond nEdgesOnEdge)
+    std::vector<double>  woe;      // nE*ME2 weightsOnEdge
+    std::vector<double>  gInvDc;   // nE     9.80616 * (1/dcEdge)   (pressure_gradient.jl:58,63)
+    std::vector<double>  dcEdge, dvEdge, fEdge;   // nE
+    // vertices
+    std::vector<int32_t> eov;      // nV*VD  edgesOnVertex
+    std::vector<double>  cv;       // nV*VD  (dcEdge[e]*(1/areaTriangle[v]))*sign  (Operators.jl:137-146)
+};
+
+int build_plan(const moka_mesh_desc *d, Plan &out);   // returns moka_status
+
+// ----------------------------------------------------------------------------------------------
+// Device view handed to kernels (raw device pointers, by value).
+// ----------------------------------------------------------------------------------------------
+struct MeshDev {
+    int32_t nC, nE, nV, K, ME, ME2, VD, nPatches;
+    const int32_t *patchCellStart, *patchEdgeStart, *patchVertStart;
+    const int32_t *eoc, *coc, *mltc;
+    const double  *sdv, *invArea, *areaCell, *rsum;
+    const int32_t *ehdr, *eoe;
+    const double  *woe, *gInvDc, *dcEdge, *dvEdge, *fEdge;
+    const int32_t *eov;
+    const double  *cv;
+    const int32_t *cellN2O, *edgeN2O, *vertN2O;
+};
+
+}  // namespace moka
+
+struct moka_plan {
+    moka::Plan p;
+};

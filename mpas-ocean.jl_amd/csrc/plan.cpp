@@ -1,0 +1,394 @@
+// plan.cpp -- host-side mesh plan: validation, 0-based conversion, cell ordering (RCB patches or
+// RCM), edge/vertex renumbering by first-touching cell, per-entity records.  No GPU needed.
+//
+// Input is the reference's mesh exactly as Julia holds it (HorzMesh.jl:64-162, VertMesh.jl:3-26).
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <new>
+#include <numeric>
+#include <queue>
+
+#include "moka_internal.hpp"
+
+namespace moka {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+const char *get_error() { return g_err.c_str(); }
+
+namespace {
+
+inline int64_t IX(int i, int64_t j, int ld) { return j * ld + i; }   // 0-based slot i of entity j
+
+#define REQUIRE(cond, msg)                 \
+    do {                                   \
+        if (!(cond)) {                     \
+            set_error(msg);                \
+            return MOKA_ERR_ARG;           \
+        }                                  \
+    } while (0)
+
+// ---- recursive coordinate bisection into patches of exactly P cells (last one may be short) ----
+void rcb_order(const moka_mesh_desc *d, int P, std::vector<int32_t> &n2o)
+{
+    const int n = d->nCells;
+    n2o.resize(n);
+    std::iota(n2o.begin(), n2o.end(), 0);
+    const double *X[3] = {d->xCell, d->yCell, d->zCell};
+    struct Range { int lo, hi; };
+    std::vector<Range> stack{{0, n}};
+    while (!stack.empty()) {
+        Range r = stack.back();
+        stack.pop_back();
+        const int cnt = r.hi - r.lo;
+        if (cnt <= P) {
+            // inside a patch: order along the patch's longest axis (cheap locality)
+            continue;
+        }
+        int axis = 0;
+        double best = -1.0;
+        for (int a = 0; a < 3; ++a) {
+            if (!X[a]) continue;
+            double mn = 1e300, mx = -1e300;
+            for (int i = r.lo; i < r.hi; ++i) {
+                double v = X[a][n2o[i]];
+                mn = std::min(mn, v);
+                mx = std::max(mx, v);
+            }
+            if (mx - mn > best) { best = mx - mn; axis = a; }
+        }
+        const int leaves = (cnt + P - 1) / P;
+        const int left = (leaves / 2) * P;   // multiple of P => every leaf but the last is full
+        const double *xa = X[axis];
+        std::nth_element(n2o.begin() + r.lo, n2o.begin() + r.lo + left, n2o.begin() + r.hi,
+                         [xa](int32_t a, int32_t b) { return xa[a] < xa[b] || (xa[a] == xa[b] && a < b); });
+        // process left first => push right first
+        stack.push_back({r.lo + left, r.hi});
+        stack.push_back({r.lo, r.lo + left});
+    }
+}
+
+// ---- reverse Cuthill-McKee on the cell graph (cells adjacent across an edge) ----
+void rcm_order(const moka_mesh_desc *d, std::vector<int32_t> &n2o)
+{
+    const int n = d->nCells;
+    std::vector<int32_t> deg(n, 0), start(n + 1, 0), adj;
+    for (int64_t e = 0; e < d->nEdges; ++e) {
+        int a = d->cellsOnEdge[2 * e] - 1, b = d->cellsOnEdge[2 * e + 1] - 1;
+        if (a >= 0 && b >= 0 && a != b) { ++deg[a]; ++deg[b]; }
+    }
+    for (int i = 0; i < n; ++i) start[i + 1] = start[i] + deg[i];
+    adj.resize(start[n]);
+    std::vector<int32_t> fill(start.begin(), start.end() - 1);
+    for (int64_t e = 0; e < d->nEdges; ++e) {
+        int a = d->cellsOnEdge[2 * e] - 1, b = d->cellsOnEdge[2 * e + 1] - 1;
+        if (a >= 0 && b >= 0 && a != b) { adj[fill[a]++] = b; adj[fill[b]++] = a; }
+    }
+    std::vector<char> seen(n, 0);
+    std::vector<int32_t> order;
+    order.reserve(n);
+    auto bfs_far = [&](int s, std::vector<int32_t> &lvl) {   // returns last node of a BFS from s
+        std::vector<int32_t> q{s};
+        lvl.assign(n, -1);
+        lvl[s] = 0;
+        size_t h = 0;
+        while (h < q.size()) {
+            int u = q[h++];
+            for (int k = start[u]; k < start[u + 1]; ++k)
+                if (lvl[adj[k]] < 0 && !seen[adj[k]]) { lvl[adj[k]] = lvl[u] + 1; q.push_back(adj[k]); }
+        }
+        return q.back();
+    };
+    std::vector<int32_t> lvl;
+    for (int s0 = 0; s0 < n; ++s0) {
+        if (seen[s0]) continue;
+        int s = bfs_far(bfs_far(s0, lvl), lvl);   // two sweeps: pseudo-peripheral start
+        std::vector<int32_t> q{s};
+        seen[s] = 1;
+        size_t h = 0;
+        std::vector<int32_t> nb;
+        while (h < q.size()) {
+            int u = q[h++];
+            nb.clear();
+            for (int k = start[u]; k < start[u + 1]; ++k)
+                if (!seen[adj[k]]) { seen[adj[k]] = 1; nb.push_back(adj[k]); }
+            std::sort(nb.begin(), nb.end(), [&](int a, int b) { return deg[a] < deg[b] || (deg[a] == deg[b] && a < b); });
+            q.insert(q.end(), nb.begin(), nb.end());
+        }
+        order.insert(order.end(), q.begin(), q.end());
+    }
+    n2o.assign(order.rbegin(), order.rend());
+}
+
+}  // namespace
+
+int build_plan(const moka_mesh_desc *d, Plan &p)
+{
+    REQUIRE(d != nullptr, "mesh descriptor is NULL");
+    REQUIRE(d->nCells > 0 && d->nEdges > 0 && d->nVertices > 0, "mesh counts must be positive");
+    REQUIRE(d->nVertLevels >= 1, "nVertLevels must be >= 1");
+    REQUIRE(d->maxEdges >= 3 && d->maxEdges2 >= 1 && d->vertexDegree >= 3, "bad maxEdges/maxEdges2/vertexDegree");
+    REQUIRE(d->nEdgesOnCell && d->edgesOnCell && d->edgeSignOnCell && d->areaCell, "PrimaryCells arrays missing");
+    REQUIRE(d->cellsOnEdge && d->nEdgesOnEdge && d->edgesOnEdge && d->weightsOnEdge && d->dvEdge && d->dcEdge && d->fEdge,
+            "Edges arrays missing");
+    REQUIRE(d->edgesOnVertex && d->edgeSignOnVertex && d->areaTriangle, "DualCells arrays missing");
+    REQUIRE(d->restingThicknessSum, "restingThicknessSum missing");
+    const int nC = d->nCells, nE = d->nEdges, nV = d->nVertices, VD = d->vertexDegree;
+    const int ldSV = d->edgeSignOnVertexLD > 0 ? d->edgeSignOnVertexLD : VD;
+    REQUIRE(ldSV >= VD, "edgeSignOnVertexLD < vertexDegree");
+
+    // ---- validation of connectivity ranges ----
+    int maxEoC = 0, maxEoE = 0;
+    for (int c = 0; c < nC; ++c) {
+        int n = d->nEdgesOnCell[c];
+        REQUIRE(n >= 1 && n <= d->maxEdges, "nEdgesOnCell out of range");
+        maxEoC = std::max(maxEoC, n);
+        for (int i = 0; i < n; ++i) {
+            int e = d->edgesOnCell[IX(i, c, d->maxEdges)];
+            REQUIRE(e >= 1 && e <= nE, "edgesOnCell out of range");
+            int s = d->edgeSignOnCell[IX(i, c, d->maxEdges)];
+            REQUIRE(s == 1 || s == -1, "edgeSignOnCell must be +-1 on active slots");
+        }
+        REQUIRE(d->areaCell[c] > 0.0, "areaCell must be positive");
+    }
+    for (int e = 0; e < nE; ++e) {
+        int a = d->cellsOnEdge[2 * (int64_t)e], b = d->cellsOnEdge[2 * (int64_t)e + 1];
+        REQUIRE(a >= 1 && a <= nC && b >= 1 && b <= nC, "cellsOnEdge out of range (non-periodic meshes are not supported, VertMesh.jl:50)");
+        int n = d->nEdgesOnEdge[e];
+        REQUIRE(n >= 0 && n <= d->maxEdges2, "nEdgesOnEdge out of range");
+        maxEoE = std::max(maxEoE, n);
+        for (int i = 0; i < n; ++i) {
+            int x = d->edgesOnEdge[IX(i, e, d->maxEdges2)];
+            REQUIRE(x >= 0 && x <= nE, "edgesOnEdge out of range");
+        }
+        REQUIRE(d->dcEdge[e] > 0.0, "dcEdge must be positive");
+        if (d->maxLevelEdgeTop) REQUIRE(d->maxLevelEdgeTop[e] >= 0 && d->maxLevelEdgeTop[e] <= d->nVertLevels, "maxLevelEdgeTop out of range");
+    }
+    for (int v = 0; v < nV; ++v) {
+        for (int j = 0; j < VD; ++j) {
+            int e = d->edgesOnVertex[IX(j, v, VD)];
+            REQUIRE(e >= 1 && e <= nE, "edgesOnVertex out of range");
+            int s = d->edgeSignOnVertex[IX(j, v, ldSV)];
+            REQUIRE(s == 1 || s == -1, "edgeSignOnVertex must be +-1");
+        }
+        REQUIRE(d->areaTriangle[v] > 0.0, "areaTriangle must be positive");
+    }
+
+    p.nC = nC; p.nE = nE; p.nV = nV; p.K = d->nVertLevels; p.VD = VD;
+    p.ME = maxEoC <= 6 ? 6 : (maxEoC <= 8 ? 8 : maxEoC);
+    p.ME2 = maxEoE <= 10 ? 10 : (maxEoE <= 14 ? 14 : maxEoE);
+    if (p.ME == 8 && p.ME2 < 14) p.ME2 = 14;   // kernels are instantiated for (6,10), (6,14), (8,14)
+    p.P = d->patch_cells > 0 ? d->patch_cells : 32;
+    REQUIRE(p.P <= 4096, "patch_cells too large");
+
+    // ---- cell ordering ----
+    int ordering = d->ordering;
+    const bool haveXYZ = d->xCell && d->yCell;
+    if (ordering == MOKA_ORDER_DEFAULT) ordering = haveXYZ ? MOKA_ORDER_RCB : MOKA_ORDER_RCM;
+    REQUIRE(ordering >= MOKA_ORDER_NONE && ordering <= MOKA_ORDER_RCB, "unknown ordering");
+    REQUIRE(ordering != MOKA_ORDER_RCB || haveXYZ, "RCB ordering needs xCell/yCell");
+    p.ordering = ordering;
+    if (ordering == MOKA_ORDER_RCB) rcb_order(d, p.P, p.cellN2O);
+    else if (ordering == MOKA_ORDER_RCM) rcm_order(d, p.cellN2O);
+    else { p.cellN2O.resize(nC); std::iota(p.cellN2O.begin(), p.cellN2O.end(), 0); }
+    p.cellO2N.assign(nC, -1);
+    for (int i = 0; i < nC; ++i) p.cellO2N[p.cellN2O[i]] = i;
+
+    // ---- edges / vertices numbered by their lowest-numbered (new) cell: counting sort by owner ----
+    auto renumber = [&](int n, auto owner_of, std::vector<int32_t> &n2o, std::vector<int32_t> &o2n) {
+        std::vector<int32_t> owner(n), cnt(nC + 1, 0);
+        for (int i = 0; i < n; ++i) { owner[i] = owner_of(i); ++cnt[owner[i] + 1]; }
+        for (int c = 0; c < nC; ++c) cnt[c + 1] += cnt[c];
+        n2o.resize(n); o2n.resize(n);
+        for (int i = 0; i < n; ++i) { int pos = cnt[owner[i]]++; n2o[pos] = i; o2n[i] = pos; }
+        return owner;
+    };
+    auto edgeOwner = renumber(nE, [&](int e) {
+        return std::min(p.cellO2N[d->cellsOnEdge[2 * (int64_t)e] - 1], p.cellO2N[d->cellsOnEdge[2 * (int64_t)e + 1] - 1]);
+    }, p.edgeN2O, p.edgeO2N);
+    auto vertOwner = renumber(nV, [&](int v) {
+        int best = nC;
+        for (int j = 0; j < VD; ++j) {
+            if (d->cellsOnVertex) {
+                int c = d->cellsOnVertex[IX(j, v, VD)];
+                if (c >= 1 && c <= nC) best = std::min(best, (int)p.cellO2N[c - 1]);
+            } else {
+                int e = d->edgesOnVertex[IX(j, v, VD)] - 1;
+                best = std::min(best, (int)p.cellO2N[d->cellsOnEdge[2 * (int64_t)e] - 1]);
+                best = std::min(best, (int)p.cellO2N[d->cellsOnEdge[2 * (int64_t)e + 1] - 1]);
+            }
+        }
+        return best == nC ? 0 : best;
+    }, p.vertN2O, p.vertO2N);
+
+    // ---- patches: P consecutive cells + the edges / vertices they own ----
+    p.nPatches = (nC + p.P - 1) / p.P;
+    p.patchCellStart.resize(p.nPatches + 1);
+    p.patchEdgeStart.assign(p.nPatches + 1, 0);
+    p.patchVertStart.assign(p.nPatches + 1, 0);
+    for (int q = 0; q <= p.nPatches; ++q) p.patchCellStart[q] = std::min(q * p.P, nC);
+    {
+        std::vector<int32_t> ce(p.nPatches + 1, 0), cv(p.nPatches + 1, 0);
+        for (int e = 0; e < nE; ++e) ++ce[edgeOwner[e] / p.P + 1];
+        for (int v = 0; v < nV; ++v) ++cv[vertOwner[v] / p.P + 1];
+        for (int q = 0; q < p.nPatches; ++q) { ce[q + 1] += ce[q]; cv[q + 1] += cv[q]; }
+        p.patchEdgeStart = ce;
+        p.patchVertStart = cv;
+    }
+
+    // ---- records ----
+    const int ME = p.ME, ME2 = p.ME2;
+    p.eoc.assign((size_t)nC * ME, -1);
+    p.coc.assign((size_t)nC * ME, -1);
+    p.mltc.assign((size_t)nC * ME, 0);
+    p.sdv.assign((size_t)nC * ME, 0.0);
+    p.invArea.resize(nC); p.areaCell.resize(nC); p.rsum.resize(nC);
+    p.cellBandwidth = 0;
+    for (int cn = 0; cn < nC; ++cn) {
+        const int co = p.cellN2O[cn];
+        const int n = d->nEdgesOnCell[co];
+        for (int i = 0; i < n; ++i) {
+            const int eo = d->edgesOnCell[IX(i, co, d->maxEdges)] - 1;
+            const int a = d->cellsOnEdge[2 * (int64_t)eo] - 1, b = d->cellsOnEdge[2 * (int64_t)eo + 1] - 1;
+            REQUIRE(a == co || b == co, "edgesOnCell / cellsOnEdge are inconsistent");
+            const int other = (a == co) ? b : a;
+            p.eoc[IX(i, cn, ME)] = p.edgeO2N[eo];
+            p.coc[IX(i, cn, ME)] = p.cellO2N[other];
+            p.mltc[IX(i, cn, ME)] = d->maxLevelEdgeTop ? d->maxLevelEdgeTop[eo] : 1;
+            p.sdv[IX(i, cn, ME)] = d->dvEdge[eo] * (double)d->edgeSignOnCell[IX(i, co, d->maxEdges)];
+            p.cellBandwidth = std::max<int64_t>(p.cellBandwidth, std::abs((int64_t)p.cellO2N[other] - cn));
+        }
+        p.invArea[cn] = 1. / d->areaCell[co];
+        p.areaCell[cn] = d->areaCell[co];
+        p.rsum[cn] = d->restingThicknessSum[co];
+    }
+    p.ehdr.resize((size_t)nE * 4);
+    p.eoe.assign((size_t)nE * ME2, -1);
+    p.woe.assign((size_t)nE * ME2, 0.0);
+    p.gInvDc.resize(nE); p.dcEdge.resize(nE); p.dvEdge.resize(nE); p.fEdge.resize(nE);
+    for (int en = 0; en < nE; ++en) {
+        const int eo = p.edgeN2O[en];
+        const int n = d->nEdgesOnEdge[eo];
+        p.ehdr[4 * (size_t)en + 0] = p.cellO2N[d->cellsOnEdge[2 * (int64_t)eo] - 1];
+        p.ehdr[4 * (size_t)en + 1] = p.cellO2N[d->cellsOnEdge[2 * (int64_t)eo + 1] - 1];
+        p.ehdr[4 * (size_t)en + 2] = n;
+        p.ehdr[4 * (size_t)en + 3] = d->maxLevelEdgeTop ? d->maxLevelEdgeTop[eo] : 1;
+        for (int i = 0; i < n; ++i) {
+            const int x = d->edgesOnEdge[IX(i, eo, d->maxEdges2)];
+            p.eoe[IX(i, en, ME2)] = x == 0 ? -1 : p.edgeO2N[x - 1];   // eoe == 0 => skipped (:67)
+            p.woe[IX(i, en, ME2)] = d->weightsOnEdge[IX(i, eo, d->maxEdges2)];
+        }
+        const double invDc = 1. / d->dcEdge[eo];
+        p.gInvDc[en] = 9.80616 * invDc;
+        p.dcEdge[en] = d->dcEdge[eo];
+        p.dvEdge[en] = d->dvEdge[eo];
+        p.fEdge[en] = d->fEdge[eo];
+    }
+    p.eov.resize((size_t)nV * VD);
+    p.cv.resize((size_t)nV * VD);
+    for (int vn = 0; vn < nV; ++vn) {
+        const int vo = p.vertN2O[vn];
+        const double invA = 1.0 / d->areaTriangle[vo];
+        for (int j = 0; j < VD; ++j) {
+            const int eo = d->edgesOnVertex[IX(j, vo, VD)] - 1;
+            p.eov[IX(j, vn, VD)] = p.edgeO2N[eo];
+            p.cv[IX(j, vn, VD)] = (d->dcEdge[eo] * invA) * (double)d->edgeSignOnVertex[IX(j, vo, ldSV)];
+        }
+    }
+    return MOKA_OK;
+}
+
+}  // namespace moka
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: plan
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int moka_plan_create(const moka_mesh_desc *desc, moka_plan **out)
+{
+    if (!out) { moka::set_error("out is NULL"); return MOKA_ERR_ARG; }
+    *out = nullptr;
+    moka_plan *pl = new (std::nothrow) moka_plan();
+    if (!pl) { moka::set_error("out of host memory"); return MOKA_ERR_ALLOC; }
+    int rc;
+    try {
+        rc = moka::build_plan(desc, pl->p);
+    } catch (const std::bad_alloc &) {
+        moka::set_error("out of host memory while building the mesh plan");
+        rc = MOKA_ERR_ALLOC;
+    }
+    if (rc != MOKA_OK) { delete pl; return rc; }
+    *out = pl;
+    return MOKA_OK;
+}
+
+void moka_plan_destroy(moka_plan *plan) { delete plan; }
+
+static int lanes_per_column(int K)
+{
+    int l = 1;
+    while (l < K && l < 64) l <<= 1;
+    return l;
+}
+
+static void fill_info(const moka::Plan &p, moka_mesh_info *info)
+{
+    info->nCells = p.nC; info->nEdges = p.nE; info->nVertices = p.nV; info->nVertLevels = p.K;
+    info->ordering = p.ordering; info->patch_cells = p.P; info->nPatches = p.nPatches;
+    info->maxEdgesUsed = p.ME; info->maxEdges2Used = p.ME2;
+    info->lanesPerColumn = lanes_per_column(p.K);
+    info->cellBandwidth = p.cellBandwidth;
+    info->meshBytesDevice =
+        (int64_t)p.nC * (p.ME * (3 * 4 + 8) + 3 * 8) + (int64_t)p.nE * (16 + p.ME2 * 12 + 4 * 8) +
+        (int64_t)p.nV * p.VD * 12 + (int64_t)(p.nPatches + 1) * 12 + 4ll * (p.nC + p.nE + p.nV);
+}
+
+int moka_plan_info(const moka_plan *plan, moka_mesh_info *info)
+{
+    if (!plan || !info) { moka::set_error("NULL argument"); return MOKA_ERR_ARG; }
+    fill_info(plan->p, info);
+    return MOKA_OK;
+}
+
+int moka_plan_permutation(const moka_plan *plan, int kind, int32_t *new_to_old)
+{
+    if (!plan || !new_to_old) { moka::set_error("NULL argument"); return MOKA_ERR_ARG; }
+    const std::vector<int32_t> *v = kind == MOKA_CELL ? &plan->p.cellN2O : kind == MOKA_EDGE ? &plan->p.edgeN2O
+                                  : kind == MOKA_VERTEX ? &plan->p.vertN2O : nullptr;
+    if (!v) { moka::set_error("kind must be MOKA_CELL, MOKA_EDGE or MOKA_VERTEX"); return MOKA_ERR_ARG; }
+    std::copy(v->begin(), v->end(), new_to_old);
+    return MOKA_OK;
+}
+
+int moka_plan_patch_ranges(const moka_plan *plan, int32_t *cellStart, int32_t *edgeStart, int32_t *vertexStart)
+{
+    if (!plan) { moka::set_error("NULL argument"); return MOKA_ERR_ARG; }
+    const moka::Plan &p = plan->p;
+    if (cellStart) std::copy(p.patchCellStart.begin(), p.patchCellStart.end(), cellStart);
+    if (edgeStart) std::copy(p.patchEdgeStart.begin(), p.patchEdgeStart.end(), edgeStart);
+    if (vertexStart) std::copy(p.patchVertStart.begin(), p.patchVertStart.end(), vertexStart);
+    return MOKA_OK;
+}
+
+int moka_plan_array(const moka_plan *plan, int which, const void **data, int64_t *count)
+{
+    if (!plan || !data || !count) { moka::set_error("NULL argument"); return MOKA_ERR_ARG; }
+    const moka::Plan &p = plan->p;
+#define VEC(id, v) case id: *data = p.v.data(); *count = (int64_t)p.v.size(); return MOKA_OK;
+    switch (which) {
+        VEC(MOKA_PA_EOC, eoc) VEC(MOKA_PA_COC, coc) VEC(MOKA_PA_MLTC, mltc) VEC(MOKA_PA_SDV, sdv)
+        VEC(MOKA_PA_INVAREA, invArea) VEC(MOKA_PA_AREACELL, areaCell) VEC(MOKA_PA_RSUM, rsum)
+        VEC(MOKA_PA_EHDR, ehdr) VEC(MOKA_PA_EOE, eoe) VEC(MOKA_PA_WOE, woe) VEC(MOKA_PA_GINVDC, gInvDc)
+        VEC(MOKA_PA_DCEDGE, dcEdge) VEC(MOKA_PA_DVEDGE, dvEdge) VEC(MOKA_PA_FEDGE, fEdge)
+        VEC(MOKA_PA_EOV, eov) VEC(MOKA_PA_CV, cv)
+        default: moka::set_error("unknown plan array id"); return MOKA_ERR_ARG;
+    }
+#undef VEC
+}
+
+}  // extern "C"
+
+// shared with api.hip
+namespace moka { void fill_mesh_info(const Plan &p, moka_mesh_info *info) { fill_info(p, info); } }

@@ -1,0 +1,454 @@
+"""Host-side mirror of the MOKA.jl forward-model interface for the `MokaHIP` backend.
+
+Every class/function names the reference definition it mirrors.  Arrays handed in and out are
+numpy arrays in the reference's memory layout ((n, K) C-order == Julia (K, n)).  Device-resident
+fields are exposed as `DeviceField` objects (the Julia shim's lazily synchronised arrays): reading
+one downloads it, assigning to it uploads.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import datetime as _dt
+import math
+
+import numpy as np
+
+from . import lib as L
+
+__all__ = [
+    "MokaHIP", "MokaError", "ForwardEuler", "RungeKutta4", "HorzMesh", "VerticalMesh", "Mesh", "ModelSetup",
+    "PrognosticVars", "DiagnosticVars", "TendencyVars", "DeviceField",
+    "GradientOnEdge", "DivergenceOnCell", "CurlOnVertex", "interpolateCell2Edge",
+    "advanceTimeLevels", "diagnostic_compute", "computeNormalVelocityTendency", "computeLayerThicknessTendency",
+    "computeTendency", "ocn_timestep", "ocn_run_loop", "ocn_init_from_arrays", "ocn_init_alarms",
+    "Clock", "OneTimeAlarm", "PeriodicAlarm", "advance", "isRinging", "reset", "changeTimeStep",
+    "REFERENCE_COMPAT",
+]
+
+MokaError = L.MokaError
+REFERENCE_COMPAT = L.FE_REFERENCE_COMPAT
+
+
+class ForwardEuler:      # abstract type ForwardEuler <: timeStepper   (time_integration.jl:4)
+    pass
+
+
+class RungeKutta4:       # abstract type RungeKutta4 <: timeStepper    (time_integration.jl:5)
+    pass
+
+
+class MokaHIP:
+    """The backend tag (`struct MokaHIP <: KA.Backend` in the Julia shim); owns one moka_ctx.
+    Replaces `backend = CUDABackend()` at src/driver/mpas_ocean.jl:28."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        L.check(L.lib().moka_ctx_create(int(device), C.byref(self._h)))
+        self.device = device
+
+    def synchronize(self):           # KA.synchronize(backend)
+        L.check(L.lib().moka_sync(self._h), self._h)
+
+    def timer_start(self):
+        L.check(L.lib().moka_timer_start(self._h), self._h)
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        L.check(L.lib().moka_timer_stop(self._h, C.byref(ms)), self._h)
+        return float(ms.value)
+
+    def set_kernel_variant(self, v: int):
+        L.check(L.lib().moka_set_kernel_variant(self._h, int(v)), self._h)
+
+    def close(self):
+        if self._h:
+            L.lib().moka_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------
+# mesh  (src/infra/MPASMesh)
+# ---------------------------------------------------------------------------------------------
+class HorzMesh:
+    """HorzMesh{PrimaryCells, DualCells, Edges} (HorzMesh.jl:45-49); `data` carries the SoA arrays
+    with ASCII field names (moka_hip.meshgen.MeshData or anything with the same attributes)."""
+
+    def __init__(self, data):
+        self.data = data
+        self.PrimaryCells = data
+        self.DualCells = data
+        self.Edges = data
+
+
+class _ActiveLevels:     # ActiveLevels (VertMesh.jl:19-26)
+    def __init__(self, n, top):
+        self.Top = np.full(n, top, dtype=np.int32)
+        self.Bot = np.full(n, top, dtype=np.int32)
+
+
+class VerticalMesh:
+    """VerticalMesh (VertMesh.jl:3-17).  `VerticalMesh(horz, nVertLevels=K)` is the unit-test
+    constructor (:92-117: unit resting thickness, maxLevelEdge.Top all ones).  Passing
+    `restingThickness` (nCells, K) mirrors the file constructor (:46-82).  `multilayer=True`
+    selects the N3 semantics maxLevelEdge.Top = nVertLevels (the commented-out factor at :32)."""
+
+    def __init__(self, horz: HorzMesh, nVertLevels: int = 1, restingThickness=None, multilayer: bool = False):
+        m = horz.data
+        self.nVertLevels = int(nVertLevels)
+        self.minLevelCell = np.ones(m.nCells, dtype=np.int32)
+        self.maxLevelCell = np.full(m.nCells, nVertLevels, dtype=np.int32)
+        top = self.nVertLevels if multilayer else 1
+        self.maxLevelEdge = _ActiveLevels(m.nEdges, top)
+        self.maxLevelVertex = _ActiveLevels(m.nVertices, top)
+        if restingThickness is None:
+            self.restingThickness = np.ones(m.nCells)
+            self.restingThicknessSum = np.ones(m.nCells)
+        else:
+            self.restingThickness = np.asarray(restingThickness, dtype=np.float64)
+            self.restingThicknessSum = self.restingThickness.reshape(m.nCells, -1).sum(axis=1)   # sum(dims=1), :73
+
+
+class Mesh:
+    """struct Mesh{HM,VM} (MPASMesh.jl:19-24).  `Mesh(h, v, backend=...)` is
+    Adapt.adapt_structure(backend, mesh) (:26): the library reorders and uploads the mesh."""
+
+    def __init__(self, horz: HorzMesh, vert: VerticalMesh, backend: MokaHIP | None = None,
+                 ordering: int = L.ORDER_DEFAULT, patch_cells: int = 0):
+        self.HorzMesh, self.VertMesh = horz, vert
+        self.backend = backend
+        self._h = C.c_void_p()
+        if backend is not None:
+            desc, keep = L.make_desc(horz.data, vert.nVertLevels, vert.restingThicknessSum,
+                                     vert.maxLevelEdge.Top, ordering, patch_cells)
+            L.check(L.lib().moka_mesh_create(backend._h, C.byref(desc), C.byref(self._h)), backend._h)
+
+    def info(self) -> dict:
+        inf = L.MeshInfo()
+        L.check(L.lib().moka_mesh_info_get(self._h, C.byref(inf)))
+        return inf.as_dict()
+
+    def _need_device(self):
+        if not self._h:
+            raise MokaError(L.ERR_ARG, "Mesh is not on a MokaHIP backend (there is no CPU path in this package)")
+
+    def close(self):
+        if self._h:
+            L.lib().moka_mesh_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class ModelSetup:        # struct ModelSetup(config, mesh, timeManager)  (ModelSetup.jl:4)
+    def __init__(self, config, mesh, timeManager):
+        self.config, self.mesh, self.timeManager = config, mesh, timeManager
+
+
+# ---------------------------------------------------------------------------------------------
+# operators  (src/ocn/Operators.jl) -- host arrays in, host arrays out, synchronous
+# ---------------------------------------------------------------------------------------------
+def _chk_arr(a, shape, name):
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags.c_contiguous or a.shape != shape:
+        raise MokaError(L.ERR_ARG, f"{name} must be a C-contiguous float64 array of shape {shape}")
+
+
+def GradientOnEdge(grad, h, mesh: Mesh, backend=None, workgroupsize=64):
+    """GradientOnEdge!(grad, hᵢ, Mesh; backend, workgroupsize)   Operators.jl:102"""
+    mesh._need_device()
+    m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+    _chk_arr(grad, (m.nEdges, K), "grad"); _chk_arr(h, (m.nCells, K), "h")
+    L.check(L.lib().moka_gradient_on_edge(mesh._h, L.f64(h), L.f64(grad)), mesh.backend._h)
+
+
+def DivergenceOnCell(div, vecEdge, temp, mesh: Mesh, backend=None, nthreads=50):
+    """DivergenceOnCell!(DivCell, VecEdge, temp, Mesh; backend, nthreads)   Operators.jl:46"""
+    mesh._need_device()
+    m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+    _chk_arr(div, (m.nCells, K), "div"); _chk_arr(vecEdge, (m.nEdges, K), "VecEdge")
+    if temp is not None:
+        _chk_arr(temp, (m.nEdges, K), "temp")
+    L.check(L.lib().moka_divergence_on_cell(mesh._h, L.f64(vecEdge), L.f64(temp) if temp is not None else None,
+                                            L.f64(div)), mesh.backend._h)
+
+
+def CurlOnVertex(curl, vecEdge, mesh: Mesh, backend=None):
+    """CurlOnVertex!(CurlVertex, VecEdge, Mesh; backend)   Operators.jl:151 -- accumulates into `curl`"""
+    mesh._need_device()
+    m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+    _chk_arr(curl, (m.nVertices, K), "curl"); _chk_arr(vecEdge, (m.nEdges, K), "VecEdge")
+    L.check(L.lib().moka_curl_on_vertex(mesh._h, L.f64(vecEdge), L.f64(curl)), mesh.backend._h)
+
+
+def interpolateCell2Edge(edgeValue, cellValue, mesh: Mesh, backend=None, nlev: int = 1):
+    """interpolateCell2Edge!(edgeValue, cellValue, Mesh; backend)   Operators.jl:179 (level 1 only)"""
+    mesh._need_device()
+    m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+    _chk_arr(edgeValue, (m.nEdges, K), "edgeValue"); _chk_arr(cellValue, (m.nCells, K), "cellValue")
+    L.check(L.lib().moka_interpolate_cell2edge(mesh._h, L.f64(cellValue), L.f64(edgeValue), int(nlev)), mesh.backend._h)
+
+
+# ---------------------------------------------------------------------------------------------
+# state containers  (PrognosticVars.jl, DiagnosticVars.jl, TendencyVars.jl)
+# ---------------------------------------------------------------------------------------------
+class _State:
+    """One moka_state shared by Prog / Diag / Tend of a model instance."""
+
+    def __init__(self, mesh: Mesh):
+        mesh._need_device()
+        self.mesh = mesh
+        self._h = C.c_void_p()
+        L.check(L.lib().moka_state_create(mesh.backend._h, mesh._h, C.byref(self._h)), mesh.backend._h)
+
+    def close(self):
+        if self._h:
+            L.lib().moka_state_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class DeviceField:
+    """A field resident in HBM; `np.asarray(f)` / `f.get()` downloads, `f.set(a)` uploads
+    (Adapt.adapt(backend, a) / Adapt.adapt(KA.CPU(), a))."""
+
+    def __init__(self, state: _State, field: int, level: int, shape):
+        self._s, self.field, self.level, self.shape = state, field, level, tuple(shape)
+
+    def get(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float64)
+        L.check(L.lib().moka_state_download(self._s._h, self.field, self.level, L.f64(out)), self._s.mesh.backend._h)
+        return out
+
+    def set(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != self.shape:
+            a = a.reshape(self.shape)
+        L.check(L.lib().moka_state_upload(self._s._h, self.field, self.level, L.f64(a)), self._s.mesh.backend._h)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.get()
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+
+class PrognosticVars:
+    """PrognosticVars (PrognosticVars.jl:6-57): ssh / normalVelocity / layerThickness, each a
+    Vector of nTimeLevels (= 2) arrays; index 0 = previous, -1 = current (Julia 1 / end)."""
+
+    def __init__(self, ssh, normalVelocity, layerThickness, nTimeLevels, mesh: Mesh, state: _State | None = None):
+        if nTimeLevels != 2:
+            raise MokaError(L.ERR_ARG, "nTimeLevels must be <= 2")       # time_integration.jl:23
+        m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+        self._state = state or _State(mesh)
+        s = self._state
+        self.ssh = [DeviceField(s, L.F_SSH, t, (m.nCells,)) for t in range(2)]
+        self.normalVelocity = [DeviceField(s, L.F_NORMAL_VELOCITY, t, (m.nEdges, K)) for t in range(2)]
+        self.layerThickness = [DeviceField(s, L.F_LAYER_THICKNESS, t, (m.nCells, K)) for t in range(2)]
+        for t in range(2):           # deepcopy into every time level (:50-54)
+            self.ssh[t].set(ssh)
+            self.normalVelocity[t].set(normalVelocity)
+            self.layerThickness[t].set(layerThickness)
+
+
+class DiagnosticVars:
+    """DiagnosticVars (DiagnosticVars.jl:6-73), zero-initialised on the backend (:90-93)."""
+
+    def __init__(self, config, mesh: Mesh, state: _State):
+        m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+        self._state = state
+        self.layerThicknessEdge = DeviceField(state, L.F_LAYER_THICKNESS_EDGE, 1, (m.nEdges, K))
+        self.thicknessFlux = DeviceField(state, L.F_THICKNESS_FLUX, 1, (m.nEdges, K))
+        self.velocityDivCell = DeviceField(state, L.F_VELOCITY_DIV_CELL, 1, (m.nCells, K))
+        self.relativeVorticity = DeviceField(state, L.F_RELATIVE_VORTICITY, 1, (m.nVertices, K))
+
+
+class TendencyVars:
+    """TendencyVars (TendencyVars.jl:7-49)."""
+
+    def __init__(self, config, mesh: Mesh, state: _State):
+        m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+        self._state = state
+        self.tendNormalVelocity = DeviceField(state, L.F_TEND_NORMAL_VELOCITY, 1, (m.nEdges, K))
+        self.tendLayerThickness = DeviceField(state, L.F_TEND_LAYER_THICKNESS, 1, (m.nCells, K))
+
+
+# ---------------------------------------------------------------------------------------------
+# forward model  (src/forward, src/ocn/DiagnosticVars.jl, src/ocn/Tendencies)
+# ---------------------------------------------------------------------------------------------
+def _st(x):
+    return x._state._h, x._state.mesh.backend._h
+
+
+def advanceTimeLevels(Prog: PrognosticVars, backend=None):
+    """advanceTimeLevels!(Prog; backend)   time_integration.jl:10"""
+    h, c = _st(Prog)
+    L.check(L.lib().moka_advance_time_levels(h, 0), c)
+
+
+def diagnostic_compute(mesh: Mesh, Diag: DiagnosticVars, Prog: PrognosticVars, backend=None,
+                       flags: int = REFERENCE_COMPAT):
+    """diagnostic_compute!(Mesh, Diag, Prog; backend)   DiagnosticVars.jl:108"""
+    h, c = _st(Prog)
+    L.check(L.lib().moka_diagnostic_compute(h, flags), c)
+
+
+def computeNormalVelocityTendency(Tend, Prog, Diag, mesh, Config=None, backend=None, flags: int = REFERENCE_COMPAT):
+    """computeNormalVelocityTendency!(Tend, Prog, Diag, Mesh, Config; backend)   normalVelocity.jl:21"""
+    h, c = _st(Prog)
+    L.check(L.lib().moka_compute_normal_velocity_tendency(h, flags), c)
+
+
+def computeLayerThicknessTendency(Tend, Prog, Diag, mesh, Config=None, backend=None, flags: int = REFERENCE_COMPAT):
+    """computeLayerThicknessTendency!(Tend, Prog, Diag, Mesh, Config; backend)   layerThickness.jl:14"""
+    h, c = _st(Prog)
+    L.check(L.lib().moka_compute_layer_thickness_tendency(h, flags), c)
+
+
+def computeTendency(mesh, Diag, Prog, Tend):
+    """The helper the reference's RK4 calls but never defines (time_integration.jl:114-115): one
+    fused tendency evaluation (u,h) -> (tendU,tendH) with consistent diagnostics."""
+    h, c = _st(Prog)
+    L.check(L.lib().moka_tendencies(h), c)
+
+
+def ocn_timestep(*args, backend=None, flags: int | None = None):
+    """ocn_timestep(timestep, Prog, Diag, Tend, S, ForwardEuler; backend)   time_integration.jl:150
+       ocn_timestep(Prog, Diag, Tend, S, RungeKutta4; backend)              time_integration.jl:61
+    `timestep` is the reference's 1-element array (mpas_ocean.jl:36-37) or a float."""
+    if len(args) == 6:
+        timestep, Prog, Diag, Tend, S, method = args
+    elif len(args) == 5:
+        Prog, Diag, Tend, S, method = args
+        timestep = float(S.timeManager.timeStep.total_seconds())       # :75
+    else:
+        raise MokaError(L.ERR_ARG, "ocn_timestep: wrong number of arguments")
+    dt = float(np.asarray(timestep).reshape(-1)[0])
+    h, c = _st(Prog)
+    if method is ForwardEuler:
+        L.check(L.lib().moka_step_fe(h, dt, REFERENCE_COMPAT if flags is None else flags), c)
+    elif method is RungeKutta4:
+        L.check(L.lib().moka_step_rk4(h, dt), c)
+    else:
+        raise MokaError(L.ERR_ARG, "unknown timeStepper")
+
+
+def ocn_run_loop(*args, backend=None, flags: int | None = None):
+    """ocn_run_loop(timestep, Prog, Diag, Tend, Setup, ForwardEuler, clock, simulationAlarm, outputAlarm)
+    (run_loop.jl:8-22) and the (sumCPU, sumGPU, ...) variant (:26-45) that returns sum(ssh^2)."""
+    want_sum = len(args) == 11
+    if want_sum:
+        sumCPU, sumGPU, *args = args
+    timestep, Prog, Diag, Tend, Setup, method, clock, simulationAlarm, outputAlarm = args
+    while not isRinging(simulationAlarm):
+        advance(clock)
+        ocn_timestep(timestep, Prog, Diag, Tend, Setup, method, flags=flags)
+        if isRinging(outputAlarm):
+            reset(outputAlarm)
+    if want_sum:
+        out = C.c_double()
+        h, c = _st(Prog)
+        L.check(L.lib().moka_sum_sq(h, L.F_SSH, 1, C.byref(out)), c)
+        sumCPU[0] = out.value
+        return out.value
+    return None
+
+
+def ocn_init_from_arrays(mesh_data, ssh, normalVelocity, layerThickness, restingThickness, config: dict,
+                         backend: MokaHIP, multilayer: bool = False, ordering: int = L.ORDER_DEFAULT,
+                         patch_cells: int = 0):
+    """ocn_init(config_fp; backend) (init.jl:3-30) with the NetCDF/YAML reads replaced by arrays:
+    returns (Setup, Diag, Tend, Prog) like the reference."""
+    K = np.asarray(normalVelocity).reshape(mesh_data.nEdges, -1).shape[1]
+    h_mesh = HorzMesh(mesh_data)
+    v_mesh = VerticalMesh(h_mesh, nVertLevels=K, restingThickness=restingThickness, multilayer=multilayer)
+    mesh = Mesh(h_mesh, v_mesh, backend=backend, ordering=ordering, patch_cells=patch_cells)
+    clock = ocn_setup_clock(config)
+    Setup = ModelSetup(config, mesh, clock)
+    Prog = PrognosticVars(ssh, normalVelocity, layerThickness,
+                          config.get("time_integration", {}).get("config_number_of_time_levels", 2), mesh)
+    Diag = DiagnosticVars(config, mesh, Prog._state)
+    Tend = TendencyVars(config, mesh, Prog._state)
+    return Setup, Diag, Tend, Prog
+
+
+# ---------------------------------------------------------------------------------------------
+# minimal clock / alarms  (src/infra/TimeManager.jl) -- host-only, enough to replay the driver
+# ---------------------------------------------------------------------------------------------
+class _Alarm:
+    def __init__(self, name):
+        self.name, self.clock = name, None
+
+
+class OneTimeAlarm(_Alarm):      # TimeManager.jl:54
+    def __init__(self, name, ringTime):
+        super().__init__(name)
+        self.ringTime = ringTime
+
+
+class PeriodicAlarm(_Alarm):     # TimeManager.jl:80
+    def __init__(self, name, interval, startTime):
+        super().__init__(name)
+        self.interval, self.ringTime = interval, startTime + interval
+
+
+class Clock:                     # TimeManager.jl:5
+    def __init__(self, startTime, timeStep):
+        self.startTime = self.currTime = startTime
+        self.timeStep = timeStep
+        self.alarms = {}
+
+
+def attachAlarm(clock, alarm):
+    alarm.clock = clock
+    clock.alarms[alarm.name] = alarm
+
+
+def advance(clock):              # advance!(clock)  TimeManager.jl:150
+    clock.currTime = clock.currTime + clock.timeStep
+
+
+def isRinging(alarm):            # rings only on equality for one-time alarms (TimeManager.jl:127-129)
+    if isinstance(alarm, OneTimeAlarm):
+        return alarm.clock.currTime == alarm.ringTime
+    return alarm.clock.currTime >= alarm.ringTime
+
+
+def reset(alarm):                # reset!(alarm)  TimeManager.jl:173
+    while alarm.ringTime <= alarm.clock.currTime:
+        alarm.ringTime = alarm.ringTime + alarm.interval
+
+
+def changeTimeStep(clock, timeStep):
+    clock.timeStep = timeStep
+
+
+def ocn_setup_clock(config: dict) -> Clock:
+    """ocn_setup_clock (init.jl:57-108) on an already-parsed config dict (datetime / timedelta values)."""
+    tm = config["time_management"]
+    ti = config["time_integration"]
+    out = config.get("output", {})
+    start = tm.get("config_start_time", _dt.datetime(1, 1, 1))
+    dt = ti.get("config_dt", _dt.timedelta(seconds=1))
+    run_duration, stop_time = tm.get("config_run_duration", "none"), tm.get("config_stop_time", "none")
+    if run_duration != "none":
+        stop_time = start + run_duration
+    elif stop_time == "none":
+        raise MokaError(L.ERR_ARG, "Error: Neither config_run_duration nor config_stop_time were specified.")  # :94
+    clock = Clock(start, dt)
+    attachAlarm(clock, OneTimeAlarm("simulation_end", stop_time))
+    attachAlarm(clock, PeriodicAlarm("outputAlarm", out.get("output_interval", _dt.timedelta(days=1)),
+                                     out.get("reference_time", start)))
+    return clock
+
+
+def ocn_init_alarms(Setup: ModelSetup):
+    """ocn_init_alarms (init.jl:111-127): dt := floor(2*(mean dcEdge/1e3)*mean dcEdge/200e3) seconds."""
+    dc = Setup.mesh.HorzMesh.data.dcEdge
+    dt = math.floor(2 * (float(np.mean(dc)) / 1e3) * float(np.mean(dc)) / 200e3)
+    changeTimeStep(Setup.timeManager, _dt.timedelta(seconds=dt))
+    clock = Setup.timeManager
+    return clock, clock.alarms["simulation_end"], clock.alarms["outputAlarm"]

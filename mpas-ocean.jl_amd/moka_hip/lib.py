@@ -1,0 +1,235 @@
+"""ctypes binding of libmoka_hip.so (include/moka_hip.h).  Fails loudly: no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))     # mpas-ocean.jl_amd/
+LIB_PATH = os.path.join(PKG_DIR, "libmoka_hip.so")
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+OK = 0
+ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6
+ORDER_DEFAULT, ORDER_NONE, ORDER_RCM, ORDER_RCB = 0, 1, 2, 3
+CELL, EDGE, VERTEX = 0, 1, 2
+(F_SSH, F_NORMAL_VELOCITY, F_LAYER_THICKNESS, F_LAYER_THICKNESS_EDGE, F_THICKNESS_FLUX,
+ F_VELOCITY_DIV_CELL, F_RELATIVE_VORTICITY, F_TEND_NORMAL_VELOCITY, F_TEND_LAYER_THICKNESS) = range(9)
+FE_STALE_HEDGE, FE_ACCUM_VORT, FE_LEVEL1_ONLY, FE_REFERENCE_COMPAT = 1, 2, 4, 7
+FORWARD_EULER, RUNGE_KUTTA_4 = 0, 1
+
+
+class MokaError(RuntimeError):
+    """Julia side: `error(msg)` raised by the shim when a call returns non-zero."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libmoka_hip error {code}: {msg}")
+        self.code = code
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [
+        ("nCells", C.c_int32), ("nEdges", C.c_int32), ("nVertices", C.c_int32),
+        ("maxEdges", C.c_int32), ("maxEdges2", C.c_int32), ("vertexDegree", C.c_int32),
+        ("nVertLevels", C.c_int32), ("edgeSignOnVertexLD", C.c_int32),
+        ("xCell", _f64p), ("yCell", _f64p), ("zCell", _f64p),
+        ("nEdgesOnCell", _i32p), ("edgesOnCell", _i32p), ("edgeSignOnCell", _i32p), ("areaCell", _f64p),
+        ("cellsOnEdge", _i32p), ("verticesOnEdge", _i32p), ("nEdgesOnEdge", _i32p), ("edgesOnEdge", _i32p),
+        ("weightsOnEdge", _f64p), ("dvEdge", _f64p), ("dcEdge", _f64p), ("fEdge", _f64p),
+        ("edgesOnVertex", _i32p), ("cellsOnVertex", _i32p), ("edgeSignOnVertex", _i32p), ("areaTriangle", _f64p),
+        ("maxLevelEdgeTop", _i32p), ("restingThicknessSum", _f64p),
+        ("ordering", C.c_int32), ("patch_cells", C.c_int32),
+    ]
+
+
+class MeshInfo(C.Structure):
+    _fields_ = [
+        ("nCells", C.c_int32), ("nEdges", C.c_int32), ("nVertices", C.c_int32), ("nVertLevels", C.c_int32),
+        ("ordering", C.c_int32), ("patch_cells", C.c_int32), ("nPatches", C.c_int32),
+        ("maxEdgesUsed", C.c_int32), ("maxEdges2Used", C.c_int32), ("lanesPerColumn", C.c_int32),
+        ("meshBytesDevice", C.c_int64), ("cellBandwidth", C.c_int64),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/moka_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "moka_version", "moka_ctx_create", "moka_ctx_destroy", "moka_last_error", "moka_sync",
+    "moka_timer_start", "moka_timer_stop",
+    "moka_plan_create", "moka_plan_destroy", "moka_plan_info", "moka_plan_permutation", "moka_plan_patch_ranges", "moka_plan_array",
+    "moka_mesh_create", "moka_mesh_destroy", "moka_mesh_info_get",
+    "moka_gradient_on_edge", "moka_divergence_on_cell", "moka_curl_on_vertex", "moka_interpolate_cell2edge",
+    "moka_state_create", "moka_state_destroy", "moka_state_upload", "moka_state_download",
+    "moka_advance_time_levels", "moka_diagnostic_compute", "moka_compute_normal_velocity_tendency",
+    "moka_compute_layer_thickness_tendency", "moka_tendencies", "moka_step_fe", "moka_step_rk4", "moka_run",
+    "moka_sum_sq", "moka_set_kernel_variant",
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile libmoka_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", PKG_DIR, "--no-print-directory", "clean"])
+    subprocess.check_call(["make", "-C", PKG_DIR, "--no-print-directory", "-j4"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MokaError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: build it with `make -C {PKG_DIR}` "
+                                       "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.moka_version.restype = C.c_char_p
+    L.moka_last_error.restype = C.c_char_p
+    L.moka_last_error.argtypes = [vp]
+    L.moka_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.moka_ctx_destroy.argtypes = [vp]
+    L.moka_ctx_destroy.restype = None
+    L.moka_sync.argtypes = [vp]
+    L.moka_timer_start.argtypes = [vp]
+    L.moka_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    L.moka_plan_create.argtypes = [C.POINTER(MeshDesc), C.POINTER(vp)]
+    L.moka_plan_destroy.argtypes = [vp]
+    L.moka_plan_destroy.restype = None
+    L.moka_plan_info.argtypes = [vp, C.POINTER(MeshInfo)]
+    L.moka_plan_permutation.argtypes = [vp, C.c_int, _i32p]
+    L.moka_plan_patch_ranges.argtypes = [vp, _i32p, _i32p, _i32p]
+    L.moka_plan_array.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.moka_mesh_create.argtypes = [vp, C.POINTER(MeshDesc), C.POINTER(vp)]
+    L.moka_mesh_destroy.argtypes = [vp]
+    L.moka_mesh_destroy.restype = None
+    L.moka_mesh_info_get.argtypes = [vp, C.POINTER(MeshInfo)]
+    L.moka_gradient_on_edge.argtypes = [vp, _f64p, _f64p]
+    L.moka_divergence_on_cell.argtypes = [vp, _f64p, _f64p, _f64p]
+    L.moka_curl_on_vertex.argtypes = [vp, _f64p, _f64p]
+    L.moka_interpolate_cell2edge.argtypes = [vp, _f64p, _f64p, C.c_int]
+    L.moka_state_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.moka_state_destroy.argtypes = [vp]
+    L.moka_state_destroy.restype = None
+    L.moka_state_upload.argtypes = [vp, C.c_int, C.c_int, _f64p]
+    L.moka_state_download.argtypes = [vp, C.c_int, C.c_int, _f64p]
+    L.moka_advance_time_levels.argtypes = [vp, C.c_int]
+    L.moka_diagnostic_compute.argtypes = [vp, C.c_int]
+    L.moka_compute_normal_velocity_tendency.argtypes = [vp, C.c_int]
+    L.moka_compute_layer_thickness_tendency.argtypes = [vp, C.c_int]
+    L.moka_tendencies.argtypes = [vp]
+    L.moka_step_fe.argtypes = [vp, C.c_double, C.c_int]
+    L.moka_step_rk4.argtypes = [vp, C.c_double]
+    L.moka_run.argtypes = [vp, C.c_int, C.c_double, C.c_int64, C.c_int]
+    L.moka_sum_sq.argtypes = [vp, C.c_int, C.c_int, _f64p]
+    L.moka_set_kernel_variant.argtypes = [vp, C.c_int]
+    _lib = L
+    return L
+
+
+def check(rc, ctx=None):
+    if rc != OK:
+        msg = lib().moka_last_error(ctx)
+        raise MokaError(rc, msg.decode() if msg else "unknown")
+
+
+def f64(a):
+    return a.ctypes.data_as(_f64p)
+
+
+def i32(a):
+    return a.ctypes.data_as(_i32p)
+
+
+def make_desc(mesh, K, resting_thickness_sum=None, max_level_edge_top=None, ordering=ORDER_DEFAULT, patch_cells=0):
+    """Build a moka_mesh_desc from reference-convention arrays.  Returns (desc, keepalive)."""
+    keep = {}
+
+    def A(name, dt, val=None):
+        arr = np.ascontiguousarray(getattr(mesh, name) if val is None else val, dtype=dt)
+        keep[name] = arr
+        return arr
+
+    d = MeshDesc()
+    d.nCells, d.nEdges, d.nVertices = mesh.nCells, mesh.nEdges, mesh.nVertices
+    d.maxEdges, d.maxEdges2, d.vertexDegree = mesh.maxEdges, mesh.maxEdges2, mesh.vertexDegree
+    d.nVertLevels = int(K)
+    esv = A("edgeSignOnVertex", np.int32)
+    d.edgeSignOnVertexLD = esv.shape[1]
+    d.edgeSignOnVertex = i32(esv)
+    for n in ("xCell", "yCell", "zCell", "areaCell", "weightsOnEdge", "dvEdge", "dcEdge", "fEdge", "areaTriangle"):
+        setattr(d, n, f64(A(n, np.float64)))
+    for n in ("nEdgesOnCell", "edgesOnCell", "edgeSignOnCell", "cellsOnEdge", "verticesOnEdge", "nEdgesOnEdge",
+              "edgesOnEdge", "edgesOnVertex", "cellsOnVertex"):
+        setattr(d, n, i32(A(n, np.int32)))
+    if max_level_edge_top is None:
+        d.maxLevelEdgeTop = None                       # all ones, VertMesh.jl:32
+    else:
+        mlt = np.full(mesh.nEdges, int(max_level_edge_top), np.int32) if np.isscalar(max_level_edge_top) \
+            else np.asarray(max_level_edge_top)
+        d.maxLevelEdgeTop = i32(A("maxLevelEdgeTop", np.int32, mlt))
+    if resting_thickness_sum is None:
+        resting_thickness_sum = np.ones(mesh.nCells)   # VertMesh.jl:99-100 (test constructor)
+    d.restingThicknessSum = f64(A("restingThicknessSum", np.float64, np.asarray(resting_thickness_sum).reshape(-1)))
+    d.ordering, d.patch_cells = int(ordering), int(patch_cells)
+    return d, keep
+
+
+PLAN_ARRAYS = {  # name -> (id, dtype)
+    "eoc": (0, np.int32), "coc": (1, np.int32), "mltc": (2, np.int32), "sdv": (3, np.float64),
+    "invArea": (4, np.float64), "areaCell": (5, np.float64), "rsum": (6, np.float64),
+    "ehdr": (7, np.int32), "eoe": (8, np.int32), "woe": (9, np.float64), "gInvDc": (10, np.float64),
+    "dcEdge": (11, np.float64), "dvEdge": (12, np.float64), "fEdge": (13, np.float64),
+    "eov": (14, np.int32), "cv": (15, np.float64),
+}
+
+
+class Plan:
+    """Host-only reordered mesh (moka_plan_*): usable without a GPU."""
+
+    def __init__(self, mesh, K, resting_thickness_sum=None, max_level_edge_top=None, ordering=ORDER_DEFAULT,
+                 patch_cells=0):
+        self._h = C.c_void_p()
+        desc, self._keep = make_desc(mesh, K, resting_thickness_sum, max_level_edge_top, ordering, patch_cells)
+        check(lib().moka_plan_create(C.byref(desc), C.byref(self._h)))
+        inf = MeshInfo()
+        check(lib().moka_plan_info(self._h, C.byref(inf)))
+        self.info = inf.as_dict()
+
+    def permutation(self, kind):
+        n = {CELL: self.info["nCells"], EDGE: self.info["nEdges"], VERTEX: self.info["nVertices"]}[kind]
+        out = np.empty(n, dtype=np.int32)
+        check(lib().moka_plan_permutation(self._h, kind, i32(out)))
+        return out
+
+    def patch_ranges(self):
+        n = self.info["nPatches"] + 1
+        a, b, c = (np.empty(n, dtype=np.int32) for _ in range(3))
+        check(lib().moka_plan_patch_ranges(self._h, i32(a), i32(b), i32(c)))
+        return a, b, c
+
+    def array(self, name):
+        which, dt = PLAN_ARRAYS[name]
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        check(lib().moka_plan_array(self._h, which, C.byref(ptr), C.byref(cnt)))
+        buf = (C.c_char * (cnt.value * np.dtype(dt).itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    def close(self):
+        if self._h:
+            lib().moka_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,341 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the
+same seeded inputs.  fp64 throughout; the bar is BIT-EXACT equality (np.array_equal), which is
+stricter than the 1e-12 relative tolerance BASELINE.md states -- the kernels evaluate every
+expression in the reference's operand order with FMA contraction off."""
+import datetime as dt
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import moka_hip as mk
+from analytic import PlanarSetup, areas, error_measures
+from moka_hip import lib as L
+from moka_hip import meshgen as mg
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "operator_norms.json")))
+IGW = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "igw_expectations.json")))
+
+
+@pytest.fixture(scope="module")
+def backend():
+    b = mk.MokaHIP(0)          # raises MokaError if the HIP extension or the GPU is missing
+    yield b
+    b.close()
+
+
+_MESH_CACHE = {}
+
+
+def get_mesh(name):
+    if name not in _MESH_CACHE:
+        _MESH_CACHE[name] = {"planar48": lambda: mg.planar_hex_mesh(48, 48, 1.0),
+                             "planar": lambda: mg.planar_hex_mesh(20, 18, 1000.0, f0=1e-4),
+                             "igw200": lambda: mg.igw_mesh(200.0),
+                             "ico16": lambda: mg.icosahedral_mesh(16),
+                             "ico32": lambda: mg.icosahedral_mesh(32)}[name]()
+    return _MESH_CACHE[name]
+
+
+def device_mesh(backend, mesh, K, rest=None, multilayer=True, ordering=L.ORDER_DEFAULT, P=0):
+    hm = mk.HorzMesh(mesh)
+    vm = mk.VerticalMesh(hm, nVertLevels=K, restingThickness=rest, multilayer=multilayer)
+    return mk.Mesh(hm, vm, backend=backend, ordering=ordering, patch_cells=P)
+
+
+# ------------------------------------------------------------------------------------------------
+# operators: reference known-answer vectors through the C ABI + bitwise vs the oracle
+# ------------------------------------------------------------------------------------------------
+def test_operator_known_answers_and_bitwise(backend):
+    mesh = get_mesh("planar48")
+    K = GOLD["mesh"]["nVertLevels"]
+    M = device_mesh(backend, mesh, K, multilayer=False)
+    om = orc.OracleMesh(mesh, K)
+    ts = PlanarSetup(mesh, K)
+    grad = np.zeros((mesh.nEdges, K))
+    mk.GradientOnEdge(grad, ts.h(), M)
+    linf, l2 = error_measures(grad, ts.grad_h_edge(), areas(mesh)["edge"])
+    assert abs(linf - GOLD["grad"]["L_inf"]) < GOLD["atol"] and abs(l2 - GOLD["grad"]["L_two"]) < GOLD["atol"]
+    assert np.array_equal(grad, om.gradient_on_edge(ts.h()))
+
+    div, temp = np.zeros((mesh.nCells, K)), np.zeros((mesh.nEdges, K))
+    mk.DivergenceOnCell(div, ts.F_edge(), temp, M)
+    linf, l2 = error_measures(div, ts.div_F(), areas(mesh)["cell"])
+    assert abs(linf - GOLD["div"]["L_inf"]) < GOLD["atol"] and abs(l2 - GOLD["div"]["L_two"]) < GOLD["atol"]
+    otemp = np.zeros_like(temp)
+    assert np.array_equal(div, om.divergence_on_cell(ts.F_edge(), temp=otemp))
+    assert np.array_equal(temp, otemp)
+
+    curl = np.zeros((mesh.nVertices, K))
+    mk.CurlOnVertex(curl, ts.F_edge(), M)
+    linf, l2 = error_measures(curl, ts.curl_F(), areas(mesh)["vertex"])
+    assert abs(linf - GOLD["curl"]["L_inf"]) < GOLD["atol"] and abs(l2 - GOLD["curl"]["L_two"]) < GOLD["atol"]
+    assert np.array_equal(curl, om.curl_on_vertex(ts.F_edge()))
+    # CurlOnVertex! accumulates (Operators.jl:135,142)
+    mk.CurlOnVertex(curl, ts.F_edge(), M)
+    assert np.array_equal(curl, om.curl_on_vertex(ts.F_edge(), curl=om.curl_on_vertex(ts.F_edge())))
+
+    # interpolateCell2Edge! touches level 1 only (Operators.jl:207-208)
+    e = np.full((mesh.nEdges, K), 7.0)
+    mk.interpolateCell2Edge(e, ts.h(), M)
+    oe = np.full((mesh.nEdges, K), 7.0)
+    om.interpolate_cell2edge(ts.h(), nlev=1, out=oe)
+    assert np.array_equal(e, oe)
+    M.close()
+
+
+def test_operator_argument_errors(backend):
+    mesh = get_mesh("planar")
+    M = device_mesh(backend, mesh, 2)
+    with pytest.raises(mk.MokaError):
+        mk.GradientOnEdge(np.zeros((mesh.nEdges, 3)), np.zeros((mesh.nCells, 2)), M)
+    with pytest.raises(mk.MokaError, match="nlev"):
+        mk.interpolateCell2Edge(np.zeros((mesh.nEdges, 2)), np.zeros((mesh.nCells, 2)), M, nlev=5)
+    M.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# fused tendency kernel vs oracle, across lane-group widths, orderings, patch sizes
+# ------------------------------------------------------------------------------------------------
+def random_state(mesh, K, seed):
+    rng = np.random.default_rng(seed)
+    rest = np.full((mesh.nCells, K), 1000.0 / K) + rng.uniform(0, 0.1, (mesh.nCells, K))
+    h = rest + rng.uniform(-1, 1, (mesh.nCells, K))
+    u = rng.uniform(-1, 1, (mesh.nEdges, K))
+    ssh = h.sum(1) - rest.sum(1)
+    return ssh, u, h, rest
+
+
+@pytest.mark.parametrize("meshname,K,ordering,P", [
+    ("planar", 1, L.ORDER_RCB, 0), ("planar", 1, L.ORDER_NONE, 16), ("ico16", 1, L.ORDER_RCB, 0),
+    ("ico16", 2, L.ORDER_RCM, 8), ("ico16", 3, L.ORDER_RCB, 0), ("ico16", 5, L.ORDER_RCB, 5),
+    ("ico16", 10, L.ORDER_RCB, 0), ("ico16", 17, L.ORDER_RCB, 0), ("ico16", 33, L.ORDER_RCM, 0),
+    ("ico16", 60, L.ORDER_RCB, 0), ("ico16", 64, L.ORDER_NONE, 0), ("ico16", 80, L.ORDER_RCB, 0),
+    ("ico32", 60, L.ORDER_RCB, 32), ("ico16", 130, L.ORDER_RCB, 64),
+])
+def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
+    mesh = get_mesh(meshname)
+    ssh, u, h, rest = random_state(mesh, K, 11 + K)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True,
+                                                       ordering=ordering, patch_cells=P)
+    mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    tu, th, ossh = om.tendencies_clean(u, h)
+    assert np.array_equal(Tend.tendNormalVelocity.get(), tu)
+    assert np.array_equal(Tend.tendLayerThickness.get(), th)
+    assert np.array_equal(Prog.ssh[-1].get(), ossh)
+    Prog._state.close(); Setup.mesh.close()
+
+
+def test_max_level_edge_top_masks_levels(backend):
+    """k <= maxLevelEdgeTop[e] loops (pressure_gradient.jl:61, coriolis.jl:69, horizontal_advection.jl:63)."""
+    mesh = get_mesh("ico16")
+    K = 6
+    ssh, u, h, rest = random_state(mesh, K, 5)
+    mlt = np.random.default_rng(2).integers(0, K + 1, mesh.nEdges).astype(np.int32)
+    hm = mk.HorzMesh(mesh)
+    vm = mk.VerticalMesh(hm, nVertLevels=K, restingThickness=rest)
+    vm.maxLevelEdge.Top[:] = mlt
+    M = mk.Mesh(hm, vm, backend=backend)
+    Prog = mk.PrognosticVars(ssh, u, h, 2, M)
+    Diag, Tend = mk.DiagnosticVars(None, M, Prog._state), mk.TendencyVars(None, M, Prog._state)
+    mk.computeTendency(M, Diag, Prog, Tend)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=mlt)
+    tu, th, _ = om.tendencies_clean(u, h)
+    assert np.array_equal(Tend.tendNormalVelocity.get(), tu) and np.array_equal(Tend.tendLayerThickness.get(), th)
+    Prog._state.close(); M.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# Forward Euler: the live reference step, quirks included
+# ------------------------------------------------------------------------------------------------
+CONFIG = {"time_management": {"config_start_time": dt.datetime(1, 1, 1), "config_run_duration": dt.timedelta(hours=10)},
+          "time_integration": {"config_dt": dt.timedelta(seconds=400), "config_number_of_time_levels": 2},
+          "output": {"output_interval": dt.timedelta(hours=1)}}
+
+
+def all_fields(Prog, Diag, Tend):
+    return {"ssh0": Prog.ssh[0].get(), "ssh1": Prog.ssh[-1].get(), "u0": Prog.normalVelocity[0].get(),
+            "u1": Prog.normalVelocity[-1].get(), "h0": Prog.layerThickness[0].get(), "h1": Prog.layerThickness[-1].get(),
+            "hEdge": Diag.layerThicknessEdge.get(), "F": Diag.thicknessFlux.get(), "div": Diag.velocityDivCell.get(),
+            "vort": Diag.relativeVorticity.get(), "tendU": Tend.tendNormalVelocity.get(),
+            "tendH": Tend.tendLayerThickness.get()}
+
+
+def oracle_fields(st):
+    return {"ssh0": st.ssh[0], "ssh1": st.ssh[1], "u0": st.u[0], "u1": st.u[1], "h0": st.h[0], "h1": st.h[1],
+            "hEdge": st.hEdge, "F": st.F, "div": st.div, "vort": st.vort, "tendU": st.tendU, "tendH": st.tendH}
+
+
+@pytest.mark.parametrize("flags", [7, 0, 1, 2, 3])
+def test_forward_euler_igw_bitwise(backend, flags):
+    mesh = get_mesh("igw200")
+    ssh, u, h, rest = mg.igw_initial_state(mesh)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend)
+    om = orc.OracleMesh(mesh, 1, resting_thickness_sum=rest.sum(1))
+    st = orc.OracleState(om, ssh, u, h)
+    for step in range(12):
+        mk.ocn_timestep(np.array([400.0]), Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=flags)
+        st.step_fe(400.0, flags)
+        if step in (0, 1, 11):
+            got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+            for k in exp:
+                assert np.array_equal(got[k], exp[k]), (k, step, flags)
+    Prog._state.close(); Setup.mesh.close()
+
+
+@pytest.mark.parametrize("K,flags,multilayer", [(3, 7, False), (3, 3, True), (4, 0, True), (70, 3, True)])
+def test_forward_euler_multilayer_bitwise(backend, K, flags, multilayer):
+    """K > 1: flags 7 = strict reference (only level 1 evolves); otherwise N3 semantics."""
+    mesh = get_mesh("ico16")
+    ssh, u, h, rest = random_state(mesh, K, 3)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=multilayer)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K if multilayer else 1)
+    st = orc.OracleState(om, ssh, u, h)
+    for step in range(4):
+        mk.ocn_timestep(np.array([30.0]), Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=flags)
+        st.step_fe(30.0, flags)
+    got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    Prog._state.close(); Setup.mesh.close()
+
+
+def test_reference_call_sequence_piecewise(backend):
+    """The separately exported reference entry points, called in the order of time_integration.jl:163-177,
+    give the same Diag/Tend arrays as the oracle's restatement of that order."""
+    mesh = get_mesh("igw200")
+    ssh, u, h, rest = mg.igw_initial_state(mesh)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend)
+    om = orc.OracleMesh(mesh, 1, resting_thickness_sum=rest.sum(1))
+    st = orc.OracleState(om, ssh, u, h)
+    M = Setup.mesh
+    for _ in range(2):
+        mk.advanceTimeLevels(Prog)
+        mk.diagnostic_compute(M, Diag, Prog)
+        mk.computeNormalVelocityTendency(Tend, Prog, Diag, M, None)
+        mk.computeLayerThicknessTendency(Tend, Prog, Diag, M, None)
+        orc.lib().oracle_diagnostic_compute(om.ref, orc._p(st.hEdge), orc._p(st.F), orc._p(st.div), orc._p(st.vort),
+                                            orc._p(st.u[1]), orc._p(st.h[1]), 1)
+        orc.lib().oracle_normal_velocity_tendency(om.ref, orc._p(st.tendU), orc._p(st.ssh[1]), orc._p(st.u[1]), 1)
+        orc.lib().oracle_layer_thickness_tendency(om.ref, orc._p(st.tendH), orc._p(st.F), 1)
+        got = all_fields(Prog, Diag, Tend)
+        for k in ("hEdge", "F", "div", "vort", "tendU", "tendH"):
+            assert np.array_equal(got[k], oracle_fields(st)[k]), k
+    Prog._state.close(); M.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# RK4 stage loop
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("meshname,K,nsteps", [("igw200", 1, 10), ("ico16", 1, 5), ("ico16", 60, 3), ("ico16", 80, 2)])
+def test_rk4_bitwise(backend, meshname, K, nsteps):
+    mesh = get_mesh(meshname)
+    if meshname == "igw200":
+        ssh, u, h, rest = mg.igw_initial_state(mesh)
+        dtv = 400.0
+    else:
+        ssh, u, h, rest = random_state(mesh, K, 9)
+        dtv = 20.0
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dtv))
+    for _ in range(nsteps):
+        mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)
+        st.step_rk4(dtv)
+    for name, got, exp in (("ssh1", Prog.ssh[-1], st.ssh[1]), ("u1", Prog.normalVelocity[-1], st.u[1]),
+                           ("h1", Prog.layerThickness[-1], st.h[1]), ("u0", Prog.normalVelocity[0], st.u[0]),
+                           ("h0", Prog.layerThickness[0], st.h[0]), ("ssh0", Prog.ssh[0], st.ssh[0])):
+        assert np.array_equal(got.get(), exp), name
+    Prog._state.close(); Setup.mesh.close()
+
+
+def test_driver_replay_igw_forward_euler_and_rk4(backend):
+    """Replays src/driver/mpas_ocean.jl:20-53: init -> ocn_init_alarms (dt override, init.jl:118) ->
+    timestep[1] = dt -> ocn_run_loop until the simulation alarm rings -> download; RMS error vs the
+    analytic solution lands on the oracle's numbers (tests/golden/igw_expectations.json)."""
+    mesh = get_mesh("igw200")
+    ssh, u, h, rest = mg.igw_initial_state(mesh)
+    exp = IGW["cases"]["200km"]
+    for method, key in ((mk.ForwardEuler, "fe_compat"), (mk.RungeKutta4, "rk4")):
+        Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend)
+        clock, simAlarm, outAlarm = mk.ocn_init_alarms(Setup)
+        assert clock.timeStep == dt.timedelta(seconds=400)
+        timestep = np.zeros(1)
+        timestep[0] = clock.timeStep.total_seconds()
+        sumCPU, sumGPU = np.zeros(1), np.zeros(1)
+        total = mk.ocn_run_loop(sumCPU, sumGPU, timestep, Prog, Diag, Tend, Setup, method, clock, simAlarm, outAlarm)
+        assert clock.currTime == dt.datetime(1, 1, 1, 10)
+        es, eu = mg.igw_exact(mesh, 36000.0)
+        got_ssh, got_u = Prog.ssh[-1].get(), Prog.normalVelocity[-1].get()[:, 0]
+        rms = lambda a: float(np.sqrt(np.mean(a * a)))
+        assert math.isclose(rms(got_ssh - es), exp[key]["ssh"], rel_tol=IGW["rtol"])
+        assert math.isclose(rms(got_u - eu), exp[key]["u"], rel_tol=IGW["rtol"])
+        # sumArray (run_loop.jl:47-51): strictly serial order, bitwise
+        assert total == orc.lib().oracle_sum_sq(orc._p(np.ascontiguousarray(got_ssh)), got_ssh.size)
+        Prog._state.close(); Setup.mesh.close()
+
+
+def test_upload_download_roundtrip_and_errors(backend):
+    mesh = get_mesh("ico16")
+    K = 7
+    ssh, u, h, rest = random_state(mesh, K, 1)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    assert np.array_equal(Prog.normalVelocity[0].get(), u) and np.array_equal(Prog.layerThickness[-1].get(), h)
+    assert np.array_equal(Prog.ssh[0].get(), ssh)
+    assert np.all(Diag.relativeVorticity.get() == 0) and np.all(Tend.tendLayerThickness.get() == 0)
+    with pytest.raises(mk.MokaError, match="nTimeLevels"):
+        mk.PrognosticVars(ssh, u, h, 3, Setup.mesh)
+    out = np.zeros(3)
+    rc = L.lib().moka_state_download(Prog._state._h, 99, 1, L.f64(out))
+    assert rc == L.ERR_ARG and b"unknown field" in L.lib().moka_last_error(backend._h)
+    Prog._state.close(); Setup.mesh.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size (BASELINE config 4: 1 024 002 cells x 60 layers) through size-independent properties
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties(backend):
+    mesh = mg.icosahedral_mesh(320)
+    K = 60
+    ssh, u, h, rest, dts = mg.sphere_synthetic_state(mesh, K)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
+    th, tu = Tend.tendLayerThickness.get(), Tend.tendNormalVelocity.get()
+    assert np.all(np.isfinite(th)) and np.all(np.isfinite(tu))
+    # (a) flux form: sum_c areaCell * tendH[k,c] = 0 for every level, to round-off of the summands
+    tot = (mesh.areaCell[:, None] * th).sum(0)
+    scale = (mesh.areaCell[:, None] * np.abs(th)).sum(0)
+    assert np.all(np.abs(tot) <= 1e-11 * scale)
+    # (b) bitwise agreement with the oracle on a random sample of whole columns is impossible without the
+    #     full oracle run; instead compare a patch-independent subset: first 3000 cells / edges (caller numbering)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    orc.set_threads(os.cpu_count() or 1)
+    otu, oth, ossh = om.tendencies_clean(u, h)
+    orc.set_threads(1)
+    assert np.array_equal(th, oth) and np.array_equal(tu, otu) and np.array_equal(Prog.ssh[-1].get(), ossh)
+    # (c) K identical layers (h_k = h/K, u_k = u) => same ssh as the single-layer model (N3 invariant), RK4
+    mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dts))
+    u1 = u[:, :1].copy()
+    hK = np.repeat(h.sum(1, keepdims=True) / K, K, axis=1)
+    for f, a in ((Prog.normalVelocity, np.repeat(u1, K, axis=1)), (Prog.layerThickness, hK)):
+        f[0].set(a); f[-1].set(a)
+    for _ in range(3):
+        mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)
+    sshK = Prog.ssh[-1].get()
+    uK = Prog.normalVelocity[-1].get()
+    assert np.abs(uK - uK[:, :1]).max() == 0.0          # layers stay identical, bit for bit
+    Prog._state.close(); Setup.mesh.close()
+    S1, D1, T1, P1 = mk.ocn_init_from_arrays(mesh, ssh, u1, h.sum(1, keepdims=True), rest.sum(1, keepdims=True),
+                                             CONFIG, backend, multilayer=True)
+    mk.changeTimeStep(S1.timeManager, dt.timedelta(seconds=dts))
+    for _ in range(3):
+        mk.ocn_timestep(P1, D1, T1, S1, mk.RungeKutta4)
+    assert np.abs(P1.ssh[-1].get() - sshK).max() < 1e-8
+    assert np.abs(P1.normalVelocity[-1].get()[:, 0] - uK[:, 0]).max() < 1e-12
+    P1._state.close(); S1.mesh.close()
