@@ -58,11 +58,24 @@ def get_mesh(m):
     return mesh
 
 
+def host_cores():
+    """Threads this process may really use: affinity mask, cgroup quota, and the 16-core share a one-GPU box
+    is given (oversubscribing the 256 hardware threads it *shows* made the OpenMP leg slower than 1 thread)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("MOKA_BENCH_THREADS", "16"))))
+
+
 def cpu_baseline(mesh, K, ssh, u, h, rest, dts, budget_s=25.0):
     """Oracle (C restatement of the reference loop nests) timed on this box's host cores: clean RK4 step,
     all cores (OpenMP), on the same mesh when one step fits the budget, else on a smaller sphere."""
     import oracle as orc
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     orc.set_threads(cores)
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     st = orc.OracleState(om, ssh, u, h)

@@ -44,6 +44,12 @@ struct moka_state {
     LevelBufs rk[2];                  // RK4 provisional states (lazily allocated)
     double *scalar = nullptr;         // 1 double (sum_sq result)
     bool sshConsistent = false;       // lev[1].ssh == ksum(lev[1].h) - restingThicknessSum
+    // moka_step_rk4 ends with diagnostic_compute! of the new state and leaves the stage-4 tendencies in
+    // Tend (time_integration.jl:114-147).  Neither is needed by the next RK4 step, so they are produced
+    // lazily -- on the first read (download, Forward-Euler step, reference-sequenced calls) -- with
+    // results identical to computing them at the end of the step.
+    bool diagDirty = false;
+    bool tendDirty = false;           // stage-4 provisional state still sits in rk[0]
     std::vector<void *> allocs;
 };
 
@@ -191,6 +197,29 @@ FeArgs fe_args(moka_state *st, int ops, int flags, double dt)
     a.u_new = st->lev[0].u; a.h_new = st->lev[0].h; a.ssh_new = st->lev[0].ssh;
     return a;
 }
+
+int flush_lazy(moka_state *st, bool diag, bool tend)
+{
+    if (diag && st->diagDirty) {
+        // clean diagnostics of the current state: hEdge = interp(h); F = u*hEdge; div; vort zeroed + curl
+        FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE, 0, 0.0);
+        a.nlev = st->mesh->plan.K;
+        HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
+        std::swap(st->hEdge[0], st->hEdge[1]);
+        st->diagDirty = false;
+    }
+    if (tend && st->tendDirty) {
+        StageArgs g{};
+        g.pu = st->rk[0].u; g.ph = st->rk[0].h; g.ssh = st->rk[0].ssh;
+        g.tendU = st->tendU; g.tendH = st->tendH;
+        HIPCHK(st->ctx, launch_stage(st->mesh->dev, g, st->mesh->lpc, st->ctx->stream));
+        st->tendDirty = false;
+    }
+    return MOKA_OK;
+}
+
+bool is_diag_field(int f) { return f >= MOKA_F_LAYER_THICKNESS_EDGE && f <= MOKA_F_RELATIVE_VORTICITY; }
+bool is_tend_field(int f) { return f == MOKA_F_TEND_NORMAL_VELOCITY || f == MOKA_F_TEND_LAYER_THICKNESS; }
 
 }  // namespace
 
@@ -437,6 +466,9 @@ int moka_state_upload(moka_state *st, int field, int time_level, const double *h
     int rc = field_ref(st, field, time_level, &r);
     if (rc) return rc;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    const bool prog1 = field <= MOKA_F_LAYER_THICKNESS && time_level == 1;   // pending lazy results refer to the old state
+    if ((rc = flush_lazy(st, prog1 || is_diag_field(field), prog1 || is_tend_field(field)))) return rc;
+    if ((rc = field_ref(st, field, time_level, &r))) return rc;   // flush may have swapped buffers
     if (time_level == 1 && (field == MOKA_F_SSH || field == MOKA_F_LAYER_THICKNESS)) st->sshConsistent = false;
     return put_rows(st->mesh, r.ptr, host, r.kind, r.n, r.K);
 }
@@ -448,6 +480,8 @@ int moka_state_download(moka_state *st, int field, int time_level, double *host)
     int rc = field_ref(st, field, time_level, &r);
     if (rc) return rc;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if ((rc = flush_lazy(st, is_diag_field(field), is_tend_field(field)))) return rc;
+    if ((rc = field_ref(st, field, time_level, &r))) return rc;   // flush may have swapped buffers
     return get_rows(st->mesh, host, r.ptr, r.kind, r.n, r.K);
 }
 
@@ -471,6 +505,7 @@ int moka_diagnostic_compute(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (int rcl = flush_lazy(st, true, false)) return rcl;
     FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE, flags, 0.0);
     HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
     std::swap(st->hEdge[0], st->hEdge[1]);
@@ -481,6 +516,7 @@ int moka_compute_normal_velocity_tendency(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (int rcl = flush_lazy(st, false, true)) return rcl;
     FeArgs a = fe_args(st, FE_TENDU, flags, 0.0);
     HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
     return MOKA_OK;
@@ -490,6 +526,7 @@ int moka_compute_layer_thickness_tendency(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (int rcl = flush_lazy(st, true, true)) return rcl;
     FeArgs a = fe_args(st, FE_TENDH | FE_TENDH_FROM_F, flags, 0.0);
     HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
     return MOKA_OK;
@@ -515,6 +552,7 @@ int moka_tendencies(moka_state *st)
     a.pu = st->lev[1].u; a.ph = st->lev[1].h; a.ssh = st->lev[1].ssh;
     a.tendU = st->tendU; a.tendH = st->tendH;
     HIPCHK(st->ctx, launch_stage(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
+    st->tendDirty = false;
     return MOKA_OK;
 }
 
@@ -522,6 +560,7 @@ int moka_step_fe(moka_state *st, double dt, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (int rcl = flush_lazy(st, true, true)) return rcl;
     // advanceTimeLevels! + diagnostic_compute! + both tendencies + updates (time_integration.jl:163-189)
     // in one launch: new values are written into the previous level's buffers, then the levels swap.
     FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE | FE_TENDU | FE_TENDH | FE_UPDATE, flags, dt);
@@ -568,6 +607,8 @@ int moka_step_rk4(moka_state *st, double dt)
     HIPCHK(st->ctx, launch_stage(m, g, lpc, s));
     std::swap(st->lev[0], st->lev[1]);
     st->sshConsistent = true;
+    st->diagDirty = true;
+    st->tendDirty = true;
     return MOKA_OK;
 }
 

@@ -34,6 +34,12 @@ __device__ __forceinline__ double group_sum(double v)
     return v;
 }
 
+// Mesh records and other kernel-invariant data are read through the constant address space: with a
+// wave-uniform address (LPC = 64) the compiler then emits scalar loads (s_load_dwordx4/x8/x16 into SGPRs)
+// instead of 64 identical vector loads, which frees the vector memory pipe and ~50 VGPRs per lane.
+template <class T> using CP = const T __attribute__((address_space(4))) *;
+template <class T> __device__ __forceinline__ CP<T> cptr(const T *p) { return (CP<T>)(uintptr_t)p; }
+
 template <int LPC>
 __device__ __forceinline__ int uniform_if_wave(int x)
 {
@@ -70,13 +76,13 @@ __global__ __launch_bounds__(BLOCK) void k_stage(const MeshDev m, const StageArg
     const int Kc = ((K + LPC - 1) / LPC) * LPC;
 
     // ---------------- cells ----------------
-    const int c0 = m.patchCellStart[p], c1 = m.patchCellStart[p + 1];
+    const int c0 = cptr(m.patchCellStart)[p], c1 = cptr(m.patchCellStart)[p + 1];
     for (int c = c0 + grp; c < c1; c += NG) {
-        const int32_t *re = m.eoc + (size_t)c * ME;
-        const int32_t *rc = m.coc + (size_t)c * ME;
-        const int32_t *rm = m.mltc + (size_t)c * ME;
-        const double *rs = m.sdv + (size_t)c * ME;
-        const double invA = m.invArea[c];
+        CP<int32_t> re = cptr(m.eoc) + (size_t)c * ME;
+        CP<int32_t> rc = cptr(m.coc) + (size_t)c * ME;
+        CP<int32_t> rm = cptr(m.mltc) + (size_t)c * ME;
+        CP<double> rs = cptr(m.sdv) + (size_t)c * ME;
+        const double invA = cptr(m.invArea)[c];
         int ei[ME], ci[ME], mi[ME];
         double si[ME];
 #pragma unroll
@@ -133,16 +139,17 @@ __global__ __launch_bounds__(BLOCK) void k_stage(const MeshDev m, const StageArg
         }
         if (a.ssh_out) {
             const double s = group_sum<LPC>(sshAcc);
-            if (l == 0) a.ssh_out[c] = s - m.rsum[c];              // time_integration.jl:209 (+N3)
+            if (l == 0) a.ssh_out[c] = s - cptr(m.rsum)[c];        // time_integration.jl:209 (+N3)
         }
     }
 
     // ---------------- edges ----------------
-    const int e0 = m.patchEdgeStart[p], e1 = m.patchEdgeStart[p + 1];
+    const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
     for (int e = e0 + grp; e < e1; e += NG) {
-        const int4 hdr = *reinterpret_cast<const int4 *>(m.ehdr + (size_t)e * 4);
-        const int32_t *re = m.eoe + (size_t)e * ME2;
-        const double *rw = m.woe + (size_t)e * ME2;
+        CP<int32_t> rh = cptr(m.ehdr) + (size_t)e * 4;
+        const int4 hdr = make_int4(rh[0], rh[1], rh[2], rh[3]);
+        CP<int32_t> re = cptr(m.eoe) + (size_t)e * ME2;
+        CP<double> rw = cptr(m.woe) + (size_t)e * ME2;
         int xi[ME2];
         double wi[ME2], fi[ME2];
 #pragma unroll
@@ -151,9 +158,10 @@ __global__ __launch_bounds__(BLOCK) void k_stage(const MeshDev m, const StageArg
             wi[i] = rw[i];
         }
 #pragma unroll
-        for (int i = 0; i < ME2; ++i) fi[i] = m.fEdge[xi[i] >= 0 ? xi[i] : e];
-        const double g = m.gInvDc[e];
-        const double ds = a.ssh[hdr.y] - a.ssh[hdr.x];            // ssh[c2] - ssh[c1]
+        for (int i = 0; i < ME2; ++i) fi[i] = cptr(m.fEdge)[xi[i] >= 0 ? xi[i] : e];
+        const double g = cptr(m.gInvDc)[e];
+        // ssh was written by the previous launch and is never written by this one (ssh_out is another buffer)
+        const double ds = cptr(a.ssh)[hdr.y] - cptr(a.ssh)[hdr.x];   // ssh[c2] - ssh[c1]
         const int mlt = hdr.w;
         for (int k = l; k < K; k += LPC) {
             const size_t off = (size_t)e * K + k;
