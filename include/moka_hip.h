@@ -96,6 +96,8 @@ typedef struct moka_mesh_info {
     int32_t lanesPerColumn;                          /* wavefront lanes that span one k-column   */
     int64_t meshBytesDevice;                         /* reordered mesh resident in HBM           */
     int64_t cellBandwidth;                           /* max |new(c1)-new(c2)| over edges         */
+    int32_t maxPatchRows;                            /* most u-rows (own + halo edges) any patch stages in LDS */
+    int32_t ldsBytesPerBlock;                        /* dynamic LDS of the LDS-tiled stage kernel (0: not applicable) */
 } moka_mesh_info;
 
 /* entity kinds for permutations */
@@ -149,7 +151,7 @@ int  moka_plan_patch_ranges(const moka_plan *plan, int32_t *cellStart, int32_t *
 enum {
     MOKA_PA_EOC = 0, MOKA_PA_COC, MOKA_PA_MLTC, MOKA_PA_SDV, MOKA_PA_INVAREA, MOKA_PA_AREACELL, MOKA_PA_RSUM,
     MOKA_PA_EHDR, MOKA_PA_EOE, MOKA_PA_WOE, MOKA_PA_GINVDC, MOKA_PA_DCEDGE, MOKA_PA_DVEDGE, MOKA_PA_FEDGE,
-    MOKA_PA_EOV, MOKA_PA_CV
+    MOKA_PA_EOV, MOKA_PA_CV, MOKA_PA_HALO_START, MOKA_PA_HALO_EDGE, MOKA_PA_LEOC, MOKA_PA_LEOE
 };
 int  moka_plan_array(const moka_plan *plan, int which, const void **data, int64_t *count);
 

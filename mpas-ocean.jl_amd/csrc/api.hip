@@ -27,6 +27,7 @@ struct moka_mesh {
     moka::MeshDev dev{};
     std::vector<void *> allocs;
     int lpc = 1;
+    size_t ldsBytes = 0;      // > 0: the LDS-tiled stage kernel is usable for this mesh
     double *opBuf[3] = {nullptr, nullptr, nullptr};   // operator / transfer scratch, lazily sized
     size_t opBufElems = 0;
 };
@@ -198,6 +199,16 @@ FeArgs fe_args(moka_state *st, int ops, int flags, double dt)
     return a;
 }
 
+// variant 0 (auto): LDS-tiled kernel when it fits two workgroups per CU, else the direct kernel
+hipError_t run_stage(moka_state *st, const StageArgs &g)
+{
+    const moka_mesh *m = st->mesh;
+    const int v = st->ctx->variant;
+    const bool lds = m->ldsBytes > 0 && (v == 2 || (v == 0 && m->ldsBytes <= 80 * 1024));
+    if (lds) return launch_stage_lds(m->dev, g, m->ldsBytes, st->ctx->stream);
+    return launch_stage(m->dev, g, m->lpc, st->ctx->stream);
+}
+
 int flush_lazy(moka_state *st, bool diag, bool tend)
 {
     if (diag && st->diagDirty) {
@@ -212,7 +223,7 @@ int flush_lazy(moka_state *st, bool diag, bool tend)
         StageArgs g{};
         g.pu = st->rk[0].u; g.ph = st->rk[0].h; g.ssh = st->rk[0].ssh;
         g.tendU = st->tendU; g.tendH = st->tendH;
-        HIPCHK(st->ctx, launch_stage(st->mesh->dev, g, st->mesh->lpc, st->ctx->stream));
+        HIPCHK(st->ctx, run_stage(st, g));
         st->tendDirty = false;
     }
     return MOKA_OK;
@@ -341,7 +352,19 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     UP(eoc) UP(coc) UP(mltc) UP(sdv) UP(invArea) UP(areaCell) UP(rsum)
     UP(ehdr) UP(eoe) UP(woe) UP(gInvDc) UP(dcEdge) UP(dvEdge) UP(fEdge)
     UP(eov) UP(cv) UP(cellN2O) UP(edgeN2O) UP(vertN2O)
+    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe)
 #undef UP
+    d.maxRows = p.maxRows; d.maxOwnE = p.maxOwnE; d.maxOwnC = p.maxOwnC;
+    if (p.ldsOk && p.K % 2 == 0 && p.K >= 8) {
+        const int64_t need = lds_stage_bytes(p.K, p.ME, p.ME2, p.maxRows, p.maxOwnE, p.maxOwnC);
+        if (need <= 160 * 1024) {
+            if (hipError_t e = prepare_stage_lds((size_t)need); e != hipSuccess) {
+                moka_mesh_destroy(m);
+                return fail(ctx, MOKA_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
+            }
+            m->ldsBytes = (size_t)need;
+        }
+    }
     *out = m;
     return MOKA_OK;
 }
@@ -551,7 +574,7 @@ int moka_tendencies(moka_state *st)
     StageArgs a{};
     a.pu = st->lev[1].u; a.ph = st->lev[1].h; a.ssh = st->lev[1].ssh;
     a.tendU = st->tendU; a.tendH = st->tendH;
-    HIPCHK(st->ctx, launch_stage(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
+    HIPCHK(st->ctx, run_stage(st, a));
     st->tendDirty = false;
     return MOKA_OK;
 }
@@ -577,9 +600,6 @@ int moka_step_rk4(moka_state *st, double dt)
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     int rc = ensure_rk_bufs(st);
     if (rc) return rc;
-    const MeshDev &m = st->mesh->dev;
-    const int lpc = st->mesh->lpc;
-    hipStream_t s = st->ctx->stream;
     const double a[3] = {dt / 2., dt / 2., dt};                         // time_integration.jl:77
     const double b[4] = {dt / 6., dt / 3., dt / 3., dt / 6.};           // :78
     LevelBufs &A = st->lev[1];   // Curr (becomes the previous level)
@@ -594,17 +614,17 @@ int moka_step_rk4(moka_state *st, double dt)
     // stage 1: Provis == Curr == A;  New = Curr + b1*k1 -> B;  Provis' = Curr + a1*k1 -> R1
     g.pu = A.u; g.ph = A.h; g.ssh = ssh0; g.cu = nullptr; g.ch = nullptr; g.nu_in = nullptr; g.nh_in = nullptr;
     g.nu_out = B.u; g.nh_out = B.h; g.pu_out = R1.u; g.ph_out = R1.h; g.ssh_out = R1.ssh; g.a = a[0]; g.b = b[0];
-    HIPCHK(st->ctx, launch_stage(m, g, lpc, s));
+    HIPCHK(st->ctx, run_stage(st, g));
     // stage 2: Provis = R1 -> R2
     g.pu = R1.u; g.ph = R1.h; g.ssh = R1.ssh; g.cu = A.u; g.ch = A.h; g.nu_in = B.u; g.nh_in = B.h;
     g.pu_out = R2.u; g.ph_out = R2.h; g.ssh_out = R2.ssh; g.a = a[1]; g.b = b[1];
-    HIPCHK(st->ctx, launch_stage(m, g, lpc, s));
+    HIPCHK(st->ctx, run_stage(st, g));
     // stage 3: Provis = R2 -> R1
     g.pu = R2.u; g.ph = R2.h; g.ssh = R2.ssh; g.pu_out = R1.u; g.ph_out = R1.h; g.ssh_out = R1.ssh; g.a = a[2]; g.b = b[2];
-    HIPCHK(st->ctx, launch_stage(m, g, lpc, s));
+    HIPCHK(st->ctx, run_stage(st, g));
     // stage 4: Provis = R1; New += b4*k4; ssh of New
     g.pu = R1.u; g.ph = R1.h; g.ssh = R1.ssh; g.pu_out = nullptr; g.ph_out = nullptr; g.ssh_out = B.ssh; g.a = 0.0; g.b = b[3];
-    HIPCHK(st->ctx, launch_stage(m, g, lpc, s));
+    HIPCHK(st->ctx, run_stage(st, g));
     std::swap(st->lev[0], st->lev[1]);
     st->sshConsistent = true;
     st->diagDirty = true;

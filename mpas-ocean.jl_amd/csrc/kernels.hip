@@ -183,6 +183,204 @@ __global__ __launch_bounds__(BLOCK) void k_stage(const MeshDev m, const StageArg
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS patch-tiled variant of the fused tendency / RK-stage kernel (same arithmetic, same results).
+//
+// The direct kernel above re-reads every u-row ~12 times through the vector L1 (10 Coriolis
+// neighbours + 2 cells), which rocprof shows as ~60 % TA utilisation and ~70 % of wave time parked
+// on memory.  Here one 512-thread workgroup owns one patch and
+//   1. stages the u-rows of every edge the patch touches (own + halo, <= 254 rows of K*8 bytes) and
+//      all of the patch's connectivity / weight records into LDS in one burst of coalesced 16-byte
+//      loads (many rows in flight per wave -> deep memory-level parallelism),
+//   2. after one barrier, evaluates its cells and edges out of LDS: a 32-lane half-wave owns one
+//      entity, each lane two consecutive levels (ds_read_b128, conflict-free on 480-byte rows);
+//      neighbour indices are patch-local bytes read from LDS.
+// h-rows (7 per cell) and the RK Curr/New rows are read straight from global memory.
+// Two workgroups fit a CU (<= 80 KB LDS each) so one loads while the other computes.
+// ------------------------------------------------------------------------------------------------
+constexpr int LBLOCK = 512;
+
+__device__ __forceinline__ double2 shfl_xor2(double2 v, int s)
+{
+    return make_double2(__shfl_xor(v.x, s, 64), __shfl_xor(v.y, s, 64));
+}
+
+template <int ME, int ME2>
+__global__ __launch_bounds__(LBLOCK, 4) void k_stage_lds(const MeshDev m, const StageArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int p = patch_of_block(m.nPatches);
+    if (p >= m.nPatches) return;
+    const int K = m.K, K2 = K >> 1;                 // K is even (checked on the host)
+    constexpr int NG = LBLOCK / 32;                 // 16 half-wave groups
+    const int tid = threadIdx.x, grp = tid >> 5, l = tid & 31;
+
+    double *ubuf = reinterpret_cast<double *>(smem);
+    double *fbuf = ubuf + (size_t)m.maxRows * K;
+    double *wbuf = fbuf + m.maxRows;
+    double *gbuf = wbuf + (size_t)m.maxOwnE * ME2;
+    double *sbuf = gbuf + m.maxOwnE;
+    double *iabuf = sbuf + (size_t)m.maxOwnC * ME;
+    double *rsbuf = iabuf + m.maxOwnC;
+    int32_t *hbuf = reinterpret_cast<int32_t *>(rsbuf + m.maxOwnC);
+    int32_t *cbuf = hbuf + (size_t)m.maxOwnE * 4;
+    int32_t *mbuf = cbuf + (size_t)m.maxOwnC * ME;
+    uint32_t *lebuf = reinterpret_cast<uint32_t *>(mbuf + (size_t)m.maxOwnC * ME);
+    uint32_t *lcbuf = lebuf + (size_t)m.maxOwnE * 4;
+    double2 *ubuf2 = reinterpret_cast<double2 *>(ubuf);
+
+    const int c0 = cptr(m.patchCellStart)[p], c1 = cptr(m.patchCellStart)[p + 1];
+    const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
+    const int h0 = cptr(m.haloStart)[p], h1 = cptr(m.haloStart)[p + 1];
+    const int nOwnC = c1 - c0, nOwnE = e1 - e0, R = nOwnE + (h1 - h0);
+
+    // ---- 1. stage: u rows (own edges are contiguous in memory, halo rows are gathered) ----
+    const double2 *pu2 = reinterpret_cast<const double2 *>(a.pu);
+    constexpr int RB = 5;                           // rows per half-wave per batch: 16*5*480 B = 38 KB in flight
+    static_assert(RB == 5, "the staging batch below is written out for 5 rows");
+    for (int j0 = 0; j0 < K2; j0 += 32) {
+        const int j = j0 + l;
+        const int jc = j < K2 ? j : K2 - 1;         // clamped: every lane issues a valid load
+        for (int rb = 0; rb < R; rb += NG * RB) {
+            double2 t0, t1, t2, t3, t4;
+            auto row = [&](int i) {
+                const int r = rb + grp + NG * i;
+                const int rc = r < R ? r : R - 1;
+                const int src = rc < nOwnE ? e0 + rc : m.haloEdge[h0 + rc - nOwnE];
+                return pu2[(size_t)src * K2 + jc];
+            };
+            t0 = row(0); t1 = row(1); t2 = row(2); t3 = row(3); t4 = row(4);
+            auto put = [&](int i, const double2 &v) {
+                const int r = rb + grp + NG * i;
+                if (r < R && j < K2) ubuf2[(size_t)r * K2 + j] = v;
+            };
+            put(0, t0); put(1, t1); put(2, t2); put(3, t3); put(4, t4);
+        }
+    }
+    for (int r = tid; r < R; r += LBLOCK) fbuf[r] = m.fEdge[r < nOwnE ? e0 + r : m.haloEdge[h0 + r - nOwnE]];
+    // patch records: contiguous ranges of the global record arrays -> straight coalesced copies
+    for (int i = tid; i < nOwnE * ME2; i += LBLOCK) wbuf[i] = m.woe[(size_t)e0 * ME2 + i];
+    for (int i = tid; i < nOwnE; i += LBLOCK) gbuf[i] = m.gInvDc[e0 + i];
+    for (int i = tid; i < nOwnE * 4; i += LBLOCK) {
+        hbuf[i] = m.ehdr[(size_t)e0 * 4 + i];
+        lebuf[i] = reinterpret_cast<const uint32_t *>(m.leoe)[(size_t)e0 * 4 + i];
+    }
+    for (int i = tid; i < nOwnC * ME; i += LBLOCK) {
+        sbuf[i] = m.sdv[(size_t)c0 * ME + i];
+        cbuf[i] = m.coc[(size_t)c0 * ME + i];
+        mbuf[i] = m.mltc[(size_t)c0 * ME + i];
+    }
+    for (int i = tid; i < nOwnC; i += LBLOCK) {
+        iabuf[i] = m.invArea[c0 + i];
+        rsbuf[i] = m.rsum[c0 + i];
+    }
+    for (int i = tid; i < nOwnC * 2; i += LBLOCK) lcbuf[i] = reinterpret_cast<const uint32_t *>(m.leoc)[(size_t)c0 * 2 + i];
+    __syncthreads();
+
+    const int K2c = (K2 + 31) & ~31;                // keep all 32 lanes in the loop for the shuffles
+    // ---- 2a. cells ----
+    const double2 *ph2 = reinterpret_cast<const double2 *>(a.ph);
+    for (int ci = grp; ci < nOwnC; ci += NG) {
+        const int c = c0 + ci;
+        const double invA = iabuf[ci];
+        int le[ME], cn[ME], ml[ME];
+        double sd[ME];
+#pragma unroll
+        for (int i = 0; i < ME; ++i) {
+            le[i] = (lcbuf[ci * 2 + (i >> 2)] >> (8 * (i & 3))) & 0xFF;
+            cn[i] = cbuf[ci * ME + i];
+            ml[i] = mbuf[ci * ME + i];
+            sd[i] = sbuf[ci * ME + i];
+        }
+        double2 sshAcc = make_double2(0.0, 0.0);
+        bool first = true;
+        for (int j = l; j < K2c; j += 32) {
+            const bool act = j < K2;
+            const size_t off = (size_t)c * K2 + j;
+            double2 hs = make_double2(0.0, 0.0);
+            if (act) {
+                const double2 hc = ph2[off];
+                double2 hv[ME], uv[ME];
+#pragma unroll
+                for (int i = 0; i < ME; ++i) {
+                    hv[i] = ph2[(size_t)(cn[i] >= 0 ? cn[i] : c) * K2 + j];
+                    uv[i] = ubuf2[(size_t)(le[i] != 0xFF ? le[i] : 0) * K2 + j];
+                }
+                double2 t = make_double2(0.0, 0.0);
+                const int k0 = 2 * j;
+#pragma unroll
+                for (int i = 0; i < ME; ++i) {
+                    if (le[i] != 0xFF) {
+                        if (k0 < ml[i]) t.x += uv[i].x * (0.5 * (hc.x + hv[i].x)) * sd[i] * invA;       // Operators.jl:217,
+                        if (k0 + 1 < ml[i]) t.y += uv[i].y * (0.5 * (hc.y + hv[i].y)) * sd[i] * invA;   // DiagnosticVars.jl:165, horizontal_advection.jl:63
+                    }
+                }
+                if (a.tendH) reinterpret_cast<double2 *>(a.tendH)[off] = t;
+                const double2 hcur = a.ch ? reinterpret_cast<const double2 *>(a.ch)[off] : hc;
+                if (a.ph_out) {
+                    hs = make_double2(hcur.x + a.a * t.x, hcur.y + a.a * t.y);                          // time_integration.jl:125
+                    reinterpret_cast<double2 *>(a.ph_out)[off] = hs;
+                }
+                if (a.nh_out) {
+                    const double2 nb = a.nh_in ? reinterpret_cast<const double2 *>(a.nh_in)[off] : hcur;
+                    const double2 hn = make_double2(nb.x + a.b * t.x, nb.y + a.b * t.y);                // :135
+                    reinterpret_cast<double2 *>(a.nh_out)[off] = hn;
+                    if (!a.ph_out) hs = hn;
+                }
+            }
+            sshAcc = first ? hs : make_double2(sshAcc.x + hs.x, sshAcc.y + hs.y);
+            first = false;
+        }
+        if (a.ssh_out) {
+            // oracle_ksum order: lane-xor 16,8,4,2,1 on (even, odd) levels == level-xor 32,...,2; then level-xor 1
+#pragma unroll
+            for (int s = 16; s >= 1; s >>= 1) {
+                const double2 o = shfl_xor2(sshAcc, s);
+                sshAcc = make_double2(sshAcc.x + o.x, sshAcc.y + o.y);
+            }
+            if (l == 0) a.ssh_out[c] = (sshAcc.x + sshAcc.y) - rsbuf[ci];                               // :209 (+N3)
+        }
+    }
+
+    // ---- 2b. edges ----
+    for (int ei = grp; ei < nOwnE; ei += NG) {
+        const int e = e0 + ei;
+        const int cA = hbuf[ei * 4], cB = hbuf[ei * 4 + 1], mlt = hbuf[ei * 4 + 3];
+        const double g = gbuf[ei];
+        const double ds = a.ssh[cB] - a.ssh[cA];                                                        // ssh[c2] - ssh[c1]
+        uint32_t lw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lw[i] = lebuf[ei * 4 + i];
+        for (int j = l; j < K2; j += 32) {
+            const size_t off = (size_t)e * K2 + j;
+            double2 t = make_double2(0.0, 0.0);
+            const int k0 = 2 * j;
+            const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
+            if (ax) t.x -= g * ds;                                                                      // pressure_gradient.jl:63
+            if (ay) t.y -= g * ds;
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) {
+                const int le = (lw[i >> 2] >> (8 * (i & 3))) & 0xFF;
+                if (le != 0xFF) {
+                    const double2 uv = ubuf2[(size_t)le * K2 + j];
+                    const double w = wbuf[ei * ME2 + i], f = fbuf[le];
+                    if (ax) t.x += w * uv.x * f;                                                        // coriolis.jl:70-72
+                    if (ay) t.y += w * uv.y * f;
+                }
+            }
+            if (a.tendU) reinterpret_cast<double2 *>(a.tendU)[off] = t;
+            const double2 up = ubuf2[(size_t)ei * K2 + j];                                              // own row = local row ei
+            const double2 ucur = a.cu ? reinterpret_cast<const double2 *>(a.cu)[off] : up;
+            if (a.pu_out) reinterpret_cast<double2 *>(a.pu_out)[off] = make_double2(ucur.x + a.a * t.x, ucur.y + a.a * t.y);
+            if (a.nu_out) {
+                const double2 nb = a.nu_in ? reinterpret_cast<const double2 *>(a.nu_in)[off] : ucur;
+                reinterpret_cast<double2 *>(a.nu_out)[off] = make_double2(nb.x + a.b * t.x, nb.y + a.b * t.y);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Forward-Euler step / reference-sequenced pieces (time_integration.jl:150-193) in one launch.
 // `ops` selects which reference calls are performed, `flags` the quirks of SURVEY.md 0.6.
@@ -471,6 +669,26 @@ hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream
 #define CALL(L) launch_stage_lpc<L>(m, a, s)
     DISPATCH_LPC(lpc, CALL)
 #undef CALL
+}
+
+hipError_t launch_stage_lds(const MeshDev &m, const StageArgs &a, size_t ldsBytes, hipStream_t s)
+{
+    const dim3 g(patch_grid(m)), b(LBLOCK);
+    if (m.ME == 6 && m.ME2 == 10) hipLaunchKernelGGL((k_stage_lds<6, 10>), g, b, ldsBytes, s, m, a);
+    else if (m.ME == 8 && m.ME2 == 14) hipLaunchKernelGGL((k_stage_lds<8, 14>), g, b, ldsBytes, s, m, a);
+    else if (m.ME <= 6 && m.ME2 <= 14) hipLaunchKernelGGL((k_stage_lds<6, 14>), g, b, ldsBytes, s, m, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t prepare_stage_lds(size_t ldsBytes)
+{
+    // > 64 KB of dynamic LDS needs the opt-in attribute
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void *)k_stage_lds<6, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_stage_lds<8, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_stage_lds<6, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes))) return e;
+    return hipSuccess;
 }
 
 hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s)

@@ -43,6 +43,8 @@ struct OpArgs {
 };
 
 hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream_t s);
+hipError_t launch_stage_lds(const MeshDev &m, const StageArgs &a, size_t ldsBytes, hipStream_t s);
+hipError_t prepare_stage_lds(size_t ldsBytes);
 hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s);
 hipError_t launch_operator(const MeshDev &m, const OpArgs &a, int lpc, hipStream_t s);
 hipError_t launch_update_ssh(const MeshDev &m, const double *h, double *ssh, int nlev, int lpc, hipStream_t s);

@@ -42,6 +42,15 @@ struct Plan {
     std::vector<double>  woe;      // nE*ME2 weightsOnEdge
     std::vector<double>  gInvDc;   // nE     9.80616 * (1/dcEdge)   (pressure_gradient.jl:58,63)
     std::vector<double>  dcEdge, dvEdge, fEdge;   // nE
+    // patch-local view for the LDS-tiled kernel: the u-rows a patch needs are its own edges
+    // [patchEdgeStart[p], patchEdgeStart[p+1]) followed by haloEdge[haloStart[p] .. haloStart[p+1]);
+    // leoc / leoe hold, per cell slot / edgesOnEdge slot, the row index inside that list (0xFF = none).
+    std::vector<int32_t> haloStart;   // nPatches + 1
+    std::vector<int32_t> haloEdge;    // new edge ids
+    std::vector<uint8_t> leoc;        // nC*8
+    std::vector<uint8_t> leoe;        // nE*16
+    int32_t maxRows = 0, maxOwnE = 0, maxOwnC = 0;
+    bool ldsOk = false;               // every patch has <= 254 rows
     // vertices
     std::vector<int32_t> eov;      // nV*VD  edgesOnVertex
     std::vector<double>  cv;       // nV*VD  (dcEdge[e]*(1/areaTriangle[v]))*sign  (Operators.jl:137-146)
@@ -62,7 +71,22 @@ struct MeshDev {
     const int32_t *eov;
     const double  *cv;
     const int32_t *cellN2O, *edgeN2O, *vertN2O;
+    // LDS-tiled kernel
+    const int32_t *haloStart, *haloEdge;
+    const uint8_t *leoc, *leoe;
+    int32_t maxRows, maxOwnE, maxOwnC;
 };
+
+// Dynamic LDS the LDS-tiled stage kernel carves up (same formula on host and device):
+//   u rows [maxRows][K] | fEdge [maxRows] | weightsOnEdge [maxOwnE][ME2] | gInvDc [maxOwnE] |
+//   sdv [maxOwnC][ME] | invArea [maxOwnC] | rsum [maxOwnC] | ehdr [maxOwnE][4] i32 | coc [maxOwnC][ME] i32 |
+//   mltc [maxOwnC][ME] i32 | leoe [maxOwnE][16] u8 | leoc [maxOwnC][8] u8
+inline int64_t lds_stage_bytes(int K, int ME, int ME2, int maxRows, int maxOwnE, int maxOwnC)
+{
+    int64_t dbl = (int64_t)maxRows * K + maxRows + (int64_t)maxOwnE * ME2 + maxOwnE + (int64_t)maxOwnC * ME + 2 * maxOwnC;
+    int64_t i32 = (int64_t)maxOwnE * 4 + 2 * (int64_t)maxOwnC * ME + (int64_t)maxOwnE * 4 + (int64_t)maxOwnC * 2;
+    return dbl * 8 + i32 * 4 + 16;
+}
 
 }  // namespace moka
 

@@ -179,7 +179,12 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     p.ME = maxEoC <= 6 ? 6 : (maxEoC <= 8 ? 8 : maxEoC);
     p.ME2 = maxEoE <= 10 ? 10 : (maxEoE <= 14 ? 14 : maxEoE);
     if (p.ME == 8 && p.ME2 < 14) p.ME2 = 14;   // kernels are instantiated for (6,10), (6,14), (8,14)
-    p.P = d->patch_cells > 0 ? d->patch_cells : 32;
+    // default patch size: the LDS-tiled stage kernel keeps the u-rows a patch needs (own + halo edges,
+    // ~131 rows for 16 hexagons) in LDS at K*8 bytes each, two workgroups per CU (<= ~72 KB each)
+    {
+        const int K = d->nVertLevels;
+        p.P = d->patch_cells > 0 ? d->patch_cells : (K <= 40 ? 32 : K <= 64 ? 16 : K <= 80 ? 12 : K <= 110 ? 8 : 32);
+    }
     REQUIRE(p.P <= 4096, "patch_cells too large");
 
     // ---- cell ordering ----
@@ -296,6 +301,45 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
             p.cv[IX(j, vn, VD)] = (d->dcEdge[eo] * invA) * (double)d->edgeSignOnVertex[IX(j, vo, ldSV)];
         }
     }
+    // ---- patch-local row lists for the LDS-tiled kernel ----
+    p.haloStart.assign(p.nPatches + 1, 0);
+    p.haloEdge.clear();
+    p.leoc.assign((size_t)nC * 8, 0xFF);
+    p.leoe.assign((size_t)nE * 16, 0xFF);
+    p.maxRows = p.maxOwnE = p.maxOwnC = 0;
+    p.ldsOk = (ME <= 8 && ME2 <= 16);
+    {
+        std::vector<int32_t> local(nE, -1), touched;
+        for (int q = 0; q < p.nPatches && p.ldsOk; ++q) {
+            const int c0 = p.patchCellStart[q], c1 = p.patchCellStart[q + 1];
+            const int e0 = p.patchEdgeStart[q], e1 = p.patchEdgeStart[q + 1];
+            const int nOwn = e1 - e0;
+            int rows = nOwn;
+            touched.clear();
+            auto local_of = [&](int e) {
+                if (e >= e0 && e < e1) return e - e0;
+                if (local[e] < 0) { local[e] = rows++; touched.push_back(e); p.haloEdge.push_back(e); }
+                return local[e];
+            };
+            for (int c = c0; c < c1; ++c)
+                for (int i = 0; i < ME; ++i) {
+                    const int e = p.eoc[IX(i, c, ME)];
+                    if (e >= 0) { int r = local_of(e); p.leoc[(size_t)c * 8 + i] = (uint8_t)std::min(r, 255); }
+                }
+            for (int e = e0; e < e1; ++e)
+                for (int i = 0; i < ME2; ++i) {
+                    const int x = p.eoe[IX(i, e, ME2)];
+                    if (x >= 0) { int r = local_of(x); p.leoe[(size_t)e * 16 + i] = (uint8_t)std::min(r, 255); }
+                }
+            for (int e : touched) local[e] = -1;
+            p.haloStart[q + 1] = (int32_t)p.haloEdge.size();
+            if (rows > 254) p.ldsOk = false;
+            p.maxRows = std::max(p.maxRows, rows);
+            p.maxOwnE = std::max(p.maxOwnE, nOwn);
+            p.maxOwnC = std::max(p.maxOwnC, c1 - c0);
+        }
+        if (!p.ldsOk) { p.haloEdge.clear(); std::fill(p.haloStart.begin(), p.haloStart.end(), 0); }
+    }
     return MOKA_OK;
 }
 
@@ -340,6 +384,9 @@ static void fill_info(const moka::Plan &p, moka_mesh_info *info)
     info->maxEdgesUsed = p.ME; info->maxEdges2Used = p.ME2;
     info->lanesPerColumn = lanes_per_column(p.K);
     info->cellBandwidth = p.cellBandwidth;
+    info->maxPatchRows = p.maxRows;
+    info->ldsBytesPerBlock = (p.ldsOk && p.K % 2 == 0)
+                                 ? (int32_t)moka::lds_stage_bytes(p.K, p.ME, p.ME2, p.maxRows, p.maxOwnE, p.maxOwnC) : 0;
     info->meshBytesDevice =
         (int64_t)p.nC * (p.ME * (3 * 4 + 8) + 3 * 8) + (int64_t)p.nE * (16 + p.ME2 * 12 + 4 * 8) +
         (int64_t)p.nV * p.VD * 12 + (int64_t)(p.nPatches + 1) * 12 + 4ll * (p.nC + p.nE + p.nV);
@@ -383,6 +430,7 @@ int moka_plan_array(const moka_plan *plan, int which, const void **data, int64_t
         VEC(MOKA_PA_EHDR, ehdr) VEC(MOKA_PA_EOE, eoe) VEC(MOKA_PA_WOE, woe) VEC(MOKA_PA_GINVDC, gInvDc)
         VEC(MOKA_PA_DCEDGE, dcEdge) VEC(MOKA_PA_DVEDGE, dvEdge) VEC(MOKA_PA_FEDGE, fEdge)
         VEC(MOKA_PA_EOV, eov) VEC(MOKA_PA_CV, cv)
+        VEC(MOKA_PA_HALO_START, haloStart) VEC(MOKA_PA_HALO_EDGE, haloEdge) VEC(MOKA_PA_LEOC, leoc) VEC(MOKA_PA_LEOE, leoe)
         default: moka::set_error("unknown plan array id"); return MOKA_ERR_ARG;
     }
 #undef VEC

@@ -52,6 +52,7 @@ class MeshInfo(C.Structure):
         ("ordering", C.c_int32), ("patch_cells", C.c_int32), ("nPatches", C.c_int32),
         ("maxEdgesUsed", C.c_int32), ("maxEdges2Used", C.c_int32), ("lanesPerColumn", C.c_int32),
         ("meshBytesDevice", C.c_int64), ("cellBandwidth", C.c_int64),
+        ("maxPatchRows", C.c_int32), ("ldsBytesPerBlock", C.c_int32),
     ]
 
     def as_dict(self):
@@ -189,6 +190,7 @@ PLAN_ARRAYS = {  # name -> (id, dtype)
     "ehdr": (7, np.int32), "eoe": (8, np.int32), "woe": (9, np.float64), "gInvDc": (10, np.float64),
     "dcEdge": (11, np.float64), "dvEdge": (12, np.float64), "fEdge": (13, np.float64),
     "eov": (14, np.int32), "cv": (15, np.float64),
+    "haloStart": (16, np.int32), "haloEdge": (17, np.int32), "leoc": (18, np.uint8), "leoe": (19, np.uint8),
 }
 
 
