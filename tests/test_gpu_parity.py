@@ -115,19 +115,29 @@ def random_state(mesh, K, seed):
     ("ico16", 2, L.ORDER_RCM, 8), ("ico16", 3, L.ORDER_RCB, 0), ("ico16", 5, L.ORDER_RCB, 5),
     ("ico16", 10, L.ORDER_RCB, 0), ("ico16", 17, L.ORDER_RCB, 0), ("ico16", 33, L.ORDER_RCM, 0),
     ("ico16", 60, L.ORDER_RCB, 0), ("ico16", 64, L.ORDER_NONE, 0), ("ico16", 80, L.ORDER_RCB, 0),
-    ("ico32", 60, L.ORDER_RCB, 32), ("ico16", 130, L.ORDER_RCB, 64),
+    ("ico32", 60, L.ORDER_RCB, 32), ("ico16", 130, L.ORDER_RCB, 64), ("ico32", 60, L.ORDER_RCB, 0),
+    ("ico16", 8, L.ORDER_RCB, 0), ("ico16", 34, L.ORDER_RCB, 0), ("ico16", 100, L.ORDER_RCB, 0), ("planar", 60, L.ORDER_RCB, 0),
+    ("ico16", 60, L.ORDER_RCM, 0), ("ico16", 60, L.ORDER_NONE, 24),
 ])
 def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     mesh = get_mesh(meshname)
     ssh, u, h, rest = random_state(mesh, K, 11 + K)
     Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True,
                                                        ordering=ordering, patch_cells=P)
-    mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     tu, th, ossh = om.tendencies_clean(u, h)
-    assert np.array_equal(Tend.tendNormalVelocity.get(), tu)
-    assert np.array_equal(Tend.tendLayerThickness.get(), th)
-    assert np.array_equal(Prog.ssh[-1].get(), ossh)
+    info = Setup.mesh.info()
+    for variant in (1, 2):      # 1 = direct (L2-gather) kernel, 2 = LDS patch-tiled kernel (when the mesh/K allow it)
+        backend.set_kernel_variant(variant)
+        Tend.tendNormalVelocity.set(np.full_like(tu, np.nan)); Tend.tendLayerThickness.set(np.full_like(th, np.nan))
+        Prog.ssh[-1].set(ssh)
+        mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
+        assert np.array_equal(Tend.tendNormalVelocity.get(), tu), variant
+        assert np.array_equal(Tend.tendLayerThickness.get(), th), variant
+        assert np.array_equal(Prog.ssh[-1].get(), ossh), variant
+    backend.set_kernel_variant(0)
+    if K % 2 == 0 and K >= 8:
+        assert info["ldsBytesPerBlock"] > 0, "LDS-tiled kernel should be available for even K"
     Prog._state.close(); Setup.mesh.close()
 
 
@@ -232,8 +242,10 @@ def test_reference_call_sequence_piecewise(backend):
 # ------------------------------------------------------------------------------------------------
 # RK4 stage loop
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("meshname,K,nsteps", [("igw200", 1, 10), ("ico16", 1, 5), ("ico16", 60, 3), ("ico16", 80, 2)])
-def test_rk4_bitwise(backend, meshname, K, nsteps):
+@pytest.mark.parametrize("meshname,K,nsteps,variant", [("igw200", 1, 10, 0), ("ico16", 1, 5, 0), ("ico16", 60, 3, 1),
+                                                         ("ico16", 60, 3, 2), ("ico16", 80, 2, 2), ("ico32", 60, 2, 0)])
+def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
+    backend.set_kernel_variant(variant)
     mesh = get_mesh(meshname)
     if meshname == "igw200":
         ssh, u, h, rest = mg.igw_initial_state(mesh)
@@ -261,6 +273,7 @@ def test_rk4_bitwise(backend, meshname, K, nsteps):
         got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
         for k in exp:
             assert np.array_equal(got[k], exp[k]), k
+    backend.set_kernel_variant(0)
     Prog._state.close(); Setup.mesh.close()
 
 
