@@ -200,7 +200,8 @@ int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flag
 /* sumArray                                   src/forward/run_loop.jl:39-51 : sum_j a[j]^2 */
 int moka_sum_sq(moka_state *st, int field, int time_level, double *out);
 
-/* kernel variant selection for measurement: 0 = auto, 1 = direct (L2-gather), 2 = LDS patch-tiled */
+/* kernel variant selection for measurement: 0 = auto, 1 = column kernel (byte-offset records + buffer loads;
+ * needs nVertLevels > 32), 2 = LDS patch-tiled, 3 = generic index kernel (any nVertLevels) */
 int moka_set_kernel_variant(moka_ctx *ctx, int variant);
 
 #ifdef __cplusplus

@@ -28,6 +28,7 @@ struct moka_mesh {
     std::vector<void *> allocs;
     int lpc = 1;
     size_t ldsBytes = 0;      // > 0: the LDS-tiled stage kernel is usable for this mesh
+    bool colOk = false;       // byte-offset records exist (every field < 4 GiB)
     double *opBuf[3] = {nullptr, nullptr, nullptr};   // operator / transfer scratch, lazily sized
     size_t opBufElems = 0;
 };
@@ -204,8 +205,9 @@ hipError_t run_stage(moka_state *st, const StageArgs &g)
 {
     const moka_mesh *m = st->mesh;
     const int v = st->ctx->variant;
-    const bool lds = m->ldsBytes > 0 && (v == 2 || (v == 0 && m->ldsBytes <= 80 * 1024));
-    if (lds) return launch_stage_lds(m->dev, g, m->ldsBytes, st->ctx->stream);
+    // 1 = column kernel (byte-offset records, buffer loads), 2 = LDS patch-tiled, 3 = generic index kernel
+    if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(m->dev, g, m->ldsBytes, st->ctx->stream);
+    if (v != 3 && m->lpc == 64 && m->colOk) return launch_stage_col(m->dev, g, st->ctx->stream);
     return launch_stage(m->dev, g, m->lpc, st->ctx->stream);
 }
 
@@ -308,7 +310,7 @@ int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
 int moka_set_kernel_variant(moka_ctx *ctx, int variant)
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
-    if (variant < 0 || variant > 2) return fail(ctx, MOKA_ERR_ARG, "variant must be 0, 1 or 2");
+    if (variant < 0 || variant > 3) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..3");
     ctx->variant = variant;
     return MOKA_OK;
 }
@@ -352,8 +354,10 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     UP(eoc) UP(coc) UP(mltc) UP(sdv) UP(invArea) UP(areaCell) UP(rsum)
     UP(ehdr) UP(eoe) UP(woe) UP(gInvDc) UP(dcEdge) UP(dvEdge) UP(fEdge)
     UP(eov) UP(cv) UP(cellN2O) UP(edgeN2O) UP(vertN2O)
-    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe)
+    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe)
 #undef UP
+    d.CI = p.CI; d.EI = p.EI;
+    m->colOk = p.colOk;
     d.maxRows = p.maxRows; d.maxOwnE = p.maxOwnE; d.maxOwnC = p.maxOwnC;
     if (p.ldsOk && p.K % 2 == 0 && p.K >= 8) {
         const int64_t need = lds_stage_bytes(p.K, p.ME, p.ME2, p.maxRows, p.maxOwnE, p.maxOwnC);

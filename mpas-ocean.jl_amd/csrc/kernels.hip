@@ -185,6 +185,169 @@ __global__ __launch_bounds__(BLOCK) void k_stage(const MeshDev m, const StageArg
 
 
 // ------------------------------------------------------------------------------------------------
+// Column kernel, instruction-lean form for LPC = 64 (one wavefront per entity, lane = level).
+//
+// rocprof on the generic k_stage showed the SIMDs busy *issuing* ~150 VALU + ~150 SALU per entity
+// (64-bit index*K*8 address arithmetic, selects, SGPR spills) for ~40 essential fp64 operations,
+// and the per-CU scalar unit saturated.  Here the plan stores 32-bit BYTE offsets of every
+// neighbour row (cRec / eRec), all of an entity's connectivity arrives in SGPRs with two or three
+// s_load_dwordx8/x16, and every gather is `buffer_load_dwordx2 v, v_lane8, s[rsrc], s_off offen`:
+// no address arithmetic at all.  Weights, fEdge and metric factors are SGPR operands of the fp64
+// instructions.  Slot validity and "all levels active" are wave-uniform (scalar branches).
+// Lanes >= K read past the row (the buffer range check returns 0 past the array) and never store.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double bload(rsrc_t r, int voff, uint32_t soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bstore(rsrc_t r, int voff, uint32_t soff, double x)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, voff, (int)soff, 0);
+}
+
+// own-row access: base pointer (SGPR pair) + 32-bit byte offset (VGPR) -> global_load/store saddr form
+__device__ __forceinline__ double gload(const double *base, uint32_t off)
+{
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + off);
+}
+__device__ __forceinline__ void gstore(double *base, uint32_t off, double x)
+{
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + off) = x;
+}
+
+template <int ME, int ME2>
+__global__ __launch_bounds__(BLOCK) void k_stage_col(const ColMesh m, const StageArgs a)
+{
+    const int p = patch_of_block(m.nPatches);
+    if (p >= m.nPatches) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    const int K = m.K;
+    const uint32_t rowB = (uint32_t)K * 8u;
+    const rsrc_t ph = make_rsrc(a.ph, (uint32_t)m.nC * rowB), pu = make_rsrc(a.pu, (uint32_t)m.nE * rowB);
+
+    // ---------------- cells ----------------
+    {
+        const int c0 = cptr(m.patchCellStart)[p], c1 = cptr(m.patchCellStart)[p + 1];
+        for (int c = c0 + wave; c < c1; c += BLOCK / 64) {
+            CP<uint32_t> r = cptr(m.cRec) + (size_t)c * m.CI;
+            CP<double> rs = cptr(m.sdv) + (size_t)c * ME;
+            uint32_t eo[ME], co[ME];
+            double sd[ME];
+#pragma unroll
+            for (int i = 0; i < ME; ++i) {
+                eo[i] = r[i];
+                co[i] = r[ME + i];
+                sd[i] = rs[i];
+            }
+            const uint32_t mask = r[2 * ME], all = r[2 * ME + 1];
+            const double invA = cptr(m.invArea)[c];
+            const uint32_t own = (uint32_t)c * rowB;
+            double sshAcc = 0.0;
+            for (int kb = 0; kb < K; kb += 64) {
+                const int k = kb + l, voff = k * 8;
+                const uint32_t ooff = own + (uint32_t)voff;
+                const double hc = bload(ph, voff, own);
+                double uv[ME], hv[ME];
+#pragma unroll
+                for (int i = 0; i < ME; ++i) {
+                    uv[i] = bload(pu, voff, eo[i]);
+                    hv[i] = bload(ph, voff, co[i]);
+                }
+                double t = 0.0;
+                if (all) {
+#pragma unroll
+                    for (int i = 0; i < ME; ++i)
+                        if ((mask >> i) & 1u) t += uv[i] * (0.5 * (hc + hv[i])) * sd[i] * invA;   // Operators.jl:217,
+                } else {                                                                          // DiagnosticVars.jl:165,
+#pragma unroll
+                    for (int i = 0; i < ME; ++i)                                                   // horizontal_advection.jl:63
+                        if (((mask >> i) & 1u) && k < cptr(m.mltc)[(size_t)c * ME + i])
+                            t += uv[i] * (0.5 * (hc + hv[i])) * sd[i] * invA;
+                }
+                double hs = 0.0;
+                if (k < K) {
+                    if (a.tendH) gstore(a.tendH, ooff, t);
+                    double hcur = hc;
+                    if (a.ch) hcur = gload(a.ch, ooff);
+                    if (a.ph_out) {
+                        hs = hcur + a.a * t;                           // time_integration.jl:125
+                        gstore(a.ph_out, ooff, hs);
+                    }
+                    if (a.nh_out) {
+                        double nb = hcur;
+                        if (a.nh_in) nb = gload(a.nh_in, ooff);
+                        const double hn = nb + a.b * t;                // :135
+                        gstore(a.nh_out, ooff, hn);
+                        if (!a.ph_out) hs = hn;
+                    }
+                }
+                if (kb == 0) sshAcc = hs;
+                else sshAcc = sshAcc + hs;
+            }
+            if (a.ssh_out) {
+                const double sum = group_sum<64>(sshAcc);
+                if (l == 0) a.ssh_out[c] = sum - cptr(m.rsum)[c];      // time_integration.jl:209 (+N3)
+            }
+        }
+    }
+
+    // ---------------- edges ----------------
+    {
+        const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
+        for (int e = e0 + wave; e < e1; e += BLOCK / 64) {
+            CP<uint32_t> r = cptr(m.eRec) + (size_t)e * m.EI;
+            CP<double> rw = cptr(m.woe) + (size_t)e * ME2;
+            CP<double> rf = cptr(m.feoe) + (size_t)e * ME2;
+            uint32_t xo[ME2];
+            double wi[ME2], fi[ME2];
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) {
+                xo[i] = r[i];
+                wi[i] = rw[i];
+                fi[i] = rf[i];
+            }
+            const uint32_t cA = r[ME2], cB = r[ME2 + 1], mask = r[ME2 + 2];
+            const int mlt = (int)r[ME2 + 3];
+            const double g = cptr(m.gInvDc)[e];
+            const double ds = cptr(a.ssh)[cB] - cptr(a.ssh)[cA];       // ssh[c2] - ssh[c1]
+            const uint32_t own = (uint32_t)e * rowB;
+            for (int kb = 0; kb < K; kb += 64) {
+                const int k = kb + l, voff = k * 8;
+                const uint32_t ooff = own + (uint32_t)voff;
+                double uv[ME2];
+#pragma unroll
+                for (int i = 0; i < ME2; ++i) uv[i] = bload(pu, voff, xo[i]);
+                double t = 0.0;
+                if (k < mlt) {
+                    t -= g * ds;                                       // pressure_gradient.jl:63
+#pragma unroll
+                    for (int i = 0; i < ME2; ++i)
+                        if ((mask >> i) & 1u) t += wi[i] * uv[i] * fi[i];   // ...coriolis.jl:70-72
+                }
+                if (k < K) {
+                    if (a.tendU) gstore(a.tendU, ooff, t);
+                    const double ucur = gload(a.cu ? a.cu : a.pu, ooff);
+                    if (a.pu_out) gstore(a.pu_out, ooff, ucur + a.a * t);   // time_integration.jl:124
+                    if (a.nu_out) {
+                        double nb = ucur;
+                        if (a.nu_in) nb = gload(a.nu_in, ooff);
+                        gstore(a.nu_out, ooff, nb + a.b * t);          // :134
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS patch-tiled variant of the fused tendency / RK-stage kernel (same arithmetic, same results).
 //
 // The direct kernel above re-reads every u-row ~12 times through the vector L1 (10 Coriolis
@@ -669,6 +832,18 @@ hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream
 #define CALL(L) launch_stage_lpc<L>(m, a, s)
     DISPATCH_LPC(lpc, CALL)
 #undef CALL
+}
+
+hipError_t launch_stage_col(const MeshDev &md, const StageArgs &a, hipStream_t s)
+{
+    const dim3 g(patch_grid(md)), b(BLOCK);
+    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
+    if (md.ME == 6 && md.ME2 == 10) hipLaunchKernelGGL((k_stage_col<6, 10>), g, b, 0, s, m, a);
+    else if (md.ME == 8 && md.ME2 == 14) hipLaunchKernelGGL((k_stage_col<8, 14>), g, b, 0, s, m, a);
+    else if (md.ME <= 6 && md.ME2 <= 14) hipLaunchKernelGGL((k_stage_col<6, 14>), g, b, 0, s, m, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 hipError_t launch_stage_lds(const MeshDev &m, const StageArgs &a, size_t ldsBytes, hipStream_t s)

@@ -19,6 +19,15 @@ struct StageArgs {
     double a, b;
 };
 
+// the slice of MeshDev the column kernel reads (kept small: kernel arguments live in SGPRs)
+struct ColMesh {
+    int32_t nC, nE, K, nPatches, CI, EI;
+    const int32_t *patchCellStart, *patchEdgeStart;
+    const uint32_t *cRec, *eRec;
+    const int32_t *mltc;
+    const double *sdv, *invArea, *rsum, *woe, *feoe, *gInvDc;
+};
+
 enum : int {
     FE_FLUX = 1, FE_DIV = 2, FE_CURL = 4, FE_HEDGE = 8, FE_TENDU = 16, FE_TENDH = 32, FE_UPDATE = 64,
     FE_TENDH_FROM_F = 128
@@ -43,6 +52,7 @@ struct OpArgs {
 };
 
 hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream_t s);
+hipError_t launch_stage_col(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_lds(const MeshDev &m, const StageArgs &a, size_t ldsBytes, hipStream_t s);
 hipError_t prepare_stage_lds(size_t ldsBytes);
 hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s);

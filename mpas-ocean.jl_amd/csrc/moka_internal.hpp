@@ -42,6 +42,16 @@ struct Plan {
     std::vector<double>  woe;      // nE*ME2 weightsOnEdge
     std::vector<double>  gInvDc;   // nE     9.80616 * (1/dcEdge)   (pressure_gradient.jl:58,63)
     std::vector<double>  dcEdge, dvEdge, fEdge;   // nE
+    // packed records of the column kernel (LPC = 64): 32-bit BYTE offsets of the neighbour rows, so that
+    // a gather is one buffer_load with the offset in an SGPR and no address arithmetic at all.
+    //   cRec[c][CI]: [0,ME) u-row offsets of the cell's edges | [ME,2ME) h-row offsets of the cells across
+    //                | [2ME] valid-slot mask | [2ME+1] 1 if every valid slot has maxLevelEdgeTop >= K
+    //   eRec[e][EI]: [0,ME2) u-row offsets of edgesOnEdge | c1 | c2 | valid-slot mask | maxLevelEdgeTop
+    // invalid slots carry the entity's own (valid) offset.  feoe = fEdge[edgesOnEdge] per slot.
+    std::vector<uint32_t> cRec, eRec;
+    std::vector<double>   feoe;       // nE*ME2
+    int32_t CI = 0, EI = 0;
+    bool colOk = false;               // K*8*nE < 4 GiB: offsets fit 32 bits
     // patch-local view for the LDS-tiled kernel: the u-rows a patch needs are its own edges
     // [patchEdgeStart[p], patchEdgeStart[p+1]) followed by haloEdge[haloStart[p] .. haloStart[p+1]);
     // leoc / leoe hold, per cell slot / edgesOnEdge slot, the row index inside that list (0xFF = none).
@@ -71,6 +81,10 @@ struct MeshDev {
     const int32_t *eov;
     const double  *cv;
     const int32_t *cellN2O, *edgeN2O, *vertN2O;
+    // column kernel records
+    const uint32_t *cRec, *eRec;
+    const double *feoe;
+    int32_t CI, EI;
     // LDS-tiled kernel
     const int32_t *haloStart, *haloEdge;
     const uint8_t *leoc, *leoe;

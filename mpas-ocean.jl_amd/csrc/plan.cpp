@@ -301,6 +301,56 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
             p.cv[IX(j, vn, VD)] = (d->dcEdge[eo] * invA) * (double)d->edgeSignOnVertex[IX(j, vo, ldSV)];
         }
     }
+    // ---- packed byte-offset records of the column kernel ----
+    {
+        const uint64_t rowB = (uint64_t)p.K * 8;
+        p.colOk = rowB * (uint64_t)std::max(nE, std::max(nC, nV)) < (1ull << 32) - 1024;
+        p.CI = ((2 * ME + 2) + 3) & ~3;
+        p.EI = ((ME2 + 4) + 3) & ~3;
+        p.cRec.clear(); p.eRec.clear(); p.feoe.clear();
+        if (p.colOk) {
+            p.cRec.assign((size_t)nC * p.CI, 0u);
+            p.eRec.assign((size_t)nE * p.EI, 0u);
+            p.feoe.assign((size_t)nE * ME2, 0.0);
+            for (int c = 0; c < nC; ++c) {
+                uint32_t *r = &p.cRec[(size_t)c * p.CI];
+                uint32_t mask = 0, all = 1;
+                for (int i = 0; i < ME; ++i) {
+                    const int e = p.eoc[IX(i, c, ME)];
+                    if (e >= 0) {
+                        mask |= 1u << i;
+                        r[i] = (uint32_t)((uint64_t)e * rowB);
+                        r[ME + i] = (uint32_t)((uint64_t)p.coc[IX(i, c, ME)] * rowB);
+                        if (p.mltc[IX(i, c, ME)] < p.K) all = 0;
+                    } else {
+                        r[i] = (uint32_t)((uint64_t)p.eoc[IX(0, c, ME)] * rowB);
+                        r[ME + i] = (uint32_t)((uint64_t)c * rowB);
+                    }
+                }
+                r[2 * ME] = mask;
+                r[2 * ME + 1] = all;
+            }
+            for (int e = 0; e < nE; ++e) {
+                uint32_t *r = &p.eRec[(size_t)e * p.EI];
+                uint32_t mask = 0;
+                for (int i = 0; i < ME2; ++i) {
+                    const int x = p.eoe[IX(i, e, ME2)];
+                    if (x >= 0) {
+                        mask |= 1u << i;
+                        r[i] = (uint32_t)((uint64_t)x * rowB);
+                        p.feoe[IX(i, e, ME2)] = p.fEdge[x];
+                    } else {
+                        r[i] = (uint32_t)((uint64_t)e * rowB);
+                    }
+                }
+                r[ME2] = (uint32_t)p.ehdr[4 * (size_t)e];
+                r[ME2 + 1] = (uint32_t)p.ehdr[4 * (size_t)e + 1];
+                r[ME2 + 2] = mask;
+                r[ME2 + 3] = (uint32_t)p.ehdr[4 * (size_t)e + 3];
+            }
+        }
+    }
+
     // ---- patch-local row lists for the LDS-tiled kernel ----
     p.haloStart.assign(p.nPatches + 1, 0);
     p.haloEdge.clear();

@@ -127,7 +127,7 @@ def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     tu, th, ossh = om.tendencies_clean(u, h)
     info = Setup.mesh.info()
-    for variant in (1, 2):      # 1 = direct (L2-gather) kernel, 2 = LDS patch-tiled kernel (when the mesh/K allow it)
+    for variant in (1, 2, 3):   # 1 = column kernel (LPC = 64), 2 = LDS patch-tiled, 3 = generic index kernel
         backend.set_kernel_variant(variant)
         Tend.tendNormalVelocity.set(np.full_like(tu, np.nan)); Tend.tendLayerThickness.set(np.full_like(th, np.nan))
         Prog.ssh[-1].set(ssh)
