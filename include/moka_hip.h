@@ -200,8 +200,9 @@ int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flag
 /* sumArray                                   src/forward/run_loop.jl:39-51 : sum_j a[j]^2 */
 int moka_sum_sq(moka_state *st, int field, int time_level, double *out);
 
-/* kernel variant selection for measurement: 0 = auto, 1 = column kernel (byte-offset records + buffer loads;
- * needs nVertLevels > 32), 2 = LDS patch-tiled, 3 = generic index kernel (any nVertLevels) */
+/* kernel variant selection for measurement: 0 = auto, 1 = software-pipelined column kernel (byte-offset records +
+ * buffer loads; nVertLevels in 33..64), 2 = LDS patch-tiled, 3 = generic index kernel (any nVertLevels),
+ * 4 = column kernel without pipelining */
 int moka_set_kernel_variant(moka_ctx *ctx, int variant);
 
 #ifdef __cplusplus

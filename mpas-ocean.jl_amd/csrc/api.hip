@@ -205,9 +205,9 @@ hipError_t run_stage(moka_state *st, const StageArgs &g)
 {
     const moka_mesh *m = st->mesh;
     const int v = st->ctx->variant;
-    // 1 = column kernel (byte-offset records, buffer loads), 2 = LDS patch-tiled, 3 = generic index kernel
+    // 0/1 = pipelined column kernel, 2 = LDS patch-tiled, 3 = generic index kernel, 4 = column kernel without pipelining
     if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(m->dev, g, m->ldsBytes, st->ctx->stream);
-    if (v != 3 && m->lpc == 64 && m->colOk) return launch_stage_col(m->dev, g, st->ctx->stream);
+    if (v != 3 && m->lpc == 64 && m->colOk) return launch_stage_col(m->dev, g, v != 4, st->ctx->stream);
     return launch_stage(m->dev, g, m->lpc, st->ctx->stream);
 }
 
@@ -310,7 +310,7 @@ int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
 int moka_set_kernel_variant(moka_ctx *ctx, int variant)
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
-    if (variant < 0 || variant > 3) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..3");
+    if (variant < 0 || variant > 4) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..4");
     ctx->variant = variant;
     return MOKA_OK;
 }

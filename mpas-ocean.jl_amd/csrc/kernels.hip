@@ -348,6 +348,171 @@ __global__ __launch_bounds__(BLOCK) void k_stage_col(const ColMesh m, const Stag
 }
 
 // ------------------------------------------------------------------------------------------------
+// Software-pipelined column kernel (K <= 64, one sweep): the memory latency of a task was paid
+// twice per entity (scalar record, then the row gathers) with nothing else of that wave in flight,
+// so ~70 % of wave time was parked on s_waitcnt.  Here each wave keeps TWO entities in flight:
+// the gathers of entity t+1 are issued (into the other register set) before entity t is computed,
+// so the compiler's counted `s_waitcnt vmcnt(N)` leaves the younger batch outstanding.  The issue
+// is unconditional (the entity index is clamped) so that every compute is preceded by exactly one
+// batch: a conditional issue would force vmcnt(0) at the join.  MODE fixes which own rows are read:
+//   0 tendency only | 1 RK stage 1 (Curr == Provis) | 2 RK stage 2,3 | 3 RK stage 4 (New only)
+// ------------------------------------------------------------------------------------------------
+template <int ME, int MODE>
+struct CellBatch {
+    double hc, uv[ME], hv[ME], cur, nin;
+};
+template <int ME2, int MODE>
+struct EdgeBatch {
+    double uv[ME2], own, cur, nin;
+};
+
+template <int ME, int MODE>
+__device__ __forceinline__ void cell_issue(CellBatch<ME, MODE> &b, const ColMesh &m, const StageArgs &a, rsrc_t ph,
+                                           rsrc_t pu, int c, uint32_t rowB, int voff)
+{
+    CP<uint32_t> r = cptr(m.cRec) + (size_t)c * m.CI;
+    const uint32_t own = (uint32_t)c * rowB;
+    b.hc = bload(ph, voff, own);
+#pragma unroll
+    for (int i = 0; i < ME; ++i) {
+        b.uv[i] = bload(pu, voff, r[i]);
+        b.hv[i] = bload(ph, voff, r[ME + i]);
+    }
+    if constexpr (MODE == 2) b.cur = gload(a.ch, own + (uint32_t)voff);
+    if constexpr (MODE >= 2) b.nin = gload(a.nh_in, own + (uint32_t)voff);
+}
+
+template <int ME, int MODE>
+__device__ __forceinline__ void cell_finish(const CellBatch<ME, MODE> &b, const ColMesh &m, const StageArgs &a, int c,
+                                            uint32_t rowB, int voff, int l, int K)
+{
+    CP<uint32_t> r = cptr(m.cRec) + (size_t)c * m.CI;
+    CP<double> rs = cptr(m.sdv) + (size_t)c * ME;
+    const uint32_t mask = r[2 * ME], all = r[2 * ME + 1];
+    const double invA = cptr(m.invArea)[c];
+    const uint32_t ooff = (uint32_t)c * rowB + (uint32_t)voff;
+    double t = 0.0;
+    if (all) {
+#pragma unroll
+        for (int i = 0; i < ME; ++i)
+            if ((mask >> i) & 1u) t += b.uv[i] * (0.5 * (b.hc + b.hv[i])) * rs[i] * invA;   // Operators.jl:217,
+    } else {                                                                                // DiagnosticVars.jl:165,
+#pragma unroll
+        for (int i = 0; i < ME; ++i)                                                         // horizontal_advection.jl:63
+            if (((mask >> i) & 1u) && l < cptr(m.mltc)[(size_t)c * ME + i]) t += b.uv[i] * (0.5 * (b.hc + b.hv[i])) * rs[i] * invA;
+    }
+    double hs = 0.0;
+    if (l < K) {
+        if constexpr (MODE == 0) gstore(a.tendH, ooff, t);
+        if constexpr (MODE == 1 || MODE == 2) {
+            const double hcur = MODE == 2 ? b.cur : b.hc;
+            hs = hcur + a.a * t;                                       // time_integration.jl:125
+            gstore(a.ph_out, ooff, hs);
+            gstore(a.nh_out, ooff, (MODE == 2 ? b.nin : hcur) + a.b * t);   // :135
+        }
+        if constexpr (MODE == 3) {
+            hs = b.nin + a.b * t;
+            gstore(a.nh_out, ooff, hs);
+        }
+    }
+    if constexpr (MODE != 0) {
+        const double sum = group_sum<64>(hs);
+        if (l == 0) a.ssh_out[c] = sum - cptr(m.rsum)[c];              // time_integration.jl:209 (+N3)
+    }
+}
+
+template <int ME2, int MODE>
+__device__ __forceinline__ void edge_issue(EdgeBatch<ME2, MODE> &b, const ColMesh &m, const StageArgs &a, rsrc_t pu,
+                                           int e, uint32_t rowB, int voff)
+{
+    CP<uint32_t> r = cptr(m.eRec) + (size_t)e * m.EI;
+    const uint32_t own = (uint32_t)e * rowB;
+#pragma unroll
+    for (int i = 0; i < ME2; ++i) b.uv[i] = bload(pu, voff, r[i]);
+    if constexpr (MODE == 1) b.own = bload(pu, voff, own);
+    if constexpr (MODE == 2) b.cur = gload(a.cu, own + (uint32_t)voff);
+    if constexpr (MODE >= 2) b.nin = gload(a.nu_in, own + (uint32_t)voff);
+}
+
+template <int ME2, int MODE>
+__device__ __forceinline__ void edge_finish(const EdgeBatch<ME2, MODE> &b, const ColMesh &m, const StageArgs &a, int e,
+                                            uint32_t rowB, int voff, int l, int K)
+{
+    CP<uint32_t> r = cptr(m.eRec) + (size_t)e * m.EI;
+    CP<double> rw = cptr(m.woe) + (size_t)e * ME2;
+    CP<double> rf = cptr(m.feoe) + (size_t)e * ME2;
+    const uint32_t cA = r[ME2], cB = r[ME2 + 1], mask = r[ME2 + 2];
+    const int mlt = (int)r[ME2 + 3];
+    const double g = cptr(m.gInvDc)[e];
+    const double ds = cptr(a.ssh)[cB] - cptr(a.ssh)[cA];               // ssh[c2] - ssh[c1]
+    const uint32_t ooff = (uint32_t)e * rowB + (uint32_t)voff;
+    double t = 0.0;
+    if (l < mlt) {
+        t -= g * ds;                                                   // pressure_gradient.jl:63
+#pragma unroll
+        for (int i = 0; i < ME2; ++i)
+            if ((mask >> i) & 1u) t += rw[i] * b.uv[i] * rf[i];        // ...coriolis.jl:70-72
+    }
+    if (l < K) {
+        if constexpr (MODE == 0) gstore(a.tendU, ooff, t);
+        if constexpr (MODE == 1) {
+            gstore(a.pu_out, ooff, b.own + a.a * t);                   // time_integration.jl:124
+            gstore(a.nu_out, ooff, b.own + a.b * t);                   // :134
+        }
+        if constexpr (MODE == 2) {
+            gstore(a.pu_out, ooff, b.cur + a.a * t);
+            gstore(a.nu_out, ooff, b.nin + a.b * t);
+        }
+        if constexpr (MODE == 3) gstore(a.nu_out, ooff, b.nin + a.b * t);
+    }
+}
+
+template <int ME, int ME2, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_stage_colp(const ColMesh m, const StageArgs a)
+{
+    const int p = patch_of_block(m.nPatches);
+    if (p >= m.nPatches) return;
+    constexpr int NW = BLOCK / 64;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    const int K = m.K, voff = l * 8;
+    const uint32_t rowB = (uint32_t)K * 8u;
+    const rsrc_t ph = make_rsrc(a.ph, (uint32_t)m.nC * rowB), pu = make_rsrc(a.pu, (uint32_t)m.nE * rowB);
+    {
+        const int c0 = cptr(m.patchCellStart)[p] + wave, c1 = cptr(m.patchCellStart)[p + 1];
+        const int n = c1 > c0 ? (c1 - c0 + NW - 1) / NW : 0;           // tasks of this wave: c0, c0+NW, ...
+        if (n > 0) {
+            CellBatch<ME, MODE> A, B;
+            cell_issue<ME, MODE>(A, m, a, ph, pu, c0, rowB, voff);
+            for (int t = 0;;) {
+                cell_issue<ME, MODE>(B, m, a, ph, pu, c0 + NW * (t + 1 < n ? t + 1 : n - 1), rowB, voff);
+                cell_finish<ME, MODE>(A, m, a, c0 + NW * t, rowB, voff, l, K);
+                if (++t >= n) break;
+                cell_issue<ME, MODE>(A, m, a, ph, pu, c0 + NW * (t + 1 < n ? t + 1 : n - 1), rowB, voff);
+                cell_finish<ME, MODE>(B, m, a, c0 + NW * t, rowB, voff, l, K);
+                if (++t >= n) break;
+            }
+        }
+    }
+    {
+        const int e0 = cptr(m.patchEdgeStart)[p] + wave, e1 = cptr(m.patchEdgeStart)[p + 1];
+        const int n = e1 > e0 ? (e1 - e0 + NW - 1) / NW : 0;
+        if (n > 0) {
+            EdgeBatch<ME2, MODE> A, B;
+            edge_issue<ME2, MODE>(A, m, a, pu, e0, rowB, voff);
+            for (int t = 0;;) {
+                edge_issue<ME2, MODE>(B, m, a, pu, e0 + NW * (t + 1 < n ? t + 1 : n - 1), rowB, voff);
+                edge_finish<ME2, MODE>(A, m, a, e0 + NW * t, rowB, voff, l, K);
+                if (++t >= n) break;
+                edge_issue<ME2, MODE>(A, m, a, pu, e0 + NW * (t + 1 < n ? t + 1 : n - 1), rowB, voff);
+                edge_finish<ME2, MODE>(B, m, a, e0 + NW * t, rowB, voff, l, K);
+                if (++t >= n) break;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS patch-tiled variant of the fused tendency / RK-stage kernel (same arithmetic, same results).
 //
 // The direct kernel above re-reads every u-row ~12 times through the vector L1 (10 Coriolis
@@ -834,11 +999,43 @@ hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream
 #undef CALL
 }
 
-hipError_t launch_stage_col(const MeshDev &md, const StageArgs &a, hipStream_t s)
+template <int ME, int ME2>
+static bool launch_colp(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3 b, hipStream_t s)
+{
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_stage_colp<ME, ME2, 0>), g, b, 0, s, m, a); return true;
+        case 1: hipLaunchKernelGGL((k_stage_colp<ME, ME2, 1>), g, b, 0, s, m, a); return true;
+        case 2: hipLaunchKernelGGL((k_stage_colp<ME, ME2, 2>), g, b, 0, s, m, a); return true;
+        case 3: hipLaunchKernelGGL((k_stage_colp<ME, ME2, 3>), g, b, 0, s, m, a); return true;
+    }
+    return false;
+}
+
+// which pipelined specialisation serves this argument block (-1: none, use the plain column kernel)
+static int colp_mode(const StageArgs &a)
+{
+    const bool outs = a.pu_out || a.ph_out || a.nu_out || a.nh_out;
+    if (a.tendU && a.tendH && !outs && !a.ssh_out) return 0;
+    if (a.tendU || a.tendH) return -1;
+    if (!a.cu && !a.ch && !a.nu_in && !a.nh_in && a.pu_out && a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 1;
+    if (a.cu && a.ch && a.nu_in && a.nh_in && a.pu_out && a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 2;
+    if (a.nu_in && a.nh_in && !a.pu_out && !a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 3;
+    return -1;
+}
+
+hipError_t launch_stage_col(const MeshDev &md, const StageArgs &a, bool pipelined, hipStream_t s)
 {
     const dim3 g(patch_grid(md)), b(BLOCK);
     const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
                     md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
+    const int mode = (pipelined && md.K <= 64) ? colp_mode(a) : -1;
+    if (mode >= 0) {
+        bool ok = false;
+        if (md.ME == 6 && md.ME2 == 10) ok = launch_colp<6, 10>(m, a, mode, g, b, s);
+        else if (md.ME == 8 && md.ME2 == 14) ok = launch_colp<8, 14>(m, a, mode, g, b, s);
+        else if (md.ME <= 6 && md.ME2 <= 14) ok = launch_colp<6, 14>(m, a, mode, g, b, s);
+        if (ok) return hipGetLastError();
+    }
     if (md.ME == 6 && md.ME2 == 10) hipLaunchKernelGGL((k_stage_col<6, 10>), g, b, 0, s, m, a);
     else if (md.ME == 8 && md.ME2 == 14) hipLaunchKernelGGL((k_stage_col<8, 14>), g, b, 0, s, m, a);
     else if (md.ME <= 6 && md.ME2 <= 14) hipLaunchKernelGGL((k_stage_col<6, 14>), g, b, 0, s, m, a);

@@ -127,7 +127,7 @@ def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     tu, th, ossh = om.tendencies_clean(u, h)
     info = Setup.mesh.info()
-    for variant in (1, 2, 3):   # 1 = column kernel (LPC = 64), 2 = LDS patch-tiled, 3 = generic index kernel
+    for variant in (1, 2, 3, 4):   # 1 = pipelined column kernel, 2 = LDS patch-tiled, 3 = generic index kernel, 4 = plain column kernel
         backend.set_kernel_variant(variant)
         Tend.tendNormalVelocity.set(np.full_like(tu, np.nan)); Tend.tendLayerThickness.set(np.full_like(th, np.nan))
         Prog.ssh[-1].set(ssh)
@@ -136,8 +136,8 @@ def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
         assert np.array_equal(Tend.tendLayerThickness.get(), th), variant
         assert np.array_equal(Prog.ssh[-1].get(), ossh), variant
     backend.set_kernel_variant(0)
-    if K % 2 == 0 and K >= 8:
-        assert info["ldsBytesPerBlock"] > 0, "LDS-tiled kernel should be available for even K"
+    if K % 2 == 0 and 8 <= K <= 100 and P == 0:
+        assert info["ldsBytesPerBlock"] > 0, "LDS-tiled kernel should be available for even K at the default patch size"
     Prog._state.close(); Setup.mesh.close()
 
 
