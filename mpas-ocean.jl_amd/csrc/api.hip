@@ -207,6 +207,10 @@ hipError_t run_stage(moka_state *st, const StageArgs &g)
     const int v = st->ctx->variant;
     // 0/1 = pipelined column kernel, 2 = LDS patch-tiled, 3 = generic index kernel, 4 = column kernel without pipelining
     if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(m->dev, g, m->ldsBytes, st->ctx->stream);
+    if ((v == 5 || v == 6) && m->lpc == 64 && m->colOk) {   // 16-byte-lane column kernel: 5 plain, 6 pipelined
+        hipError_t e = launch_stage_colx(m->dev, g, v == 6, st->ctx->stream);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (v != 3 && m->lpc == 64 && m->colOk) return launch_stage_col(m->dev, g, v != 4, st->ctx->stream);
     return launch_stage(m->dev, g, m->lpc, st->ctx->stream);
 }
@@ -310,7 +314,7 @@ int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
 int moka_set_kernel_variant(moka_ctx *ctx, int variant)
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
-    if (variant < 0 || variant > 4) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..4");
+    if (variant < 0 || variant > 6) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..6");
     ctx->variant = variant;
     return MOKA_OK;
 }

@@ -513,6 +513,221 @@ __global__ __launch_bounds__(BLOCK) void k_stage_colp(const ColMesh m, const Sta
 }
 
 // ------------------------------------------------------------------------------------------------
+// Column kernel with 16-byte lanes (K even, K <= 64): rocprof's TCP_TOTAL_CACHE_ACCESSES showed the
+// vector L1 serving the 8-byte-per-lane row gathers at ~32 B per access (17-18 accesses per 480-byte
+// row), i.e. the L1, not HBM, paced the gathers.  Here lanes 0..K/2-1 of the wavefront each own two
+// consecutive levels and read 16 bytes (buffer_load_dwordx4): half the L1 accesses per row.  The
+// upper lanes are masked off; fp64 instruction count doubles (two components) but it is small.
+// Pipelined like k_stage_colp (two entities in flight per wave).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2 bload2(rsrc_t r, int voff, uint32_t soff)
+{
+    return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, (int)soff, 0));
+}
+__device__ __forceinline__ double2 gload2(const double *base, uint32_t off)
+{
+    return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + off);
+}
+__device__ __forceinline__ void gstore2(double *base, uint32_t off, double2 x)
+{
+    *reinterpret_cast<double2 *>(reinterpret_cast<char *>(base) + off) = x;
+}
+
+template <int ME, int MODE>
+struct CellBatch2 {
+    double2 hc, uv[ME], hv[ME], cur, nin;
+};
+template <int ME2, int MODE>
+struct EdgeBatch2 {
+    double2 uv[ME2], own, cur, nin;
+};
+
+template <int ME, int MODE>
+__device__ __forceinline__ void cell_issue2(CellBatch2<ME, MODE> &b, const ColMesh &m, const StageArgs &a, rsrc_t ph,
+                                            rsrc_t pu, int c, uint32_t rowB, int voff)
+{
+    CP<uint32_t> r = cptr(m.cRec) + (size_t)c * m.CI;
+    const uint32_t own = (uint32_t)c * rowB;
+    b.hc = bload2(ph, voff, own);
+#pragma unroll
+    for (int i = 0; i < ME; ++i) {
+        b.uv[i] = bload2(pu, voff, r[i]);
+        b.hv[i] = bload2(ph, voff, r[ME + i]);
+    }
+    if constexpr (MODE == 2) b.cur = gload2(a.ch, own + (uint32_t)voff);
+    if constexpr (MODE >= 2) b.nin = gload2(a.nh_in, own + (uint32_t)voff);
+}
+
+template <int ME, int MODE>
+__device__ __forceinline__ void cell_finish2(const CellBatch2<ME, MODE> &b, const ColMesh &m, const StageArgs &a, int c,
+                                             uint32_t rowB, int voff, int l, int K)
+{
+    CP<uint32_t> r = cptr(m.cRec) + (size_t)c * m.CI;
+    CP<double> rs = cptr(m.sdv) + (size_t)c * ME;
+    const uint32_t mask = r[2 * ME], all = r[2 * ME + 1];
+    const double invA = cptr(m.invArea)[c];
+    const uint32_t ooff = (uint32_t)c * rowB + (uint32_t)voff;
+    const int k0 = 2 * l;
+    double2 t = make_double2(0.0, 0.0);
+    if (all) {
+#pragma unroll
+        for (int i = 0; i < ME; ++i)
+            if ((mask >> i) & 1u) {
+                t.x += b.uv[i].x * (0.5 * (b.hc.x + b.hv[i].x)) * rs[i] * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
+                t.y += b.uv[i].y * (0.5 * (b.hc.y + b.hv[i].y)) * rs[i] * invA;   // horizontal_advection.jl:63
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ME; ++i)
+            if ((mask >> i) & 1u) {
+                const int ml = cptr(m.mltc)[(size_t)c * ME + i];
+                if (k0 < ml) t.x += b.uv[i].x * (0.5 * (b.hc.x + b.hv[i].x)) * rs[i] * invA;
+                if (k0 + 1 < ml) t.y += b.uv[i].y * (0.5 * (b.hc.y + b.hv[i].y)) * rs[i] * invA;
+            }
+    }
+    double2 hs = make_double2(0.0, 0.0);
+    if (k0 < K) {
+        if constexpr (MODE == 0) gstore2(a.tendH, ooff, t);
+        if constexpr (MODE == 1 || MODE == 2) {
+            const double2 hcur = MODE == 2 ? b.cur : b.hc;
+            const double2 nb = MODE == 2 ? b.nin : hcur;
+            hs = make_double2(hcur.x + a.a * t.x, hcur.y + a.a * t.y);                    // time_integration.jl:125
+            gstore2(a.ph_out, ooff, hs);
+            gstore2(a.nh_out, ooff, make_double2(nb.x + a.b * t.x, nb.y + a.b * t.y));    // :135
+        }
+        if constexpr (MODE == 3) {
+            hs = make_double2(b.nin.x + a.b * t.x, b.nin.y + a.b * t.y);
+            gstore2(a.nh_out, ooff, hs);
+        }
+    }
+    if constexpr (MODE != 0) {
+        // oracle_ksum order: lane-xor 16..1 on (even, odd) levels == level-xor 32..2, then level-xor 1
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) {
+            const double ox = __shfl_xor(hs.x, sft, 64), oy = __shfl_xor(hs.y, sft, 64);
+            hs = make_double2(hs.x + ox, hs.y + oy);
+        }
+        if (l == 0) a.ssh_out[c] = (hs.x + hs.y) - cptr(m.rsum)[c];                       // :209 (+N3)
+    }
+}
+
+template <int ME2, int MODE>
+__device__ __forceinline__ void edge_issue2(EdgeBatch2<ME2, MODE> &b, const ColMesh &m, const StageArgs &a, rsrc_t pu,
+                                            int e, uint32_t rowB, int voff)
+{
+    CP<uint32_t> r = cptr(m.eRec) + (size_t)e * m.EI;
+    const uint32_t own = (uint32_t)e * rowB;
+#pragma unroll
+    for (int i = 0; i < ME2; ++i) b.uv[i] = bload2(pu, voff, r[i]);
+    if constexpr (MODE == 1) b.own = bload2(pu, voff, own);
+    if constexpr (MODE == 2) b.cur = gload2(a.cu, own + (uint32_t)voff);
+    if constexpr (MODE >= 2) b.nin = gload2(a.nu_in, own + (uint32_t)voff);
+}
+
+template <int ME2, int MODE>
+__device__ __forceinline__ void edge_finish2(const EdgeBatch2<ME2, MODE> &b, const ColMesh &m, const StageArgs &a, int e,
+                                             uint32_t rowB, int voff, int l, int K)
+{
+    CP<uint32_t> r = cptr(m.eRec) + (size_t)e * m.EI;
+    CP<double> rw = cptr(m.woe) + (size_t)e * ME2;
+    CP<double> rf = cptr(m.feoe) + (size_t)e * ME2;
+    const uint32_t cA = r[ME2], cB = r[ME2 + 1], mask = r[ME2 + 2];
+    const int mlt = (int)r[ME2 + 3];
+    const double g = cptr(m.gInvDc)[e];
+    const double ds = cptr(a.ssh)[cB] - cptr(a.ssh)[cA];               // ssh[c2] - ssh[c1]
+    const uint32_t ooff = (uint32_t)e * rowB + (uint32_t)voff;
+    const int k0 = 2 * l;
+    double2 t = make_double2(0.0, 0.0);
+    if (k0 < mlt) {
+        t.x -= g * ds;                                                 // pressure_gradient.jl:63
+#pragma unroll
+        for (int i = 0; i < ME2; ++i)
+            if ((mask >> i) & 1u) t.x += rw[i] * b.uv[i].x * rf[i];    // ...coriolis.jl:70-72
+    }
+    if (k0 + 1 < mlt) {
+        t.y -= g * ds;
+#pragma unroll
+        for (int i = 0; i < ME2; ++i)
+            if ((mask >> i) & 1u) t.y += rw[i] * b.uv[i].y * rf[i];
+    }
+    if (k0 < K) {
+        if constexpr (MODE == 0) gstore2(a.tendU, ooff, t);
+        if constexpr (MODE == 1) {
+            gstore2(a.pu_out, ooff, make_double2(b.own.x + a.a * t.x, b.own.y + a.a * t.y));   // time_integration.jl:124
+            gstore2(a.nu_out, ooff, make_double2(b.own.x + a.b * t.x, b.own.y + a.b * t.y));   // :134
+        }
+        if constexpr (MODE == 2) {
+            gstore2(a.pu_out, ooff, make_double2(b.cur.x + a.a * t.x, b.cur.y + a.a * t.y));
+            gstore2(a.nu_out, ooff, make_double2(b.nin.x + a.b * t.x, b.nin.y + a.b * t.y));
+        }
+        if constexpr (MODE == 3) gstore2(a.nu_out, ooff, make_double2(b.nin.x + a.b * t.x, b.nin.y + a.b * t.y));
+    }
+}
+
+template <int ME, int ME2, int MODE, bool PIPE>
+__global__ __launch_bounds__(BLOCK) void k_stage_colx(const ColMesh m, const StageArgs a)
+{
+    const int p = patch_of_block(m.nPatches);
+    if (p >= m.nPatches) return;
+    constexpr int NW = BLOCK / 64;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (l >= 32) return;                     // 16-byte lanes: the lower half-wave covers K <= 64 levels
+    const int K = m.K, voff = l * 16;
+    const uint32_t rowB = (uint32_t)K * 8u;
+    const rsrc_t ph = make_rsrc(a.ph, (uint32_t)m.nC * rowB), pu = make_rsrc(a.pu, (uint32_t)m.nE * rowB);
+    {
+        const int c0 = cptr(m.patchCellStart)[p] + wave, c1 = cptr(m.patchCellStart)[p + 1];
+        const int n = c1 > c0 ? (c1 - c0 + NW - 1) / NW : 0;
+        if (n > 0) {
+            if constexpr (PIPE) {
+                CellBatch2<ME, MODE> A, B;
+                cell_issue2<ME, MODE>(A, m, a, ph, pu, c0, rowB, voff);
+                for (int t = 0;;) {
+                    cell_issue2<ME, MODE>(B, m, a, ph, pu, c0 + NW * (t + 1 < n ? t + 1 : n - 1), rowB, voff);
+                    cell_finish2<ME, MODE>(A, m, a, c0 + NW * t, rowB, voff, l, K);
+                    if (++t >= n) break;
+                    cell_issue2<ME, MODE>(A, m, a, ph, pu, c0 + NW * (t + 1 < n ? t + 1 : n - 1), rowB, voff);
+                    cell_finish2<ME, MODE>(B, m, a, c0 + NW * t, rowB, voff, l, K);
+                    if (++t >= n) break;
+                }
+            } else {
+                for (int t = 0; t < n; ++t) {
+                    CellBatch2<ME, MODE> A;
+                    cell_issue2<ME, MODE>(A, m, a, ph, pu, c0 + NW * t, rowB, voff);
+                    cell_finish2<ME, MODE>(A, m, a, c0 + NW * t, rowB, voff, l, K);
+                }
+            }
+        }
+    }
+    {
+        const int e0 = cptr(m.patchEdgeStart)[p] + wave, e1 = cptr(m.patchEdgeStart)[p + 1];
+        const int n = e1 > e0 ? (e1 - e0 + NW - 1) / NW : 0;
+        if (n > 0) {
+            if constexpr (PIPE) {
+                EdgeBatch2<ME2, MODE> A, B;
+                edge_issue2<ME2, MODE>(A, m, a, pu, e0, rowB, voff);
+                for (int t = 0;;) {
+                    edge_issue2<ME2, MODE>(B, m, a, pu, e0 + NW * (t + 1 < n ? t + 1 : n - 1), rowB, voff);
+                    edge_finish2<ME2, MODE>(A, m, a, e0 + NW * t, rowB, voff, l, K);
+                    if (++t >= n) break;
+                    edge_issue2<ME2, MODE>(A, m, a, pu, e0 + NW * (t + 1 < n ? t + 1 : n - 1), rowB, voff);
+                    edge_finish2<ME2, MODE>(B, m, a, e0 + NW * t, rowB, voff, l, K);
+                    if (++t >= n) break;
+                }
+            } else {
+                for (int t = 0; t < n; ++t) {
+                    EdgeBatch2<ME2, MODE> A;
+                    edge_issue2<ME2, MODE>(A, m, a, pu, e0 + NW * t, rowB, voff);
+                    edge_finish2<ME2, MODE>(A, m, a, e0 + NW * t, rowB, voff, l, K);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS patch-tiled variant of the fused tendency / RK-stage kernel (same arithmetic, same results).
 //
 // The direct kernel above re-reads every u-row ~12 times through the vector L1 (10 Coriolis
@@ -1011,6 +1226,18 @@ static bool launch_colp(const ColMesh &m, const StageArgs &a, int mode, dim3 g, 
     return false;
 }
 
+template <int ME, int ME2, bool PIPE>
+static bool launch_colx(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3 b, hipStream_t s)
+{
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_stage_colx<ME, ME2, 0, PIPE>), g, b, 0, s, m, a); return true;
+        case 1: hipLaunchKernelGGL((k_stage_colx<ME, ME2, 1, PIPE>), g, b, 0, s, m, a); return true;
+        case 2: hipLaunchKernelGGL((k_stage_colx<ME, ME2, 2, PIPE>), g, b, 0, s, m, a); return true;
+        case 3: hipLaunchKernelGGL((k_stage_colx<ME, ME2, 3, PIPE>), g, b, 0, s, m, a); return true;
+    }
+    return false;
+}
+
 // which pipelined specialisation serves this argument block (-1: none, use the plain column kernel)
 static int colp_mode(const StageArgs &a)
 {
@@ -1021,6 +1248,26 @@ static int colp_mode(const StageArgs &a)
     if (a.cu && a.ch && a.nu_in && a.nh_in && a.pu_out && a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 2;
     if (a.nu_in && a.nh_in && !a.pu_out && !a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 3;
     return -1;
+}
+
+hipError_t launch_stage_colx(const MeshDev &md, const StageArgs &a, bool pipelined, hipStream_t s)
+{
+    const dim3 g(patch_grid(md)), b(BLOCK);
+    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
+    const int mode = colp_mode(a);
+    if (mode < 0 || md.K > 64 || (md.K & 1)) return hipErrorNotSupported;
+    bool ok = false;
+    if (pipelined) {
+        if (md.ME == 6 && md.ME2 == 10) ok = launch_colx<6, 10, true>(m, a, mode, g, b, s);
+        else if (md.ME == 8 && md.ME2 == 14) ok = launch_colx<8, 14, true>(m, a, mode, g, b, s);
+        else if (md.ME <= 6 && md.ME2 <= 14) ok = launch_colx<6, 14, true>(m, a, mode, g, b, s);
+    } else {
+        if (md.ME == 6 && md.ME2 == 10) ok = launch_colx<6, 10, false>(m, a, mode, g, b, s);
+        else if (md.ME == 8 && md.ME2 == 14) ok = launch_colx<8, 14, false>(m, a, mode, g, b, s);
+        else if (md.ME <= 6 && md.ME2 <= 14) ok = launch_colx<6, 14, false>(m, a, mode, g, b, s);
+    }
+    return ok ? hipGetLastError() : hipErrorNotSupported;
 }
 
 hipError_t launch_stage_col(const MeshDev &md, const StageArgs &a, bool pipelined, hipStream_t s)
