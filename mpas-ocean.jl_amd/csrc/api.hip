@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -201,8 +202,11 @@ FeArgs fe_args(moka_state *st, int ops, int flags, double dt)
 }
 
 // variant 0 (auto): LDS-tiled kernel when it fits two workgroups per CU, else the direct kernel
-hipError_t run_stage(moka_state *st, const StageArgs &g)
+hipError_t run_stage(moka_state *st, const StageArgs &g_in)
 {
+    StageArgs g = g_in;
+    static const int dbg = [] { const char *e = std::getenv("MOKA_DBG"); return e ? std::atoi(e) : 0; }();
+    g.dbg = dbg;   // diagnostics only; 0 in normal operation
     const moka_mesh *m = st->mesh;
     const int v = st->ctx->variant;
     // 0/1 = pipelined column kernel, 2 = LDS patch-tiled, 3 = generic index kernel, 4 = column kernel without pipelining

@@ -247,6 +247,10 @@ __global__ __launch_bounds__(BLOCK) void k_stage_col(const ColMesh m, const Stag
                 co[i] = r[ME + i];
                 sd[i] = rs[i];
             }
+            if (a.dbg & 2) {
+#pragma unroll
+                for (int i = 0; i < ME; ++i) { eo[i] = (uint32_t)c * rowB; co[i] = (uint32_t)c * rowB; }
+            }
             const uint32_t mask = r[2 * ME], all = r[2 * ME + 1];
             const double invA = cptr(m.invArea)[c];
             const uint32_t own = (uint32_t)c * rowB;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(BLOCK) void k_stage_col(const ColMesh m, const Stag
                             t += uv[i] * (0.5 * (hc + hv[i])) * sd[i] * invA;
                 }
                 double hs = 0.0;
-                if (k < K) {
+                if (k < K && !((a.dbg & 1) && t != 12345.678)) {
                     if (a.tendH) gstore(a.tendH, ooff, t);
                     double hcur = hc;
                     if (a.ch) hcur = gload(a.ch, ooff);
@@ -303,9 +307,10 @@ __global__ __launch_bounds__(BLOCK) void k_stage_col(const ColMesh m, const Stag
     {
         const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
         for (int e = e0 + wave; e < e1; e += BLOCK / 64) {
-            CP<uint32_t> r = cptr(m.eRec) + (size_t)e * m.EI;
-            CP<double> rw = cptr(m.woe) + (size_t)e * ME2;
-            CP<double> rf = cptr(m.feoe) + (size_t)e * ME2;
+            const size_t er = (a.dbg & 4) ? (size_t)(e & 3) : (size_t)e;
+            CP<uint32_t> r = cptr(m.eRec) + er * m.EI;
+            CP<double> rw = cptr(m.woe) + er * ME2;
+            CP<double> rf = cptr(m.feoe) + er * ME2;
             uint32_t xo[ME2];
             double wi[ME2], fi[ME2];
 #pragma unroll
@@ -313,6 +318,10 @@ __global__ __launch_bounds__(BLOCK) void k_stage_col(const ColMesh m, const Stag
                 xo[i] = r[i];
                 wi[i] = rw[i];
                 fi[i] = rf[i];
+            }
+            if (a.dbg & 2) {
+#pragma unroll
+                for (int i = 0; i < ME2; ++i) xo[i] = (uint32_t)e * rowB;
             }
             const uint32_t cA = r[ME2], cB = r[ME2 + 1], mask = r[ME2 + 2];
             const int mlt = (int)r[ME2 + 3];
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(BLOCK) void k_stage_col(const ColMesh m, const Stag
                     for (int i = 0; i < ME2; ++i)
                         if ((mask >> i) & 1u) t += wi[i] * uv[i] * fi[i];   // ...coriolis.jl:70-72
                 }
-                if (k < K) {
+                if (k < K && !((a.dbg & 1) && t != 12345.678)) {
                     if (a.tendU) gstore(a.tendU, ooff, t);
                     const double ucur = gload(a.cu ? a.cu : a.pu, ooff);
                     if (a.pu_out) gstore(a.pu_out, ooff, ucur + a.a * t);   // time_integration.jl:124

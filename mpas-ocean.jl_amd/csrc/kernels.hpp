@@ -17,6 +17,7 @@ struct StageArgs {
     double *ssh_out;              // ssh of ph_out (or of nh_out when ph_out == NULL)
     double *tendU, *tendH;        // tendencies
     double a, b;
+    int dbg;                      // diagnostics only (MOKA_DBG): 1 no stores, 2 gathers read the own row, 4 constant records
 };
 
 // the slice of MeshDev the column kernel reads (kept small: kernel arguments live in SGPRs)
