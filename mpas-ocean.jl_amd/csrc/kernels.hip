@@ -737,6 +737,222 @@ __global__ __launch_bounds__(BLOCK) void k_stage_colx(const ColMesh m, const Sta
 }
 
 // ------------------------------------------------------------------------------------------------
+// Record-staged column kernel ("rec"): the default for 33 <= K <= 64.
+//
+// Ablation (MOKA_DBG on the plain column kernel, profiles/r01_ablation.txt) showed that neither the
+// neighbour gathers nor the stores set the time: with every gather redirected to the entity's own
+// (L1-hot) row the kernel was just as slow.  What each wave waited for, once per entity and with
+// nothing else of its own in flight, was the *scalar load of the entity's connectivity record*: a
+// cold, never-reused stream (~840 MB per evaluation) that misses the scalar cache and pays a full
+// HBM round trip (~2.8 us per entity per wave).
+// Here a workgroup first copies the records of its whole patch (contiguous ranges of eRec / woe /
+// feoe / gInvDc / cRec / sdv / invArea / rsum: ~27 KB for 32 cells) into LDS with coalesced vector
+// loads -- one round trip per patch instead of one per entity -- and each wave then reads its
+// entity's offsets and weights from LDS (broadcast reads).  Row gathers are software-pipelined two
+// entities deep per wave (register sets A/B, counted vmcnt), ssh[c1], ssh[c2] ride in the same batch.
+// ------------------------------------------------------------------------------------------------
+struct RecLds {
+    uint32_t *eRec, *cRec;
+    double *woe, *feoe, *g, *sdv, *invA, *rsum;
+};
+
+__device__ __forceinline__ RecLds rec_carve(unsigned char *smem, const ColMesh &m, int ME, int ME2, int maxOwnE, int maxOwnC)
+{
+    RecLds L;
+    L.woe = reinterpret_cast<double *>(smem);
+    L.feoe = L.woe + (size_t)maxOwnE * ME2;
+    L.g = L.feoe + (size_t)maxOwnE * ME2;
+    L.sdv = L.g + maxOwnE;
+    L.invA = L.sdv + (size_t)maxOwnC * ME;
+    L.rsum = L.invA + maxOwnC;
+    L.eRec = reinterpret_cast<uint32_t *>(L.rsum + maxOwnC);
+    L.cRec = L.eRec + (size_t)maxOwnE * m.EI;
+    return L;
+}
+
+template <int ME, int MODE>
+struct RCell {
+    double hc, uv[ME], hv[ME], cur, nin;
+};
+template <int ME2, int MODE>
+struct REdge {
+    double uv[ME2], sA, sB, own, cur, nin;
+};
+
+template <int ME, int MODE>
+__device__ __forceinline__ void rcell_issue(RCell<ME, MODE> &b, const RecLds &L, const ColMesh &m, const StageArgs &a,
+                                            int ci, int c, uint32_t rowB, uint32_t voff)
+{
+    const uint32_t *r = L.cRec + (size_t)ci * m.CI;
+    const uint32_t own = (uint32_t)c * rowB + voff;
+    b.hc = gload(a.ph, own);
+#pragma unroll
+    for (int i = 0; i < ME; ++i) {
+        b.uv[i] = gload(a.pu, r[i] + voff);
+        b.hv[i] = gload(a.ph, r[ME + i] + voff);
+    }
+    if constexpr (MODE == 2) b.cur = gload(a.ch, own);
+    if constexpr (MODE >= 2) b.nin = gload(a.nh_in, own);
+}
+
+template <int ME, int MODE>
+__device__ __forceinline__ void rcell_finish(const RCell<ME, MODE> &b, const RecLds &L, const ColMesh &m, const StageArgs &a,
+                                             int ci, int c, uint32_t rowB, uint32_t voff, int l, int K)
+{
+    const uint32_t *r = L.cRec + (size_t)ci * m.CI;
+    const double *rs = L.sdv + (size_t)ci * ME;
+    const uint32_t mask = __builtin_amdgcn_readfirstlane(r[2 * ME]), all = __builtin_amdgcn_readfirstlane(r[2 * ME + 1]);
+    const double invA = L.invA[ci];
+    const uint32_t ooff = (uint32_t)c * rowB + voff;
+    double t = 0.0;
+    if (all) {
+#pragma unroll
+        for (int i = 0; i < ME; ++i)
+            if ((mask >> i) & 1u) t += b.uv[i] * (0.5 * (b.hc + b.hv[i])) * rs[i] * invA;   // Operators.jl:217,
+    } else {                                                                                // DiagnosticVars.jl:165,
+#pragma unroll
+        for (int i = 0; i < ME; ++i)                                                         // horizontal_advection.jl:63
+            if (((mask >> i) & 1u) && l < cptr(m.mltc)[(size_t)c * ME + i]) t += b.uv[i] * (0.5 * (b.hc + b.hv[i])) * rs[i] * invA;
+    }
+    double hs = 0.0;
+    if (l < K) {
+        if constexpr (MODE == 0) gstore(a.tendH, ooff, t);
+        if constexpr (MODE == 1 || MODE == 2) {
+            const double hcur = MODE == 2 ? b.cur : b.hc;
+            hs = hcur + a.a * t;                                       // time_integration.jl:125
+            gstore(a.ph_out, ooff, hs);
+            gstore(a.nh_out, ooff, (MODE == 2 ? b.nin : hcur) + a.b * t);   // :135
+        }
+        if constexpr (MODE == 3) {
+            hs = b.nin + a.b * t;
+            gstore(a.nh_out, ooff, hs);
+        }
+    }
+    if constexpr (MODE != 0) {
+        const double sum = group_sum<64>(hs);
+        if (l == 0) a.ssh_out[c] = sum - L.rsum[ci];                   // time_integration.jl:209 (+N3)
+    }
+}
+
+template <int ME2, int MODE>
+__device__ __forceinline__ void redge_issue(REdge<ME2, MODE> &b, const RecLds &L, const ColMesh &m, const StageArgs &a,
+                                            int ei, int e, uint32_t rowB, uint32_t voff)
+{
+    const uint32_t *r = L.eRec + (size_t)ei * m.EI;
+    const uint32_t own = (uint32_t)e * rowB + voff;
+#pragma unroll
+    for (int i = 0; i < ME2; ++i) b.uv[i] = gload(a.pu, r[i] + voff);
+    b.sA = a.ssh[r[ME2]];
+    b.sB = a.ssh[r[ME2 + 1]];
+    if constexpr (MODE == 1) b.own = gload(a.pu, own);
+    if constexpr (MODE == 2) b.cur = gload(a.cu, own);
+    if constexpr (MODE >= 2) b.nin = gload(a.nu_in, own);
+}
+
+template <int ME2, int MODE>
+__device__ __forceinline__ void redge_finish(const REdge<ME2, MODE> &b, const RecLds &L, const ColMesh &m, const StageArgs &a,
+                                             int ei, int e, uint32_t rowB, uint32_t voff, int l, int K)
+{
+    const uint32_t *r = L.eRec + (size_t)ei * m.EI;
+    const double *rw = L.woe + (size_t)ei * ME2;
+    const double *rf = L.feoe + (size_t)ei * ME2;
+    const uint32_t mask = __builtin_amdgcn_readfirstlane(r[ME2 + 2]);
+    const int mlt = (int)r[ME2 + 3];
+    const double g = L.g[ei];
+    const double ds = b.sB - b.sA;                                     // ssh[c2] - ssh[c1]
+    const uint32_t ooff = (uint32_t)e * rowB + voff;
+    double t = 0.0;
+    if (l < mlt) {
+        t -= g * ds;                                                   // pressure_gradient.jl:63
+#pragma unroll
+        for (int i = 0; i < ME2; ++i)
+            if ((mask >> i) & 1u) t += rw[i] * b.uv[i] * rf[i];        // ...coriolis.jl:70-72
+    }
+    if (l < K) {
+        if constexpr (MODE == 0) gstore(a.tendU, ooff, t);
+        if constexpr (MODE == 1) {
+            gstore(a.pu_out, ooff, b.own + a.a * t);                   // time_integration.jl:124
+            gstore(a.nu_out, ooff, b.own + a.b * t);                   // :134
+        }
+        if constexpr (MODE == 2) {
+            gstore(a.pu_out, ooff, b.cur + a.a * t);
+            gstore(a.nu_out, ooff, b.nin + a.b * t);
+        }
+        if constexpr (MODE == 3) gstore(a.nu_out, ooff, b.nin + a.b * t);
+    }
+}
+
+template <int ME, int ME2, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_stage_rec(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int p = patch_of_block(m.nPatches);
+    if (p >= m.nPatches) return;
+    constexpr int NW = BLOCK / 64;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+    const int K = m.K;
+    const uint32_t voff = (uint32_t)l * 8u, rowB = (uint32_t)K * 8u;
+    const RecLds L = rec_carve(smem, m, ME, ME2, maxOwnE, maxOwnC);
+    const int c0 = cptr(m.patchCellStart)[p], c1 = cptr(m.patchCellStart)[p + 1];
+    const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
+    const int nOwnC = c1 - c0, nOwnE = e1 - e0;
+
+    // ---- 1. the patch's records: contiguous ranges -> coalesced copies, one round trip per patch ----
+    for (int i = tid; i < nOwnE * m.EI; i += BLOCK) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
+    for (int i = tid; i < nOwnE * ME2; i += BLOCK) {
+        L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
+        L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
+    }
+    for (int i = tid; i < nOwnE; i += BLOCK) L.g[i] = m.gInvDc[e0 + i];
+    for (int i = tid; i < nOwnC * m.CI; i += BLOCK) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
+    for (int i = tid; i < nOwnC * ME; i += BLOCK) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
+    for (int i = tid; i < nOwnC; i += BLOCK) {
+        L.invA[i] = m.invArea[c0 + i];
+        L.rsum[i] = m.rsum[c0 + i];
+    }
+    __syncthreads();
+
+    // ---- 2. cells, two in flight per wave ----
+    {
+        const int n = nOwnC > wave ? (nOwnC - wave + NW - 1) / NW : 0;   // local ids wave, wave+NW, ...
+        if (n > 0) {
+            RCell<ME, MODE> A, B;
+            rcell_issue<ME, MODE>(A, L, m, a, wave, c0 + wave, rowB, voff);
+            for (int t = 0;;) {
+                int nx = wave + NW * (t + 1 < n ? t + 1 : n - 1);
+                rcell_issue<ME, MODE>(B, L, m, a, nx, c0 + nx, rowB, voff);
+                rcell_finish<ME, MODE>(A, L, m, a, wave + NW * t, c0 + wave + NW * t, rowB, voff, l, K);
+                if (++t >= n) break;
+                nx = wave + NW * (t + 1 < n ? t + 1 : n - 1);
+                rcell_issue<ME, MODE>(A, L, m, a, nx, c0 + nx, rowB, voff);
+                rcell_finish<ME, MODE>(B, L, m, a, wave + NW * t, c0 + wave + NW * t, rowB, voff, l, K);
+                if (++t >= n) break;
+            }
+        }
+    }
+    // ---- 3. edges, two in flight per wave ----
+    {
+        const int n = nOwnE > wave ? (nOwnE - wave + NW - 1) / NW : 0;
+        if (n > 0) {
+            REdge<ME2, MODE> A, B;
+            redge_issue<ME2, MODE>(A, L, m, a, wave, e0 + wave, rowB, voff);
+            for (int t = 0;;) {
+                int nx = wave + NW * (t + 1 < n ? t + 1 : n - 1);
+                redge_issue<ME2, MODE>(B, L, m, a, nx, e0 + nx, rowB, voff);
+                redge_finish<ME2, MODE>(A, L, m, a, wave + NW * t, e0 + wave + NW * t, rowB, voff, l, K);
+                if (++t >= n) break;
+                nx = wave + NW * (t + 1 < n ? t + 1 : n - 1);
+                redge_issue<ME2, MODE>(A, L, m, a, nx, e0 + nx, rowB, voff);
+                redge_finish<ME2, MODE>(B, L, m, a, wave + NW * t, e0 + wave + NW * t, rowB, voff, l, K);
+                if (++t >= n) break;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS patch-tiled variant of the fused tendency / RK-stage kernel (same arithmetic, same results).
 //
 // The direct kernel above re-reads every u-row ~12 times through the vector L1 (10 Coriolis
@@ -1257,6 +1473,39 @@ static int colp_mode(const StageArgs &a)
     if (a.cu && a.ch && a.nu_in && a.nh_in && a.pu_out && a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 2;
     if (a.nu_in && a.nh_in && !a.pu_out && !a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 3;
     return -1;
+}
+
+template <int ME, int ME2>
+static bool launch_rec(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3 b, size_t lds, int mE, int mC, hipStream_t s)
+{
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_stage_rec<ME, ME2, 0>), g, b, lds, s, m, a, mE, mC); return true;
+        case 1: hipLaunchKernelGGL((k_stage_rec<ME, ME2, 1>), g, b, lds, s, m, a, mE, mC); return true;
+        case 2: hipLaunchKernelGGL((k_stage_rec<ME, ME2, 2>), g, b, lds, s, m, a, mE, mC); return true;
+        case 3: hipLaunchKernelGGL((k_stage_rec<ME, ME2, 3>), g, b, lds, s, m, a, mE, mC); return true;
+    }
+    return false;
+}
+
+size_t rec_lds_bytes(const MeshDev &md)
+{
+    return (size_t)md.maxOwnE * (2 * md.ME2 + 1) * 8 + (size_t)md.maxOwnC * (md.ME + 2) * 8 +
+           ((size_t)md.maxOwnE * md.EI + (size_t)md.maxOwnC * md.CI) * 4 + 16;
+}
+
+hipError_t launch_stage_rec(const MeshDev &md, const StageArgs &a, hipStream_t s)
+{
+    const dim3 g(patch_grid(md)), b(BLOCK);
+    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
+    const int mode = colp_mode(a);
+    const size_t lds = rec_lds_bytes(md);
+    if (mode < 0 || md.K > 64 || lds > 64 * 1024) return hipErrorNotSupported;
+    bool ok = false;
+    if (md.ME == 6 && md.ME2 == 10) ok = launch_rec<6, 10>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    else if (md.ME == 8 && md.ME2 == 14) ok = launch_rec<8, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    else if (md.ME <= 6 && md.ME2 <= 14) ok = launch_rec<6, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    return ok ? hipGetLastError() : hipErrorNotSupported;
 }
 
 hipError_t launch_stage_colx(const MeshDev &md, const StageArgs &a, bool pipelined, hipStream_t s)
