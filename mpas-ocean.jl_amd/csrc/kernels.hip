@@ -786,10 +786,18 @@ __device__ __forceinline__ void rcell_issue(RCell<ME, MODE> &b, const RecLds &L,
     const uint32_t *r = L.cRec + (size_t)ci * m.CI;
     const uint32_t own = (uint32_t)c * rowB + voff;
     b.hc = gload(a.ph, own);
+    if (a.dbg & 8) {
 #pragma unroll
-    for (int i = 0; i < ME; ++i) {
-        b.uv[i] = gload(a.pu, r[i] + voff);
-        b.hv[i] = gload(a.ph, r[ME + i] + voff);
+        for (int i = 0; i < ME; ++i) {
+            b.uv[i] = (i & 1) ? 1.0 : gload(a.pu, r[i] + voff);
+            b.hv[i] = (i & 1) ? 1.0 : gload(a.ph, r[ME + i] + voff);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ME; ++i) {
+            b.uv[i] = gload(a.pu, r[i] + voff);
+            b.hv[i] = gload(a.ph, r[ME + i] + voff);
+        }
     }
     if constexpr (MODE == 2) b.cur = gload(a.ch, own);
     if constexpr (MODE >= 2) b.nin = gload(a.nh_in, own);
@@ -840,8 +848,13 @@ __device__ __forceinline__ void redge_issue(REdge<ME2, MODE> &b, const RecLds &L
 {
     const uint32_t *r = L.eRec + (size_t)ei * m.EI;
     const uint32_t own = (uint32_t)e * rowB + voff;
+    if (a.dbg & 8) {   // diagnostics: issue only half of the gathers (results are wrong, timing only)
 #pragma unroll
-    for (int i = 0; i < ME2; ++i) b.uv[i] = gload(a.pu, r[i] + voff);
+        for (int i = 0; i < ME2; ++i) b.uv[i] = (i & 1) ? 1.0 : gload(a.pu, r[i] + voff);
+    } else {
+#pragma unroll
+        for (int i = 0; i < ME2; ++i) b.uv[i] = gload(a.pu, r[i] + voff);
+    }
     b.sA = a.ssh[r[ME2]];
     b.sB = a.ssh[r[ME2 + 1]];
     if constexpr (MODE == 1) b.own = gload(a.pu, own);
