@@ -211,7 +211,11 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in)
     const int v = st->ctx->variant;
     // 0/1 = pipelined column kernel, 2 = LDS patch-tiled, 3 = generic index kernel, 4 = column kernel without pipelining
     if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(m->dev, g, m->ldsBytes, st->ctx->stream);
-    if ((v == 0 || v == 7) && m->lpc == 64 && m->colOk) {   // record-staged pipelined column kernel (default)
+    if ((v == 0 || v == 8) && m->lpc == 64 && m->colOk) {   // record-staged, 16-byte lanes, two entities per wave (default)
+        hipError_t e = launch_stage_rec2(m->dev, g, st->ctx->stream);
+        if (e != hipErrorNotSupported) return e;
+    }
+    if ((v == 0 || v == 7) && m->lpc == 64 && m->colOk) {   // record-staged pipelined column kernel
         hipError_t e = launch_stage_rec(m->dev, g, st->ctx->stream);
         if (e != hipErrorNotSupported) return e;
     }
@@ -322,7 +326,7 @@ int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
 int moka_set_kernel_variant(moka_ctx *ctx, int variant)
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
-    if (variant < 0 || variant > 7) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..7");
+    if (variant < 0 || variant > 8) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..8");
     ctx->variant = variant;
     return MOKA_OK;
 }

@@ -966,6 +966,211 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec(const ColMesh m, const Stag
 }
 
 // ------------------------------------------------------------------------------------------------
+// Record-staged column kernel with 16-byte lanes and two entities per wavefront ("rec2").
+//
+// Measured on k_stage_rec (profiles/r01_ablation.txt): TA_BUSY 86 % of the kernel, and removing
+// half of the row gathers removed 0.65 ms = 16 cycles per wave-level load per CU: the texture
+// address path moves 4 lanes per cycle whatever their width, so an 8-byte-per-lane row read costs
+// the same 16 cycles as a 16-byte-per-lane one.  Here each 32-lane half-wave owns one entity and
+// each lane two consecutive levels (K even, K <= 64): every vector memory instruction moves two
+// 480-byte rows (1 KiB) in those 16 cycles -- twice the bytes per TA cycle, for loads and stores.
+// Records still come from LDS (per-half broadcast reads), gathers are pipelined two deep.
+// ------------------------------------------------------------------------------------------------
+template <int ME, int MODE>
+struct R2Cell {
+    double2 hc, uv[ME], hv[ME], cur, nin;
+};
+template <int ME2, int MODE>
+struct R2Edge {
+    double2 uv[ME2], own, cur, nin;
+    double sA, sB;
+};
+
+template <int ME, int MODE>
+__device__ __forceinline__ void r2cell_issue(R2Cell<ME, MODE> &b, const RecLds &L, const ColMesh &m, const StageArgs &a,
+                                             int ci, int c, uint32_t rowB, uint32_t voff)
+{
+    const uint32_t *r = L.cRec + (size_t)ci * m.CI;
+    const uint32_t own = (uint32_t)c * rowB + voff;
+    b.hc = gload2(a.ph, own);
+#pragma unroll
+    for (int i = 0; i < ME; ++i) {
+        b.uv[i] = gload2(a.pu, r[i] + voff);
+        b.hv[i] = gload2(a.ph, r[ME + i] + voff);
+    }
+    if constexpr (MODE == 2) b.cur = gload2(a.ch, own);
+    if constexpr (MODE >= 2) b.nin = gload2(a.nh_in, own);
+}
+
+template <int ME, int MODE>
+__device__ __forceinline__ void r2cell_finish(const R2Cell<ME, MODE> &b, const RecLds &L, const ColMesh &m, const StageArgs &a,
+                                              int ci, int c, uint32_t rowB, uint32_t voff, int l, int K, bool valid)
+{
+    const uint32_t *r = L.cRec + (size_t)ci * m.CI;
+    const double *rs = L.sdv + (size_t)ci * ME;
+    const uint32_t mask = r[2 * ME], all = r[2 * ME + 1];
+    const double invA = L.invA[ci];
+    const uint32_t ooff = (uint32_t)c * rowB + voff;
+    const int k0 = 2 * l;
+    double2 t = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int i = 0; i < ME; ++i) {
+        const int ml = all ? K : cptr(m.mltc)[(size_t)c * ME + i];
+        const bool on = (mask >> i) & 1u;
+        const double dx = b.uv[i].x * (0.5 * (b.hc.x + b.hv[i].x)) * rs[i] * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
+        const double dy = b.uv[i].y * (0.5 * (b.hc.y + b.hv[i].y)) * rs[i] * invA;   // horizontal_advection.jl:63
+        if (on && k0 < ml) t.x += dx;
+        if (on && k0 + 1 < ml) t.y += dy;
+    }
+    double2 hs = make_double2(0.0, 0.0);
+    if (valid && k0 < K) {
+        if constexpr (MODE == 0) gstore2(a.tendH, ooff, t);
+        if constexpr (MODE == 1 || MODE == 2) {
+            const double2 hcur = MODE == 2 ? b.cur : b.hc;
+            const double2 nb = MODE == 2 ? b.nin : hcur;
+            hs = make_double2(hcur.x + a.a * t.x, hcur.y + a.a * t.y);                    // time_integration.jl:125
+            gstore2(a.ph_out, ooff, hs);
+            gstore2(a.nh_out, ooff, make_double2(nb.x + a.b * t.x, nb.y + a.b * t.y));    // :135
+        }
+        if constexpr (MODE == 3) {
+            hs = make_double2(b.nin.x + a.b * t.x, b.nin.y + a.b * t.y);
+            gstore2(a.nh_out, ooff, hs);
+        }
+    }
+    if constexpr (MODE != 0) {
+        // oracle_ksum order: lane-xor 16..1 on (even, odd) levels == level-xor 32..2, then level-xor 1
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) {
+            const double ox = __shfl_xor(hs.x, sft, 64), oy = __shfl_xor(hs.y, sft, 64);
+            hs = make_double2(hs.x + ox, hs.y + oy);
+        }
+        if (valid && l == 0) a.ssh_out[c] = (hs.x + hs.y) - L.rsum[ci];                   // :209 (+N3)
+    }
+}
+
+template <int ME2, int MODE>
+__device__ __forceinline__ void r2edge_issue(R2Edge<ME2, MODE> &b, const RecLds &L, const ColMesh &m, const StageArgs &a,
+                                             int ei, int e, uint32_t rowB, uint32_t voff)
+{
+    const uint32_t *r = L.eRec + (size_t)ei * m.EI;
+    const uint32_t own = (uint32_t)e * rowB + voff;
+#pragma unroll
+    for (int i = 0; i < ME2; ++i) b.uv[i] = gload2(a.pu, r[i] + voff);
+    b.sA = a.ssh[r[ME2]];
+    b.sB = a.ssh[r[ME2 + 1]];
+    if constexpr (MODE == 1) b.own = gload2(a.pu, own);
+    if constexpr (MODE == 2) b.cur = gload2(a.cu, own);
+    if constexpr (MODE >= 2) b.nin = gload2(a.nu_in, own);
+}
+
+template <int ME2, int MODE>
+__device__ __forceinline__ void r2edge_finish(const R2Edge<ME2, MODE> &b, const RecLds &L, const ColMesh &m, const StageArgs &a,
+                                              int ei, int e, uint32_t rowB, uint32_t voff, int l, int K, bool valid)
+{
+    const uint32_t *r = L.eRec + (size_t)ei * m.EI;
+    const double *rw = L.woe + (size_t)ei * ME2;
+    const double *rf = L.feoe + (size_t)ei * ME2;
+    const uint32_t mask = r[ME2 + 2];
+    const int mlt = (int)r[ME2 + 3];
+    const double g = L.g[ei];
+    const double ds = b.sB - b.sA;                                     // ssh[c2] - ssh[c1]
+    const uint32_t ooff = (uint32_t)e * rowB + voff;
+    const int k0 = 2 * l;
+    const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
+    double2 t = make_double2(0.0, 0.0);
+    if (ax) t.x -= g * ds;                                             // pressure_gradient.jl:63
+    if (ay) t.y -= g * ds;
+#pragma unroll
+    for (int i = 0; i < ME2; ++i) {
+        const bool on = (mask >> i) & 1u;
+        const double px = rw[i] * b.uv[i].x * rf[i], py = rw[i] * b.uv[i].y * rf[i];   // ...coriolis.jl:70-72
+        if (on && ax) t.x += px;
+        if (on && ay) t.y += py;
+    }
+    if (valid && k0 < K) {
+        if constexpr (MODE == 0) gstore2(a.tendU, ooff, t);
+        if constexpr (MODE == 1) {
+            gstore2(a.pu_out, ooff, make_double2(b.own.x + a.a * t.x, b.own.y + a.a * t.y));   // time_integration.jl:124
+            gstore2(a.nu_out, ooff, make_double2(b.own.x + a.b * t.x, b.own.y + a.b * t.y));   // :134
+        }
+        if constexpr (MODE == 2) {
+            gstore2(a.pu_out, ooff, make_double2(b.cur.x + a.a * t.x, b.cur.y + a.a * t.y));
+            gstore2(a.nu_out, ooff, make_double2(b.nin.x + a.b * t.x, b.nin.y + a.b * t.y));
+        }
+        if constexpr (MODE == 3) gstore2(a.nu_out, ooff, make_double2(b.nin.x + a.b * t.x, b.nin.y + a.b * t.y));
+    }
+}
+
+template <int ME, int ME2, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_stage_rec2(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int p = patch_of_block(m.nPatches);
+    if (p >= m.nPatches) return;
+    constexpr int NG = BLOCK / 32;               // 8 half-wave groups
+    const int tid = threadIdx.x;
+    const int grp = tid >> 5, l = tid & 31;
+    const int K = m.K;
+    const uint32_t voff = (uint32_t)l * 16u, rowB = (uint32_t)K * 8u;
+    const RecLds L = rec_carve(smem, m, ME, ME2, maxOwnE, maxOwnC);
+    const int c0 = cptr(m.patchCellStart)[p], c1 = cptr(m.patchCellStart)[p + 1];
+    const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
+    const int nOwnC = c1 - c0, nOwnE = e1 - e0;
+
+    for (int i = tid; i < nOwnE * m.EI; i += BLOCK) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
+    for (int i = tid; i < nOwnE * ME2; i += BLOCK) {
+        L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
+        L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
+    }
+    for (int i = tid; i < nOwnE; i += BLOCK) L.g[i] = m.gInvDc[e0 + i];
+    for (int i = tid; i < nOwnC * m.CI; i += BLOCK) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
+    for (int i = tid; i < nOwnC * ME; i += BLOCK) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
+    for (int i = tid; i < nOwnC; i += BLOCK) {
+        L.invA[i] = m.invArea[c0 + i];
+        L.rsum[i] = m.rsum[c0 + i];
+    }
+    __syncthreads();
+
+    // the two half-waves of a wave run in lockstep: both iterate max(n_lo, n_hi) times, indices clamped
+    {
+        const int n = nOwnC > grp ? (nOwnC - grp + NG - 1) / NG : 0;
+        const int no = __shfl_xor(n, 32, 64);
+        const int nmax = n > no ? n : no;
+        if (nmax > 0) {
+            auto idx = [&](int t) { int tc = t < n ? t : n - 1; return tc < 0 ? 0 : grp + NG * tc; };
+            R2Cell<ME, MODE> A, B;
+            r2cell_issue<ME, MODE>(A, L, m, a, idx(0), c0 + idx(0), rowB, voff);
+            for (int t = 0;;) {
+                r2cell_issue<ME, MODE>(B, L, m, a, idx(t + 1), c0 + idx(t + 1), rowB, voff);
+                r2cell_finish<ME, MODE>(A, L, m, a, idx(t), c0 + idx(t), rowB, voff, l, K, t < n);
+                if (++t >= nmax) break;
+                r2cell_issue<ME, MODE>(A, L, m, a, idx(t + 1), c0 + idx(t + 1), rowB, voff);
+                r2cell_finish<ME, MODE>(B, L, m, a, idx(t), c0 + idx(t), rowB, voff, l, K, t < n);
+                if (++t >= nmax) break;
+            }
+        }
+    }
+    {
+        const int n = nOwnE > grp ? (nOwnE - grp + NG - 1) / NG : 0;
+        const int no = __shfl_xor(n, 32, 64);
+        const int nmax = n > no ? n : no;
+        if (nmax > 0) {
+            auto idx = [&](int t) { int tc = t < n ? t : n - 1; return tc < 0 ? 0 : grp + NG * tc; };
+            R2Edge<ME2, MODE> A, B;
+            r2edge_issue<ME2, MODE>(A, L, m, a, idx(0), e0 + idx(0), rowB, voff);
+            for (int t = 0;;) {
+                r2edge_issue<ME2, MODE>(B, L, m, a, idx(t + 1), e0 + idx(t + 1), rowB, voff);
+                r2edge_finish<ME2, MODE>(A, L, m, a, idx(t), e0 + idx(t), rowB, voff, l, K, t < n);
+                if (++t >= nmax) break;
+                r2edge_issue<ME2, MODE>(A, L, m, a, idx(t + 1), e0 + idx(t + 1), rowB, voff);
+                r2edge_finish<ME2, MODE>(B, L, m, a, idx(t), e0 + idx(t), rowB, voff, l, K, t < n);
+                if (++t >= nmax) break;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS patch-tiled variant of the fused tendency / RK-stage kernel (same arithmetic, same results).
 //
 // The direct kernel above re-reads every u-row ~12 times through the vector L1 (10 Coriolis
@@ -1500,10 +1705,37 @@ static bool launch_rec(const ColMesh &m, const StageArgs &a, int mode, dim3 g, d
     return false;
 }
 
+template <int ME, int ME2>
+static bool launch_rec2(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3 b, size_t lds, int mE, int mC, hipStream_t s)
+{
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_stage_rec2<ME, ME2, 0>), g, b, lds, s, m, a, mE, mC); return true;
+        case 1: hipLaunchKernelGGL((k_stage_rec2<ME, ME2, 1>), g, b, lds, s, m, a, mE, mC); return true;
+        case 2: hipLaunchKernelGGL((k_stage_rec2<ME, ME2, 2>), g, b, lds, s, m, a, mE, mC); return true;
+        case 3: hipLaunchKernelGGL((k_stage_rec2<ME, ME2, 3>), g, b, lds, s, m, a, mE, mC); return true;
+    }
+    return false;
+}
+
 size_t rec_lds_bytes(const MeshDev &md)
 {
     return (size_t)md.maxOwnE * (2 * md.ME2 + 1) * 8 + (size_t)md.maxOwnC * (md.ME + 2) * 8 +
            ((size_t)md.maxOwnE * md.EI + (size_t)md.maxOwnC * md.CI) * 4 + 16;
+}
+
+hipError_t launch_stage_rec2(const MeshDev &md, const StageArgs &a, hipStream_t s)
+{
+    const dim3 g(patch_grid(md)), b(BLOCK);
+    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
+    const int mode = colp_mode(a);
+    const size_t lds = rec_lds_bytes(md);
+    if (mode < 0 || md.K > 64 || (md.K & 1) || lds > 64 * 1024 || md.maxOwnC < 1 || md.maxOwnE < 1) return hipErrorNotSupported;
+    bool ok = false;
+    if (md.ME == 6 && md.ME2 == 10) ok = launch_rec2<6, 10>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    else if (md.ME == 8 && md.ME2 == 14) ok = launch_rec2<8, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    else if (md.ME <= 6 && md.ME2 <= 14) ok = launch_rec2<6, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    return ok ? hipGetLastError() : hipErrorNotSupported;
 }
 
 hipError_t launch_stage_rec(const MeshDev &md, const StageArgs &a, hipStream_t s)

@@ -127,7 +127,7 @@ def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     tu, th, ossh = om.tendencies_clean(u, h)
     info = Setup.mesh.info()
-    for variant in (7, 1, 2, 3, 4, 5, 6):   # 1 pipelined column, 2 LDS patch-tiled, 3 generic index, 4 plain column, 5/6 16-byte-lane column (plain/pipelined)
+    for variant in (8, 7, 1, 2, 3, 4, 5, 6):   # 1 pipelined column, 2 LDS patch-tiled, 3 generic index, 4 plain column, 5/6 16-byte-lane column (plain/pipelined)
         backend.set_kernel_variant(variant)
         Tend.tendNormalVelocity.set(np.full_like(tu, np.nan)); Tend.tendLayerThickness.set(np.full_like(th, np.nan))
         Prog.ssh[-1].set(ssh)
