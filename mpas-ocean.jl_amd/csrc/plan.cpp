@@ -179,12 +179,10 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     p.ME = maxEoC <= 6 ? 6 : (maxEoC <= 8 ? 8 : maxEoC);
     p.ME2 = maxEoE <= 10 ? 10 : (maxEoE <= 14 ? 14 : maxEoE);
     if (p.ME == 8 && p.ME2 < 14) p.ME2 = 14;   // kernels are instantiated for (6,10), (6,14), (8,14)
-    // default patch size: the LDS-tiled stage kernel keeps the u-rows a patch needs (own + halo edges,
-    // ~131 rows for 16 hexagons) in LDS at K*8 bytes each, two workgroups per CU (<= ~72 KB each)
-    {
-        const int K = d->nVertLevels;
-        p.P = d->patch_cells > 0 ? d->patch_cells : (K <= 40 ? 32 : K <= 64 ? 16 : K <= 80 ? 12 : K <= 110 ? 8 : 32);
-    }
+    // default patch size: 32 cells (+ ~96 edges) per workgroup measured best for the record-staged column
+    // kernels (bench sweep 16/24/32/64 in profiles/r01_variants.txt); the LDS-tiled kernel (variant 2) wants
+    // patch_cells = 16 at K = 60 so that two workgroups fit a CU.
+    p.P = d->patch_cells > 0 ? d->patch_cells : 32;
     REQUIRE(p.P <= 4096, "patch_cells too large");
 
     // ---- cell ordering ----

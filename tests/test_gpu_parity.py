@@ -117,7 +117,7 @@ def random_state(mesh, K, seed):
     ("ico16", 60, L.ORDER_RCB, 0), ("ico16", 64, L.ORDER_NONE, 0), ("ico16", 80, L.ORDER_RCB, 0),
     ("ico32", 60, L.ORDER_RCB, 32), ("ico16", 130, L.ORDER_RCB, 64), ("ico32", 60, L.ORDER_RCB, 0),
     ("ico16", 8, L.ORDER_RCB, 0), ("ico16", 34, L.ORDER_RCB, 0), ("ico16", 100, L.ORDER_RCB, 0), ("planar", 60, L.ORDER_RCB, 0),
-    ("ico16", 60, L.ORDER_RCM, 0), ("ico16", 60, L.ORDER_NONE, 24),
+    ("ico16", 60, L.ORDER_RCM, 0), ("ico16", 60, L.ORDER_NONE, 24), ("ico32", 60, L.ORDER_RCB, 16), ("ico16", 62, L.ORDER_RCB, 16),
 ])
 def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     mesh = get_mesh(meshname)
@@ -136,8 +136,8 @@ def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
         assert np.array_equal(Tend.tendLayerThickness.get(), th), variant
         assert np.array_equal(Prog.ssh[-1].get(), ossh), variant
     backend.set_kernel_variant(0)
-    if K % 2 == 0 and 8 <= K <= 100 and P == 0:
-        assert info["ldsBytesPerBlock"] > 0, "LDS-tiled kernel should be available for even K at the default patch size"
+    if K % 2 == 0 and 8 <= K <= 64 and P == 16:
+        assert 0 < info["ldsBytesPerBlock"] <= 80 * 1024, "LDS-tiled kernel should fit two workgroups per CU at P = 16"
     Prog._state.close(); Setup.mesh.close()
 
 
