@@ -87,6 +87,10 @@ typedef struct moka_mesh_desc {
     /* layout controls */
     int32_t ordering;                                /* moka_ordering                            */
     int32_t patch_cells;                             /* cells per patch (0 = library default)    */
+    /* (opt) (nCells) small non-negative class per cell; cells are ordered by class first, then by `ordering`
+     * inside a class.  The multi-GPU layer passes 0 = owned & needed by another rank, 1 = owned interior,
+     * 2 = halo, so that patch ranges [0,pb) / [pb,po) / [po,nPatches) are boundary / interior / halo. */
+    const int32_t *cellClass;
 } moka_mesh_desc;
 
 typedef struct moka_mesh_info {
@@ -199,6 +203,30 @@ int moka_step_rk4(moka_state *st, double dt);
 int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flags);
 /* sumArray                                   src/forward/run_loop.jl:39-51 : sum_j a[j]^2 */
 int moka_sum_sq(moka_state *st, int field, int time_level, double *out);
+
+/* ---- multi-GPU (one process per GPU) --------------------------------------
+ * The mesh handed to moka_mesh_create is the rank's LOCAL mesh: owned cells + a one-cell-deep halo, with
+ * cellClass = 0 (owned, needed by another rank) / 1 (owned interior) / 2 (halo).  The library packs the rows
+ * other ranks need into one device buffer and unpacks received rows; moving the buffers between ranks is the
+ * host layer's job (torch.distributed on RCCL over xGMI in bench.py; gloo in the tests; MPI.jl from Julia).
+ *   buffer layout: [cells x K doubles of layerThickness][cells x 1 double of ssh][edges x K doubles of normalVelocity]
+ * Entity ids are in the caller's (local mesh) numbering. */
+typedef struct moka_halo moka_halo;
+int  moka_ctx_streams(moka_ctx *ctx, void **compute_stream, void **comm_stream);   /* hipStream_t handles */
+int  moka_halo_create(moka_state *st, const int32_t *sendCells, int64_t nSendCells, const int32_t *sendEdges,
+                      int64_t nSendEdges, const int32_t *recvCells, int64_t nRecvCells, const int32_t *recvEdges,
+                      int64_t nRecvEdges, int32_t nPatchesBoundary, int32_t nPatchesOwned, moka_halo **out);
+void moka_halo_destroy(moka_halo *h);
+int  moka_halo_buffer_elems(const moka_halo *h, int64_t *sendElems, int64_t *recvElems);
+/* what: 0 = current time level, 1..4 = output of RK4 stage `what`.  pack runs on the comm stream after the work
+ * already queued on the compute stream; unpack makes later compute-stream work wait for it. */
+int  moka_halo_pack(moka_halo *h, int what, double *sendbuf_device);
+int  moka_halo_unpack(moka_halo *h, int what, const double *recvbuf_device);
+/* distributed form of moka_step_rk4: begin; for stage 1..4 { stage(s,0) boundary patches; pack(s); stage(s,1)
+ * interior patches (overlaps the transport); transport; unpack(s) }; end */
+int  moka_rk4_dist_begin(moka_halo *h, double dt);
+int  moka_rk4_dist_stage(moka_halo *h, int stage, int part);
+int  moka_rk4_dist_end(moka_halo *h);
 
 /* kernel variant selection for measurement: 0 = auto, 1 = software-pipelined column kernel (byte-offset records +
  * buffer loads; nVertLevels in 33..64), 2 = LDS patch-tiled, 3 = generic index kernel (any nVertLevels),

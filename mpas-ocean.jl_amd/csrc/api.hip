@@ -17,7 +17,9 @@ namespace moka { void fill_mesh_info(const Plan &p, moka_mesh_info *info); }
 struct moka_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t comm = nullptr;                       // halo pack / transport / unpack
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evBoundary = nullptr, evInterior = nullptr, evHalo = nullptr;
     int variant = 0;
     std::string err;
 };
@@ -202,29 +204,33 @@ FeArgs fe_args(moka_state *st, int ops, int flags, double dt)
 }
 
 // variant 0 (auto): LDS-tiled kernel when it fits two workgroups per CU, else the direct kernel
-hipError_t run_stage(moka_state *st, const StageArgs &g_in)
+hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int pCount = -1)
 {
     StageArgs g = g_in;
     static const int dbg = [] { const char *e = std::getenv("MOKA_DBG"); return e ? std::atoi(e) : 0; }();
     g.dbg = dbg;   // diagnostics only; 0 in normal operation
     const moka_mesh *m = st->mesh;
+    MeshDev dev = m->dev;                 // the launch covers patches [pBegin, pBegin + pCount)
+    if (pCount >= 0) { dev.patchBegin = pBegin; dev.nPatches = pCount; }
+    if (dev.nPatches <= 0) return hipSuccess;
+    hipStream_t s = st->ctx->stream;
     const int v = st->ctx->variant;
-    // 0/1 = pipelined column kernel, 2 = LDS patch-tiled, 3 = generic index kernel, 4 = column kernel without pipelining
-    if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(m->dev, g, m->ldsBytes, st->ctx->stream);
-    if ((v == 0 || v == 8) && m->lpc == 64 && m->colOk) {   // record-staged, 16-byte lanes, two entities per wave (default)
-        hipError_t e = launch_stage_rec2(m->dev, g, st->ctx->stream);
+    // 0 = auto; 8 rec2 (record-staged, 16-byte lanes, 2 entities/wave), 7 rec, 1 colp, 4 col, 5/6 colx, 2 LDS-tiled, 3 generic
+    if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(dev, g, m->ldsBytes, s);
+    if ((v == 0 || v == 8) && m->lpc == 64 && m->colOk) {
+        hipError_t e = launch_stage_rec2(dev, g, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if ((v == 0 || v == 7) && m->lpc == 64 && m->colOk) {   // record-staged pipelined column kernel
-        hipError_t e = launch_stage_rec(m->dev, g, st->ctx->stream);
+    if ((v == 0 || v == 7) && m->lpc == 64 && m->colOk) {
+        hipError_t e = launch_stage_rec(dev, g, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if ((v == 5 || v == 6) && m->lpc == 64 && m->colOk) {   // 16-byte-lane column kernel: 5 plain, 6 pipelined
-        hipError_t e = launch_stage_colx(m->dev, g, v == 6, st->ctx->stream);
+    if ((v == 5 || v == 6) && m->lpc == 64 && m->colOk) {
+        hipError_t e = launch_stage_colx(dev, g, v == 6, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if (v != 3 && m->lpc == 64 && m->colOk) return launch_stage_col(m->dev, g, v != 4, st->ctx->stream);
-    return launch_stage(m->dev, g, m->lpc, st->ctx->stream);
+    if (v != 3 && m->lpc == 64 && m->colOk) return launch_stage_col(dev, g, v == 1, s);
+    return launch_stage(dev, g, m->lpc, s);
 }
 
 int flush_lazy(moka_state *st, bool diag, bool tend)
@@ -281,6 +287,10 @@ int moka_ctx_create(int device, moka_ctx **out)
     hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     hipError_t e2 = hipEventCreate(&c->ev0);
     hipError_t e3 = hipEventCreate(&c->ev1);
+    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->evBoundary, hipEventDisableTiming);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->evInterior, hipEventDisableTiming);
+    if (e3 == hipSuccess) e3 = hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         delete c;
         return fail(nullptr, MOKA_ERR_HIP, "failed to create stream/events");
@@ -294,6 +304,8 @@ void moka_ctx_destroy(moka_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) { (void)hipStreamSynchronize(ctx->comm); (void)hipStreamDestroy(ctx->comm); }
+    for (hipEvent_t e : {ctx->evBoundary, ctx->evInterior, ctx->evHalo}) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -304,6 +316,15 @@ int moka_sync(moka_ctx *ctx)
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->comm));
+    return MOKA_OK;
+}
+
+int moka_ctx_streams(moka_ctx *ctx, void **compute, void **comm)
+{
+    if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
+    if (compute) *compute = (void *)ctx->stream;
+    if (comm) *comm = (void *)ctx->comm;
     return MOKA_OK;
 }
 
@@ -614,41 +635,66 @@ int moka_step_fe(moka_state *st, double dt, int flags)
     return MOKA_OK;
 }
 
-int moka_step_rk4(moka_state *st, double dt)
+// Argument block of RK4 stage s (1..4).  A = Curr (current level), B = New accumulator (the previous
+// level's buffers, becomes the current level at the end), R1/R2 = provisional states.
+static StageArgs rk4_stage_args(moka_state *st, int s, double dt, const double *ssh0)
 {
-    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
-    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
-    int rc = ensure_rk_bufs(st);
-    if (rc) return rc;
     const double a[3] = {dt / 2., dt / 2., dt};                         // time_integration.jl:77
     const double b[4] = {dt / 6., dt / 3., dt / 3., dt / 6.};           // :78
-    LevelBufs &A = st->lev[1];   // Curr (becomes the previous level)
-    LevelBufs &B = st->lev[0];   // New accumulator (becomes the current level)
-    LevelBufs &R1 = st->rk[0], &R2 = st->rk[1];
-    const double *ssh0 = A.ssh;
-    if (!st->sshConsistent) {    // the tendency of stage 1 uses ssh computed from layerThickness
-        if ((rc = make_ssh_consistent(st, R2.ssh))) return rc;
-        ssh0 = R2.ssh;
-    }
+    LevelBufs &A = st->lev[1], &B = st->lev[0], &R1 = st->rk[0], &R2 = st->rk[1];
     StageArgs g{};
-    // stage 1: Provis == Curr == A;  New = Curr + b1*k1 -> B;  Provis' = Curr + a1*k1 -> R1
-    g.pu = A.u; g.ph = A.h; g.ssh = ssh0; g.cu = nullptr; g.ch = nullptr; g.nu_in = nullptr; g.nh_in = nullptr;
-    g.nu_out = B.u; g.nh_out = B.h; g.pu_out = R1.u; g.ph_out = R1.h; g.ssh_out = R1.ssh; g.a = a[0]; g.b = b[0];
-    HIPCHK(st->ctx, run_stage(st, g));
-    // stage 2: Provis = R1 -> R2
-    g.pu = R1.u; g.ph = R1.h; g.ssh = R1.ssh; g.cu = A.u; g.ch = A.h; g.nu_in = B.u; g.nh_in = B.h;
-    g.pu_out = R2.u; g.ph_out = R2.h; g.ssh_out = R2.ssh; g.a = a[1]; g.b = b[1];
-    HIPCHK(st->ctx, run_stage(st, g));
-    // stage 3: Provis = R2 -> R1
-    g.pu = R2.u; g.ph = R2.h; g.ssh = R2.ssh; g.pu_out = R1.u; g.ph_out = R1.h; g.ssh_out = R1.ssh; g.a = a[2]; g.b = b[2];
-    HIPCHK(st->ctx, run_stage(st, g));
-    // stage 4: Provis = R1; New += b4*k4; ssh of New
-    g.pu = R1.u; g.ph = R1.h; g.ssh = R1.ssh; g.pu_out = nullptr; g.ph_out = nullptr; g.ssh_out = B.ssh; g.a = 0.0; g.b = b[3];
-    HIPCHK(st->ctx, run_stage(st, g));
+    g.nu_out = B.u; g.nh_out = B.h; g.b = b[s - 1];
+    if (s == 1) {          // Provis == Curr == A;  New = Curr + b1*k1 -> B;  Provis' = Curr + a1*k1 -> R1
+        g.pu = A.u; g.ph = A.h; g.ssh = ssh0;
+        g.pu_out = R1.u; g.ph_out = R1.h; g.ssh_out = R1.ssh; g.a = a[0];
+    } else if (s == 2) {   // Provis = R1 -> R2
+        g.pu = R1.u; g.ph = R1.h; g.ssh = R1.ssh; g.cu = A.u; g.ch = A.h; g.nu_in = B.u; g.nh_in = B.h;
+        g.pu_out = R2.u; g.ph_out = R2.h; g.ssh_out = R2.ssh; g.a = a[1];
+    } else if (s == 3) {   // Provis = R2 -> R1
+        g.pu = R2.u; g.ph = R2.h; g.ssh = R2.ssh; g.cu = A.u; g.ch = A.h; g.nu_in = B.u; g.nh_in = B.h;
+        g.pu_out = R1.u; g.ph_out = R1.h; g.ssh_out = R1.ssh; g.a = a[2];
+    } else {               // Provis = R1; New += b4*k4; ssh of New
+        g.pu = R1.u; g.ph = R1.h; g.ssh = R1.ssh; g.cu = A.u; g.ch = A.h; g.nu_in = B.u; g.nh_in = B.h;
+        g.ssh_out = B.ssh; g.a = 0.0;
+    }
+    return g;
+}
+
+// buffers a stage writes that other ranks gather from next: stage 1,3 -> R1; 2 -> R2; 4 -> B; 0 -> current level
+static LevelBufs &rk4_stage_output(moka_state *st, int s)
+{
+    return s == 0 ? st->lev[1] : s == 4 ? st->lev[0] : s == 2 ? st->rk[1] : st->rk[0];
+}
+
+static int rk4_begin(moka_state *st, const double **ssh0)
+{
+    int rc = ensure_rk_bufs(st);
+    if (rc) return rc;
+    *ssh0 = st->lev[1].ssh;
+    if (!st->sshConsistent) {    // the tendency of stage 1 uses ssh computed from layerThickness
+        if ((rc = make_ssh_consistent(st, st->rk[1].ssh))) return rc;
+        *ssh0 = st->rk[1].ssh;
+    }
+    return MOKA_OK;
+}
+
+static void rk4_end(moka_state *st)
+{
     std::swap(st->lev[0], st->lev[1]);
     st->sshConsistent = true;
     st->diagDirty = true;
     st->tendDirty = true;
+}
+
+int moka_step_rk4(moka_state *st, double dt)
+{
+    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    const double *ssh0 = nullptr;
+    int rc = rk4_begin(st, &ssh0);
+    if (rc) return rc;
+    for (int s = 1; s <= 4; ++s) HIPCHK(st->ctx, run_stage(st, rk4_stage_args(st, s, dt, ssh0)));
+    rk4_end(st);
     return MOKA_OK;
 }
 
@@ -679,6 +725,149 @@ int moka_sum_sq(moka_state *st, int field, int time_level, double *out)
     HIPCHK(st->ctx, launch_sum_sq_serial(st->mesh->opBuf[2], r.n * r.K, st->scalar, s));
     HIPCHK(st->ctx, hipMemcpyAsync(out, st->scalar, sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(st->ctx, hipStreamSynchronize(s));
+    return MOKA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU: halo lists + distributed RK4 stages.  Transport between ranks is the
+// host layer's business (torch.distributed on RCCL over xGMI, or gloo in tests): the library packs the rows
+// other ranks need into one contiguous device buffer, and unpacks the rows it receives.
+//   send buffer = [sendCells x K doubles of h][sendCells x 1 double of ssh][sendEdges x K doubles of u]
+// ---------------------------------------------------------------------------------------------
+struct moka_halo {
+    moka_state *st = nullptr;
+    int32_t *sendCells = nullptr, *sendEdges = nullptr, *recvCells = nullptr, *recvEdges = nullptr;   // device numbering
+    int64_t nSendCells = 0, nSendEdges = 0, nRecvCells = 0, nRecvEdges = 0;
+    int32_t pBoundary = 0, pOwned = 0;
+    double dt = 0.0;
+    const double *ssh0 = nullptr;
+};
+
+static int upload_ids(moka_state *st, const int32_t *ids, int64_t n, const std::vector<int32_t> &o2n, int32_t **out)
+{
+    *out = nullptr;
+    if (n <= 0) return MOKA_OK;
+    std::vector<int32_t> dev((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (ids[i] < 0 || (size_t)ids[i] >= o2n.size()) return fail(st->ctx, MOKA_ERR_ARG, "halo list entry out of range");
+        dev[(size_t)i] = o2n[(size_t)ids[i]];
+    }
+    void *d = nullptr;
+    HIPCHK(st->ctx, hipMalloc(&d, (size_t)n * sizeof(int32_t)));
+    st->allocs.push_back(d);
+    HIPCHK(st->ctx, hipMemcpy(d, dev.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    *out = static_cast<int32_t *>(d);
+    return MOKA_OK;
+}
+
+int moka_halo_create(moka_state *st, const int32_t *sendCells, int64_t nSendCells, const int32_t *sendEdges,
+                     int64_t nSendEdges, const int32_t *recvCells, int64_t nRecvCells, const int32_t *recvEdges,
+                     int64_t nRecvEdges, int32_t nPatchesBoundary, int32_t nPatchesOwned, moka_halo **out)
+{
+    if (!st || !out) return fail(st ? st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    const Plan &p = st->mesh->plan;
+    if (nPatchesBoundary < 0 || nPatchesOwned < nPatchesBoundary || nPatchesOwned > p.nPatches)
+        return fail(st->ctx, MOKA_ERR_ARG, "patch ranges must satisfy 0 <= boundary <= owned <= nPatches");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    moka_halo *h = new (std::nothrow) moka_halo();
+    if (!h) return fail(st->ctx, MOKA_ERR_ALLOC, "out of host memory");
+    h->st = st;
+    h->nSendCells = nSendCells; h->nSendEdges = nSendEdges; h->nRecvCells = nRecvCells; h->nRecvEdges = nRecvEdges;
+    h->pBoundary = nPatchesBoundary; h->pOwned = nPatchesOwned;
+    int rc;
+    if ((rc = upload_ids(st, sendCells, nSendCells, p.cellO2N, &h->sendCells)) ||
+        (rc = upload_ids(st, sendEdges, nSendEdges, p.edgeO2N, &h->sendEdges)) ||
+        (rc = upload_ids(st, recvCells, nRecvCells, p.cellO2N, &h->recvCells)) ||
+        (rc = upload_ids(st, recvEdges, nRecvEdges, p.edgeO2N, &h->recvEdges))) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return MOKA_OK;
+}
+
+void moka_halo_destroy(moka_halo *h) { delete h; }
+
+int moka_halo_buffer_elems(const moka_halo *h, int64_t *sendElems, int64_t *recvElems)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    const int K = h->st->mesh->plan.K;
+    if (sendElems) *sendElems = h->nSendCells * (K + 1) + h->nSendEdges * K;
+    if (recvElems) *recvElems = h->nRecvCells * (K + 1) + h->nRecvEdges * K;
+    return MOKA_OK;
+}
+
+// what: 0 = the current time level, 1..4 = the output of RK4 stage `what` (valid between dist_begin and dist_end)
+int moka_halo_pack(moka_halo *h, int what, double *sendbuf)
+{
+    if (!h || (!sendbuf && (h->nSendCells || h->nSendEdges))) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
+    moka_state *st = h->st;
+    moka_ctx *c = st->ctx;
+    const int K = st->mesh->plan.K;
+    HIPCHK(c, hipSetDevice(c->device));
+    const LevelBufs &o = rk4_stage_output(st, what);
+    // the rows to send are produced by the boundary patches (or by whatever last ran on the compute stream)
+    HIPCHK(c, hipEventRecord(c->evBoundary, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm, c->evBoundary, 0));
+    double *bh = sendbuf, *bs = bh + h->nSendCells * K, *bu = bs + h->nSendCells;
+    HIPCHK(c, launch_pack_rows(bh, o.h, h->sendCells, h->nSendCells, K, 0, c->comm));
+    HIPCHK(c, launch_pack_rows(bs, o.ssh, h->sendCells, h->nSendCells, 1, 0, c->comm));
+    HIPCHK(c, launch_pack_rows(bu, o.u, h->sendEdges, h->nSendEdges, K, 0, c->comm));
+    return MOKA_OK;
+}
+
+int moka_halo_unpack(moka_halo *h, int what, const double *recvbuf)
+{
+    if (!h || (!recvbuf && (h->nRecvCells || h->nRecvEdges))) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
+    moka_state *st = h->st;
+    moka_ctx *c = st->ctx;
+    const int K = st->mesh->plan.K;
+    HIPCHK(c, hipSetDevice(c->device));
+    const LevelBufs &o = rk4_stage_output(st, what);
+    // the interior launch may still be writing the (to be overwritten) halo rows of a straddling patch
+    HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
+    const double *bh = recvbuf, *bs = bh + h->nRecvCells * K, *bu = bs + h->nRecvCells;
+    HIPCHK(c, launch_pack_rows(const_cast<double *>(bh), o.h, h->recvCells, h->nRecvCells, K, 1, c->comm));
+    HIPCHK(c, launch_pack_rows(const_cast<double *>(bs), o.ssh, h->recvCells, h->nRecvCells, 1, 1, c->comm));
+    HIPCHK(c, launch_pack_rows(const_cast<double *>(bu), o.u, h->recvEdges, h->nRecvEdges, K, 1, c->comm));
+    HIPCHK(c, hipEventRecord(c->evHalo, c->comm));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evHalo, 0));     // whatever comes next on the compute stream sees the halo
+    return MOKA_OK;
+}
+
+int moka_rk4_dist_begin(moka_halo *h, double dt)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    moka_state *st = h->st;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    int rc = flush_lazy(st, true, true);
+    if (rc) return rc;
+    h->dt = dt;
+    return rk4_begin(st, &h->ssh0);
+}
+
+// part 0: patches [0, boundary) -- their rows are what other ranks need; part 1: [boundary, owned).
+// Halo patches [owned, nPatches) are never computed: their rows arrive through moka_halo_unpack.
+int moka_rk4_dist_stage(moka_halo *h, int stage, int part)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    if (stage < 1 || stage > 4 || part < 0 || part > 1) return fail(h->st->ctx, MOKA_ERR_ARG, "stage must be 1..4, part 0 or 1");
+    moka_state *st = h->st;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    const StageArgs g = rk4_stage_args(st, stage, h->dt, h->ssh0);
+    const int p0 = part == 0 ? 0 : h->pBoundary, cnt = part == 0 ? h->pBoundary : h->pOwned - h->pBoundary;
+    HIPCHK(st->ctx, run_stage(st, g, p0, cnt));
+    return MOKA_OK;
+}
+
+int moka_rk4_dist_end(moka_halo *h)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    rk4_end(h->st);
     return MOKA_OK;
 }
 

@@ -67,8 +67,9 @@ __device__ __forceinline__ int patch_of_block(int nPatches)
 template <int LPC, int ME, int ME2>
 __global__ __launch_bounds__(BLOCK) void k_stage(const MeshDev m, const StageArgs a)
 {
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);      // m.nPatches = patches in this launch
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
     constexpr int NG = BLOCK / LPC;
     const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC);
     const int l = threadIdx.x % LPC;
@@ -225,8 +226,9 @@ __device__ __forceinline__ void gstore(double *base, uint32_t off, double x)
 template <int ME, int ME2>
 __global__ __launch_bounds__(BLOCK) void k_stage_col(const ColMesh m, const StageArgs a)
 {
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);      // m.nPatches = patches in this launch
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l = threadIdx.x & 63;
     const int K = m.K;
@@ -479,8 +481,9 @@ __device__ __forceinline__ void edge_finish(const EdgeBatch<ME2, MODE> &b, const
 template <int ME, int ME2, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_stage_colp(const ColMesh m, const StageArgs a)
 {
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);      // m.nPatches = patches in this launch
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
     constexpr int NW = BLOCK / 64;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l = threadIdx.x & 63;
@@ -677,8 +680,9 @@ __device__ __forceinline__ void edge_finish2(const EdgeBatch2<ME2, MODE> &b, con
 template <int ME, int ME2, int MODE, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void k_stage_colx(const ColMesh m, const StageArgs a)
 {
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);      // m.nPatches = patches in this launch
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
     constexpr int NW = BLOCK / 64;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l = threadIdx.x & 63;
@@ -899,8 +903,9 @@ template <int ME, int ME2, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_stage_rec(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);      // m.nPatches = patches in this launch
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
     constexpr int NW = BLOCK / 64;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1105,8 +1110,9 @@ template <int ME, int ME2, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_stage_rec2(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);      // m.nPatches = patches in this launch
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
     constexpr int NG = BLOCK / 32;               // 8 half-wave groups
     const int tid = threadIdx.x;
     const int grp = tid >> 5, l = tid & 31;
@@ -1196,8 +1202,9 @@ template <int ME, int ME2>
 __global__ __launch_bounds__(LBLOCK, 4) void k_stage_lds(const MeshDev m, const StageArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);      // m.nPatches = patches in this launch
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
     const int K = m.K, K2 = K >> 1;                 // K is even (checked on the host)
     constexpr int NG = LBLOCK / 32;                 // 16 half-wave groups
     const int tid = threadIdx.x, grp = tid >> 5, l = tid & 31;
@@ -1376,8 +1383,9 @@ __global__ __launch_bounds__(LBLOCK, 4) void k_stage_lds(const MeshDev m, const 
 template <int LPC, int ME, int ME2>
 __global__ __launch_bounds__(BLOCK) void k_fe(const MeshDev m, const FeArgs a)
 {
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);      // m.nPatches = patches in this launch
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
     constexpr int NG = BLOCK / LPC;
     const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC);
     const int l = threadIdx.x % LPC;
@@ -1504,8 +1512,9 @@ __global__ __launch_bounds__(BLOCK) void k_fe(const MeshDev m, const FeArgs a)
 template <int LPC>
 __global__ __launch_bounds__(BLOCK) void k_operator(const MeshDev m, const OpArgs a)
 {
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);      // m.nPatches = patches in this launch
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
     constexpr int NG = BLOCK / LPC;
     const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC);
     const int l = threadIdx.x % LPC;
@@ -1605,6 +1614,19 @@ __global__ __launch_bounds__(64) void k_sum_sq_serial(const double *a, int64_t n
         }
     }
     if (lane == 0) *out = sum;
+}
+
+// halo pack (unpack = 0): buf[i][k] = field[rows[i]][k];  unpack: field[rows[i]][k] = buf[i][k]
+__global__ __launch_bounds__(BLOCK) void k_pack_rows(double *buf, double *field, const int32_t *rows, int64_t n, int K, int unpack)
+{
+    const int64_t total = n * K;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+        const int64_t r = i / K;
+        const int k = (int)(i - r * K);
+        const int64_t o = (int64_t)rows[r] * K + k;
+        if (unpack) field[o] = buf[i];
+        else buf[i] = field[o];
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_copy(double *dst, const double *src, int64_t n)
@@ -1726,7 +1748,7 @@ size_t rec_lds_bytes(const MeshDev &md)
 hipError_t launch_stage_rec2(const MeshDev &md, const StageArgs &a, hipStream_t s)
 {
     const dim3 g(patch_grid(md)), b(BLOCK);
-    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
                     md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
     const int mode = colp_mode(a);
     const size_t lds = rec_lds_bytes(md);
@@ -1741,7 +1763,7 @@ hipError_t launch_stage_rec2(const MeshDev &md, const StageArgs &a, hipStream_t 
 hipError_t launch_stage_rec(const MeshDev &md, const StageArgs &a, hipStream_t s)
 {
     const dim3 g(patch_grid(md)), b(BLOCK);
-    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
                     md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
     const int mode = colp_mode(a);
     const size_t lds = rec_lds_bytes(md);
@@ -1756,7 +1778,7 @@ hipError_t launch_stage_rec(const MeshDev &md, const StageArgs &a, hipStream_t s
 hipError_t launch_stage_colx(const MeshDev &md, const StageArgs &a, bool pipelined, hipStream_t s)
 {
     const dim3 g(patch_grid(md)), b(BLOCK);
-    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
                     md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
     const int mode = colp_mode(a);
     if (mode < 0 || md.K > 64 || (md.K & 1)) return hipErrorNotSupported;
@@ -1776,7 +1798,7 @@ hipError_t launch_stage_colx(const MeshDev &md, const StageArgs &a, bool pipelin
 hipError_t launch_stage_col(const MeshDev &md, const StageArgs &a, bool pipelined, hipStream_t s)
 {
     const dim3 g(patch_grid(md)), b(BLOCK);
-    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
                     md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
     const int mode = (pipelined && md.K <= 64) ? colp_mode(a) : -1;
     if (mode >= 0) {
@@ -1864,6 +1886,15 @@ hipError_t launch_permute_rows(double *dst, const double *src, const int32_t *n2
 hipError_t launch_sum_sq_serial(const double *a, int64_t n, double *out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_sum_sq_serial, dim3(1), dim3(64), 0, s, a, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_rows(double *buf, const double *field, const int32_t *rows, int64_t n, int K, int unpack, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n * K + BLOCK - 1) / BLOCK;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(BLOCK), 0, s, buf, const_cast<double *>(field), rows, n, K, unpack);
     return hipGetLastError();
 }
 

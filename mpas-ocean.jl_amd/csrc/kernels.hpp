@@ -22,7 +22,7 @@ struct StageArgs {
 
 // the slice of MeshDev the column kernel reads (kept small: kernel arguments live in SGPRs)
 struct ColMesh {
-    int32_t nC, nE, K, nPatches, CI, EI;
+    int32_t nC, nE, K, nPatches, patchBegin, CI, EI;
     const int32_t *patchCellStart, *patchEdgeStart;
     const uint32_t *cRec, *eRec;
     const int32_t *mltc;
@@ -66,5 +66,7 @@ hipError_t launch_permute_rows(double *dst, const double *src, const int32_t *n2
                                hipStream_t s);
 hipError_t launch_sum_sq_serial(const double *a, int64_t n, double *out, hipStream_t s);
 hipError_t launch_copy(double *dst, const double *src, int64_t n, hipStream_t s);
+// halo pack / unpack: rows of (K doubles) gathered into / scattered from a contiguous buffer
+hipError_t launch_pack_rows(double *buf, const double *field, const int32_t *rows, int64_t n, int K, int unpack, hipStream_t s);
 
 }  // namespace moka

@@ -73,6 +73,7 @@ int build_plan(const moka_mesh_desc *d, Plan &out);   // returns moka_status
 // ----------------------------------------------------------------------------------------------
 struct MeshDev {
     int32_t nC, nE, nV, K, ME, ME2, VD, nPatches;
+    int32_t patchBegin;   // first patch of this launch (nPatches = patches in the launch)
     const int32_t *patchCellStart, *patchEdgeStart, *patchVertStart;
     const int32_t *eoc, *coc, *mltc;
     const double  *sdv, *invArea, *areaCell, *rsum;

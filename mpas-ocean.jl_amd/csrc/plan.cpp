@@ -30,6 +30,23 @@ inline int64_t IX(int i, int64_t j, int ld) { return j * ld + i; }   // 0-based 
     } while (0)
 
 // ---- recursive coordinate bisection into patches of exactly P cells (last one may be short) ----
+// stable partition of an ordering by cell class; returns the class boundaries
+std::vector<int> partition_by_class(const moka_mesh_desc *d, std::vector<int32_t> &n2o)
+{
+    std::vector<int> bounds{0};
+    if (!d->cellClass) { bounds.push_back((int)n2o.size()); return bounds; }
+    int maxc = 0;
+    for (int c = 0; c < d->nCells; ++c) maxc = std::max(maxc, (int)d->cellClass[c]);
+    std::vector<int32_t> out;
+    out.reserve(n2o.size());
+    for (int k = 0; k <= maxc; ++k) {
+        for (int32_t c : n2o) if (d->cellClass[c] == k) out.push_back(c);
+        bounds.push_back((int)out.size());
+    }
+    n2o.swap(out);
+    return bounds;
+}
+
 void rcb_order(const moka_mesh_desc *d, int P, std::vector<int32_t> &n2o)
 {
     const int n = d->nCells;
@@ -37,7 +54,11 @@ void rcb_order(const moka_mesh_desc *d, int P, std::vector<int32_t> &n2o)
     std::iota(n2o.begin(), n2o.end(), 0);
     const double *X[3] = {d->xCell, d->yCell, d->zCell};
     struct Range { int lo, hi; };
-    std::vector<Range> stack{{0, n}};
+    std::vector<Range> stack;
+    {
+        const std::vector<int> b = partition_by_class(d, n2o);   // RCB inside each class range
+        for (size_t i = b.size() - 1; i >= 1; --i) if (b[i] > b[i - 1]) stack.push_back({b[i - 1], b[i]});
+    }
     while (!stack.empty()) {
         Range r = stack.back();
         stack.pop_back();
@@ -192,9 +213,11 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     REQUIRE(ordering >= MOKA_ORDER_NONE && ordering <= MOKA_ORDER_RCB, "unknown ordering");
     REQUIRE(ordering != MOKA_ORDER_RCB || haveXYZ, "RCB ordering needs xCell/yCell");
     p.ordering = ordering;
+    if (d->cellClass)
+        for (int c = 0; c < nC; ++c) REQUIRE(d->cellClass[c] >= 0 && d->cellClass[c] < 64, "cellClass out of range");
     if (ordering == MOKA_ORDER_RCB) rcb_order(d, p.P, p.cellN2O);
-    else if (ordering == MOKA_ORDER_RCM) rcm_order(d, p.cellN2O);
-    else { p.cellN2O.resize(nC); std::iota(p.cellN2O.begin(), p.cellN2O.end(), 0); }
+    else if (ordering == MOKA_ORDER_RCM) { rcm_order(d, p.cellN2O); partition_by_class(d, p.cellN2O); }
+    else { p.cellN2O.resize(nC); std::iota(p.cellN2O.begin(), p.cellN2O.end(), 0); partition_by_class(d, p.cellN2O); }
     p.cellO2N.assign(nC, -1);
     for (int i = 0; i < nC; ++i) p.cellO2N[p.cellN2O[i]] = i;
 

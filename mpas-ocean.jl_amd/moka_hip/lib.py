@@ -43,6 +43,7 @@ class MeshDesc(C.Structure):
         ("edgesOnVertex", _i32p), ("cellsOnVertex", _i32p), ("edgeSignOnVertex", _i32p), ("areaTriangle", _f64p),
         ("maxLevelEdgeTop", _i32p), ("restingThicknessSum", _f64p),
         ("ordering", C.c_int32), ("patch_cells", C.c_int32),
+        ("cellClass", _i32p),
     ]
 
 
@@ -70,6 +71,8 @@ EXPORTS = [
     "moka_advance_time_levels", "moka_diagnostic_compute", "moka_compute_normal_velocity_tendency",
     "moka_compute_layer_thickness_tendency", "moka_tendencies", "moka_step_fe", "moka_step_rk4", "moka_run",
     "moka_sum_sq", "moka_set_kernel_variant",
+    "moka_ctx_streams", "moka_halo_create", "moka_halo_destroy", "moka_halo_buffer_elems", "moka_halo_pack",
+    "moka_halo_unpack", "moka_rk4_dist_begin", "moka_rk4_dist_stage", "moka_rk4_dist_end",
 ]
 
 
@@ -132,6 +135,17 @@ def lib():
     L.moka_run.argtypes = [vp, C.c_int, C.c_double, C.c_int64, C.c_int]
     L.moka_sum_sq.argtypes = [vp, C.c_int, C.c_int, _f64p]
     L.moka_set_kernel_variant.argtypes = [vp, C.c_int]
+    L.moka_ctx_streams.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.moka_halo_create.argtypes = [vp, _i32p, C.c_int64, _i32p, C.c_int64, _i32p, C.c_int64, _i32p, C.c_int64,
+                                   C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.moka_halo_destroy.argtypes = [vp]
+    L.moka_halo_destroy.restype = None
+    L.moka_halo_buffer_elems.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.moka_halo_pack.argtypes = [vp, C.c_int, vp]
+    L.moka_halo_unpack.argtypes = [vp, C.c_int, vp]
+    L.moka_rk4_dist_begin.argtypes = [vp, C.c_double]
+    L.moka_rk4_dist_stage.argtypes = [vp, C.c_int, C.c_int]
+    L.moka_rk4_dist_end.argtypes = [vp]
     _lib = L
     return L
 
@@ -150,7 +164,8 @@ def i32(a):
     return a.ctypes.data_as(_i32p)
 
 
-def make_desc(mesh, K, resting_thickness_sum=None, max_level_edge_top=None, ordering=ORDER_DEFAULT, patch_cells=0):
+def make_desc(mesh, K, resting_thickness_sum=None, max_level_edge_top=None, ordering=ORDER_DEFAULT, patch_cells=0,
+              cell_class=None):
     """Build a moka_mesh_desc from reference-convention arrays.  Returns (desc, keepalive)."""
     keep = {}
 
@@ -181,6 +196,7 @@ def make_desc(mesh, K, resting_thickness_sum=None, max_level_edge_top=None, orde
         resting_thickness_sum = np.ones(mesh.nCells)   # VertMesh.jl:99-100 (test constructor)
     d.restingThicknessSum = f64(A("restingThicknessSum", np.float64, np.asarray(resting_thickness_sum).reshape(-1)))
     d.ordering, d.patch_cells = int(ordering), int(patch_cells)
+    d.cellClass = i32(A("cellClass", np.int32, cell_class)) if cell_class is not None else None
     return d, keep
 
 
@@ -198,9 +214,10 @@ class Plan:
     """Host-only reordered mesh (moka_plan_*): usable without a GPU."""
 
     def __init__(self, mesh, K, resting_thickness_sum=None, max_level_edge_top=None, ordering=ORDER_DEFAULT,
-                 patch_cells=0):
+                 patch_cells=0, cell_class=None):
         self._h = C.c_void_p()
-        desc, self._keep = make_desc(mesh, K, resting_thickness_sum, max_level_edge_top, ordering, patch_cells)
+        desc, self._keep = make_desc(mesh, K, resting_thickness_sum, max_level_edge_top, ordering, patch_cells,
+                                     cell_class)
         check(lib().moka_plan_create(C.byref(desc), C.byref(self._h)))
         inf = MeshInfo()
         check(lib().moka_plan_info(self._h, C.byref(inf)))

@@ -1,0 +1,274 @@
+"""Multi-GPU layer: owner-computes cell partition, one-cell-deep halo, halo exchange per
+RK stage overlapped with the interior patches.  One process per GPU.
+
+The reference has no distributed code at all; this is new.  Pure-numpy pieces (partition, local mesh,
+exchange lists) need no GPU and are covered by world-size-2 gloo tests; the device pieces (pack / unpack kernels,
+patch-range launches, streams) live in libmoka_hip (moka_halo_*, moka_rk4_dist_*).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import types
+
+import numpy as np
+
+from . import lib as L
+
+__all__ = ["partition_cells", "build_local", "LocalMesh", "DistributedModel"]
+
+
+# ---------------------------------------------------------------------------------------------
+# partition: recursive coordinate bisection (no METIS in this image; a METIS file can be dropped in as `part`)
+# ---------------------------------------------------------------------------------------------
+def partition_cells(mesh, nparts: int) -> np.ndarray:
+    X = np.stack([mesh.xCell, mesh.yCell, mesh.zCell], axis=1)
+    part = np.zeros(mesh.nCells, dtype=np.int32)
+
+    def split(idx, p0, n):
+        if n == 1:
+            part[idx] = p0
+            return
+        nl = n // 2
+        ext = X[idx].max(0) - X[idx].min(0)
+        ax = int(np.argmax(ext))
+        k = int(round(idx.size * nl / n))
+        order = np.argpartition(X[idx, ax], k - 1 if k > 0 else 0)
+        split(idx[order[:k]], p0, nl)
+        split(idx[order[k:]], p0 + nl, n - nl)
+
+    split(np.arange(mesh.nCells), 0, int(nparts))
+    return part
+
+
+class LocalMesh:
+    """A rank's local mesh (owned cells + one ring of halo cells, every edge of those cells) in reference
+    conventions, plus the maps needed for the exchange."""
+    pass
+
+
+def _halo_sets(mesh, part, r):
+    """(ring cells of rank r, local edge mask, edges rank r must receive)."""
+    coe = mesh.cellsOnEdge.astype(np.int64) - 1
+    own = part == r
+    o1, o2 = own[coe[:, 0]], own[coe[:, 1]]
+    ring = np.zeros(mesh.nCells, dtype=bool)
+    ring[coe[o1 & ~o2, 1]] = True
+    ring[coe[o2 & ~o1, 0]] = True
+    local_c = own | ring
+    local_e = local_c[coe[:, 0]] | local_c[coe[:, 1]]
+    recv_e = local_e & ~o1 & ~o2                      # no owned cell incident: cannot be computed here
+    return ring, local_c, local_e, recv_e
+
+
+def build_local(mesh, part: np.ndarray, rank: int, world: int) -> LocalMesh:
+    coe = mesh.cellsOnEdge.astype(np.int64) - 1
+    own = part == rank
+    ring, local_c, local_e, recv_e = _halo_sets(mesh, part, rank)
+    edge_owner = part[coe[:, 0]]                       # an edge is owned by the rank of cellsOnEdge[1]
+
+    # ---- exchange lists (global ids, sorted: both sides derive the same order) ----
+    recv_cells = {q: np.nonzero(ring & (part == q))[0] for q in range(world) if q != rank}
+    recv_edges = {q: np.nonzero(recv_e & (edge_owner == q))[0] for q in range(world) if q != rank}
+    send_cells, send_edges = {}, {}
+    for q in range(world):
+        if q == rank:
+            continue
+        ring_q, _, _, recv_e_q = _halo_sets(mesh, part, q)
+        send_cells[q] = np.nonzero(ring_q & own)[0]
+        send_edges[q] = np.nonzero(recv_e_q & (edge_owner == rank))[0]
+    nbrs = [q for q in range(world) if q != rank and
+            (recv_cells[q].size or recv_edges[q].size or send_cells[q].size or send_edges[q].size)]
+
+    # ---- cell classes: 0 owned & needed elsewhere, 1 owned interior, 2 halo ----
+    boundary = np.zeros(mesh.nCells, dtype=bool)
+    for q in nbrs:
+        boundary[send_cells[q]] = True
+        boundary[coe[send_edges[q], 0]] = True
+    assert not np.any(boundary & ~own)
+
+    cells_g = np.concatenate([np.nonzero(own)[0], np.nonzero(ring)[0]])
+    edges_g = np.nonzero(local_e)[0]
+    g2l_c = -np.ones(mesh.nCells, dtype=np.int64)
+    g2l_c[cells_g] = np.arange(cells_g.size)
+    g2l_e = -np.ones(mesh.nEdges, dtype=np.int64)
+    g2l_e[edges_g] = np.arange(edges_g.size)
+    # vertices: those whose edges are all local
+    eov = mesh.edgesOnVertex.astype(np.int64) - 1
+    vert_ok = np.all(g2l_e[eov] >= 0, axis=1)
+    verts_g = np.nonzero(vert_ok)[0]
+    if verts_g.size == 0:
+        raise ValueError("partition too small: no complete dual cell on this rank")
+
+    m = types.SimpleNamespace()
+    m.nCells, m.nEdges, m.nVertices = int(cells_g.size), int(edges_g.size), int(verts_g.size)
+    m.maxEdges, m.maxEdges2, m.vertexDegree = mesh.maxEdges, mesh.maxEdges2, mesh.vertexDegree
+    for n in ("xCell", "yCell", "zCell", "areaCell"):
+        setattr(m, n, np.ascontiguousarray(getattr(mesh, n)[cells_g]))
+    m.nEdgesOnCell = np.ascontiguousarray(mesh.nEdgesOnCell[cells_g])
+    eoc = mesh.edgesOnCell[cells_g].astype(np.int64) - 1
+    m.edgesOnCell = np.where(eoc >= 0, g2l_e[np.maximum(eoc, 0)] + 1, 0).astype(np.int32)
+    assert np.all(m.edgesOnCell[np.arange(mesh.maxEdges)[None, :] < m.nEdgesOnCell[:, None]] > 0)
+    m.edgeSignOnCell = np.ascontiguousarray(mesh.edgeSignOnCell[cells_g])
+    lc = g2l_c[coe[edges_g]]                           # (nEl, 2) local cells, -1 outside
+    inside = np.where(lc[:, 0] >= 0, lc[:, 0], lc[:, 1])
+    lc = np.where(lc >= 0, lc, inside[:, None])       # outer boundary of the halo: both sides -> the inside cell
+    m.cellsOnEdge = (lc + 1).astype(np.int32)
+    m.verticesOnEdge = np.zeros((m.nEdges, 2), dtype=np.int32)   # not used by the hot path
+    eoe = mesh.edgesOnEdge[edges_g].astype(np.int64) - 1
+    m.edgesOnEdge = np.where(eoe >= 0, g2l_e[np.maximum(eoe, 0)] + 1, 0).astype(np.int32)   # non-local -> 0 (skipped)
+    m.nEdgesOnEdge = np.ascontiguousarray(mesh.nEdgesOnEdge[edges_g])
+    for n in ("weightsOnEdge", "dvEdge", "dcEdge", "fEdge"):
+        setattr(m, n, np.ascontiguousarray(getattr(mesh, n)[edges_g]))
+    m.edgesOnVertex = (g2l_e[eov[verts_g]] + 1).astype(np.int32)
+    m.cellsOnVertex = np.zeros((m.nVertices, mesh.vertexDegree), dtype=np.int32)   # 0: let the library derive it
+    m.edgeSignOnVertex = np.ascontiguousarray(mesh.edgeSignOnVertex[verts_g])
+    m.areaTriangle = np.ascontiguousarray(mesh.areaTriangle[verts_g])
+
+    lm = LocalMesh()
+    lm.rank, lm.world, lm.mesh = rank, world, m
+    lm.cells_g, lm.edges_g, lm.verts_g = cells_g, edges_g, verts_g
+    lm.n_owned_cells = int(own.sum())
+    lm.owned_cell_mask = own[cells_g]
+    lm.owned_edge_mask = (edge_owner[edges_g] == rank) & (own[coe[edges_g, 0]])
+    lm.cell_class = np.where(boundary[cells_g], 0, np.where(own[cells_g], 1, 2)).astype(np.int32)
+    lm.neighbors = nbrs
+    # local ids, concatenated in neighbour order, + per-neighbour offsets
+    cat = lambda d, g2l: (np.concatenate([g2l[d[q]] for q in nbrs]).astype(np.int32) if nbrs else np.zeros(0, np.int32),
+                          np.cumsum([0] + [d[q].size for q in nbrs]))
+    lm.send_cells, lm.send_cell_off = cat(send_cells, g2l_c)
+    lm.send_edges, lm.send_edge_off = cat(send_edges, g2l_e)
+    lm.recv_cells, lm.recv_cell_off = cat(recv_cells, g2l_c)
+    lm.recv_edges, lm.recv_edge_off = cat(recv_edges, g2l_e)
+    return lm
+
+
+def message_slices(lm: LocalMesh, K: int, send: bool):
+    """Per neighbour: the three contiguous slices (h rows, ssh, u rows) of the packed buffer
+    [cells x K | cells | edges x K] that go to / come from that neighbour."""
+    co, eo = (lm.send_cell_off, lm.send_edge_off) if send else (lm.recv_cell_off, lm.recv_edge_off)
+    nc = int(co[-1])
+    out = []
+    for i, q in enumerate(lm.neighbors):
+        out.append((q, [(int(co[i]) * K, int(co[i + 1]) * K),
+                        (nc * K + int(co[i]), nc * K + int(co[i + 1])),
+                        (nc * K + nc + int(eo[i]) * K, nc * K + nc + int(eo[i + 1]) * K)]))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# device model
+# ---------------------------------------------------------------------------------------------
+class DistributedModel:
+    """Partitioned shallow-water model: RK4 steps with halo exchange between stages.
+
+    transport = "nccl": torch.distributed P2P on device buffers (RCCL over xGMI), issued on the library's comm
+    stream so that the interior patches of the stage overlap the exchange;  "gloo": staged through the host
+    (tests: two ranks may share one GPU)."""
+
+    def __init__(self, mesh, ssh, u, h, rest, dt, backend, rank, world, ordering=0, patch_cells=0,
+                 transport="nccl", part=None):
+        import torch
+        import torch.distributed as dist
+        from . import api
+        self.torch, self.dist = torch, dist
+        self.rank, self.world, self.dt, self.backend, self.transport = rank, world, float(dt), backend, transport
+        K = np.asarray(u).reshape(mesh.nEdges, -1).shape[1]
+        self.K = K
+        self.part = partition_cells(mesh, world) if part is None else np.asarray(part, dtype=np.int32)
+        lm = self.lm = build_local(mesh, self.part, rank, world)
+        rest = np.asarray(rest).reshape(mesh.nCells, -1)
+        h_mesh = api.HorzMesh(lm.mesh)
+        v_mesh = api.VerticalMesh(h_mesh, nVertLevels=K, restingThickness=rest[lm.cells_g], multilayer=True)
+        self.mesh = api.Mesh.__new__(api.Mesh)
+        self.mesh.HorzMesh, self.mesh.VertMesh, self.mesh.backend = h_mesh, v_mesh, backend
+        self.mesh._h = C.c_void_p()
+        desc, keep = L.make_desc(lm.mesh, K, v_mesh.restingThicknessSum, v_mesh.maxLevelEdge.Top, ordering,
+                                 patch_cells, cell_class=lm.cell_class)
+        desc.cellsOnVertex = None
+        desc.verticesOnEdge = None
+        L.check(L.lib().moka_mesh_create(backend._h, C.byref(desc), C.byref(self.mesh._h)), backend._h)
+        self.Prog = api.PrognosticVars(np.asarray(ssh)[lm.cells_g], np.asarray(u).reshape(mesh.nEdges, K)[lm.edges_g],
+                                       np.asarray(h).reshape(mesh.nCells, K)[lm.cells_g], 2, self.mesh)
+        self.Diag = api.DiagnosticVars(None, self.mesh, self.Prog._state)
+        self.Tend = api.TendencyVars(None, self.mesh, self.Prog._state)
+        P = self.mesh.info()["patch_cells"]
+        nB = int((lm.cell_class == 0).sum())
+        nO = int((lm.cell_class <= 1).sum())
+        self.p_boundary, self.p_owned = -(-nB // P), -(-nO // P)
+        self._halo = C.c_void_p()
+        i32 = lambda a: L.i32(np.ascontiguousarray(a, dtype=np.int32))
+        self._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (lm.send_cells, lm.send_edges, lm.recv_cells, lm.recv_edges)]
+        L.check(L.lib().moka_halo_create(self.Prog._state._h, L.i32(self._keep[0]), self._keep[0].size,
+                                         L.i32(self._keep[1]), self._keep[1].size, L.i32(self._keep[2]), self._keep[2].size,
+                                         L.i32(self._keep[3]), self._keep[3].size, self.p_boundary, self.p_owned,
+                                         C.byref(self._halo)), backend._h)
+        ns, nr = C.c_int64(), C.c_int64()
+        L.check(L.lib().moka_halo_buffer_elems(self._halo, C.byref(ns), C.byref(nr)))
+        dev = torch.device("cuda", backend.device)
+        self.sendbuf = torch.zeros(max(ns.value, 1), dtype=torch.float64, device=dev)
+        self.recvbuf = torch.zeros(max(nr.value, 1), dtype=torch.float64, device=dev)
+        self.send_slices = message_slices(lm, K, True)
+        self.recv_slices = message_slices(lm, K, False)
+        cs, ms = C.c_void_p(), C.c_void_p()
+        L.check(L.lib().moka_ctx_streams(backend._h, C.byref(cs), C.byref(ms)))
+        self.comm_stream = torch.cuda.ExternalStream(ms.value, device=dev)
+        self.halo_bytes_per_stage = 8 * (ns.value + nr.value)
+
+    # ---- transport of the packed buffers ----
+    def _transport(self):
+        torch, dist = self.torch, self.dist
+        if not self.lm.neighbors:
+            return
+        if self.transport == "nccl":
+            with torch.cuda.stream(self.comm_stream):
+                ops = []
+                for q, sl in self.recv_slices:
+                    ops += [dist.P2POp(dist.irecv, self.recvbuf[a:b], q) for a, b in sl if b > a]
+                for q, sl in self.send_slices:
+                    ops += [dist.P2POp(dist.isend, self.sendbuf[a:b], q) for a, b in sl if b > a]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()                     # stream-ordered: the comm stream waits, the host does not
+        else:                                    # gloo: through the host
+            self.backend.synchronize()
+            send_cpu, recv_cpu = self.sendbuf.cpu(), torch.empty_like(self.recvbuf, device="cpu")
+            reqs = []
+            for q, sl in self.recv_slices:
+                reqs += [dist.irecv(recv_cpu[a:b], q) for a, b in sl if b > a]
+            for q, sl in self.send_slices:
+                reqs += [dist.isend(send_cpu[a:b].contiguous(), q) for a, b in sl if b > a]
+            for w in reqs:
+                w.wait()
+            self.recvbuf.copy_(recv_cpu)
+            torch.cuda.synchronize()
+
+    def exchange_state(self):
+        """Halo exchange of the current time level (e.g. after an upload)."""
+        lib, h = L.lib(), self._halo
+        L.check(lib.moka_halo_pack(h, 0, self.sendbuf.data_ptr()), self.backend._h)
+        self._transport()
+        L.check(lib.moka_halo_unpack(h, 0, self.recvbuf.data_ptr()), self.backend._h)
+
+    def step_rk4(self):
+        lib, h, ctx = L.lib(), self._halo, self.backend._h
+        L.check(lib.moka_rk4_dist_begin(h, self.dt), ctx)
+        for s in (1, 2, 3, 4):
+            L.check(lib.moka_rk4_dist_stage(h, s, 0), ctx)            # boundary patches
+            L.check(lib.moka_halo_pack(h, s, self.sendbuf.data_ptr()), ctx)
+            L.check(lib.moka_rk4_dist_stage(h, s, 1), ctx)            # interior patches overlap the exchange
+            self._transport()
+            L.check(lib.moka_halo_unpack(h, s, self.recvbuf.data_ptr()), ctx)
+        L.check(lib.moka_rk4_dist_end(h), ctx)
+
+    def owned_state(self):
+        """(global cell ids, ssh, h), (global edge ids, u) of the entities this rank owns."""
+        lm = self.lm
+        ssh, hh, uu = self.Prog.ssh[-1].get(), self.Prog.layerThickness[-1].get(), self.Prog.normalVelocity[-1].get()
+        cm, em = lm.owned_cell_mask, lm.owned_edge_mask
+        return (lm.cells_g[cm], ssh[cm], hh[cm]), (lm.edges_g[em], uu[em])
+
+    def info(self):
+        d = self.mesh.info()
+        d.update({"rank_cells_owned": self.lm.n_owned_cells, "rank_cells_local": self.lm.mesh.nCells,
+                  "neighbors": len(self.lm.neighbors), "halo_bytes_per_stage": self.halo_bytes_per_stage,
+                  "patches_boundary": self.p_boundary, "patches_owned": self.p_owned})
+        return d

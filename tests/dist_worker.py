@@ -1,0 +1,117 @@
+"""Worker for the multi-rank tests (launched under torch.distributed.run).
+
+mode cpu : validates the partition, the local meshes and the exchange lists with the CPU ORACLE as each rank's
+           compute (gloo, no GPU): the distributed RK4 must reproduce the single-domain oracle bit for bit.
+mode gpu : the same check for the HIP path (DistributedModel); ranks share GPU 0 and exchange through gloo.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "mpas-ocean.jl_amd"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import oracle as orc  # noqa: E402
+from moka_hip import meshgen as mg  # noqa: E402
+from moka_hip import parallel as par  # noqa: E402
+
+
+def exchange_numpy(lm, K, fields, dist):
+    """fields = (ssh, u, h) local arrays; halo rows are overwritten with the owners' values (gloo)."""
+    ssh, u, h = fields
+    sc, se, rc, re = lm.send_cells, lm.send_edges, lm.recv_cells, lm.recv_edges
+    sendbuf = torch.from_numpy(np.concatenate([h[sc].ravel(), ssh[sc], u[se].ravel()]))
+    recvbuf = torch.zeros(rc.size * (K + 1) + re.size * K, dtype=torch.float64)
+    reqs = []
+    for q, sl in par.message_slices(lm, K, False):
+        reqs += [dist.irecv(recvbuf[a:b], q) for a, b in sl if b > a]
+    for q, sl in par.message_slices(lm, K, True):
+        reqs += [dist.isend(sendbuf[a:b].contiguous(), q) for a, b in sl if b > a]
+    for w in reqs:
+        w.wait()
+    r = recvbuf.numpy()
+    nc = rc.size
+    h[rc] = r[:nc * K].reshape(nc, K)
+    ssh[rc] = r[nc * K:nc * K + nc]
+    u[re] = r[nc * K + nc:].reshape(re.size, K)
+
+
+def main():
+    mode = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    K, nsteps, dt = (4, 3, 30.0) if mode == "cpu" else (int(sys.argv[2]) if len(sys.argv) > 2 else 60, 3, 20.0)
+    mesh = mg.icosahedral_mesh(8 if mode == "cpu" else 16)
+    rng = np.random.default_rng(5)
+    rest = np.full((mesh.nCells, K), 1000.0 / K) + rng.uniform(0, 0.1, (mesh.nCells, K))
+    h = rest + rng.uniform(-1, 1, (mesh.nCells, K))
+    u = rng.uniform(-1, 1, (mesh.nEdges, K))
+    ssh = h.sum(1) - rest.sum(1)
+    # single-domain oracle
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    ref = orc.OracleState(om, ssh, u, h)
+    for _ in range(nsteps):
+        ref.step_rk4(dt)
+
+    part = par.partition_cells(mesh, world)
+    lm = par.build_local(mesh, part, rank, world)
+    assert set(lm.neighbors) == set(range(world)) - {rank}
+    cm, em = lm.owned_cell_mask, lm.owned_edge_mask
+    # every cell is owned exactly once, every edge exactly once
+    owned_c = torch.zeros(mesh.nCells, dtype=torch.int32); owned_c[lm.cells_g[cm]] = 1
+    owned_e = torch.zeros(mesh.nEdges, dtype=torch.int32); owned_e[lm.edges_g[em]] = 1
+    dist.all_reduce(owned_c); dist.all_reduce(owned_e)
+    assert int(owned_c.min()) == 1 and int(owned_c.max()) == 1 and int(owned_e.min()) == 1 and int(owned_e.max()) == 1
+
+    if mode == "cpu":
+        oml = orc.OracleMesh(lm.mesh, K, resting_thickness_sum=rest.sum(1)[lm.cells_g], max_level_edge_top=K)
+        # local tendency of entities with an owned cell == global tendency, bit for bit
+        tu_g, th_g, _ = om.tendencies_clean(u, h)
+        tu_l, th_l, _ = oml.tendencies_clean(u[lm.edges_g], h[lm.cells_g])
+        assert np.array_equal(th_l[cm], th_g[lm.cells_g[cm]]) and np.array_equal(tu_l[em], tu_g[lm.edges_g[em]])
+        # distributed RK4 (time_integration.jl:61-148) with a halo exchange after every stage
+        cu, ch, cssh = u[lm.edges_g].copy(), h[lm.cells_g].copy(), ssh[lm.cells_g].copy()
+        rs = rest.sum(1)[lm.cells_g]
+        for _ in range(nsteps):
+            a, b = [dt / 2., dt / 2., dt], [dt / 6., dt / 3., dt / 3., dt / 6.]
+            pu, ph = cu.copy(), ch.copy()
+            nu, nh = cu.copy(), ch.copy()
+            for s in range(4):
+                tu, th, _ = oml.tendencies_clean(pu, ph)
+                if s < 3:
+                    pu, ph = cu + a[s] * tu, ch + a[s] * th
+                    pssh = oml.update_ssh(ph)
+                    exchange_numpy(lm, K, (pssh, pu, ph), dist)
+                nu, nh = nu + b[s] * tu, nh + b[s] * th
+            cssh = oml.update_ssh(nh)
+            exchange_numpy(lm, K, (cssh, nu, nh), dist)
+            cu, ch = nu, nh
+        got = (cssh, cu, ch)
+    else:
+        import moka_hip as mk
+        backend = mk.MokaHIP(0)
+        variant = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+        backend.set_kernel_variant(variant)
+        model = par.DistributedModel(mesh, ssh, u, h, rest, dt, backend, rank, world, transport="gloo", part=part)
+        assert model.p_boundary <= model.p_owned <= model.mesh.info()["nPatches"]
+        for _ in range(nsteps):
+            model.step_rk4()
+        got = (model.Prog.ssh[-1].get(), model.Prog.normalVelocity[-1].get(), model.Prog.layerThickness[-1].get())
+    assert np.array_equal(got[0][cm], ref.ssh[1][lm.cells_g[cm]]), "ssh"
+    assert np.array_equal(got[2][cm], ref.h[1][lm.cells_g[cm]]), "layerThickness"
+    assert np.array_equal(got[1][em], ref.u[1][lm.edges_g[em]]), "normalVelocity"
+    # after the final exchange the halo holds the owners' values too
+    assert np.array_equal(got[2], ref.h[1][lm.cells_g]) and np.array_equal(got[0], ref.ssh[1][lm.cells_g])
+    ok = torch.ones(1)
+    dist.all_reduce(ok)
+    if rank == 0:
+        print(f"dist_worker {mode}: OK on {world} ranks ({mesh.nCells} cells x {K} layers, {nsteps} RK4 steps)")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""Multi-rank coverage: partition, local meshes and exchange lists with gloo on CPU
+(world size 2 and 3), and the HIP DistributedModel with two ranks sharing one GPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from moka_hip import lib as L
+from moka_hip import meshgen as mg
+from moka_hip import parallel as par
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_workers(nproc, *args, timeout=300):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), *map(str, args)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "OK on" in r.stdout
+    return r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_rk4_with_oracle_compute_gloo(world):
+    run_workers(world, "cpu")
+
+
+def test_partition_and_local_mesh_properties():
+    mesh = mg.icosahedral_mesh(10)
+    for world in (2, 4, 8):
+        part = par.partition_cells(mesh, world)
+        counts = np.bincount(part, minlength=world)
+        assert counts.min() > 0 and counts.max() - counts.min() <= world        # balanced
+        sent, recvd = {}, {}
+        for r in range(world):
+            lm = par.build_local(mesh, part, r, world)
+            assert lm.n_owned_cells == counts[r]
+            assert np.all(lm.cell_class[lm.owned_cell_mask] <= 1) and np.all(lm.cell_class[~lm.owned_cell_mask] == 2)
+            # every halo cell is received, every local edge without an owned cell is received
+            assert set(lm.recv_cells.tolist()) == set(np.nonzero(~lm.owned_cell_mask)[0].tolist())
+            # the local mesh is accepted by the host plan, classes order the patches
+            plan = L.Plan(lm.mesh, 3, max_level_edge_top=3, ordering=L.ORDER_RCB, patch_cells=8, cell_class=lm.cell_class)
+            cperm = plan.permutation(L.CELL)
+            cls = lm.cell_class[cperm]
+            assert np.all(np.diff(cls) >= 0)                                     # class-major ordering
+            for i, q in enumerate(lm.neighbors):
+                sent[(r, q)] = (lm.cells_g[lm.send_cells[lm.send_cell_off[i]:lm.send_cell_off[i + 1]]],
+                                lm.edges_g[lm.send_edges[lm.send_edge_off[i]:lm.send_edge_off[i + 1]]])
+                recvd[(q, r)] = (lm.cells_g[lm.recv_cells[lm.recv_cell_off[i]:lm.recv_cell_off[i + 1]]],
+                                 lm.edges_g[lm.recv_edges[lm.recv_edge_off[i]:lm.recv_edge_off[i + 1]]])
+        assert set(sent) == set(recvd)
+        for k in sent:                                                            # both sides agree, in order
+            assert np.array_equal(sent[k][0], recvd[k][0]) and np.array_equal(sent[k][1], recvd[k][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,variant", [(60, 0), (1, 0), (60, 3)])
+def test_distributed_rk4_hip_two_ranks_one_gpu(K, variant):
+    run_workers(2, "gpu", K, variant)
