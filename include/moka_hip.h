@@ -102,6 +102,7 @@ typedef struct moka_mesh_info {
     int64_t cellBandwidth;                           /* max |new(c1)-new(c2)| over edges         */
     int32_t maxPatchRows;                            /* most u-rows (own + halo edges) any patch stages in LDS */
     int32_t ldsBytesPerBlock;                        /* dynamic LDS of the LDS-tiled stage kernel (0: not applicable) */
+    int32_t maxPatchCells, maxPatchEdges;            /* largest own cell / edge range of any patch (sizes the record staging) */
 } moka_mesh_info;
 
 /* entity kinds for permutations */
@@ -155,7 +156,8 @@ int  moka_plan_patch_ranges(const moka_plan *plan, int32_t *cellStart, int32_t *
 enum {
     MOKA_PA_EOC = 0, MOKA_PA_COC, MOKA_PA_MLTC, MOKA_PA_SDV, MOKA_PA_INVAREA, MOKA_PA_AREACELL, MOKA_PA_RSUM,
     MOKA_PA_EHDR, MOKA_PA_EOE, MOKA_PA_WOE, MOKA_PA_GINVDC, MOKA_PA_DCEDGE, MOKA_PA_DVEDGE, MOKA_PA_FEDGE,
-    MOKA_PA_EOV, MOKA_PA_CV, MOKA_PA_HALO_START, MOKA_PA_HALO_EDGE, MOKA_PA_LEOC, MOKA_PA_LEOE
+    MOKA_PA_EOV, MOKA_PA_CV, MOKA_PA_HALO_START, MOKA_PA_HALO_EDGE, MOKA_PA_LEOC, MOKA_PA_LEOE,
+    MOKA_PA_CREC, MOKA_PA_EREC, MOKA_PA_FEOE
 };
 int  moka_plan_array(const moka_plan *plan, int which, const void **data, int64_t *count);
 

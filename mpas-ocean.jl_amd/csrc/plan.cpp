@@ -378,6 +378,10 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     p.leoc.assign((size_t)nC * 8, 0xFF);
     p.leoe.assign((size_t)nE * 16, 0xFF);
     p.maxRows = p.maxOwnE = p.maxOwnC = 0;
+    for (int q = 0; q < p.nPatches; ++q) {   // needed by every LDS-staging kernel: must cover ALL patches
+        p.maxOwnE = std::max(p.maxOwnE, p.patchEdgeStart[q + 1] - p.patchEdgeStart[q]);
+        p.maxOwnC = std::max(p.maxOwnC, p.patchCellStart[q + 1] - p.patchCellStart[q]);
+    }
     p.ldsOk = (ME <= 8 && ME2 <= 16);
     {
         std::vector<int32_t> local(nE, -1), touched;
@@ -406,8 +410,6 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
             p.haloStart[q + 1] = (int32_t)p.haloEdge.size();
             if (rows > 254) p.ldsOk = false;
             p.maxRows = std::max(p.maxRows, rows);
-            p.maxOwnE = std::max(p.maxOwnE, nOwn);
-            p.maxOwnC = std::max(p.maxOwnC, c1 - c0);
         }
         if (!p.ldsOk) { p.haloEdge.clear(); std::fill(p.haloStart.begin(), p.haloStart.end(), 0); }
     }
@@ -456,6 +458,8 @@ static void fill_info(const moka::Plan &p, moka_mesh_info *info)
     info->lanesPerColumn = lanes_per_column(p.K);
     info->cellBandwidth = p.cellBandwidth;
     info->maxPatchRows = p.maxRows;
+    info->maxPatchCells = p.maxOwnC;
+    info->maxPatchEdges = p.maxOwnE;
     info->ldsBytesPerBlock = (p.ldsOk && p.K % 2 == 0)
                                  ? (int32_t)moka::lds_stage_bytes(p.K, p.ME, p.ME2, p.maxRows, p.maxOwnE, p.maxOwnC) : 0;
     info->meshBytesDevice =
@@ -502,6 +506,7 @@ int moka_plan_array(const moka_plan *plan, int which, const void **data, int64_t
         VEC(MOKA_PA_DCEDGE, dcEdge) VEC(MOKA_PA_DVEDGE, dvEdge) VEC(MOKA_PA_FEDGE, fEdge)
         VEC(MOKA_PA_EOV, eov) VEC(MOKA_PA_CV, cv)
         VEC(MOKA_PA_HALO_START, haloStart) VEC(MOKA_PA_HALO_EDGE, haloEdge) VEC(MOKA_PA_LEOC, leoc) VEC(MOKA_PA_LEOE, leoe)
+        VEC(MOKA_PA_CREC, cRec) VEC(MOKA_PA_EREC, eRec) VEC(MOKA_PA_FEOE, feoe)
         default: moka::set_error("unknown plan array id"); return MOKA_ERR_ARG;
     }
 #undef VEC

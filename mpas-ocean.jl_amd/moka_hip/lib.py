@@ -54,6 +54,7 @@ class MeshInfo(C.Structure):
         ("maxEdgesUsed", C.c_int32), ("maxEdges2Used", C.c_int32), ("lanesPerColumn", C.c_int32),
         ("meshBytesDevice", C.c_int64), ("cellBandwidth", C.c_int64),
         ("maxPatchRows", C.c_int32), ("ldsBytesPerBlock", C.c_int32),
+        ("maxPatchCells", C.c_int32), ("maxPatchEdges", C.c_int32),
     ]
 
     def as_dict(self):
@@ -207,6 +208,7 @@ PLAN_ARRAYS = {  # name -> (id, dtype)
     "dcEdge": (11, np.float64), "dvEdge": (12, np.float64), "fEdge": (13, np.float64),
     "eov": (14, np.int32), "cv": (15, np.float64),
     "haloStart": (16, np.int32), "haloEdge": (17, np.int32), "leoc": (18, np.uint8), "leoe": (19, np.uint8),
+    "cRec": (20, np.uint32), "eRec": (21, np.uint32), "feoe": (22, np.float64),
 }
 
 

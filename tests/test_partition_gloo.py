@@ -55,6 +55,8 @@ def test_partition_and_local_mesh_properties():
             cperm = plan.permutation(L.CELL)
             cls = lm.cell_class[cperm]
             assert np.all(np.diff(cls) >= 0)                                     # class-major ordering
+            cs, es, _ = plan.patch_ranges()      # the record-staging kernels size their LDS from these maxima
+            assert plan.info["maxPatchEdges"] == np.diff(es).max() and plan.info["maxPatchCells"] == np.diff(cs).max()
             for i, q in enumerate(lm.neighbors):
                 sent[(r, q)] = (lm.cells_g[lm.send_cells[lm.send_cell_off[i]:lm.send_cell_off[i + 1]]],
                                 lm.edges_g[lm.send_edges[lm.send_edge_off[i]:lm.send_edge_off[i + 1]]])
