@@ -166,12 +166,13 @@ class DistributedModel:
     (tests: two ranks may share one GPU)."""
 
     def __init__(self, mesh, ssh, u, h, rest, dt, backend, rank, world, ordering=0, patch_cells=0,
-                 transport="nccl", part=None):
+                 transport="nccl", part=None, group=None):
         import torch
         import torch.distributed as dist
         from . import api
         self.torch, self.dist = torch, dist
         self.rank, self.world, self.dt, self.backend, self.transport = rank, world, float(dt), backend, transport
+        self.group = group                 # process group of the gloo transport (None = default group)
         K = np.asarray(u).reshape(mesh.nEdges, -1).shape[1]
         self.K = K
         self.part = partition_cells(mesh, world) if part is None else np.asarray(part, dtype=np.int32)
@@ -233,9 +234,9 @@ class DistributedModel:
             send_cpu, recv_cpu = self.sendbuf.cpu(), torch.empty_like(self.recvbuf, device="cpu")
             reqs = []
             for q, sl in self.recv_slices:
-                reqs += [dist.irecv(recv_cpu[a:b], q) for a, b in sl if b > a]
+                reqs += [dist.irecv(recv_cpu[a:b], q, group=self.group) for a, b in sl if b > a]
             for q, sl in self.send_slices:
-                reqs += [dist.isend(send_cpu[a:b].contiguous(), q) for a, b in sl if b > a]
+                reqs += [dist.isend(send_cpu[a:b].contiguous(), q, group=self.group) for a, b in sl if b > a]
             for w in reqs:
                 w.wait()
             self.recvbuf.copy_(recv_cpu)
