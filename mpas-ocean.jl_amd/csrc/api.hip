@@ -32,6 +32,7 @@ struct moka_mesh {
     int lpc = 1;
     size_t ldsBytes = 0;      // > 0: the LDS-tiled stage kernel is usable for this mesh
     bool colOk = false;       // byte-offset records exist (every field < 4 GiB)
+    bool tileOk = false;      // the tiled stage kernel (u rows + records in LDS) fits this mesh
     double *opBuf[3] = {nullptr, nullptr, nullptr};   // operator / transfer scratch, lazily sized
     size_t opBufElems = 0;
 };
@@ -217,6 +218,10 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
     const int v = st->ctx->variant;
     // 0 = auto; 8 rec2 (record-staged, 16-byte lanes, 2 entities/wave), 7 rec, 1 colp, 4 col, 5/6 colx, 2 LDS-tiled, 3 generic
     if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(dev, g, m->ldsBytes, s);
+    if (v == 9 && m->tileOk) {             // tiled: u rows + records in LDS (needs patch_cells <= 16)
+        hipError_t e = launch_stage_tile(dev, g, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if ((v == 0 || v == 8) && m->lpc == 64 && m->colOk) {
         hipError_t e = launch_stage_rec2(dev, g, s);
         if (e != hipErrorNotSupported) return e;
@@ -347,7 +352,7 @@ int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
 int moka_set_kernel_variant(moka_ctx *ctx, int variant)
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
-    if (variant < 0 || variant > 8) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..8");
+    if (variant < 0 || variant > 9) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..9");
     ctx->variant = variant;
     return MOKA_OK;
 }
@@ -395,6 +400,7 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
 #undef UP
     d.CI = p.CI; d.EI = p.EI;
     m->colOk = p.colOk;
+    if (p.colOk && stage_tile_usable(d, p.ldsOk) && prepare_stage_tile(d) == hipSuccess) m->tileOk = true;
     d.maxRows = p.maxRows; d.maxOwnE = p.maxOwnE; d.maxOwnC = p.maxOwnC;
     if (p.ldsOk && p.K % 2 == 0 && p.K >= 8) {
         const int64_t need = lds_stage_bytes(p.K, p.ME, p.ME2, p.maxRows, p.maxOwnE, p.maxOwnC);

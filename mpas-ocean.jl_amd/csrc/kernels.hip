@@ -1177,6 +1177,255 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2(const ColMesh m, const Sta
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tiled stage kernel ("tile"): u-rows AND records of a 16-cell patch in LDS, everything else a workgroup
+// needs fetched in two dependent bursts, then a compute phase that touches global memory only for stores.
+//
+// Why: k_stage_rec2 is paced by the per-CU texture-address path (TA_BUSY 82 %): every u-row is fetched
+// ~12 times per evaluation (10 Coriolis neighbours + 2 cells), each fetch a 13-cycle TA transaction even
+// when it hits L1.  Here each u-row a patch touches (own + halo edges, <= 136 rows) crosses the TA once,
+// into LDS; the 36 u-reads per cell become ds_read_b128.  Per 16-cell patch that is ~270 vector memory
+// instructions instead of ~520.
+// Shape: 256 threads = 8 half-wave groups; lane = two consecutive levels (16 B).  Group g stages rows
+// g, g+8, ... and later owns cells g, g+8 and edges g, g+8, ...  Two workgroups per CU (<= 80 KB LDS each),
+// 2 waves per SIMD, so up to 256 VGPRs: the h-rows of the group's two cells are prefetched into registers
+// in the same burst as the row staging.  One thread per own edge fetches ssh[c1], ssh[c2] and leaves
+// ssh[c2]-ssh[c1] in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int TILE_RB = 17;        // staged rows per group: 8 * 17 = 136 >= rows of a 16-cell patch
+constexpr int TILE_MAXC = 2;       // cells per group: 16-cell patches
+
+struct TileLds {
+    double *ubuf, *woe, *feoe, *g, *ds, *sdv, *invA, *rsum;
+    int32_t *ehdr, *coc, *mltc;
+    uint32_t *leoe, *leoc;
+};
+
+__device__ __forceinline__ TileLds tile_carve(unsigned char *smem, int K, int ME, int ME2, int maxRows, int maxOwnE, int maxOwnC)
+{
+    TileLds L;
+    L.ubuf = reinterpret_cast<double *>(smem);
+    L.woe = L.ubuf + (size_t)maxRows * K;
+    L.feoe = L.woe + (size_t)maxOwnE * ME2;
+    L.g = L.feoe + (size_t)maxOwnE * ME2;
+    L.ds = L.g + maxOwnE;
+    L.sdv = L.ds + maxOwnE;
+    L.invA = L.sdv + (size_t)maxOwnC * ME;
+    L.rsum = L.invA + maxOwnC;
+    L.ehdr = reinterpret_cast<int32_t *>(L.rsum + maxOwnC);
+    L.coc = L.ehdr + (size_t)maxOwnE * 4;
+    L.mltc = L.coc + (size_t)maxOwnC * ME;
+    L.leoe = reinterpret_cast<uint32_t *>(L.mltc + (size_t)maxOwnC * ME);
+    L.leoc = L.leoe + (size_t)maxOwnE * 4;
+    return L;
+}
+
+template <int ME, int MODE>
+struct TCell {
+    double2 hc, hv[ME], cur, nin;
+};
+
+template <int ME, int ME2, int MODE>
+__global__ __launch_bounds__(BLOCK, 2) void k_stage_tile(const MeshDev m, const StageArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int pl_ = patch_of_block(m.nPatches);
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
+    constexpr int NG = BLOCK / 32;
+    const int tid = threadIdx.x, grp = tid >> 5, l = tid & 31;
+    const int K = m.K, K2 = K >> 1;
+    const uint32_t rowB = (uint32_t)K * 8u, voff = (uint32_t)l * 16u;
+    const bool act = l < K2;
+    const uint32_t voffc = act ? voff : 0u;                            // clamped: every lane issues a valid load
+    const TileLds L = tile_carve(smem, K, ME, ME2, m.maxRows, m.maxOwnE, m.maxOwnC);
+    const int c0 = cptr(m.patchCellStart)[p], c1 = cptr(m.patchCellStart)[p + 1];
+    const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
+    const int h0 = cptr(m.haloStart)[p], h1 = cptr(m.haloStart)[p + 1];
+    const int nOwnC = c1 - c0, nOwnE = e1 - e0, R = nOwnE + (h1 - h0);
+
+    // ---------------- burst 1: indices ----------------
+    int src[TILE_RB];                                                  // global edge of each row this group stages
+#pragma unroll
+    for (int i = 0; i < TILE_RB; ++i) {
+        const int r = grp + NG * i;
+        const int rc = r < R ? r : (R > 0 ? R - 1 : 0);
+        src[i] = (rc < nOwnE || R == 0) ? e0 + (R > 0 ? rc : 0) : m.haloEdge[h0 + rc - nOwnE];
+        if (R == 0) src[i] = 0;
+    }
+    int cn[TILE_MAXC][ME];
+    int cidx[TILE_MAXC];
+#pragma unroll
+    for (int j = 0; j < TILE_MAXC; ++j) {
+        const int ci = grp + NG * j;
+        cidx[j] = c0 + (ci < nOwnC ? ci : 0);
+#pragma unroll
+        for (int i = 0; i < ME; ++i) {
+            const int x = m.coc[(size_t)cidx[j] * ME + i];
+            cn[j][i] = x >= 0 ? x : cidx[j];
+        }
+    }
+    int4 hdr = make_int4(0, 0, 0, 0);
+    if (tid < nOwnE) hdr = *reinterpret_cast<const int4 *>(m.ehdr + (size_t)(e0 + tid) * 4);
+
+    // ---------------- burst 2: rows ----------------
+    double2 st[TILE_RB];
+#pragma unroll
+    for (int i = 0; i < TILE_RB; ++i) st[i] = gload2(a.pu, (uint32_t)src[i] * rowB + voffc);
+    TCell<ME, MODE> tc[TILE_MAXC];
+#pragma unroll
+    for (int j = 0; j < TILE_MAXC; ++j) {
+        const uint32_t own = (uint32_t)cidx[j] * rowB + voffc;
+        tc[j].hc = gload2(a.ph, own);
+#pragma unroll
+        for (int i = 0; i < ME; ++i) tc[j].hv[i] = gload2(a.ph, (uint32_t)cn[j][i] * rowB + voffc);
+        if constexpr (MODE == 2) tc[j].cur = gload2(a.ch, own);
+        if constexpr (MODE >= 2) tc[j].nin = gload2(a.nh_in, own);
+    }
+    double sA = 0.0, sB = 0.0;
+    if (tid < nOwnE) {
+        sA = a.ssh[hdr.x];
+        sB = a.ssh[hdr.y];
+    }
+    // records of the patch -> LDS (contiguous ranges, coalesced)
+    for (int i = tid; i < nOwnE * ME2; i += BLOCK) {
+        L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
+        L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
+    }
+    for (int i = tid; i < nOwnE; i += BLOCK) L.g[i] = m.gInvDc[e0 + i];
+    for (int i = tid; i < nOwnE * 4; i += BLOCK) L.leoe[i] = reinterpret_cast<const uint32_t *>(m.leoe)[(size_t)e0 * 4 + i];
+    if (tid < nOwnE) {
+        L.ehdr[tid * 4 + 0] = hdr.x; L.ehdr[tid * 4 + 1] = hdr.y; L.ehdr[tid * 4 + 2] = hdr.z; L.ehdr[tid * 4 + 3] = hdr.w;
+    }
+    for (int i = tid; i < nOwnC * ME; i += BLOCK) {
+        L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
+        L.mltc[i] = m.mltc[(size_t)c0 * ME + i];
+    }
+    for (int i = tid; i < nOwnC; i += BLOCK) {
+        L.invA[i] = m.invArea[c0 + i];
+        L.rsum[i] = m.rsum[c0 + i];
+    }
+    for (int i = tid; i < nOwnC * 2; i += BLOCK) L.leoc[i] = reinterpret_cast<const uint32_t *>(m.leoc)[(size_t)c0 * 2 + i];
+    // staged rows -> LDS
+    double2 *ubuf2 = reinterpret_cast<double2 *>(L.ubuf);
+#pragma unroll
+    for (int i = 0; i < TILE_RB; ++i) {
+        const int r = grp + NG * i;
+        if (r < R && act) ubuf2[(size_t)r * K2 + l] = st[i];
+    }
+    if (tid < nOwnE) L.ds[tid] = sB - sA;                              // ssh[c2] - ssh[c1]
+    __syncthreads();
+
+    // ---------------- cells (registers + LDS only) ----------------
+    const int k0 = 2 * l;
+#pragma unroll
+    for (int j = 0; j < TILE_MAXC; ++j) {
+        const int ci = grp + NG * j;
+        const bool valid = ci < nOwnC;
+        const int cc = valid ? ci : 0;
+        const int c = c0 + cc;
+        const double invA = L.invA[cc];
+        const uint32_t w0 = L.leoc[cc * 2], w1 = L.leoc[cc * 2 + 1];
+        double2 t = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < ME; ++i) {
+            const uint32_t le = ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xFFu;
+            const bool on = le != 0xFFu;
+            const double2 uv = ubuf2[(size_t)(on ? le : 0u) * K2 + (act ? l : 0)];
+            const int ml = L.mltc[cc * ME + i];
+            const double sd = L.sdv[cc * ME + i];
+            const double dx = uv.x * (0.5 * (tc[j].hc.x + tc[j].hv[i].x)) * sd * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
+            const double dy = uv.y * (0.5 * (tc[j].hc.y + tc[j].hv[i].y)) * sd * invA;   // horizontal_advection.jl:63
+            if (on && k0 < ml) t.x += dx;
+            if (on && k0 + 1 < ml) t.y += dy;
+        }
+        const uint32_t ooff = (uint32_t)c * rowB + voff;
+        double2 hs = make_double2(0.0, 0.0);
+        if (valid && act) {
+            if constexpr (MODE == 0) gstore2(a.tendH, ooff, t);
+            if constexpr (MODE == 1 || MODE == 2) {
+                const double2 hcur = MODE == 2 ? tc[j].cur : tc[j].hc;
+                const double2 nb = MODE == 2 ? tc[j].nin : hcur;
+                hs = make_double2(hcur.x + a.a * t.x, hcur.y + a.a * t.y);                    // time_integration.jl:125
+                gstore2(a.ph_out, ooff, hs);
+                gstore2(a.nh_out, ooff, make_double2(nb.x + a.b * t.x, nb.y + a.b * t.y));    // :135
+            }
+            if constexpr (MODE == 3) {
+                hs = make_double2(tc[j].nin.x + a.b * t.x, tc[j].nin.y + a.b * t.y);
+                gstore2(a.nh_out, ooff, hs);
+            }
+        }
+        if constexpr (MODE != 0) {
+#pragma unroll
+            for (int sft = 16; sft >= 1; sft >>= 1) {                   // oracle_ksum order (see k_stage_rec2)
+                const double ox = __shfl_xor(hs.x, sft, 64), oy = __shfl_xor(hs.y, sft, 64);
+                hs = make_double2(hs.x + ox, hs.y + oy);
+            }
+            if (valid && l == 0) a.ssh_out[c] = (hs.x + hs.y) - L.rsum[cc];                   // :209 (+N3)
+        }
+    }
+
+    // ---------------- edges: u from LDS; own Curr/New rows pipelined two deep ----------------
+    {
+        const int n = nOwnE > grp ? (nOwnE - grp + NG - 1) / NG : 0;
+        const int no = __shfl_xor(n, 32, 64);
+        const int nmax = n > no ? n : no;
+        auto idx = [&](int t) { int tcl = t < n ? t : n - 1; return tcl < 0 ? 0 : grp + NG * tcl; };
+        auto issue = [&](double2 &cur, double2 &nin, int ei) {
+            const uint32_t own = (uint32_t)(e0 + ei) * rowB + voffc;
+            if constexpr (MODE == 2) cur = gload2(a.cu, own);
+            if constexpr (MODE >= 2) nin = gload2(a.nu_in, own);
+        };
+        auto finish = [&](const double2 &cur, const double2 &nin, int ei, bool valid) {
+            const int mlt = L.ehdr[ei * 4 + 3];
+            const double g = L.g[ei], ds = L.ds[ei];
+            const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
+            double2 t = make_double2(0.0, 0.0);
+            if (ax) t.x -= g * ds;                                      // pressure_gradient.jl:63
+            if (ay) t.y -= g * ds;
+            uint32_t lw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lw[i] = L.leoe[ei * 4 + i];
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) {
+                const uint32_t le = (lw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                const bool on = le != 0xFFu;
+                const double2 uv = ubuf2[(size_t)(on ? le : 0u) * K2 + (act ? l : 0)];
+                const double w = L.woe[ei * ME2 + i], f = L.feoe[ei * ME2 + i];
+                const double px = w * uv.x * f, py = w * uv.y * f;      // ...coriolis.jl:70-72
+                if (on && ax) t.x += px;
+                if (on && ay) t.y += py;
+            }
+            const uint32_t ooff = (uint32_t)(e0 + ei) * rowB + voff;
+            if (valid && act) {
+                if constexpr (MODE == 0) gstore2(a.tendU, ooff, t);
+                if constexpr (MODE == 1) {
+                    const double2 up = ubuf2[(size_t)ei * K2 + l];      // own row = local row ei
+                    gstore2(a.pu_out, ooff, make_double2(up.x + a.a * t.x, up.y + a.a * t.y));   // time_integration.jl:124
+                    gstore2(a.nu_out, ooff, make_double2(up.x + a.b * t.x, up.y + a.b * t.y));   // :134
+                }
+                if constexpr (MODE == 2) {
+                    gstore2(a.pu_out, ooff, make_double2(cur.x + a.a * t.x, cur.y + a.a * t.y));
+                    gstore2(a.nu_out, ooff, make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y));
+                }
+                if constexpr (MODE == 3) gstore2(a.nu_out, ooff, make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y));
+            }
+        };
+        if (nmax > 0) {
+            double2 cA = make_double2(0, 0), nA = cA, cB = cA, nB = cA;
+            issue(cA, nA, idx(0));
+            for (int t = 0;;) {
+                issue(cB, nB, idx(t + 1));
+                finish(cA, nA, idx(t), t < n);
+                if (++t >= nmax) break;
+                issue(cA, nA, idx(t + 1));
+                finish(cB, nB, idx(t), t < n);
+                if (++t >= nmax) break;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS patch-tiled variant of the fused tendency / RK-stage kernel (same arithmetic, same results).
 //
 // The direct kernel above re-reads every u-row ~12 times through the vector L1 (10 Coriolis
@@ -1727,6 +1976,8 @@ static bool launch_rec(const ColMesh &m, const StageArgs &a, int mode, dim3 g, d
     return false;
 }
 
+static int colp_mode(const StageArgs &a);
+
 template <int ME, int ME2>
 static bool launch_rec2(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3 b, size_t lds, int mE, int mC, hipStream_t s)
 {
@@ -1737,6 +1988,63 @@ static bool launch_rec2(const ColMesh &m, const StageArgs &a, int mode, dim3 g, 
         case 3: hipLaunchKernelGGL((k_stage_rec2<ME, ME2, 3>), g, b, lds, s, m, a, mE, mC); return true;
     }
     return false;
+}
+
+size_t tile_lds_bytes(const MeshDev &md)
+{
+    return ((size_t)md.maxRows * md.K + (size_t)md.maxOwnE * (2 * md.ME2 + 2) + (size_t)md.maxOwnC * (md.ME + 2)) * 8 +
+           ((size_t)md.maxOwnE * 8 + (size_t)md.maxOwnC * (2 * md.ME + 2)) * 4 + 16;
+}
+
+template <int ME, int ME2>
+static bool launch_tile(const MeshDev &m, const StageArgs &a, int mode, dim3 g, dim3 b, size_t lds, hipStream_t s)
+{
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 0>), g, b, lds, s, m, a); return true;
+        case 1: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 1>), g, b, lds, s, m, a); return true;
+        case 2: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 2>), g, b, lds, s, m, a); return true;
+        case 3: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 3>), g, b, lds, s, m, a); return true;
+    }
+    return false;
+}
+
+template <int ME, int ME2>
+static hipError_t prepare_tile(size_t lds)
+{
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return e;
+    return hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+// usable when the patch-local row lists exist, K is even and <= 64, and a patch fits the static shape
+bool stage_tile_usable(const MeshDev &md, bool ldsOk)
+{
+    return ldsOk && md.K >= 2 && md.K <= 64 && !(md.K & 1) && md.maxRows <= 8 * TILE_RB && md.maxOwnC <= 8 * TILE_MAXC &&
+           md.maxOwnE <= BLOCK && tile_lds_bytes(md) <= 160 * 1024;
+}
+
+hipError_t prepare_stage_tile(const MeshDev &md)
+{
+    const size_t lds = tile_lds_bytes(md);
+    if (md.ME == 6 && md.ME2 == 10) return prepare_tile<6, 10>(lds);
+    if (md.ME == 8 && md.ME2 == 14) return prepare_tile<8, 14>(lds);
+    if (md.ME <= 6 && md.ME2 <= 14) return prepare_tile<6, 14>(lds);
+    return hipErrorNotSupported;
+}
+
+hipError_t launch_stage_tile(const MeshDev &md, const StageArgs &a, hipStream_t s)
+{
+    const dim3 g(patch_grid(md)), b(BLOCK);
+    const int mode = colp_mode(a);
+    if (mode < 0) return hipErrorNotSupported;
+    const size_t lds = tile_lds_bytes(md);
+    bool ok = false;
+    if (md.ME == 6 && md.ME2 == 10) ok = launch_tile<6, 10>(md, a, mode, g, b, lds, s);
+    else if (md.ME == 8 && md.ME2 == 14) ok = launch_tile<8, 14>(md, a, mode, g, b, lds, s);
+    else if (md.ME <= 6 && md.ME2 <= 14) ok = launch_tile<6, 14>(md, a, mode, g, b, lds, s);
+    return ok ? hipGetLastError() : hipErrorNotSupported;
 }
 
 size_t rec_lds_bytes(const MeshDev &md)

@@ -53,6 +53,9 @@ struct OpArgs {
 };
 
 hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream_t s);
+bool stage_tile_usable(const MeshDev &md, bool ldsOk);
+hipError_t prepare_stage_tile(const MeshDev &md);
+hipError_t launch_stage_tile(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_rec2(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_rec(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_colx(const MeshDev &m, const StageArgs &a, bool pipelined, hipStream_t s);

@@ -127,7 +127,7 @@ def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     tu, th, ossh = om.tendencies_clean(u, h)
     info = Setup.mesh.info()
-    for variant in (8, 7, 1, 2, 3, 4, 5, 6):   # 1 pipelined column, 2 LDS patch-tiled, 3 generic index, 4 plain column, 5/6 16-byte-lane column (plain/pipelined)
+    for variant in (9, 8, 7, 1, 2, 3, 4, 5, 6):   # 1 pipelined column, 2 LDS patch-tiled, 3 generic index, 4 plain column, 5/6 16-byte-lane column (plain/pipelined)
         backend.set_kernel_variant(variant)
         Tend.tendNormalVelocity.set(np.full_like(tu, np.nan)); Tend.tendLayerThickness.set(np.full_like(th, np.nan))
         Prog.ssh[-1].set(ssh)
@@ -138,6 +138,7 @@ def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     backend.set_kernel_variant(0)
     if K % 2 == 0 and 8 <= K <= 64 and P == 16:
         assert 0 < info["ldsBytesPerBlock"] <= 80 * 1024, "LDS-tiled kernel should fit two workgroups per CU at P = 16"
+        assert info["maxPatchRows"] <= 136 and info["maxPatchCells"] <= 16, "tiled kernel (variant 9) must be exercised at P = 16"
     Prog._state.close(); Setup.mesh.close()
 
 
@@ -243,7 +244,7 @@ def test_reference_call_sequence_piecewise(backend):
 # RK4 stage loop
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("meshname,K,nsteps,variant", [("igw200", 1, 10, 0), ("ico16", 1, 5, 0), ("ico16", 60, 3, 1),
-                                                         ("ico16", 60, 3, 2), ("ico16", 80, 2, 2), ("ico32", 60, 2, 0)])
+                                                         ("ico16", 60, 3, 2), ("ico16", 80, 2, 2), ("ico32", 60, 2, 0), ("ico32", 60, 3, 9)])
 def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
     backend.set_kernel_variant(variant)
     mesh = get_mesh(meshname)
@@ -253,7 +254,8 @@ def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
     else:
         ssh, u, h, rest = random_state(mesh, K, 9)
         dtv = 20.0
-    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True,
+                                                       patch_cells=16 if variant in (2, 9) else 0)
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     st = orc.OracleState(om, ssh, u, h)
     mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dtv))
