@@ -31,6 +31,7 @@ WORKLOADS = {
     # name: (icosahedral frequency m, layers)  -- SURVEY.md section 8 size table
     "config4_1M_x60": (320, 60),
     "config3_41k_x60": (64, 60),
+    "exp_1M_x64": (320, 64),          # experiment: 512-byte rows (cache-line aligned)
     "config2_41k_x1": (64, 1),
     "small_10k_x60": (32, 60),
 }

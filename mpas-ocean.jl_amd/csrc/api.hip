@@ -400,8 +400,9 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
 #undef UP
     d.CI = p.CI; d.EI = p.EI;
     m->colOk = p.colOk;
-    if (p.colOk && stage_tile_usable(d, p.ldsOk) && prepare_stage_tile(d) == hipSuccess) m->tileOk = true;
+
     d.maxRows = p.maxRows; d.maxOwnE = p.maxOwnE; d.maxOwnC = p.maxOwnC;
+    if (p.colOk && stage_tile_usable(d, p.ldsOk) && prepare_stage_tile(d) == hipSuccess) m->tileOk = true;
     if (p.ldsOk && p.K % 2 == 0 && p.K >= 8) {
         const int64_t need = lds_stage_bytes(p.K, p.ME, p.ME2, p.maxRows, p.maxOwnE, p.maxOwnC);
         if (need <= 160 * 1024) {
