@@ -1197,7 +1197,7 @@ constexpr int TILE_MAXC = 2;       // cells per group: 16-cell patches
 struct TileLds {
     double *ubuf, *woe, *feoe, *g, *ds, *sdv, *invA, *rsum;
     int32_t *ehdr, *coc, *mltc;
-    uint32_t *leoe, *leoc;
+    uint32_t *leOff, *lcOff;
 };
 
 __device__ __forceinline__ TileLds tile_carve(unsigned char *smem, int K, int ME, int ME2, int maxRows, int maxOwnE, int maxOwnC)
@@ -1214,8 +1214,8 @@ __device__ __forceinline__ TileLds tile_carve(unsigned char *smem, int K, int ME
     L.ehdr = reinterpret_cast<int32_t *>(L.rsum + maxOwnC);
     L.coc = L.ehdr + (size_t)maxOwnE * 4;
     L.mltc = L.coc + (size_t)maxOwnC * ME;
-    L.leoe = reinterpret_cast<uint32_t *>(L.mltc + (size_t)maxOwnC * ME);
-    L.leoc = L.leoe + (size_t)maxOwnE * 4;
+    L.leOff = reinterpret_cast<uint32_t *>(L.mltc + (size_t)maxOwnC * ME);
+    L.lcOff = L.leOff + (size_t)maxOwnE * ME2;
     return L;
 }
 
@@ -1292,7 +1292,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_stage_tile(const MeshDev m, const 
         L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
     }
     for (int i = tid; i < nOwnE; i += BLOCK) L.g[i] = m.gInvDc[e0 + i];
-    for (int i = tid; i < nOwnE * 4; i += BLOCK) L.leoe[i] = reinterpret_cast<const uint32_t *>(m.leoe)[(size_t)e0 * 4 + i];
+    for (int i = tid; i < nOwnE * ME2; i += BLOCK) L.leOff[i] = m.leOff[(size_t)e0 * ME2 + i];
     if (tid < nOwnE) {
         L.ehdr[tid * 4 + 0] = hdr.x; L.ehdr[tid * 4 + 1] = hdr.y; L.ehdr[tid * 4 + 2] = hdr.z; L.ehdr[tid * 4 + 3] = hdr.w;
     }
@@ -1304,9 +1304,11 @@ __global__ __launch_bounds__(BLOCK, 2) void k_stage_tile(const MeshDev m, const 
         L.invA[i] = m.invArea[c0 + i];
         L.rsum[i] = m.rsum[c0 + i];
     }
-    for (int i = tid; i < nOwnC * 2; i += BLOCK) L.leoc[i] = reinterpret_cast<const uint32_t *>(m.leoc)[(size_t)c0 * 2 + i];
+    for (int i = tid; i < nOwnC * ME; i += BLOCK) L.lcOff[i] = m.lcOff[(size_t)c0 * ME + i];
     // staged rows -> LDS
     double2 *ubuf2 = reinterpret_cast<double2 *>(L.ubuf);
+    const unsigned char *ubytes = reinterpret_cast<const unsigned char *>(L.ubuf) + (act ? voff : 0u);
+    const bool regular = cptr(m.patchRegular)[p] != 0;                 // block-uniform: predicate-free fast path
 #pragma unroll
     for (int i = 0; i < TILE_RB; ++i) {
         const int r = grp + NG * i;
@@ -1324,19 +1326,28 @@ __global__ __launch_bounds__(BLOCK, 2) void k_stage_tile(const MeshDev m, const 
         const int cc = valid ? ci : 0;
         const int c = c0 + cc;
         const double invA = L.invA[cc];
-        const uint32_t w0 = L.leoc[cc * 2], w1 = L.leoc[cc * 2 + 1];
         double2 t = make_double2(0.0, 0.0);
+        if (regular) {
 #pragma unroll
-        for (int i = 0; i < ME; ++i) {
-            const uint32_t le = ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xFFu;
-            const bool on = le != 0xFFu;
-            const double2 uv = ubuf2[(size_t)(on ? le : 0u) * K2 + (act ? l : 0)];
-            const int ml = L.mltc[cc * ME + i];
-            const double sd = L.sdv[cc * ME + i];
-            const double dx = uv.x * (0.5 * (tc[j].hc.x + tc[j].hv[i].x)) * sd * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
-            const double dy = uv.y * (0.5 * (tc[j].hc.y + tc[j].hv[i].y)) * sd * invA;   // horizontal_advection.jl:63
-            if (on && k0 < ml) t.x += dx;
-            if (on && k0 + 1 < ml) t.y += dy;
+            for (int i = 0; i < ME; ++i) {
+                const double2 uv = *reinterpret_cast<const double2 *>(ubytes + L.lcOff[cc * ME + i]);
+                const double sd = L.sdv[cc * ME + i];
+                t.x += uv.x * (0.5 * (tc[j].hc.x + tc[j].hv[i].x)) * sd * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
+                t.y += uv.y * (0.5 * (tc[j].hc.y + tc[j].hv[i].y)) * sd * invA;   // horizontal_advection.jl:63
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ME; ++i) {
+                const uint32_t lo = L.lcOff[cc * ME + i];
+                const bool on = lo != 0xFFFFFFFFu;
+                const double2 uv = *reinterpret_cast<const double2 *>(ubytes + (on ? lo : 0u));
+                const int ml = L.mltc[cc * ME + i];
+                const double sd = L.sdv[cc * ME + i];
+                const double dx = uv.x * (0.5 * (tc[j].hc.x + tc[j].hv[i].x)) * sd * invA;
+                const double dy = uv.y * (0.5 * (tc[j].hc.y + tc[j].hv[i].y)) * sd * invA;
+                if (on && k0 < ml) t.x += dx;
+                if (on && k0 + 1 < ml) t.y += dy;
+            }
         }
         const uint32_t ooff = (uint32_t)c * rowB + voff;
         double2 hs = make_double2(0.0, 0.0);
@@ -1376,24 +1387,33 @@ __global__ __launch_bounds__(BLOCK, 2) void k_stage_tile(const MeshDev m, const 
             if constexpr (MODE >= 2) nin = gload2(a.nu_in, own);
         };
         auto finish = [&](const double2 &cur, const double2 &nin, int ei, bool valid) {
-            const int mlt = L.ehdr[ei * 4 + 3];
             const double g = L.g[ei], ds = L.ds[ei];
-            const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
             double2 t = make_double2(0.0, 0.0);
-            if (ax) t.x -= g * ds;                                      // pressure_gradient.jl:63
-            if (ay) t.y -= g * ds;
-            uint32_t lw[4];
+            if (regular) {
+                t.x -= g * ds;                                          // pressure_gradient.jl:63
+                t.y -= g * ds;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lw[i] = L.leoe[ei * 4 + i];
+                for (int i = 0; i < ME2; ++i) {
+                    const double2 uv = *reinterpret_cast<const double2 *>(ubytes + L.leOff[ei * ME2 + i]);
+                    const double w = L.woe[ei * ME2 + i], f = L.feoe[ei * ME2 + i];
+                    t.x += w * uv.x * f;                                // ...coriolis.jl:70-72
+                    t.y += w * uv.y * f;
+                }
+            } else {
+                const int mlt = L.ehdr[ei * 4 + 3];
+                const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
+                if (ax) t.x -= g * ds;
+                if (ay) t.y -= g * ds;
 #pragma unroll
-            for (int i = 0; i < ME2; ++i) {
-                const uint32_t le = (lw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                const bool on = le != 0xFFu;
-                const double2 uv = ubuf2[(size_t)(on ? le : 0u) * K2 + (act ? l : 0)];
-                const double w = L.woe[ei * ME2 + i], f = L.feoe[ei * ME2 + i];
-                const double px = w * uv.x * f, py = w * uv.y * f;      // ...coriolis.jl:70-72
-                if (on && ax) t.x += px;
-                if (on && ay) t.y += py;
+                for (int i = 0; i < ME2; ++i) {
+                    const uint32_t lo = L.leOff[ei * ME2 + i];
+                    const bool on = lo != 0xFFFFFFFFu;
+                    const double2 uv = *reinterpret_cast<const double2 *>(ubytes + (on ? lo : 0u));
+                    const double w = L.woe[ei * ME2 + i], f = L.feoe[ei * ME2 + i];
+                    const double px = w * uv.x * f, py = w * uv.y * f;
+                    if (on && ax) t.x += px;
+                    if (on && ay) t.y += py;
+                }
             }
             const uint32_t ooff = (uint32_t)(e0 + ei) * rowB + voff;
             if (valid && act) {
@@ -1993,7 +2013,7 @@ static bool launch_rec2(const ColMesh &m, const StageArgs &a, int mode, dim3 g, 
 size_t tile_lds_bytes(const MeshDev &md)
 {
     return ((size_t)md.maxRows * md.K + (size_t)md.maxOwnE * (2 * md.ME2 + 2) + (size_t)md.maxOwnC * (md.ME + 2)) * 8 +
-           ((size_t)md.maxOwnE * 8 + (size_t)md.maxOwnC * (2 * md.ME + 2)) * 4 + 16;
+           ((size_t)md.maxOwnE * (4 + md.ME2) + (size_t)md.maxOwnC * (3 * md.ME)) * 4 + 16;
 }
 
 template <int ME, int ME2>

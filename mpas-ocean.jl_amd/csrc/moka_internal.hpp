@@ -59,6 +59,11 @@ struct Plan {
     std::vector<int32_t> haloEdge;    // new edge ids
     std::vector<uint8_t> leoc;        // nC*8
     std::vector<uint8_t> leoe;        // nE*16
+    // the same as LDS BYTE offsets (local row * K*8; 0xFFFFFFFF = none) for the tiled kernel, and a per-patch
+    // flag "every slot valid and every level active" that selects its predicate-free fast path
+    std::vector<uint32_t> lcOff;      // nC*ME
+    std::vector<uint32_t> leOff;      // nE*ME2
+    std::vector<int32_t>  patchRegular;   // nPatches
     int32_t maxRows = 0, maxOwnE = 0, maxOwnC = 0;
     bool ldsOk = false;               // every patch has <= 254 rows
     // vertices
@@ -89,6 +94,8 @@ struct MeshDev {
     // LDS-tiled kernel
     const int32_t *haloStart, *haloEdge;
     const uint8_t *leoc, *leoe;
+    const uint32_t *lcOff, *leOff;
+    const int32_t *patchRegular;
     int32_t maxRows, maxOwnE, maxOwnC;
 };
 

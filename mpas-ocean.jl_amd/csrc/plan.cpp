@@ -413,6 +413,30 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
         }
         if (!p.ldsOk) { p.haloEdge.clear(); std::fill(p.haloStart.begin(), p.haloStart.end(), 0); }
     }
+    p.lcOff.assign((size_t)nC * ME, 0xFFFFFFFFu);
+    p.leOff.assign((size_t)nE * ME2, 0xFFFFFFFFu);
+    p.patchRegular.assign(p.nPatches, 0);
+    if (p.ldsOk) {
+        const uint32_t rowB = (uint32_t)p.K * 8u;
+        for (int c = 0; c < nC; ++c)
+            for (int i = 0; i < ME; ++i)
+                if (p.leoc[(size_t)c * 8 + i] != 0xFF) p.lcOff[IX(i, c, ME)] = p.leoc[(size_t)c * 8 + i] * rowB;
+        for (int e = 0; e < nE; ++e)
+            for (int i = 0; i < ME2; ++i)
+                if (p.leoe[(size_t)e * 16 + i] != 0xFF) p.leOff[IX(i, e, ME2)] = p.leoe[(size_t)e * 16 + i] * rowB;
+        for (int q = 0; q < p.nPatches; ++q) {
+            bool reg = true;
+            for (int c = p.patchCellStart[q]; c < p.patchCellStart[q + 1] && reg; ++c)
+                for (int i = 0; i < ME; ++i)
+                    if (p.eoc[IX(i, c, ME)] < 0 || p.mltc[IX(i, c, ME)] < p.K) { reg = false; break; }
+            for (int e = p.patchEdgeStart[q]; e < p.patchEdgeStart[q + 1] && reg; ++e) {
+                if (p.ehdr[4 * (size_t)e + 3] < p.K) { reg = false; break; }
+                for (int i = 0; i < ME2; ++i)
+                    if (p.eoe[IX(i, e, ME2)] < 0) { reg = false; break; }
+            }
+            p.patchRegular[q] = reg ? 1 : 0;
+        }
+    }
     return MOKA_OK;
 }
 

@@ -117,7 +117,7 @@ def random_state(mesh, K, seed):
     ("ico16", 60, L.ORDER_RCB, 0), ("ico16", 64, L.ORDER_NONE, 0), ("ico16", 80, L.ORDER_RCB, 0),
     ("ico32", 60, L.ORDER_RCB, 32), ("ico16", 130, L.ORDER_RCB, 64), ("ico32", 60, L.ORDER_RCB, 0),
     ("ico16", 8, L.ORDER_RCB, 0), ("ico16", 34, L.ORDER_RCB, 0), ("ico16", 100, L.ORDER_RCB, 0), ("planar", 60, L.ORDER_RCB, 0),
-    ("ico16", 60, L.ORDER_RCM, 0), ("ico16", 60, L.ORDER_NONE, 24), ("ico32", 60, L.ORDER_RCB, 16), ("ico16", 62, L.ORDER_RCB, 16),
+    ("ico16", 60, L.ORDER_RCM, 0), ("ico16", 60, L.ORDER_NONE, 24), ("ico32", 60, L.ORDER_RCB, 12), ("ico16", 62, L.ORDER_RCB, 12), ("planar", 60, L.ORDER_RCB, 12), ("ico16", 8, L.ORDER_RCB, 12),
 ])
 def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     mesh = get_mesh(meshname)
@@ -136,9 +136,9 @@ def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
         assert np.array_equal(Tend.tendLayerThickness.get(), th), variant
         assert np.array_equal(Prog.ssh[-1].get(), ossh), variant
     backend.set_kernel_variant(0)
-    if K % 2 == 0 and 8 <= K <= 64 and P == 16:
-        assert 0 < info["ldsBytesPerBlock"] <= 80 * 1024, "LDS-tiled kernel should fit two workgroups per CU at P = 16"
-        assert info["maxPatchRows"] <= 136 and info["maxPatchCells"] <= 16, "tiled kernel (variant 9) must be exercised at P = 16"
+    if K % 2 == 0 and 8 <= K <= 64 and P == 12:
+        assert 0 < info["ldsBytesPerBlock"] <= 80 * 1024, "LDS-tiled kernel (variant 2) should fit two workgroups per CU"
+        assert info["maxPatchRows"] <= 136 and info["maxPatchCells"] <= 16, "tiled kernel (variant 9) must be exercised at P = 12"
     Prog._state.close(); Setup.mesh.close()
 
 
@@ -255,7 +255,7 @@ def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
         ssh, u, h, rest = random_state(mesh, K, 9)
         dtv = 20.0
     Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True,
-                                                       patch_cells=16 if variant in (2, 9) else 0)
+                                                       patch_cells=12 if variant in (2, 9) else 0)
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     st = orc.OracleState(om, ssh, u, h)
     mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dtv))
