@@ -1061,8 +1061,12 @@ __device__ __forceinline__ void r2edge_issue(R2Edge<ME2, MODE> &b, const RecLds 
     const uint32_t own = (uint32_t)e * rowB + voff;
 #pragma unroll
     for (int i = 0; i < ME2; ++i) b.uv[i] = gload2(a.pu, r[i] + voff);
-    b.sA = a.ssh[r[ME2]];
-    b.sB = a.ssh[r[ME2 + 1]];
+    // ssh[c1], ssh[c2]: one lane pair per half-wave fetches them (a 32-lane broadcast load would cost the texture
+    // address path as much as a full row); r2edge_finish broadcasts with a shuffle
+    b.sA = 0.0;
+    b.sB = 0.0;
+    if (voff == 0u) b.sA = a.ssh[r[ME2]];
+    if (voff == 16u) b.sB = a.ssh[r[ME2 + 1]];
     if constexpr (MODE == 1) b.own = gload2(a.pu, own);
     if constexpr (MODE == 2) b.cur = gload2(a.cu, own);
     if constexpr (MODE >= 2) b.nin = gload2(a.nu_in, own);
@@ -1078,7 +1082,8 @@ __device__ __forceinline__ void r2edge_finish(const R2Edge<ME2, MODE> &b, const 
     const uint32_t mask = r[ME2 + 2];
     const int mlt = (int)r[ME2 + 3];
     const double g = L.g[ei];
-    const double ds = b.sB - b.sA;                                     // ssh[c2] - ssh[c1]
+    const double sA = __shfl(b.sA, 0, 32), sB = __shfl(b.sB, 1, 32);    // from lanes 0 / 1 of this half-wave
+    const double ds = sB - sA;                                         // ssh[c2] - ssh[c1]
     const uint32_t ooff = (uint32_t)e * rowB + voff;
     const int k0 = 2 * l;
     const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
