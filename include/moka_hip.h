@@ -211,13 +211,16 @@ int moka_sum_sq(moka_state *st, int field, int time_level, double *out);
  * cellClass = 0 (owned, needed by another rank) / 1 (owned interior) / 2 (halo).  The library packs the rows
  * other ranks need into one device buffer and unpacks received rows; moving the buffers between ranks is the
  * host layer's job (torch.distributed on RCCL over xGMI in bench.py; gloo in the tests; MPI.jl from Julia).
- *   buffer layout: [cells x K doubles of layerThickness][cells x 1 double of ssh][edges x K doubles of normalVelocity]
- * Entity ids are in the caller's (local mesh) numbering. */
+ *   buffer layout, per neighbour i (one message each way per neighbour and stage):
+ *     [K doubles of layerThickness for cells[off[i]..off[i+1])] [ssh of the same cells] [K doubles of normalVelocity
+ *      for edges[off[i]..off[i+1])]
+ * Entity ids are in the caller's (local mesh) numbering; the *Off arrays have nNeighbors+1 entries. */
 typedef struct moka_halo moka_halo;
 int  moka_ctx_streams(moka_ctx *ctx, void **compute_stream, void **comm_stream);   /* hipStream_t handles */
-int  moka_halo_create(moka_state *st, const int32_t *sendCells, int64_t nSendCells, const int32_t *sendEdges,
-                      int64_t nSendEdges, const int32_t *recvCells, int64_t nRecvCells, const int32_t *recvEdges,
-                      int64_t nRecvEdges, int32_t nPatchesBoundary, int32_t nPatchesOwned, moka_halo **out);
+int  moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCells, const int64_t *sendCellOff,
+                      const int32_t *sendEdges, const int64_t *sendEdgeOff, const int32_t *recvCells,
+                      const int64_t *recvCellOff, const int32_t *recvEdges, const int64_t *recvEdgeOff,
+                      int32_t nPatchesBoundary, int32_t nPatchesOwned, moka_halo **out);
 void moka_halo_destroy(moka_halo *h);
 int  moka_halo_buffer_elems(const moka_halo *h, int64_t *sendElems, int64_t *recvElems);
 /* what: 0 = current time level, 1..4 = output of RK4 stage `what`.  pack runs on the comm stream after the work

@@ -1903,6 +1903,19 @@ __global__ __launch_bounds__(BLOCK) void k_pack_rows(double *buf, double *field,
     }
 }
 
+// halo pack / unpack through an element map: map[j] = (field tag << 30) | element index, tag 0 = h, 1 = ssh, 2 = u
+__global__ __launch_bounds__(BLOCK) void k_halo_map(double *buf, double *h, double *ssh, double *u, const uint32_t *map,
+                                                   int64_t n, int unpack)
+{
+    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * BLOCK) {
+        const uint32_t mj = map[j];
+        const uint32_t tag = mj >> 30, idx = mj & 0x3FFFFFFFu;
+        double *f = tag == 0 ? h : tag == 1 ? ssh : u;
+        if (unpack) f[idx] = buf[j];
+        else buf[j] = f[idx];
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_copy(double *dst, const double *src, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = src[i];
@@ -2228,6 +2241,16 @@ hipError_t launch_pack_rows(double *buf, const double *field, const int32_t *row
     int64_t blocks = (n * K + BLOCK - 1) / BLOCK;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(BLOCK), 0, s, buf, const_cast<double *>(field), rows, n, K, unpack);
+    return hipGetLastError();
+}
+
+hipError_t launch_halo_map(double *buf, double *h, double *ssh, double *u, const uint32_t *map, int64_t n, int unpack,
+                           hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + BLOCK - 1) / BLOCK;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_halo_map, dim3((unsigned)blocks), dim3(BLOCK), 0, s, buf, h, ssh, u, map, n, unpack);
     return hipGetLastError();
 }
 

@@ -70,6 +70,8 @@ hipError_t launch_permute_rows(double *dst, const double *src, const int32_t *n2
 hipError_t launch_sum_sq_serial(const double *a, int64_t n, double *out, hipStream_t s);
 hipError_t launch_copy(double *dst, const double *src, int64_t n, hipStream_t s);
 // halo pack / unpack: rows of (K doubles) gathered into / scattered from a contiguous buffer
+hipError_t launch_halo_map(double *buf, double *h, double *ssh, double *u, const uint32_t *map, int64_t n, int unpack,
+                           hipStream_t s);
 hipError_t launch_pack_rows(double *buf, const double *field, const int32_t *rows, int64_t n, int K, int unpack, hipStream_t s);
 
 }  // namespace moka

@@ -137,7 +137,8 @@ def lib():
     L.moka_sum_sq.argtypes = [vp, C.c_int, C.c_int, _f64p]
     L.moka_set_kernel_variant.argtypes = [vp, C.c_int]
     L.moka_ctx_streams.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
-    L.moka_halo_create.argtypes = [vp, _i32p, C.c_int64, _i32p, C.c_int64, _i32p, C.c_int64, _i32p, C.c_int64,
+    i64p = C.POINTER(C.c_int64)
+    L.moka_halo_create.argtypes = [vp, C.c_int32, _i32p, i64p, _i32p, i64p, _i32p, i64p, _i32p, i64p,
                                    C.c_int32, C.c_int32, C.POINTER(vp)]
     L.moka_halo_destroy.argtypes = [vp]
     L.moka_halo_destroy.restype = None

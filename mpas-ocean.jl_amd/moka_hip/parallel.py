@@ -143,16 +143,37 @@ def build_local(mesh, part: np.ndarray, rank: int, world: int) -> LocalMesh:
 
 
 def message_slices(lm: LocalMesh, K: int, send: bool):
-    """Per neighbour: the three contiguous slices (h rows, ssh, u rows) of the packed buffer
-    [cells x K | cells | edges x K] that go to / come from that neighbour."""
+    """Per neighbour: the contiguous slice [h rows | ssh | u rows] of the packed buffer that goes to / comes from it."""
     co, eo = (lm.send_cell_off, lm.send_edge_off) if send else (lm.recv_cell_off, lm.recv_edge_off)
-    nc = int(co[-1])
     out = []
     for i, q in enumerate(lm.neighbors):
-        out.append((q, [(int(co[i]) * K, int(co[i + 1]) * K),
-                        (nc * K + int(co[i]), nc * K + int(co[i + 1])),
-                        (nc * K + nc + int(eo[i]) * K, nc * K + nc + int(eo[i + 1]) * K)]))
+        a = int(co[i]) * (K + 1) + int(eo[i]) * K
+        b = int(co[i + 1]) * (K + 1) + int(eo[i + 1]) * K
+        out.append((q, a, b))
     return out
+
+
+def pack_numpy(lm: LocalMesh, K: int, ssh, u, h):
+    """The library's send-buffer layout, in numpy (used by the CPU tests)."""
+    parts = []
+    for i in range(len(lm.neighbors)):
+        c = lm.send_cells[lm.send_cell_off[i]:lm.send_cell_off[i + 1]]
+        e = lm.send_edges[lm.send_edge_off[i]:lm.send_edge_off[i + 1]]
+        parts += [h[c].ravel(), ssh[c], u[e].ravel()]
+    return np.concatenate(parts) if parts else np.zeros(0)
+
+
+def unpack_numpy(lm: LocalMesh, K: int, buf, ssh, u, h):
+    pos = 0
+    for i in range(len(lm.neighbors)):
+        c = lm.recv_cells[lm.recv_cell_off[i]:lm.recv_cell_off[i + 1]]
+        e = lm.recv_edges[lm.recv_edge_off[i]:lm.recv_edge_off[i + 1]]
+        h[c] = buf[pos:pos + c.size * K].reshape(c.size, K)
+        pos += c.size * K
+        ssh[c] = buf[pos:pos + c.size]
+        pos += c.size
+        u[e] = buf[pos:pos + e.size * K].reshape(e.size, K)
+        pos += e.size * K
 
 
 # ---------------------------------------------------------------------------------------------
@@ -199,10 +220,14 @@ class DistributedModel:
         self._halo = C.c_void_p()
         i32 = lambda a: L.i32(np.ascontiguousarray(a, dtype=np.int32))
         self._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (lm.send_cells, lm.send_edges, lm.recv_cells, lm.recv_edges)]
-        L.check(L.lib().moka_halo_create(self.Prog._state._h, L.i32(self._keep[0]), self._keep[0].size,
-                                         L.i32(self._keep[1]), self._keep[1].size, L.i32(self._keep[2]), self._keep[2].size,
-                                         L.i32(self._keep[3]), self._keep[3].size, self.p_boundary, self.p_owned,
-                                         C.byref(self._halo)), backend._h)
+        offs = [np.ascontiguousarray(a, dtype=np.int64)
+                for a in (lm.send_cell_off, lm.send_edge_off, lm.recv_cell_off, lm.recv_edge_off)]
+        self._keep += offs
+        i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        L.check(L.lib().moka_halo_create(self.Prog._state._h, len(lm.neighbors),
+                                         L.i32(self._keep[0]), i64(offs[0]), L.i32(self._keep[1]), i64(offs[1]),
+                                         L.i32(self._keep[2]), i64(offs[2]), L.i32(self._keep[3]), i64(offs[3]),
+                                         self.p_boundary, self.p_owned, C.byref(self._halo)), backend._h)
         ns, nr = C.c_int64(), C.c_int64()
         L.check(L.lib().moka_halo_buffer_elems(self._halo, C.byref(ns), C.byref(nr)))
         dev = torch.device("cuda", backend.device)
@@ -210,6 +235,7 @@ class DistributedModel:
         self.recvbuf = torch.zeros(max(nr.value, 1), dtype=torch.float64, device=dev)
         self.send_slices = message_slices(lm, K, True)
         self.recv_slices = message_slices(lm, K, False)
+        self._p2p = None                      # P2POp list of the nccl transport, built once
         cs, ms = C.c_void_p(), C.c_void_p()
         L.check(L.lib().moka_ctx_streams(backend._h, C.byref(cs), C.byref(ms)))
         self.comm_stream = torch.cuda.ExternalStream(ms.value, device=dev)
@@ -221,22 +247,17 @@ class DistributedModel:
         if not self.lm.neighbors:
             return
         if self.transport == "nccl":
+            if self._p2p is None:             # one message per neighbour and direction; the op list is reused
+                self._p2p = [dist.P2POp(dist.irecv, self.recvbuf[a:b], q) for q, a, b in self.recv_slices if b > a] + \
+                            [dist.P2POp(dist.isend, self.sendbuf[a:b], q) for q, a, b in self.send_slices if b > a]
             with torch.cuda.stream(self.comm_stream):
-                ops = []
-                for q, sl in self.recv_slices:
-                    ops += [dist.P2POp(dist.irecv, self.recvbuf[a:b], q) for a, b in sl if b > a]
-                for q, sl in self.send_slices:
-                    ops += [dist.P2POp(dist.isend, self.sendbuf[a:b], q) for a, b in sl if b > a]
-                for w in dist.batch_isend_irecv(ops):
+                for w in dist.batch_isend_irecv(self._p2p):
                     w.wait()                     # stream-ordered: the comm stream waits, the host does not
         else:                                    # gloo: through the host
             self.backend.synchronize()
             send_cpu, recv_cpu = self.sendbuf.cpu(), torch.empty_like(self.recvbuf, device="cpu")
-            reqs = []
-            for q, sl in self.recv_slices:
-                reqs += [dist.irecv(recv_cpu[a:b], q, group=self.group) for a, b in sl if b > a]
-            for q, sl in self.send_slices:
-                reqs += [dist.isend(send_cpu[a:b].contiguous(), q, group=self.group) for a, b in sl if b > a]
+            reqs = [dist.irecv(recv_cpu[a:b], q, group=self.group) for q, a, b in self.recv_slices if b > a]
+            reqs += [dist.isend(send_cpu[a:b].contiguous(), q, group=self.group) for q, a, b in self.send_slices if b > a]
             for w in reqs:
                 w.wait()
             self.recvbuf.copy_(recv_cpu)

@@ -21,23 +21,16 @@ from moka_hip import parallel as par  # noqa: E402
 
 
 def exchange_numpy(lm, K, fields, dist):
-    """fields = (ssh, u, h) local arrays; halo rows are overwritten with the owners' values (gloo)."""
+    """fields = (ssh, u, h) local arrays; halo rows are overwritten with the owners' values (gloo).
+    Same buffer layout and message slices as the device path (par.pack_numpy / message_slices)."""
     ssh, u, h = fields
-    sc, se, rc, re = lm.send_cells, lm.send_edges, lm.recv_cells, lm.recv_edges
-    sendbuf = torch.from_numpy(np.concatenate([h[sc].ravel(), ssh[sc], u[se].ravel()]))
-    recvbuf = torch.zeros(rc.size * (K + 1) + re.size * K, dtype=torch.float64)
-    reqs = []
-    for q, sl in par.message_slices(lm, K, False):
-        reqs += [dist.irecv(recvbuf[a:b], q) for a, b in sl if b > a]
-    for q, sl in par.message_slices(lm, K, True):
-        reqs += [dist.isend(sendbuf[a:b].contiguous(), q) for a, b in sl if b > a]
+    sendbuf = torch.from_numpy(par.pack_numpy(lm, K, ssh, u, h))
+    recvbuf = torch.zeros(lm.recv_cells.size * (K + 1) + lm.recv_edges.size * K, dtype=torch.float64)
+    reqs = [dist.irecv(recvbuf[a:b], q) for q, a, b in par.message_slices(lm, K, False) if b > a]
+    reqs += [dist.isend(sendbuf[a:b].contiguous(), q) for q, a, b in par.message_slices(lm, K, True) if b > a]
     for w in reqs:
         w.wait()
-    r = recvbuf.numpy()
-    nc = rc.size
-    h[rc] = r[:nc * K].reshape(nc, K)
-    ssh[rc] = r[nc * K:nc * K + nc]
-    u[re] = r[nc * K + nc:].reshape(re.size, K)
+    par.unpack_numpy(lm, K, recvbuf.numpy(), ssh, u, h)
 
 
 def main():
