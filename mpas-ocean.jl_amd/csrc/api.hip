@@ -743,35 +743,55 @@ int moka_sum_sq(moka_state *st, int field, int time_level, double *out)
 // ---------------------------------------------------------------------------------------------
 struct moka_halo {
     moka_state *st = nullptr;
-    int32_t *sendCells = nullptr, *sendEdges = nullptr, *recvCells = nullptr, *recvEdges = nullptr;   // device numbering
-    int64_t nSendCells = 0, nSendEdges = 0, nRecvCells = 0, nRecvEdges = 0;
+    uint32_t *sendMap = nullptr, *recvMap = nullptr;     // element maps, device
+    int64_t nSend = 0, nRecv = 0;                        // doubles
     int32_t pBoundary = 0, pOwned = 0;
     double dt = 0.0;
     const double *ssh0 = nullptr;
 };
 
-static int upload_ids(moka_state *st, const int32_t *ids, int64_t n, const std::vector<int32_t> &o2n, int32_t **out)
+// Element map of one direction.  Per neighbour i the buffer segment is
+//   [h rows of cells[co[i]..co[i+1]) | ssh of the same cells | u rows of edges[eo[i]..eo[i+1])]   (one message)
+static int build_halo_map(moka_state *st, int nNbr, const int32_t *cells, const int64_t *co, const int32_t *edges,
+                          const int64_t *eo, uint32_t **outDev, int64_t *outN)
 {
-    *out = nullptr;
-    if (n <= 0) return MOKA_OK;
-    std::vector<int32_t> dev((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        if (ids[i] < 0 || (size_t)ids[i] >= o2n.size()) return fail(st->ctx, MOKA_ERR_ARG, "halo list entry out of range");
-        dev[(size_t)i] = o2n[(size_t)ids[i]];
+    const Plan &p = st->mesh->plan;
+    const int K = p.K;
+    if ((int64_t)p.K * std::max(p.nE, p.nC) >= (1ll << 30))
+        return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "halo element map: a local field has more than 2^30 elements");
+    std::vector<uint32_t> map;
+    map.reserve((size_t)(co[nNbr] * (K + 1) + eo[nNbr] * K));
+    for (int i = 0; i < nNbr; ++i) {
+        for (int64_t j = co[i]; j < co[i + 1]; ++j) {
+            if (cells[j] < 0 || cells[j] >= p.nC) return fail(st->ctx, MOKA_ERR_ARG, "halo cell id out of range");
+            const uint32_t base = (uint32_t)p.cellO2N[cells[j]] * (uint32_t)K;
+            for (int k = 0; k < K; ++k) map.push_back((0u << 30) | (base + k));
+        }
+        for (int64_t j = co[i]; j < co[i + 1]; ++j) map.push_back((1u << 30) | (uint32_t)p.cellO2N[cells[j]]);
+        for (int64_t j = eo[i]; j < eo[i + 1]; ++j) {
+            if (edges[j] < 0 || edges[j] >= p.nE) return fail(st->ctx, MOKA_ERR_ARG, "halo edge id out of range");
+            const uint32_t base = (uint32_t)p.edgeO2N[edges[j]] * (uint32_t)K;
+            for (int k = 0; k < K; ++k) map.push_back((2u << 30) | (base + k));
+        }
     }
+    *outN = (int64_t)map.size();
+    *outDev = nullptr;
+    if (map.empty()) return MOKA_OK;
     void *d = nullptr;
-    HIPCHK(st->ctx, hipMalloc(&d, (size_t)n * sizeof(int32_t)));
+    HIPCHK(st->ctx, hipMalloc(&d, map.size() * sizeof(uint32_t)));
     st->allocs.push_back(d);
-    HIPCHK(st->ctx, hipMemcpy(d, dev.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
-    *out = static_cast<int32_t *>(d);
+    HIPCHK(st->ctx, hipMemcpy(d, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    *outDev = static_cast<uint32_t *>(d);
     return MOKA_OK;
 }
 
-int moka_halo_create(moka_state *st, const int32_t *sendCells, int64_t nSendCells, const int32_t *sendEdges,
-                     int64_t nSendEdges, const int32_t *recvCells, int64_t nRecvCells, const int32_t *recvEdges,
-                     int64_t nRecvEdges, int32_t nPatchesBoundary, int32_t nPatchesOwned, moka_halo **out)
+int moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCells, const int64_t *sendCellOff,
+                     const int32_t *sendEdges, const int64_t *sendEdgeOff, const int32_t *recvCells,
+                     const int64_t *recvCellOff, const int32_t *recvEdges, const int64_t *recvEdgeOff,
+                     int32_t nPatchesBoundary, int32_t nPatchesOwned, moka_halo **out)
 {
-    if (!st || !out) return fail(st ? st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (!st || !out || nNeighbors < 0 || !sendCellOff || !sendEdgeOff || !recvCellOff || !recvEdgeOff)
+        return fail(st ? st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
     *out = nullptr;
     const Plan &p = st->mesh->plan;
     if (nPatchesBoundary < 0 || nPatchesOwned < nPatchesBoundary || nPatchesOwned > p.nPatches)
@@ -780,15 +800,17 @@ int moka_halo_create(moka_state *st, const int32_t *sendCells, int64_t nSendCell
     moka_halo *h = new (std::nothrow) moka_halo();
     if (!h) return fail(st->ctx, MOKA_ERR_ALLOC, "out of host memory");
     h->st = st;
-    h->nSendCells = nSendCells; h->nSendEdges = nSendEdges; h->nRecvCells = nRecvCells; h->nRecvEdges = nRecvEdges;
     h->pBoundary = nPatchesBoundary; h->pOwned = nPatchesOwned;
     int rc;
-    if ((rc = upload_ids(st, sendCells, nSendCells, p.cellO2N, &h->sendCells)) ||
-        (rc = upload_ids(st, sendEdges, nSendEdges, p.edgeO2N, &h->sendEdges)) ||
-        (rc = upload_ids(st, recvCells, nRecvCells, p.cellO2N, &h->recvCells)) ||
-        (rc = upload_ids(st, recvEdges, nRecvEdges, p.edgeO2N, &h->recvEdges))) {
+    try {
+        if ((rc = build_halo_map(st, nNeighbors, sendCells, sendCellOff, sendEdges, sendEdgeOff, &h->sendMap, &h->nSend)) ||
+            (rc = build_halo_map(st, nNeighbors, recvCells, recvCellOff, recvEdges, recvEdgeOff, &h->recvMap, &h->nRecv))) {
+            delete h;
+            return rc;
+        }
+    } catch (const std::bad_alloc &) {
         delete h;
-        return rc;
+        return fail(st->ctx, MOKA_ERR_ALLOC, "out of host memory building the halo maps");
     }
     *out = h;
     return MOKA_OK;
@@ -799,48 +821,39 @@ void moka_halo_destroy(moka_halo *h) { delete h; }
 int moka_halo_buffer_elems(const moka_halo *h, int64_t *sendElems, int64_t *recvElems)
 {
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
-    const int K = h->st->mesh->plan.K;
-    if (sendElems) *sendElems = h->nSendCells * (K + 1) + h->nSendEdges * K;
-    if (recvElems) *recvElems = h->nRecvCells * (K + 1) + h->nRecvEdges * K;
+    if (sendElems) *sendElems = h->nSend;
+    if (recvElems) *recvElems = h->nRecv;
     return MOKA_OK;
 }
 
 // what: 0 = the current time level, 1..4 = the output of RK4 stage `what` (valid between dist_begin and dist_end)
 int moka_halo_pack(moka_halo *h, int what, double *sendbuf)
 {
-    if (!h || (!sendbuf && (h->nSendCells || h->nSendEdges))) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (!h || (!sendbuf && h->nSend)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
     if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
     moka_state *st = h->st;
     moka_ctx *c = st->ctx;
-    const int K = st->mesh->plan.K;
     HIPCHK(c, hipSetDevice(c->device));
     const LevelBufs &o = rk4_stage_output(st, what);
     // the rows to send are produced by the boundary patches (or by whatever last ran on the compute stream)
     HIPCHK(c, hipEventRecord(c->evBoundary, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm, c->evBoundary, 0));
-    double *bh = sendbuf, *bs = bh + h->nSendCells * K, *bu = bs + h->nSendCells;
-    HIPCHK(c, launch_pack_rows(bh, o.h, h->sendCells, h->nSendCells, K, 0, c->comm));
-    HIPCHK(c, launch_pack_rows(bs, o.ssh, h->sendCells, h->nSendCells, 1, 0, c->comm));
-    HIPCHK(c, launch_pack_rows(bu, o.u, h->sendEdges, h->nSendEdges, K, 0, c->comm));
+    HIPCHK(c, launch_halo_map(sendbuf, o.h, o.ssh, o.u, h->sendMap, h->nSend, 0, c->comm));
     return MOKA_OK;
 }
 
 int moka_halo_unpack(moka_halo *h, int what, const double *recvbuf)
 {
-    if (!h || (!recvbuf && (h->nRecvCells || h->nRecvEdges))) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (!h || (!recvbuf && h->nRecv)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
     if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
     moka_state *st = h->st;
     moka_ctx *c = st->ctx;
-    const int K = st->mesh->plan.K;
     HIPCHK(c, hipSetDevice(c->device));
     const LevelBufs &o = rk4_stage_output(st, what);
     // the interior launch may still be writing the (to be overwritten) halo rows of a straddling patch
     HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
-    const double *bh = recvbuf, *bs = bh + h->nRecvCells * K, *bu = bs + h->nRecvCells;
-    HIPCHK(c, launch_pack_rows(const_cast<double *>(bh), o.h, h->recvCells, h->nRecvCells, K, 1, c->comm));
-    HIPCHK(c, launch_pack_rows(const_cast<double *>(bs), o.ssh, h->recvCells, h->nRecvCells, 1, 1, c->comm));
-    HIPCHK(c, launch_pack_rows(const_cast<double *>(bu), o.u, h->recvEdges, h->nRecvEdges, K, 1, c->comm));
+    HIPCHK(c, launch_halo_map(const_cast<double *>(recvbuf), o.h, o.ssh, o.u, h->recvMap, h->nRecv, 1, c->comm));
     HIPCHK(c, hipEventRecord(c->evHalo, c->comm));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->evHalo, 0));     // whatever comes next on the compute stream sees the halo
     return MOKA_OK;
