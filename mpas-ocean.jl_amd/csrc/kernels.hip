@@ -55,6 +55,18 @@ __device__ __forceinline__ int patch_of_block(int nPatches)
     return (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
 }
 
+// experiment (MOKA_DBG 16 / 32): 16 = identity map (consecutive patches on different XCDs); 32 = tiles of 64
+// consecutive patches per XCD, tiles dealt round-robin, so the 8 XCDs sweep memory together
+__device__ __forceinline__ int patch_of_block_dbg(int nPatches, int dbg)
+{
+    if (dbg & 16) return (int)blockIdx.x;
+    if (dbg & 32) {
+        const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+        return ((j >> 6) * 8 + x) * 64 + (j & 63);
+    }
+    return patch_of_block(nPatches);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused tendency / RK-stage kernel.
 //   cells : hEdge (K5, Operators.jl:217) -> thicknessFlux (K7, DiagnosticVars.jl:165)
@@ -1115,7 +1127,7 @@ template <int ME, int ME2, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_stage_rec2(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int pl_ = patch_of_block(m.nPatches);      // m.nPatches = patches in this launch
+    const int pl_ = patch_of_block_dbg(m.nPatches, a.dbg);      // m.nPatches = patches in this launch
     if (pl_ >= m.nPatches) return;
     const int p = pl_ + m.patchBegin;
     constexpr int NG = BLOCK / 32;               // 8 half-wave groups
