@@ -1208,8 +1208,8 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2(const ColMesh m, const Sta
 // in the same burst as the row staging.  One thread per own edge fetches ssh[c1], ssh[c2] and leaves
 // ssh[c2]-ssh[c1] in LDS.
 // ------------------------------------------------------------------------------------------------
-constexpr int TILE_RB = 17;        // staged rows per group: 8 * 17 = 136 >= rows of a 16-cell patch
-constexpr int TILE_MAXC = 2;       // cells per group: 16-cell patches
+// staged rows per group (RB) and cells per group (MAXC) are template parameters: (17, 2) covers 16-cell patches at
+// two workgroups per CU; (11, 1) covers 8-cell patches (<= 88 rows) at three workgroups per CU
 
 struct TileLds {
     double *ubuf, *woe, *feoe, *g, *ds, *sdv, *invA, *rsum;
@@ -1241,8 +1241,8 @@ struct TCell {
     double2 hc, hv[ME], cur, nin;
 };
 
-template <int ME, int ME2, int MODE>
-__global__ __launch_bounds__(BLOCK, 2) void k_stage_tile(const MeshDev m, const StageArgs a)
+template <int ME, int ME2, int MODE, int TILE_RB, int TILE_MAXC>
+__global__ __launch_bounds__(BLOCK, (TILE_RB <= 11 ? 3 : 2)) void k_stage_tile(const MeshDev m, const StageArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int pl_ = patch_of_block(m.nPatches);
@@ -2046,42 +2046,41 @@ size_t tile_lds_bytes(const MeshDev &md)
            ((size_t)md.maxOwnE * (4 + md.ME2) + (size_t)md.maxOwnC * (3 * md.ME)) * 4 + 16;
 }
 
-template <int ME, int ME2>
+template <int ME, int ME2, int RB, int MC>
 static bool launch_tile(const MeshDev &m, const StageArgs &a, int mode, dim3 g, dim3 b, size_t lds, hipStream_t s)
 {
     switch (mode) {
-        case 0: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 0>), g, b, lds, s, m, a); return true;
-        case 1: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 1>), g, b, lds, s, m, a); return true;
-        case 2: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 2>), g, b, lds, s, m, a); return true;
-        case 3: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 3>), g, b, lds, s, m, a); return true;
+        case 0: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 0, RB, MC>), g, b, lds, s, m, a); return true;
+        case 1: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 1, RB, MC>), g, b, lds, s, m, a); return true;
+        case 2: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 2, RB, MC>), g, b, lds, s, m, a); return true;
+        case 3: hipLaunchKernelGGL((k_stage_tile<ME, ME2, 3, RB, MC>), g, b, lds, s, m, a); return true;
     }
     return false;
 }
 
-template <int ME, int ME2>
+template <int ME, int ME2, int RB, int MC>
 static hipError_t prepare_tile(size_t lds)
 {
     hipError_t e;
-    if ((e = hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return e;
-    if ((e = hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return e;
-    if ((e = hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return e;
-    return hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if ((e = hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 0, RB, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 1, RB, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 2, RB, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return e;
+    return hipFuncSetAttribute((const void *)k_stage_tile<ME, ME2, 3, RB, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-// usable when the patch-local row lists exist, K is even and <= 64, and a patch fits the static shape
+static bool tile_small(const MeshDev &md) { return md.maxRows <= 8 * 11 && md.maxOwnC <= 8; }
+
+// usable when the patch-local row lists exist, K is even and <= 64, and a patch fits one of the static shapes
 bool stage_tile_usable(const MeshDev &md, bool ldsOk)
 {
-    return ldsOk && md.K >= 2 && md.K <= 64 && !(md.K & 1) && md.maxRows <= 8 * TILE_RB && md.maxOwnC <= 8 * TILE_MAXC &&
-           md.maxOwnE <= BLOCK && tile_lds_bytes(md) <= 160 * 1024;
+    return ldsOk && md.K >= 2 && md.K <= 64 && !(md.K & 1) && md.maxRows <= 8 * 17 && md.maxOwnC <= 8 * 2 &&
+           md.maxOwnE <= BLOCK && tile_lds_bytes(md) <= 160 * 1024 && md.ME == 6 && md.ME2 == 10;
 }
 
 hipError_t prepare_stage_tile(const MeshDev &md)
 {
     const size_t lds = tile_lds_bytes(md);
-    if (md.ME == 6 && md.ME2 == 10) return prepare_tile<6, 10>(lds);
-    if (md.ME == 8 && md.ME2 == 14) return prepare_tile<8, 14>(lds);
-    if (md.ME <= 6 && md.ME2 <= 14) return prepare_tile<6, 14>(lds);
-    return hipErrorNotSupported;
+    return tile_small(md) ? prepare_tile<6, 10, 11, 1>(lds) : prepare_tile<6, 10, 17, 2>(lds);
 }
 
 hipError_t launch_stage_tile(const MeshDev &md, const StageArgs &a, hipStream_t s)
@@ -2090,10 +2089,8 @@ hipError_t launch_stage_tile(const MeshDev &md, const StageArgs &a, hipStream_t 
     const int mode = colp_mode(a);
     if (mode < 0) return hipErrorNotSupported;
     const size_t lds = tile_lds_bytes(md);
-    bool ok = false;
-    if (md.ME == 6 && md.ME2 == 10) ok = launch_tile<6, 10>(md, a, mode, g, b, lds, s);
-    else if (md.ME == 8 && md.ME2 == 14) ok = launch_tile<8, 14>(md, a, mode, g, b, lds, s);
-    else if (md.ME <= 6 && md.ME2 <= 14) ok = launch_tile<6, 14>(md, a, mode, g, b, lds, s);
+    const bool ok = tile_small(md) ? launch_tile<6, 10, 11, 1>(md, a, mode, g, b, lds, s)
+                                   : launch_tile<6, 10, 17, 2>(md, a, mode, g, b, lds, s);
     return ok ? hipGetLastError() : hipErrorNotSupported;
 }
 
