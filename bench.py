@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--ordering", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--tend-iters", type=int, default=20)
-    ap.add_argument("--transport", default="nccl", choices=["nccl", "gloo"],
+    ap.add_argument("--transport", default="nccl", choices=["nccl", "nccl-default-stream", "gloo"],
                     help="halo transport for N > 1: nccl = RCCL over xGMI (default); gloo = host-staged (rehearsal on one GPU)")
     args = ap.parse_args()
 
@@ -150,7 +150,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(device_index)
-        if args.transport == "nccl":
+        if args.transport.startswith("nccl"):
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group("gloo")
@@ -170,6 +170,16 @@ def main():
         model = mp.DistributedModel(mesh, ssh, u, h, rest, dts, backend, rank, world, ordering=args.ordering,
                                     patch_cells=args.patch_cells, transport=args.transport, group=gloo_group)
         log(f"[bench] rank {rank}: partition + local plan + upload: {time.time() - t0:.1f}s  {model.info()}")
+        if args.transport == "nccl":
+            # the overlapped form issues RCCL P2P on the library's comm stream (torch.cuda.ExternalStream); if this
+            # torch build rejects that, fall back to the same P2P on the default stream rather than lose the run
+            try:
+                model.step_rk4()
+                backend.synchronize(); torch.cuda.synchronize()
+            except Exception as exc:             # noqa: BLE001
+                log(f"[bench] rank {rank}: overlapped nccl transport failed ({exc!r}); using nccl-default-stream")
+                model.transport = "nccl-default-stream"
+                args.transport = "nccl-default-stream"
         step = model.step_rk4
         sync = backend.synchronize
         info = model.info()
@@ -198,7 +208,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed, ev_ms], device="cuda" if args.transport == "nccl" else "cpu", dtype=torch.float64)
+        tt = torch.tensor([elapsed, ev_ms], device="cuda" if args.transport.startswith("nccl") else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(tt[0]), float(tt[1])
     ms_per_step = elapsed / args.steps * 1e3

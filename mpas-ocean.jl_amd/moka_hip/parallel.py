@@ -253,6 +253,14 @@ class DistributedModel:
             with torch.cuda.stream(self.comm_stream):
                 for w in dist.batch_isend_irecv(self._p2p):
                     w.wait()                     # stream-ordered: the comm stream waits, the host does not
+        elif self.transport == "nccl-default-stream":
+            # conservative form: same RCCL P2P, but on torch's current stream with full synchronisation either side
+            self.backend.synchronize()
+            for w in dist.batch_isend_irecv(
+                    [dist.P2POp(dist.irecv, self.recvbuf[a:b], q) for q, a, b in self.recv_slices if b > a] +
+                    [dist.P2POp(dist.isend, self.sendbuf[a:b], q) for q, a, b in self.send_slices if b > a]):
+                w.wait()
+            torch.cuda.synchronize()
         else:                                    # gloo: through the host
             self.backend.synchronize()
             send_cpu, recv_cpu = self.sendbuf.cpu(), torch.empty_like(self.recvbuf, device="cpu")

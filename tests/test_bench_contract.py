@@ -1,0 +1,23 @@
+"""bench.py host-side contract: the algorithmic-bytes formula is SURVEY.md section 8(d)'s, sizes are BASELINE's."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def test_algorithmic_bytes_match_survey_numbers():
+    nC, nE, K = 1024002, 3072000, 60                      # config 4 (SURVEY section 8 size table)
+    b_mesh, b_tend, b_step = bench.algorithmic_bytes(nC, nE, K)
+    assert abs(b_mesh / 1e9 - 0.56) < 0.01                # "B_mesh = 0.56 GB"
+    assert abs(b_tend / 1e9 - 4.49) < 0.01                # "B_tend = 3.93 + 0.56 = 4.49 GB"
+    assert abs(b_step / 1e9 - 37.6) < 0.1                 # "B_step = 37.6 GB"
+    assert b_tend == 2 * 8 * K * (nE + nC) + b_mesh and b_step == 18 * 8 * K * (nE + nC) + 4 * b_mesh
+
+
+def test_default_workload_is_config4():
+    m, K = bench.WORKLOADS["config4_1M_x60"]
+    assert 10 * m * m + 2 == 1024002 and K == 60
+    assert bench.HBM_PEAK_GBS == 8000.0
