@@ -21,6 +21,7 @@ struct moka_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evBoundary = nullptr, evInterior = nullptr, evHalo = nullptr;
     int variant = 0;
+    int nCUs = 256;
     std::string err;
 };
 
@@ -33,6 +34,7 @@ struct moka_mesh {
     size_t ldsBytes = 0;      // > 0: the LDS-tiled stage kernel is usable for this mesh
     bool colOk = false;       // byte-offset records exist (every field < 4 GiB)
     bool tileOk = false;      // the tiled stage kernel (u rows + records in LDS) fits this mesh
+    bool ptileOk = false;     // the persistent double-buffered tiled kernel fits this mesh
     double *opBuf[3] = {nullptr, nullptr, nullptr};   // operator / transfer scratch, lazily sized
     size_t opBufElems = 0;
 };
@@ -218,6 +220,10 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
     const int v = st->ctx->variant;
     // 0 = auto; 8 rec2 (record-staged, 16-byte lanes, 2 entities/wave), 7 rec, 1 colp, 4 col, 5/6 colx, 2 LDS-tiled, 3 generic
     if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(dev, g, m->ldsBytes, s);
+    if (v == 10 && m->ptileOk) {           // persistent double-buffered tiled kernel (needs patch_cells <= ~14)
+        hipError_t e = launch_stage_ptile(dev, g, st->ctx->nCUs, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (v == 9 && m->tileOk) {             // tiled: u rows + records in LDS (needs patch_cells <= 16)
         hipError_t e = launch_stage_tile(dev, g, s);
         if (e != hipErrorNotSupported) return e;
@@ -289,6 +295,7 @@ int moka_ctx_create(int device, moka_ctx **out)
     moka_ctx *c = new (std::nothrow) moka_ctx();
     if (!c) return fail(nullptr, MOKA_ERR_ALLOC, "out of host memory");
     c->device = device;
+    c->nCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     hipError_t e2 = hipEventCreate(&c->ev0);
     hipError_t e3 = hipEventCreate(&c->ev1);
@@ -352,7 +359,7 @@ int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
 int moka_set_kernel_variant(moka_ctx *ctx, int variant)
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
-    if (variant < 0 || variant > 9) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..9");
+    if (variant < 0 || variant > 10) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..10");
     ctx->variant = variant;
     return MOKA_OK;
 }
@@ -403,6 +410,7 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
 
     d.maxRows = p.maxRows; d.maxOwnE = p.maxOwnE; d.maxOwnC = p.maxOwnC;
     if (p.colOk && stage_tile_usable(d, p.ldsOk) && prepare_stage_tile(d) == hipSuccess) m->tileOk = true;
+    if (p.colOk && stage_ptile_usable(d, p.ldsOk) && prepare_stage_ptile(d) == hipSuccess) m->ptileOk = true;
     if (p.ldsOk && p.K % 2 == 0 && p.K >= 8) {
         const int64_t need = lds_stage_bytes(p.K, p.ME, p.ME2, p.maxRows, p.maxOwnE, p.maxOwnC);
         if (need <= 160 * 1024) {

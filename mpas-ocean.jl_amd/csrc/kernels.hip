@@ -1463,6 +1463,277 @@ __global__ __launch_bounds__(BLOCK, (TILE_RB <= 11 ? 3 : 2)) void k_stage_tile(c
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent, double-buffered tiled stage kernel ("ptile").
+//
+// k_stage_tile showed that staging u-rows + records in LDS takes the texture-address path out of the
+// picture (TA_BUSY 24-40 %) but serialises every workgroup into load -> barrier -> compute with only 2-3
+// workgroups per CU to overlap.  Here ONE 512-thread workgroup per CU walks a contiguous chunk of patches
+// and software-pipelines across patches: at the top of iteration q it issues *every* global load patch q+1
+// needs (u rows to stage, the h rows of its cells, the Curr/New rows of its own cells and edges, ssh pairs,
+// records), then computes patch q purely from registers + LDS buffer q&1, and only then parks the arrived
+// rows of patch q+1 in LDS buffer (q+1)&1.  One barrier per patch.  vmcnt is in-order, so the compute
+// phase must not consume any load younger than the burst: that is why the own rows are prefetched too.
+// Index data (row ids, neighbour cells, edge headers) is prefetched one patch further ahead.
+// Shape: 16 half-wave groups; per group <= RB staged rows, 1 cell, <= EPG edges per patch.
+// ------------------------------------------------------------------------------------------------
+constexpr int PBLOCK = 512;
+
+template <int ME, int MODE>
+struct PCell {
+    double2 hc, hv[ME], cur, nin;
+};
+struct PEdgeOwn {
+    double2 cur, nin;
+};
+
+template <int ME, int ME2, int MODE, int RB, int EPG>
+__global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, const StageArgs a, int patchesPerBlock, size_t bufBytes)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NG = PBLOCK / 32;
+    const int tid = threadIdx.x, grp = tid >> 5, l = tid & 31;
+    const int K = m.K, K2 = K >> 1;
+    const uint32_t rowB = (uint32_t)K * 8u, voff = (uint32_t)l * 16u;
+    const bool act = l < K2;
+    const uint32_t voffc = act ? voff : 0u;
+    const int k0 = 2 * l;
+    // blocks of one XCD (blockIdx % 8) take adjacent chunks of patches
+    const int nb = (int)gridDim.x, chunkB = (nb + 7) >> 3;
+    const int bl = (int)(blockIdx.x & 7) * chunkB + (int)(blockIdx.x >> 3);
+    const int first = m.patchBegin + bl * patchesPerBlock;
+    int n = m.patchBegin + m.nPatches - first;
+    if (n > patchesPerBlock) n = patchesPerBlock;
+    if (bl >= nb || n <= 0) return;                                    // whole workgroup leaves together
+    // two LDS buffers; never indexed with a runtime value (that would push the pointer table to scratch)
+    const TileLds L0 = tile_carve(smem, K, ME, ME2, m.maxRows, m.maxOwnE, m.maxOwnC);
+    const TileLds L1 = tile_carve(smem + bufBytes, K, ME, ME2, m.maxRows, m.maxOwnE, m.maxOwnC);
+
+    struct IdxS {                                                      // wave-uniform (SGPR) part
+        int c0, e0, nOwnC, nOwnE, R, h0;
+    };
+    struct IdxV {                                                      // per-group part, only needed to issue the loads
+        int src[RB];
+        int cn[ME];
+        int cidx;
+        int4 hdr;
+    };
+    auto load_idx_s = [&](int q) {
+        IdxS I;
+        const int p = first + (q < n ? q : n - 1);
+        I.c0 = cptr(m.patchCellStart)[p];
+        I.e0 = cptr(m.patchEdgeStart)[p];
+        I.nOwnC = cptr(m.patchCellStart)[p + 1] - I.c0;
+        I.nOwnE = cptr(m.patchEdgeStart)[p + 1] - I.e0;
+        I.h0 = cptr(m.haloStart)[p];
+        I.R = I.nOwnE + (cptr(m.haloStart)[p + 1] - I.h0);
+        return I;
+    };
+    auto load_idx_v = [&](const IdxS &I) {
+        IdxV V;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = grp + NG * i;
+            const int rc = r < I.R ? r : (I.R > 0 ? I.R - 1 : 0);
+            V.src[i] = (rc < I.nOwnE || I.R == 0) ? I.e0 + (I.R > 0 ? rc : 0) : m.haloEdge[I.h0 + rc - I.nOwnE];
+        }
+        V.cidx = I.c0 + (grp < I.nOwnC ? grp : 0);
+#pragma unroll
+        for (int i = 0; i < ME; ++i) {
+            const int x = m.coc[(size_t)V.cidx * ME + i];
+            V.cn[i] = x >= 0 ? x : V.cidx;
+        }
+        V.hdr = make_int4(0, 0, 0, 0);
+        if (tid < I.nOwnE) V.hdr = *reinterpret_cast<const int4 *>(m.ehdr + (size_t)(I.e0 + tid) * 4);
+        return V;
+    };
+
+    double2 st[RB];                                                    // rows in flight for the NEXT patch
+    PCell<ME, MODE> cellC;                                             // h rows (+ own rows) of this group's cell
+    PEdgeOwn eoC[EPG], eoN[EPG];                                       // own rows of this group's edges: current / next patch
+    double sA = 0.0, sB = 0.0;
+    int hdrw = 0;
+
+    auto issue = [&](const IdxS &I, const IdxV &V) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) st[i] = gload2(a.pu, (uint32_t)V.src[i] * rowB + voffc);
+        const uint32_t own = (uint32_t)V.cidx * rowB + voffc;
+        cellC.hc = gload2(a.ph, own);
+#pragma unroll
+        for (int i = 0; i < ME; ++i) cellC.hv[i] = gload2(a.ph, (uint32_t)V.cn[i] * rowB + voffc);
+        if constexpr (MODE == 2) cellC.cur = gload2(a.ch, own);
+        if constexpr (MODE >= 2) cellC.nin = gload2(a.nh_in, own);
+#pragma unroll
+        for (int j = 0; j < EPG; ++j) {
+            const int ei = grp + NG * j;
+            const uint32_t eown = (uint32_t)(I.e0 + (ei < I.nOwnE ? ei : 0)) * rowB + voffc;
+            if constexpr (MODE == 2) eoN[j].cur = gload2(a.cu, eown);
+            if constexpr (MODE >= 2) eoN[j].nin = gload2(a.nu_in, eown);
+        }
+        sA = 0.0;
+        sB = 0.0;
+        hdrw = V.hdr.w;
+        if (tid < I.nOwnE) {
+            sA = a.ssh[V.hdr.x];
+            sB = a.ssh[V.hdr.y];
+        }
+    };
+    // records of the patch: global -> LDS straight away (small; they ride in the same burst)
+    auto stage_records = [&](const IdxS &I, const TileLds &L) {
+        const int e0 = I.e0, c0 = I.c0;
+        for (int i = tid; i < I.nOwnE * ME2; i += PBLOCK) {
+            L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
+            L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
+            L.leOff[i] = m.leOff[(size_t)e0 * ME2 + i];
+        }
+        for (int i = tid; i < I.nOwnE; i += PBLOCK) L.g[i] = m.gInvDc[e0 + i];
+        for (int i = tid; i < I.nOwnC * ME; i += PBLOCK) {
+            L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
+            L.mltc[i] = m.mltc[(size_t)c0 * ME + i];
+            L.lcOff[i] = m.lcOff[(size_t)c0 * ME + i];
+        }
+        for (int i = tid; i < I.nOwnC; i += PBLOCK) {
+            L.invA[i] = m.invArea[c0 + i];
+            L.rsum[i] = m.rsum[c0 + i];
+        }
+    };
+    auto park = [&](const IdxS &I, const TileLds &L) {                  // arrived rows -> LDS
+        double2 *ubuf2 = reinterpret_cast<double2 *>(L.ubuf);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = grp + NG * i;
+            if (r < I.R && act) ubuf2[(size_t)r * K2 + l] = st[i];
+        }
+        if (tid < I.nOwnE) {
+            L.ds[tid] = sB - sA;                                       // ssh[c2] - ssh[c1]
+            L.ehdr[tid * 4 + 3] = hdrw;
+        }
+    };
+
+    auto compute_cell = [&](const IdxS &I, const TileLds &L) {
+        const unsigned char *ubytes = reinterpret_cast<const unsigned char *>(L.ubuf) + (act ? voff : 0u);
+        const bool valid = grp < I.nOwnC;
+        const int cc = valid ? grp : 0;
+        const int c = I.c0 + cc;
+        const double invA = L.invA[cc];
+        double2 t = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < ME; ++i) {
+            const uint32_t lo = L.lcOff[cc * ME + i];
+            const bool on = lo != 0xFFFFFFFFu;
+            const double2 uv = *reinterpret_cast<const double2 *>(ubytes + (on ? lo : 0u));
+            const int ml = L.mltc[cc * ME + i];
+            const double sd = L.sdv[cc * ME + i];
+            const double dx = uv.x * (0.5 * (cellC.hc.x + cellC.hv[i].x)) * sd * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
+            const double dy = uv.y * (0.5 * (cellC.hc.y + cellC.hv[i].y)) * sd * invA;   // horizontal_advection.jl:63
+            if (on && k0 < ml) t.x += dx;
+            if (on && k0 + 1 < ml) t.y += dy;
+        }
+        const uint32_t ooff = (uint32_t)c * rowB + voff;
+        double2 hs = make_double2(0.0, 0.0);
+        if (valid && act) {
+            if constexpr (MODE == 0) gstore2(a.tendH, ooff, t);
+            if constexpr (MODE == 1 || MODE == 2) {
+                const double2 hcur = MODE == 2 ? cellC.cur : cellC.hc;
+                const double2 nbv = MODE == 2 ? cellC.nin : hcur;
+                hs = make_double2(hcur.x + a.a * t.x, hcur.y + a.a * t.y);                    // time_integration.jl:125
+                gstore2(a.ph_out, ooff, hs);
+                gstore2(a.nh_out, ooff, make_double2(nbv.x + a.b * t.x, nbv.y + a.b * t.y));  // :135
+            }
+            if constexpr (MODE == 3) {
+                hs = make_double2(cellC.nin.x + a.b * t.x, cellC.nin.y + a.b * t.y);
+                gstore2(a.nh_out, ooff, hs);
+            }
+        }
+        if constexpr (MODE != 0) {
+#pragma unroll
+            for (int sft = 16; sft >= 1; sft >>= 1) {                   // oracle_ksum order (see k_stage_rec2)
+                const double ox = __shfl_xor(hs.x, sft, 64), oy = __shfl_xor(hs.y, sft, 64);
+                hs = make_double2(hs.x + ox, hs.y + oy);
+            }
+            if (valid && l == 0) a.ssh_out[c] = (hs.x + hs.y) - L.rsum[cc];                   // :209 (+N3)
+        }
+    };
+    auto compute_edges = [&](const IdxS &I, const TileLds &L) {
+        const unsigned char *ubytes = reinterpret_cast<const unsigned char *>(L.ubuf) + (act ? voff : 0u);
+        const double2 *ubuf2 = reinterpret_cast<const double2 *>(L.ubuf);
+#pragma unroll
+        for (int j = 0; j < EPG; ++j) {
+            const int eiq = grp + NG * j;
+            const bool valid = eiq < I.nOwnE;
+            const int ei = valid ? eiq : 0;
+            const int mlt = L.ehdr[ei * 4 + 3];
+            const double g = L.g[ei], ds = L.ds[ei];
+            const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
+            double2 t = make_double2(0.0, 0.0);
+            if (ax) t.x -= g * ds;                                      // pressure_gradient.jl:63
+            if (ay) t.y -= g * ds;
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) {
+                const uint32_t lo = L.leOff[ei * ME2 + i];
+                const bool on = lo != 0xFFFFFFFFu;
+                const double2 uv = *reinterpret_cast<const double2 *>(ubytes + (on ? lo : 0u));
+                const double w = L.woe[ei * ME2 + i], f = L.feoe[ei * ME2 + i];
+                const double px = w * uv.x * f, py = w * uv.y * f;      // ...coriolis.jl:70-72
+                if (on && ax) t.x += px;
+                if (on && ay) t.y += py;
+            }
+            const uint32_t ooff = (uint32_t)(I.e0 + ei) * rowB + voff;
+            if (valid && act) {
+                if constexpr (MODE == 0) gstore2(a.tendU, ooff, t);
+                if constexpr (MODE == 1) {
+                    const double2 up = ubuf2[(size_t)ei * K2 + l];      // own row = local row ei
+                    gstore2(a.pu_out, ooff, make_double2(up.x + a.a * t.x, up.y + a.a * t.y));   // time_integration.jl:124
+                    gstore2(a.nu_out, ooff, make_double2(up.x + a.b * t.x, up.y + a.b * t.y));   // :134
+                }
+                if constexpr (MODE == 2) {
+                    gstore2(a.pu_out, ooff, make_double2(eoC[j].cur.x + a.a * t.x, eoC[j].cur.y + a.a * t.y));
+                    gstore2(a.nu_out, ooff, make_double2(eoC[j].nin.x + a.b * t.x, eoC[j].nin.y + a.b * t.y));
+                }
+                if constexpr (MODE == 3) gstore2(a.nu_out, ooff, make_double2(eoC[j].nin.x + a.b * t.x, eoC[j].nin.y + a.b * t.y));
+            }
+            __builtin_amdgcn_sched_barrier(0);                          // keep one edge's LDS reads from piling onto the next's
+        }
+    };
+
+    // ---------------- prologue: patch 0 into buffer 0 ----------------
+    IdxS Icur = load_idx_s(0);
+    {
+        const IdxV V0 = load_idx_v(Icur);
+        issue(Icur, V0);
+    }
+    stage_records(Icur, L0);
+    IdxS Inext = load_idx_s(1);
+    IdxV Vnext = load_idx_v(Inext);
+    park(Icur, L0);
+#pragma unroll
+    for (int j = 0; j < EPG; ++j) eoC[j] = eoN[j];
+    __syncthreads();
+
+    // ---------------- steady state ----------------
+    auto iteration = [&](int q, const TileLds &Lcur, const TileLds &Lnxt) {
+        compute_cell(Icur, Lcur);                                      // frees cellC for the next patch
+        __builtin_amdgcn_sched_barrier(0);
+        issue(Inext, Vnext);                                           // unconditional (index clamped): static load count
+        stage_records(Inext, Lnxt);
+        const IdxS Iafter = load_idx_s(q + 2);
+        Vnext = load_idx_v(Iafter);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_edges(Icur, Lcur);                                     // registers + LDS only: overlaps the burst above
+        __builtin_amdgcn_sched_barrier(0);
+        park(Inext, Lnxt);
+#pragma unroll
+        for (int j = 0; j < EPG; ++j) eoC[j] = eoN[j];
+        Icur = Inext;
+        Inext = Iafter;
+        __syncthreads();
+    };
+    for (int q = 0; q < n; q += 2) {
+        iteration(q, L0, L1);
+        if (q + 1 < n) iteration(q + 1, L1, L0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS patch-tiled variant of the fused tendency / RK-stage kernel (same arithmetic, same results).
 //
 // The direct kernel above re-reads every u-row ~12 times through the vector L1 (10 Coriolis
@@ -2092,6 +2363,50 @@ hipError_t launch_stage_tile(const MeshDev &md, const StageArgs &a, hipStream_t 
     const bool ok = tile_small(md) ? launch_tile<6, 10, 11, 1>(md, a, mode, g, b, lds, s)
                                    : launch_tile<6, 10, 17, 2>(md, a, mode, g, b, lds, s);
     return ok ? hipGetLastError() : hipErrorNotSupported;
+}
+
+// ---- persistent tiled kernel ----
+constexpr int PT_RB = 7, PT_EPG = 3;      // 16 groups x 7 rows = 112 rows, <= 16 cells, <= 48 own edges per patch (P <= 10)
+
+bool stage_ptile_usable(const MeshDev &md, bool ldsOk)
+{
+    return ldsOk && md.K >= 2 && md.K <= 64 && !(md.K & 1) && md.ME == 6 && md.ME2 == 10 && md.maxRows <= 16 * PT_RB &&
+           md.maxOwnC <= 16 && md.maxOwnE <= 16 * PT_EPG && 2 * ((tile_lds_bytes(md) + 255) & ~(size_t)255) <= 160 * 1024;
+}
+
+template <int MODE>
+static hipError_t prepare_ptile_mode(size_t lds)
+{
+    return hipFuncSetAttribute((const void *)k_stage_ptile<6, 10, MODE, PT_RB, PT_EPG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+hipError_t prepare_stage_ptile(const MeshDev &md)
+{
+    const size_t lds = 2 * ((tile_lds_bytes(md) + 255) & ~(size_t)255);
+    hipError_t e;
+    if ((e = prepare_ptile_mode<0>(lds))) return e;
+    if ((e = prepare_ptile_mode<1>(lds))) return e;
+    if ((e = prepare_ptile_mode<2>(lds))) return e;
+    return prepare_ptile_mode<3>(lds);
+}
+
+hipError_t launch_stage_ptile(const MeshDev &md, const StageArgs &a, int nCUs, hipStream_t s)
+{
+    const int mode = colp_mode(a);
+    if (mode < 0) return hipErrorNotSupported;
+    const size_t buf = (tile_lds_bytes(md) + 255) & ~(size_t)255, lds = 2 * buf;
+    int nb = nCUs > 0 ? nCUs : 256;
+    if (nb > md.nPatches) nb = md.nPatches;
+    nb = 8 * ((nb + 7) / 8);                                 // the XCD-chunk map wants a multiple of 8
+    const int ppb = (md.nPatches + nb - 1) / nb;
+    const dim3 g(nb), b(PBLOCK);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_stage_ptile<6, 10, 0, PT_RB, PT_EPG>), g, b, lds, s, md, a, ppb, buf); break;
+        case 1: hipLaunchKernelGGL((k_stage_ptile<6, 10, 1, PT_RB, PT_EPG>), g, b, lds, s, md, a, ppb, buf); break;
+        case 2: hipLaunchKernelGGL((k_stage_ptile<6, 10, 2, PT_RB, PT_EPG>), g, b, lds, s, md, a, ppb, buf); break;
+        default: hipLaunchKernelGGL((k_stage_ptile<6, 10, 3, PT_RB, PT_EPG>), g, b, lds, s, md, a, ppb, buf); break;
+    }
+    return hipGetLastError();
 }
 
 size_t rec_lds_bytes(const MeshDev &md)

@@ -53,6 +53,9 @@ struct OpArgs {
 };
 
 hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream_t s);
+bool stage_ptile_usable(const MeshDev &md, bool ldsOk);
+hipError_t prepare_stage_ptile(const MeshDev &md);
+hipError_t launch_stage_ptile(const MeshDev &m, const StageArgs &a, int nCUs, hipStream_t s);
 bool stage_tile_usable(const MeshDev &md, bool ldsOk);
 hipError_t prepare_stage_tile(const MeshDev &md);
 hipError_t launch_stage_tile(const MeshDev &m, const StageArgs &a, hipStream_t s);
