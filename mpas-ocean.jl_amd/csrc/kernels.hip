@@ -1577,23 +1577,44 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
             sB = a.ssh[V.hdr.y];
         }
     };
-    // records of the patch: global -> LDS straight away (small; they ride in the same burst)
-    auto stage_records = [&](const IdxS &I, const TileLds &L) {
-        const int e0 = I.e0, c0 = I.c0;
-        for (int i = tid; i < I.nOwnE * ME2; i += PBLOCK) {
-            L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
-            L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
-            L.leOff[i] = m.leOff[(size_t)e0 * ME2 + i];
+    // records of the patch ride in the same burst, one element per thread, and are parked with the rows: a
+    // load -> LDS-store pair placed before the compute phase would make the compute wait for the whole burst
+    // (vmcnt is in order).  16 * EPG * ME2 <= 512 and 16 * ME <= 512, so one element per thread is enough.
+    double rW = 0.0, rF = 0.0, rG = 0.0, rSd = 0.0, rIa = 0.0, rRs = 0.0;
+    uint32_t rLe = 0u, rLc = 0u;
+    int rMl = 0;
+    auto issue_records = [&](const IdxS &I) {
+        if (tid < I.nOwnE * ME2) {
+            rW = m.woe[(size_t)I.e0 * ME2 + tid];
+            rF = m.feoe[(size_t)I.e0 * ME2 + tid];
+            rLe = m.leOff[(size_t)I.e0 * ME2 + tid];
         }
-        for (int i = tid; i < I.nOwnE; i += PBLOCK) L.g[i] = m.gInvDc[e0 + i];
-        for (int i = tid; i < I.nOwnC * ME; i += PBLOCK) {
-            L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
-            L.mltc[i] = m.mltc[(size_t)c0 * ME + i];
-            L.lcOff[i] = m.lcOff[(size_t)c0 * ME + i];
+        if (tid < I.nOwnE) rG = m.gInvDc[I.e0 + tid];
+        if (tid < I.nOwnC * ME) {
+            rSd = m.sdv[(size_t)I.c0 * ME + tid];
+            rMl = m.mltc[(size_t)I.c0 * ME + tid];
+            rLc = m.lcOff[(size_t)I.c0 * ME + tid];
         }
-        for (int i = tid; i < I.nOwnC; i += PBLOCK) {
-            L.invA[i] = m.invArea[c0 + i];
-            L.rsum[i] = m.rsum[c0 + i];
+        if (tid < I.nOwnC) {
+            rIa = m.invArea[I.c0 + tid];
+            rRs = m.rsum[I.c0 + tid];
+        }
+    };
+    auto park_records = [&](const IdxS &I, const TileLds &L) {
+        if (tid < I.nOwnE * ME2) {
+            L.woe[tid] = rW;
+            L.feoe[tid] = rF;
+            L.leOff[tid] = rLe;
+        }
+        if (tid < I.nOwnE) L.g[tid] = rG;
+        if (tid < I.nOwnC * ME) {
+            L.sdv[tid] = rSd;
+            L.mltc[tid] = rMl;
+            L.lcOff[tid] = rLc;
+        }
+        if (tid < I.nOwnC) {
+            L.invA[tid] = rIa;
+            L.rsum[tid] = rRs;
         }
     };
     auto park = [&](const IdxS &I, const TileLds &L) {                  // arrived rows -> LDS
@@ -1701,10 +1722,11 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
         const IdxV V0 = load_idx_v(Icur);
         issue(Icur, V0);
     }
-    stage_records(Icur, L0);
+    issue_records(Icur);
     IdxS Inext = load_idx_s(1);
     IdxV Vnext = load_idx_v(Inext);
     park(Icur, L0);
+    park_records(Icur, L0);
 #pragma unroll
     for (int j = 0; j < EPG; ++j) eoC[j] = eoN[j];
     __syncthreads();
@@ -1714,13 +1736,14 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
         compute_cell(Icur, Lcur);                                      // frees cellC for the next patch
         __builtin_amdgcn_sched_barrier(0);
         issue(Inext, Vnext);                                           // unconditional (index clamped): static load count
-        stage_records(Inext, Lnxt);
+        issue_records(Inext);
         const IdxS Iafter = load_idx_s(q + 2);
         Vnext = load_idx_v(Iafter);
         __builtin_amdgcn_sched_barrier(0);
         compute_edges(Icur, Lcur);                                     // registers + LDS only: overlaps the burst above
         __builtin_amdgcn_sched_barrier(0);
         park(Inext, Lnxt);
+        park_records(Inext, Lnxt);
 #pragma unroll
         for (int j = 0; j < EPG; ++j) eoC[j] = eoN[j];
         Icur = Inext;
