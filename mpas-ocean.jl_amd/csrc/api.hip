@@ -403,7 +403,7 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     UP(eoc) UP(coc) UP(mltc) UP(sdv) UP(invArea) UP(areaCell) UP(rsum)
     UP(ehdr) UP(eoe) UP(woe) UP(gInvDc) UP(dcEdge) UP(dvEdge) UP(fEdge)
     UP(eov) UP(cv) UP(cellN2O) UP(edgeN2O) UP(vertN2O)
-    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(lcOff) UP(leOff) UP(patchRegular)
+    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(lcOff) UP(leOff) UP(patchRegular) UP(rowStart) UP(rowEdge)
 #undef UP
     d.CI = p.CI; d.EI = p.EI;
     m->colOk = p.colOk;

@@ -1262,12 +1262,12 @@ __global__ __launch_bounds__(BLOCK, (TILE_RB <= 11 ? 3 : 2)) void k_stage_tile(c
 
     // ---------------- burst 1: indices ----------------
     int src[TILE_RB];                                                  // global edge of each row this group stages
+    const int rs0 = cptr(m.rowStart)[p];
 #pragma unroll
     for (int i = 0; i < TILE_RB; ++i) {
         const int r = grp + NG * i;
         const int rc = r < R ? r : (R > 0 ? R - 1 : 0);
-        src[i] = (rc < nOwnE || R == 0) ? e0 + (R > 0 ? rc : 0) : m.haloEdge[h0 + rc - nOwnE];
-        if (R == 0) src[i] = 0;
+        src[i] = m.rowEdge[rs0 + rc];                                  // one unconditional load (a load inside a select gets a vmcnt(0))
     }
     int cn[TILE_MAXC][ME];
     int cidx[TILE_MAXC];
@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
     const TileLds L1 = tile_carve(smem + bufBytes, K, ME, ME2, m.maxRows, m.maxOwnE, m.maxOwnC);
 
     struct IdxS {                                                      // wave-uniform (SGPR) part
-        int c0, e0, nOwnC, nOwnE, R, h0;
+        int c0, e0, nOwnC, nOwnE, R, rs;
     };
     struct IdxV {                                                      // per-group part, only needed to issue the loads
         int src[RB];
@@ -1524,17 +1524,19 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
         I.e0 = cptr(m.patchEdgeStart)[p];
         I.nOwnC = cptr(m.patchCellStart)[p + 1] - I.c0;
         I.nOwnE = cptr(m.patchEdgeStart)[p + 1] - I.e0;
-        I.h0 = cptr(m.haloStart)[p];
-        I.R = I.nOwnE + (cptr(m.haloStart)[p + 1] - I.h0);
+        I.rs = cptr(m.rowStart)[p];
+        I.R = cptr(m.rowStart)[p + 1] - I.rs;
         return I;
     };
+    // every load below is unconditional on a clamped index: a load inside a conditional makes the compiler wait
+    // for it (vmcnt(0)) at the end of the branch, which serialised the RB halo-list reads of the first version
     auto load_idx_v = [&](const IdxS &I) {
         IdxV V;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int r = grp + NG * i;
             const int rc = r < I.R ? r : (I.R > 0 ? I.R - 1 : 0);
-            V.src[i] = (rc < I.nOwnE || I.R == 0) ? I.e0 + (I.R > 0 ? rc : 0) : m.haloEdge[I.h0 + rc - I.nOwnE];
+            V.src[i] = m.rowEdge[I.rs + rc];                            // explicit row list (+ one slack element)
         }
         V.cidx = I.c0 + (grp < I.nOwnC ? grp : 0);
 #pragma unroll
@@ -1542,8 +1544,9 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
             const int x = m.coc[(size_t)V.cidx * ME + i];
             V.cn[i] = x >= 0 ? x : V.cidx;
         }
-        V.hdr = make_int4(0, 0, 0, 0);
-        if (tid < I.nOwnE) V.hdr = *reinterpret_cast<const int4 *>(m.ehdr + (size_t)(I.e0 + tid) * 4);
+        int et = I.e0 + (tid < I.nOwnE ? tid : 0);
+        et = et < m.nE ? et : m.nE - 1;
+        V.hdr = *reinterpret_cast<const int4 *>(m.ehdr + (size_t)et * 4);
         return V;
     };
 
@@ -1569,13 +1572,9 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
             if constexpr (MODE == 2) eoN[j].cur = gload2(a.cu, eown);
             if constexpr (MODE >= 2) eoN[j].nin = gload2(a.nu_in, eown);
         }
-        sA = 0.0;
-        sB = 0.0;
         hdrw = V.hdr.w;
-        if (tid < I.nOwnE) {
-            sA = a.ssh[V.hdr.x];
-            sB = a.ssh[V.hdr.y];
-        }
+        sA = a.ssh[V.hdr.x];                                           // hdr is always a valid edge's header
+        sB = a.ssh[V.hdr.y];
     };
     // records of the patch ride in the same burst, one element per thread, and are parked with the rows: a
     // load -> LDS-store pair placed before the compute phase would make the compute wait for the whole burst
@@ -1584,21 +1583,19 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
     uint32_t rLe = 0u, rLc = 0u;
     int rMl = 0;
     auto issue_records = [&](const IdxS &I) {
-        if (tid < I.nOwnE * ME2) {
-            rW = m.woe[(size_t)I.e0 * ME2 + tid];
-            rF = m.feoe[(size_t)I.e0 * ME2 + tid];
-            rLe = m.leOff[(size_t)I.e0 * ME2 + tid];
-        }
-        if (tid < I.nOwnE) rG = m.gInvDc[I.e0 + tid];
-        if (tid < I.nOwnC * ME) {
-            rSd = m.sdv[(size_t)I.c0 * ME + tid];
-            rMl = m.mltc[(size_t)I.c0 * ME + tid];
-            rLc = m.lcOff[(size_t)I.c0 * ME + tid];
-        }
-        if (tid < I.nOwnC) {
-            rIa = m.invArea[I.c0 + tid];
-            rRs = m.rsum[I.c0 + tid];
-        }
+        const int ne = I.nOwnE * ME2, nc = I.nOwnC * ME;
+        const size_t ie = (size_t)I.e0 * ME2 + (tid < ne ? tid : 0), ic = (size_t)I.c0 * ME + (tid < nc ? tid : 0);
+        const size_t je = (size_t)I.e0 + (tid < I.nOwnE ? tid : 0), jc = (size_t)I.c0 + (tid < I.nOwnC ? tid : 0);
+        const size_t ieC = ie < (size_t)m.nE * ME2 ? ie : 0, jeC = je < (size_t)m.nE ? je : 0;
+        rW = m.woe[ieC];
+        rF = m.feoe[ieC];
+        rLe = m.leOff[ieC];
+        rG = m.gInvDc[jeC];
+        rSd = m.sdv[ic];
+        rMl = m.mltc[ic];
+        rLc = m.lcOff[ic];
+        rIa = m.invArea[jc];
+        rRs = m.rsum[jc];
     };
     auto park_records = [&](const IdxS &I, const TileLds &L) {
         if (tid < I.nOwnE * ME2) {

@@ -55,6 +55,8 @@ struct Plan {
     // patch-local view for the LDS-tiled kernel: the u-rows a patch needs are its own edges
     // [patchEdgeStart[p], patchEdgeStart[p+1]) followed by haloEdge[haloStart[p] .. haloStart[p+1]);
     // leoc / leoe hold, per cell slot / edgesOnEdge slot, the row index inside that list (0xFF = none).
+    std::vector<int32_t> rowStart;    // nPatches + 1 : the full staged-row list (own edges then halo edges) ...
+    std::vector<int32_t> rowEdge;     // ... as explicit edge ids, so kernels read it with one unconditional load
     std::vector<int32_t> haloStart;   // nPatches + 1
     std::vector<int32_t> haloEdge;    // new edge ids
     std::vector<uint8_t> leoc;        // nC*8
@@ -92,7 +94,7 @@ struct MeshDev {
     const double *feoe;
     int32_t CI, EI;
     // LDS-tiled kernel
-    const int32_t *haloStart, *haloEdge;
+    const int32_t *haloStart, *haloEdge, *rowStart, *rowEdge;
     const uint8_t *leoc, *leoe;
     const uint32_t *lcOff, *leOff;
     const int32_t *patchRegular;

@@ -412,7 +412,18 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
             p.maxRows = std::max(p.maxRows, rows);
         }
         if (!p.ldsOk) { p.haloEdge.clear(); std::fill(p.haloStart.begin(), p.haloStart.end(), 0); }
+        p.haloEdge.push_back(0);   // one element of slack: kernels read haloEdge[h0 + clamped index] unconditionally
     }
+    p.rowStart.assign(p.nPatches + 1, 0);
+    p.rowEdge.clear();
+    if (p.ldsOk) {
+        for (int q = 0; q < p.nPatches; ++q) {
+            for (int e = p.patchEdgeStart[q]; e < p.patchEdgeStart[q + 1]; ++e) p.rowEdge.push_back(e);
+            for (int j = p.haloStart[q]; j < p.haloStart[q + 1]; ++j) p.rowEdge.push_back(p.haloEdge[j]);
+            p.rowStart[q + 1] = (int32_t)p.rowEdge.size();
+        }
+    }
+    p.rowEdge.push_back(0);
     p.lcOff.assign((size_t)nC * ME, 0xFFFFFFFFu);
     p.leOff.assign((size_t)nE * ME2, 0xFFFFFFFFu);
     p.patchRegular.assign(p.nPatches, 0);
