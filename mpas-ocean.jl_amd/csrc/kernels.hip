@@ -1517,15 +1517,15 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
         int cidx;
         int4 hdr;
     };
+    // Patch ranges are read with VECTOR loads on purpose: scalar loads share lgkmcnt with the LDS reads of the
+    // compute phase and return out of order, so any LDS wait would become lgkmcnt(0) and stall on them.
     auto load_idx_s = [&](int q) {
         IdxS I;
         const int p = first + (q < n ? q : n - 1);
-        I.c0 = cptr(m.patchCellStart)[p];
-        I.e0 = cptr(m.patchEdgeStart)[p];
-        I.nOwnC = cptr(m.patchCellStart)[p + 1] - I.c0;
-        I.nOwnE = cptr(m.patchEdgeStart)[p + 1] - I.e0;
-        I.rs = cptr(m.rowStart)[p];
-        I.R = cptr(m.rowStart)[p + 1] - I.rs;
+        const int cA = m.patchCellStart[p], cB = m.patchCellStart[p + 1];
+        const int eA = m.patchEdgeStart[p], eB = m.patchEdgeStart[p + 1];
+        const int rA = m.rowStart[p], rBv = m.rowStart[p + 1];
+        I.c0 = cA; I.e0 = eA; I.nOwnC = cB - cA; I.nOwnE = eB - eA; I.rs = rA; I.R = rBv - rA;
         return I;
     };
     // every load below is unconditional on a clamped index: a load inside a conditional makes the compiler wait
@@ -1722,6 +1722,7 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
     issue_records(Icur);
     IdxS Inext = load_idx_s(1);
     IdxV Vnext = load_idx_v(Inext);
+    IdxS Iaft = load_idx_s(2);
     park(Icur, L0);
     park_records(Icur, L0);
 #pragma unroll
@@ -1729,13 +1730,16 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
     __syncthreads();
 
     // ---------------- steady state ----------------
+    // iteration q: ranges of patch q+3 and row/neighbour ids of patch q+2 are requested, the burst of patch q+1 is
+    // issued, patch q is computed.  Each of those is consumed one iteration after it was requested, behind a
+    // counted vmcnt, so nothing in an iteration waits for that iteration's own loads except the final park.
     auto iteration = [&](int q, const TileLds &Lcur, const TileLds &Lnxt) {
         compute_cell(Icur, Lcur);                                      // frees cellC for the next patch
         __builtin_amdgcn_sched_barrier(0);
         issue(Inext, Vnext);                                           // unconditional (index clamped): static load count
         issue_records(Inext);
-        const IdxS Iafter = load_idx_s(q + 2);
-        Vnext = load_idx_v(Iafter);
+        const IdxS Iaft2 = load_idx_s(q + 3);
+        const IdxV Vaft = load_idx_v(Iaft);
         __builtin_amdgcn_sched_barrier(0);
         compute_edges(Icur, Lcur);                                     // registers + LDS only: overlaps the burst above
         __builtin_amdgcn_sched_barrier(0);
@@ -1744,7 +1748,9 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
 #pragma unroll
         for (int j = 0; j < EPG; ++j) eoC[j] = eoN[j];
         Icur = Inext;
-        Inext = Iafter;
+        Inext = Iaft;
+        Vnext = Vaft;
+        Iaft = Iaft2;
         __syncthreads();
     };
     for (int q = 0; q < n; q += 2) {
