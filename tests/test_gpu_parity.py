@@ -37,7 +37,8 @@ def get_mesh(name):
                              "planar": lambda: mg.planar_hex_mesh(20, 18, 1000.0, f0=1e-4),
                              "igw200": lambda: mg.igw_mesh(200.0),
                              "ico16": lambda: mg.icosahedral_mesh(16),
-                             "ico32": lambda: mg.icosahedral_mesh(32)}[name]()
+                             "ico32": lambda: mg.icosahedral_mesh(32),
+                             "ico12f": lambda: mg.icosahedral_mesh(12, flips=8, seed=4)}[name]()
     return _MESH_CACHE[name]
 
 
@@ -117,7 +118,8 @@ def random_state(mesh, K, seed):
     ("ico16", 60, L.ORDER_RCB, 0), ("ico16", 64, L.ORDER_NONE, 0), ("ico16", 80, L.ORDER_RCB, 0),
     ("ico32", 60, L.ORDER_RCB, 32), ("ico16", 130, L.ORDER_RCB, 64), ("ico32", 60, L.ORDER_RCB, 0),
     ("ico16", 8, L.ORDER_RCB, 0), ("ico16", 34, L.ORDER_RCB, 0), ("ico16", 100, L.ORDER_RCB, 0), ("planar", 60, L.ORDER_RCB, 0),
-    ("ico16", 60, L.ORDER_RCM, 0), ("ico16", 60, L.ORDER_NONE, 24), ("ico32", 60, L.ORDER_RCB, 12), ("ico16", 62, L.ORDER_RCB, 12), ("ico32", 60, L.ORDER_RCB, 8), ("ico16", 34, L.ORDER_RCB, 7), ("planar", 60, L.ORDER_RCB, 8), ("planar", 60, L.ORDER_RCB, 12), ("ico16", 8, L.ORDER_RCB, 12),
+    ("ico16", 60, L.ORDER_RCM, 0), ("ico16", 60, L.ORDER_NONE, 24),
+    ("ico12f", 60, L.ORDER_RCB, 0), ("ico12f", 1, L.ORDER_RCB, 0), ("ico12f", 10, L.ORDER_RCM, 0), ("ico12f", 80, L.ORDER_RCB, 0), ("ico32", 60, L.ORDER_RCB, 12), ("ico16", 62, L.ORDER_RCB, 12), ("ico32", 60, L.ORDER_RCB, 8), ("ico16", 34, L.ORDER_RCB, 7), ("planar", 60, L.ORDER_RCB, 8), ("planar", 60, L.ORDER_RCB, 12), ("ico16", 8, L.ORDER_RCB, 12),
 ])
 def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     mesh = get_mesh(meshname)
@@ -244,7 +246,7 @@ def test_reference_call_sequence_piecewise(backend):
 # RK4 stage loop
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("meshname,K,nsteps,variant", [("igw200", 1, 10, 0), ("ico16", 1, 5, 0), ("ico16", 60, 3, 1),
-                                                         ("ico16", 60, 3, 2), ("ico16", 80, 2, 2), ("ico32", 60, 2, 0), ("ico32", 60, 3, 9), ("ico32", 60, 3, 10)])
+                                                         ("ico16", 60, 3, 2), ("ico16", 80, 2, 2), ("ico32", 60, 2, 0), ("ico32", 60, 3, 9), ("ico32", 60, 3, 10), ("ico12f", 60, 3, 0), ("ico12f", 3, 3, 0)])
 def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
     backend.set_kernel_variant(variant)
     mesh = get_mesh(meshname)

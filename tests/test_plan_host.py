@@ -40,6 +40,7 @@ def test_ctx_create_fails_loudly_without_gpu():
 MESHES = {
     "planar": lambda: mg.planar_hex_mesh(12, 10, 1000.0, f0=1e-4),
     "sphere": lambda: mg.icosahedral_mesh(6),
+    "sphere_5_7": lambda: mg.icosahedral_mesh(8, flips=5, seed=2),     # pentagon/heptagon pairs: maxEdges = 7
 }
 
 
