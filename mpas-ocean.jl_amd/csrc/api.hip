@@ -717,12 +717,47 @@ int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flag
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
     if (nsteps < 0) return fail(st->ctx, MOKA_ERR_ARG, "nsteps must be >= 0");
-    for (int64_t i = 0; i < nsteps; ++i) {
-        int rc = integrator == MOKA_FORWARD_EULER ? moka_step_fe(st, dt, flags)
-               : integrator == MOKA_RUNGE_KUTTA_4 ? moka_step_rk4(st, dt)
-               : fail(st->ctx, MOKA_ERR_ARG, "unknown integrator");
-        if (rc) return rc;
+    if (integrator != MOKA_FORWARD_EULER && integrator != MOKA_RUNGE_KUTTA_4) return fail(st->ctx, MOKA_ERR_ARG, "unknown integrator");
+    auto one = [&]() { return integrator == MOKA_FORWARD_EULER ? moka_step_fe(st, dt, flags) : moka_step_rk4(st, dt); };
+    int64_t done = 0;
+    int rc;
+    // Launch-bound regime (small meshes): capture TWO consecutive steps (the time-level buffers swap every step, so
+    // the pointer pattern has period 2) into a hipGraph and replay it.  The first step runs eagerly: it may have to
+    // make ssh consistent and allocate the RK buffers, neither of which may happen during capture.
+    if (nsteps >= 6) {
+        if ((rc = one())) return rc;
+        ++done;
+        HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+        if ((rc = flush_lazy(st, true, true))) return rc;      // nothing lazy may fire inside the capture
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipStream_t s = st->ctx->stream;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const bool d0 = st->diagDirty, t0 = st->tendDirty;
+            st->diagDirty = st->tendDirty = false;             // keep flush_lazy inside the steps a no-op while capturing
+            int rc1 = one();
+            st->diagDirty = st->tendDirty = false;
+            int rc2 = rc1 ? rc1 : one();
+            hipError_t ec = hipStreamEndCapture(s, &graph);
+            if (rc2 || ec != hipSuccess || !graph) {
+                if (graph) (void)hipGraphDestroy(graph);
+                st->diagDirty = d0; st->tendDirty = t0;
+                return rc2 ? rc2 : fail(st->ctx, MOKA_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
+            }
+            // the capture recorded the launches but executed nothing: the host-side level swaps of the two steps cancel
+            if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                while (nsteps - done >= 2) {
+                    HIPCHK(st->ctx, hipGraphLaunch(exec, s));
+                    done += 2;
+                }
+                (void)hipGraphExecDestroy(exec);
+            }
+            (void)hipGraphDestroy(graph);
+            st->diagDirty = st->tendDirty = (integrator == MOKA_RUNGE_KUTTA_4);
+        }
     }
+    for (; done < nsteps; ++done)
+        if ((rc = one())) return rc;
     return MOKA_OK;
 }
 

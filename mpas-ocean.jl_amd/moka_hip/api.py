@@ -20,7 +20,7 @@ __all__ = [
     "PrognosticVars", "DiagnosticVars", "TendencyVars", "DeviceField",
     "GradientOnEdge", "DivergenceOnCell", "CurlOnVertex", "interpolateCell2Edge",
     "advanceTimeLevels", "diagnostic_compute", "computeNormalVelocityTendency", "computeLayerThicknessTendency",
-    "computeTendency", "ocn_timestep", "ocn_run_loop", "ocn_init_from_arrays", "ocn_init_alarms",
+    "computeTendency", "ocn_timestep", "ocn_run_loop", "run_steps", "ocn_init_from_arrays", "ocn_init_alarms",
     "Clock", "OneTimeAlarm", "PeriodicAlarm", "advance", "isRinging", "reset", "changeTimeStep",
     "REFERENCE_COMPAT",
 ]
@@ -334,6 +334,14 @@ def ocn_timestep(*args, backend=None, flags: int | None = None):
         L.check(L.lib().moka_step_rk4(h, dt), c)
     else:
         raise MokaError(L.ERR_ARG, "unknown timeStepper")
+
+
+def run_steps(Prog, method, dt: float, nsteps: int, flags: int = REFERENCE_COMPAT):
+    """nsteps x ocn_timestep in one library call (moka_run): the body of ocn_run_loop (run_loop.jl:11-19) without
+    the host-side alarm bookkeeping; long runs are replayed from a hipGraph."""
+    h, c = _st(Prog)
+    integ = L.FORWARD_EULER if method is ForwardEuler else L.RUNGE_KUTTA_4
+    L.check(L.lib().moka_run(h, integ, float(dt), int(nsteps), int(flags)), c)
 
 
 def ocn_run_loop(*args, backend=None, flags: int | None = None):

@@ -307,6 +307,24 @@ def test_driver_replay_igw_forward_euler_and_rk4(backend):
         Prog._state.close(); Setup.mesh.close()
 
 
+@pytest.mark.parametrize("method,K,nsteps", [("rk4", 1, 9), ("rk4", 60, 8), ("fe", 1, 11), ("fe", 4, 7), ("rk4", 1, 3)])
+def test_moka_run_graph_replay_bitwise(backend, method, K, nsteps):
+    """moka_run replays long runs from a hipGraph of two captured steps: same bits as stepping one by one."""
+    mesh = get_mesh("ico16")
+    ssh, u, h, rest = random_state(mesh, K, 21)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    flags = 3
+    mk.run_steps(Prog, mk.RungeKutta4 if method == "rk4" else mk.ForwardEuler, 15.0, nsteps, flags)
+    for _ in range(nsteps):
+        st.step_rk4(15.0) if method == "rk4" else st.step_fe(15.0, flags)
+    got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    Prog._state.close(); Setup.mesh.close()
+
+
 def test_upload_download_roundtrip_and_errors(backend):
     mesh = get_mesh("ico16")
     K = 7
