@@ -224,6 +224,10 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
         hipError_t e = launch_stage_ptile(dev, g, st->ctx->nCUs, s);
         if (e != hipErrorNotSupported) return e;
     }
+    if (v == 11 && m->lpc == 64 && m->colOk) {   // rec2 + own-edge u rows cached in LDS (wants patch_cells <= ~20 at K = 60)
+        hipError_t e = launch_stage_rec2c(dev, g, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (v == 9 && m->tileOk) {             // tiled: u rows + records in LDS (needs patch_cells <= 16)
         hipError_t e = launch_stage_tile(dev, g, s);
         if (e != hipErrorNotSupported) return e;
@@ -359,7 +363,7 @@ int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
 int moka_set_kernel_variant(moka_ctx *ctx, int variant)
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
-    if (variant < 0 || variant > 10) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..10");
+    if (variant < 0 || variant > 11) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..11");
     ctx->variant = variant;
     return MOKA_OK;
 }

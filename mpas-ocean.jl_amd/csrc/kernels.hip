@@ -1760,6 +1760,167 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// rec2 + own-edge cache ("rec2c"): k_stage_rec2 with the u-rows of the patch's OWN edges copied once into LDS
+// (a contiguous range: one coalesced copy, no halo list).  ~65 % of all u gathers of a compact patch refer to
+// its own edges; those become ds_read_b128 and their texture-address transactions disappear.  A gather whose
+// row is not cached is an exec-masked global load (the two half-waves of a wave decide independently).
+// Not pipelined: loads sit behind per-lane branches, so the compiler waits with vmcnt(0) at first use; 12+
+// waves per CU cover the latency instead.
+// ------------------------------------------------------------------------------------------------
+template <int ME, int ME2, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_stage_rec2c(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int pl_ = patch_of_block(m.nPatches);
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
+    constexpr int NG = BLOCK / 32;
+    const int tid = threadIdx.x;
+    const int grp = tid >> 5, l = tid & 31;
+    const int K = m.K, K2 = K >> 1;
+    const uint32_t voff = (uint32_t)l * 16u, rowB = (uint32_t)K * 8u;
+    const RecLds L = rec_carve(smem, m, ME, ME2, maxOwnE, maxOwnC);
+    // the row cache sits behind the records
+    const size_t recBytes = ((size_t)maxOwnE * (2 * ME2 + 1) * 8 + (size_t)maxOwnC * (ME + 2) * 8 +
+                             ((size_t)maxOwnE * m.EI + (size_t)maxOwnC * m.CI) * 4 + 15) & ~(size_t)15;
+    double2 *ubuf2 = reinterpret_cast<double2 *>(smem + recBytes);
+    const unsigned char *ubytes = reinterpret_cast<const unsigned char *>(ubuf2) + voff;
+    const int c0 = cptr(m.patchCellStart)[p], c1 = cptr(m.patchCellStart)[p + 1];
+    const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
+    const int nOwnC = c1 - c0, nOwnE = e1 - e0;
+    const uint32_t e0B = (uint32_t)e0 * rowB, nOwnB = (uint32_t)nOwnE * rowB;
+
+    for (int i = tid; i < nOwnE * m.EI; i += BLOCK) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
+    for (int i = tid; i < nOwnE * ME2; i += BLOCK) {
+        L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
+        L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
+    }
+    for (int i = tid; i < nOwnE; i += BLOCK) L.g[i] = m.gInvDc[e0 + i];
+    for (int i = tid; i < nOwnC * m.CI; i += BLOCK) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
+    for (int i = tid; i < nOwnC * ME; i += BLOCK) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
+    for (int i = tid; i < nOwnC; i += BLOCK) {
+        L.invA[i] = m.invArea[c0 + i];
+        L.rsum[i] = m.rsum[c0 + i];
+    }
+    {   // own u rows: one contiguous, fully coalesced copy
+        const double2 *src = reinterpret_cast<const double2 *>(a.pu) + (size_t)e0 * K2;
+        for (int i = tid; i < nOwnE * K2; i += BLOCK) ubuf2[i] = src[i];
+    }
+    __syncthreads();
+
+    const int k0 = 2 * l;
+    const bool act = k0 < K;
+    auto urow = [&](uint32_t off) -> double2 {                         // u row at global byte offset `off`
+        const uint32_t loc = off - e0B;
+        if (loc < nOwnB) return *reinterpret_cast<const double2 *>(ubytes + loc);
+        return gload2(a.pu, off + voff);
+    };
+
+    // ---------------- cells ----------------
+    for (int ci = grp; ci < nOwnC; ci += NG) {
+        const int c = c0 + ci;
+        const uint32_t *r = L.cRec + (size_t)ci * m.CI;
+        const double *rs = L.sdv + (size_t)ci * ME;
+        const uint32_t mask = r[2 * ME], all = r[2 * ME + 1];
+        const double invA = L.invA[ci];
+        const uint32_t own = (uint32_t)c * rowB + voff;
+        double2 hc = make_double2(0.0, 0.0), uv[ME], hv[ME], cur = hc, nin = hc;
+        if (act) {
+            hc = gload2(a.ph, own);
+#pragma unroll
+            for (int i = 0; i < ME; ++i) {
+                hv[i] = gload2(a.ph, r[ME + i] + voff);
+                uv[i] = urow(r[i]);
+            }
+            if constexpr (MODE == 2) cur = gload2(a.ch, own);
+            if constexpr (MODE >= 2) nin = gload2(a.nh_in, own);
+        }
+        double2 t = make_double2(0.0, 0.0);
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < ME; ++i) {
+                const int ml = all ? K : cptr(m.mltc)[(size_t)c * ME + i];
+                const bool on = (mask >> i) & 1u;
+                const double dx = uv[i].x * (0.5 * (hc.x + hv[i].x)) * rs[i] * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
+                const double dy = uv[i].y * (0.5 * (hc.y + hv[i].y)) * rs[i] * invA;   // horizontal_advection.jl:63
+                if (on && k0 < ml) t.x += dx;
+                if (on && k0 + 1 < ml) t.y += dy;
+            }
+        }
+        double2 hs = make_double2(0.0, 0.0);
+        if (act) {
+            if constexpr (MODE == 0) gstore2(a.tendH, own, t);
+            if constexpr (MODE == 1 || MODE == 2) {
+                const double2 hcur = MODE == 2 ? cur : hc;
+                const double2 nb = MODE == 2 ? nin : hcur;
+                hs = make_double2(hcur.x + a.a * t.x, hcur.y + a.a * t.y);                    // time_integration.jl:125
+                gstore2(a.ph_out, own, hs);
+                gstore2(a.nh_out, own, make_double2(nb.x + a.b * t.x, nb.y + a.b * t.y));     // :135
+            }
+            if constexpr (MODE == 3) {
+                hs = make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y);
+                gstore2(a.nh_out, own, hs);
+            }
+        }
+        if constexpr (MODE != 0) {
+#pragma unroll
+            for (int sft = 16; sft >= 1; sft >>= 1) {                   // oracle_ksum order (see k_stage_rec2)
+                const double ox = __shfl_xor(hs.x, sft, 32), oy = __shfl_xor(hs.y, sft, 32);
+                hs = make_double2(hs.x + ox, hs.y + oy);
+            }
+            if (l == 0) a.ssh_out[c] = (hs.x + hs.y) - L.rsum[ci];                            // :209 (+N3)
+        }
+    }
+
+    // ---------------- edges ----------------
+    for (int ei = grp; ei < nOwnE; ei += NG) {
+        const int e = e0 + ei;
+        const uint32_t *r = L.eRec + (size_t)ei * m.EI;
+        const double *rw = L.woe + (size_t)ei * ME2;
+        const double *rf = L.feoe + (size_t)ei * ME2;
+        const uint32_t mask = r[ME2 + 2];
+        const int mlt = (int)r[ME2 + 3];
+        const double g = L.g[ei];
+        const uint32_t own = (uint32_t)e * rowB + voff;
+        double sA = 0.0, sB = 0.0;
+        if (l == 0) sA = a.ssh[r[ME2]];
+        if (l == 1) sB = a.ssh[r[ME2 + 1]];
+        double2 uv[ME2], cur = make_double2(0.0, 0.0), nin = cur;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) uv[i] = urow(r[i]);
+            if constexpr (MODE == 2) cur = gload2(a.cu, own);
+            if constexpr (MODE >= 2) nin = gload2(a.nu_in, own);
+        }
+        const double ds = __shfl(sB, 1, 32) - __shfl(sA, 0, 32);       // ssh[c2] - ssh[c1]
+        if (act) {
+            const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
+            double2 t = make_double2(0.0, 0.0);
+            if (ax) t.x -= g * ds;                                     // pressure_gradient.jl:63
+            if (ay) t.y -= g * ds;
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) {
+                const bool on = (mask >> i) & 1u;
+                const double px = rw[i] * uv[i].x * rf[i], py = rw[i] * uv[i].y * rf[i];   // ...coriolis.jl:70-72
+                if (on && ax) t.x += px;
+                if (on && ay) t.y += py;
+            }
+            if constexpr (MODE == 0) gstore2(a.tendU, own, t);
+            if constexpr (MODE == 1) {
+                const double2 up = ubuf2[(size_t)ei * K2 + l];          // own row is in the cache
+                gstore2(a.pu_out, own, make_double2(up.x + a.a * t.x, up.y + a.a * t.y));   // time_integration.jl:124
+                gstore2(a.nu_out, own, make_double2(up.x + a.b * t.x, up.y + a.b * t.y));   // :134
+            }
+            if constexpr (MODE == 2) {
+                gstore2(a.pu_out, own, make_double2(cur.x + a.a * t.x, cur.y + a.a * t.y));
+                gstore2(a.nu_out, own, make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y));
+            }
+            if constexpr (MODE == 3) gstore2(a.nu_out, own, make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS patch-tiled variant of the fused tendency / RK-stage kernel (same arithmetic, same results).
 //
 // The direct kernel above re-reads every u-row ~12 times through the vector L1 (10 Coriolis
@@ -2435,10 +2596,44 @@ hipError_t launch_stage_ptile(const MeshDev &md, const StageArgs &a, int nCUs, h
     return hipGetLastError();
 }
 
+size_t rec2c_lds_bytes(const MeshDev &md);
+
+template <int ME, int ME2>
+static bool launch_rec2c(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3 b, size_t lds, int mE, int mC, hipStream_t s)
+{
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 0>), g, b, lds, s, m, a, mE, mC); return true;
+        case 1: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 1>), g, b, lds, s, m, a, mE, mC); return true;
+        case 2: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 2>), g, b, lds, s, m, a, mE, mC); return true;
+        case 3: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 3>), g, b, lds, s, m, a, mE, mC); return true;
+    }
+    return false;
+}
+
 size_t rec_lds_bytes(const MeshDev &md)
 {
     return (size_t)md.maxOwnE * (2 * md.ME2 + 1) * 8 + (size_t)md.maxOwnC * (md.ME + 2) * 8 +
            ((size_t)md.maxOwnE * md.EI + (size_t)md.maxOwnC * md.CI) * 4 + 16;
+}
+
+size_t rec2c_lds_bytes(const MeshDev &md)
+{
+    return ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 8 + 16;
+}
+
+hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t s)
+{
+    const dim3 g(patch_grid(md)), b(BLOCK);
+    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
+    const int mode = colp_mode(a);
+    const size_t lds = rec2c_lds_bytes(md);
+    if (mode < 0 || md.K > 64 || (md.K & 1) || lds > 64 * 1024 || md.maxOwnC < 1 || md.maxOwnE < 1) return hipErrorNotSupported;
+    bool ok = false;
+    if (md.ME == 6 && md.ME2 == 10) ok = launch_rec2c<6, 10>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    else if (md.ME == 8 && md.ME2 == 14) ok = launch_rec2c<8, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    else if (md.ME <= 6 && md.ME2 <= 14) ok = launch_rec2c<6, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    return ok ? hipGetLastError() : hipErrorNotSupported;
 }
 
 hipError_t launch_stage_rec2(const MeshDev &md, const StageArgs &a, hipStream_t s)

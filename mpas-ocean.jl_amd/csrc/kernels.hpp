@@ -59,6 +59,7 @@ hipError_t launch_stage_ptile(const MeshDev &m, const StageArgs &a, int nCUs, hi
 bool stage_tile_usable(const MeshDev &md, bool ldsOk);
 hipError_t prepare_stage_tile(const MeshDev &md);
 hipError_t launch_stage_tile(const MeshDev &m, const StageArgs &a, hipStream_t s);
+hipError_t launch_stage_rec2c(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_rec2(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_rec(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_colx(const MeshDev &m, const StageArgs &a, bool pipelined, hipStream_t s);

@@ -129,7 +129,7 @@ def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     tu, th, ossh = om.tendencies_clean(u, h)
     info = Setup.mesh.info()
-    for variant in (10, 9, 8, 7, 1, 2, 3, 4, 5, 6):   # 1 pipelined column, 2 LDS patch-tiled, 3 generic index, 4 plain column, 5/6 16-byte-lane column (plain/pipelined)
+    for variant in (11, 10, 9, 8, 7, 1, 2, 3, 4, 5, 6):   # 1 pipelined column, 2 LDS patch-tiled, 3 generic index, 4 plain column, 5/6 16-byte-lane column (plain/pipelined)
         backend.set_kernel_variant(variant)
         Tend.tendNormalVelocity.set(np.full_like(tu, np.nan)); Tend.tendLayerThickness.set(np.full_like(th, np.nan))
         Prog.ssh[-1].set(ssh)
@@ -246,7 +246,7 @@ def test_reference_call_sequence_piecewise(backend):
 # RK4 stage loop
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("meshname,K,nsteps,variant", [("igw200", 1, 10, 0), ("ico16", 1, 5, 0), ("ico16", 60, 3, 1),
-                                                         ("ico16", 60, 3, 2), ("ico16", 80, 2, 2), ("ico32", 60, 2, 0), ("ico32", 60, 3, 9), ("ico32", 60, 3, 10), ("ico12f", 60, 3, 0), ("ico12f", 3, 3, 0)])
+                                                         ("ico16", 60, 3, 2), ("ico16", 80, 2, 2), ("ico32", 60, 2, 0), ("ico32", 60, 3, 9), ("ico32", 60, 3, 10), ("ico12f", 60, 3, 0), ("ico12f", 3, 3, 0), ("ico32", 60, 3, 11)])
 def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
     backend.set_kernel_variant(variant)
     mesh = get_mesh(meshname)
@@ -257,7 +257,7 @@ def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
         ssh, u, h, rest = random_state(mesh, K, 9)
         dtv = 20.0
     Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True,
-                                                       patch_cells=12 if variant in (2, 9) else 8 if variant == 10 else 0)
+                                                       patch_cells=12 if variant in (2, 9, 11) else 8 if variant == 10 else 0)
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     st = orc.OracleState(om, ssh, u, h)
     mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dtv))
