@@ -1785,14 +1785,10 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c(const ColMesh m, const St
                              ((size_t)maxOwnE * m.EI + (size_t)maxOwnC * m.CI) * 4 + 15) & ~(size_t)15;
     double2 *ubuf2 = reinterpret_cast<double2 *>(smem + recBytes);
     const unsigned char *ubytes = reinterpret_cast<const unsigned char *>(ubuf2) + voff;
-    double2 *hbuf2 = ubuf2 + (size_t)maxOwnE * K2;                     // own h rows (MOKA_DBG 64 switches this cache off)
-    const unsigned char *hbytes = reinterpret_cast<const unsigned char *>(hbuf2) + voff;
-    const bool hcache = !(a.dbg & 64);
     const int c0 = cptr(m.patchCellStart)[p], c1 = cptr(m.patchCellStart)[p + 1];
     const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
     const int nOwnC = c1 - c0, nOwnE = e1 - e0;
     const uint32_t e0B = (uint32_t)e0 * rowB, nOwnB = (uint32_t)nOwnE * rowB;
-    const uint32_t c0B = (uint32_t)c0 * rowB, nOwnCB = hcache ? (uint32_t)nOwnC * rowB : 0u;
 
     for (int i = tid; i < nOwnE * m.EI; i += BLOCK) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
     for (int i = tid; i < nOwnE * ME2; i += BLOCK) {
@@ -1809,9 +1805,6 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c(const ColMesh m, const St
     {   // own u rows: one contiguous, fully coalesced copy
         const double2 *src = reinterpret_cast<const double2 *>(a.pu) + (size_t)e0 * K2;
         for (int i = tid; i < nOwnE * K2; i += BLOCK) ubuf2[i] = src[i];
-        const double2 *srch = reinterpret_cast<const double2 *>(a.ph) + (size_t)c0 * K2;
-        if (hcache)
-            for (int i = tid; i < nOwnC * K2; i += BLOCK) hbuf2[i] = srch[i];
     }
     __syncthreads();
 
@@ -1821,11 +1814,6 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c(const ColMesh m, const St
         const uint32_t loc = off - e0B;
         if (loc < nOwnB) return *reinterpret_cast<const double2 *>(ubytes + loc);
         return gload2(a.pu, off + voff);
-    };
-    auto hrow = [&](uint32_t off) -> double2 {                         // h row at global byte offset `off`
-        const uint32_t loc = off - c0B;
-        if (loc < nOwnCB) return *reinterpret_cast<const double2 *>(hbytes + loc);
-        return gload2(a.ph, off + voff);
     };
 
     // ---------------- cells ----------------
@@ -1838,10 +1826,10 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c(const ColMesh m, const St
         const uint32_t own = (uint32_t)c * rowB + voff;
         double2 hc = make_double2(0.0, 0.0), uv[ME], hv[ME], cur = hc, nin = hc;
         if (act) {
-            hc = hrow((uint32_t)c * rowB);
+            hc = gload2(a.ph, own);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
-                hv[i] = hrow(r[ME + i]);
+                hv[i] = gload2(a.ph, r[ME + i] + voff);
                 uv[i] = urow(r[i]);
             }
             if constexpr (MODE == 2) cur = gload2(a.ch, own);
@@ -2630,7 +2618,7 @@ size_t rec_lds_bytes(const MeshDev &md)
 
 size_t rec2c_lds_bytes(const MeshDev &md)
 {
-    return ((rec_lds_bytes(md) + 15) & ~(size_t)15) + ((size_t)md.maxOwnE + md.maxOwnC) * md.K * 8 + 16;
+    return ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 8 + 16;
 }
 
 hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t s)
