@@ -233,9 +233,10 @@ int  moka_rk4_dist_begin(moka_halo *h, double dt);
 int  moka_rk4_dist_stage(moka_halo *h, int stage, int part);
 int  moka_rk4_dist_end(moka_halo *h);
 
-/* kernel variant selection for measurement: 0 = auto, 1 = software-pipelined column kernel (byte-offset records +
- * buffer loads; nVertLevels in 33..64), 2 = LDS patch-tiled, 3 = generic index kernel (any nVertLevels),
- * 4 = column kernel without pipelining */
+/* kernel variant selection for measurement (all variants give identical results): 0 = auto [default: 11 when it fits,
+ * else 8, 7, 4, 3]; 11 = record-staged, 16-byte lanes, two entities per wave, own u rows cached in LDS; 8 = the same
+ * without the row cache; 7 = record-staged 8-byte lanes; 1/4 = column kernel pipelined/plain; 5/6 = 16-byte-lane column;
+ * 2 = LDS patch-tiled; 9 = tiled, two-burst prefetch; 10 = persistent double-buffered tile; 3 = generic index kernel. */
 int moka_set_kernel_variant(moka_ctx *ctx, int variant);
 
 #ifdef __cplusplus

@@ -218,18 +218,19 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
     if (dev.nPatches <= 0) return hipSuccess;
     hipStream_t s = st->ctx->stream;
     const int v = st->ctx->variant;
-    // 0 = auto; 8 rec2 (record-staged, 16-byte lanes, 2 entities/wave), 7 rec, 1 colp, 4 col, 5/6 colx, 2 LDS-tiled, 3 generic
+    // 0 = auto (rec2c, then rec2, rec, col, generic as the mesh allows); 11 rec2c, 8 rec2, 7 rec, 1 colp, 4 col, 5/6 colx,
+    // 2 LDS-tiled, 9 tile, 10 ptile, 3 generic
     if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(dev, g, m->ldsBytes, s);
     if (v == 10 && m->ptileOk) {           // persistent double-buffered tiled kernel (needs patch_cells <= ~14)
         hipError_t e = launch_stage_ptile(dev, g, st->ctx->nCUs, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if (v == 11 && m->lpc == 64 && m->colOk) {   // rec2 + own-edge u rows cached in LDS (wants patch_cells <= ~20 at K = 60)
-        hipError_t e = launch_stage_rec2c(dev, g, s);
-        if (e != hipErrorNotSupported) return e;
-    }
     if (v == 9 && m->tileOk) {             // tiled: u rows + records in LDS (needs patch_cells <= 16)
         hipError_t e = launch_stage_tile(dev, g, s);
+        if (e != hipErrorNotSupported) return e;
+    }
+    if ((v == 0 || v == 11) && m->lpc == 64 && m->colOk) {   // default: rec2 + own-edge u rows cached in LDS
+        hipError_t e = launch_stage_rec2c(dev, g, s);
         if (e != hipErrorNotSupported) return e;
     }
     if ((v == 0 || v == 8) && m->lpc == 64 && m->colOk) {

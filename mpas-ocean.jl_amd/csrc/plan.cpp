@@ -200,10 +200,13 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     p.ME = maxEoC <= 6 ? 6 : (maxEoC <= 8 ? 8 : maxEoC);
     p.ME2 = maxEoE <= 10 ? 10 : (maxEoE <= 14 ? 14 : maxEoE);
     if (p.ME == 8 && p.ME2 < 14) p.ME2 = 14;   // kernels are instantiated for (6,10), (6,14), (8,14)
-    // default patch size: 32 cells (+ ~96 edges) per workgroup measured best for the record-staged column
-    // kernels (bench sweep 16/24/32/64 in profiles/r01_variants.txt); the LDS-tiled kernel (variant 2) wants
-    // patch_cells = 16 at K = 60 so that two workgroups fit a CU.
-    p.P = d->patch_cells > 0 ? d->patch_cells : 32;
+    // default patch size (bench sweeps in profiles/r01_variants.txt): 12 cells for even 34 <= K <= 64, where the
+    // default stage kernel (k_stage_rec2c) keeps the patch's own u rows in LDS and four workgroups must fit a CU;
+    // 32 cells otherwise (generic / plain column kernels).
+    {
+        const int K = d->nVertLevels;
+        p.P = d->patch_cells > 0 ? d->patch_cells : ((K >= 34 && K <= 64 && !(K & 1)) ? 12 : 32);
+    }
     REQUIRE(p.P <= 4096, "patch_cells too large");
 
     // ---- cell ordering ----
