@@ -1,9 +1,11 @@
 // api.hip -- C ABI of libmoka_hip.so (include/moka_hip.h): context, device mesh, state, steps.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <utility>
@@ -37,6 +39,9 @@ struct moka_mesh {
     bool ptileOk = false;     // the persistent double-buffered tiled kernel fits this mesh
     double *opBuf[3] = {nullptr, nullptr, nullptr};   // operator / transfer scratch, lazily sized
     size_t opBufElems = 0;
+    // (maxOwnE, maxOwnC) of a launched patch sub-range: a partition's halo-only patches own up to 6 edges per cell
+    // and are never launched, so the LDS carve of a boundary / interior launch is sized by the patches it covers
+    std::map<std::pair<int, int>, std::pair<int, int>> rangeMax;
 };
 
 struct LevelBufs {
@@ -214,7 +219,23 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
     g.dbg = dbg;   // diagnostics only; 0 in normal operation
     const moka_mesh *m = st->mesh;
     MeshDev dev = m->dev;                 // the launch covers patches [pBegin, pBegin + pCount)
-    if (pCount >= 0) { dev.patchBegin = pBegin; dev.nPatches = pCount; }
+    if (pCount >= 0) {
+        dev.patchBegin = pBegin; dev.nPatches = pCount;
+        if (pCount > 0) {
+            auto &cache = st->mesh->rangeMax;
+            auto it = cache.find({pBegin, pCount});
+            if (it == cache.end()) {
+                const moka::Plan &p = m->plan;
+                int mE = 1, mC = 1;
+                for (int q = pBegin; q < pBegin + pCount; ++q) {
+                    mE = std::max(mE, p.patchEdgeStart[q + 1] - p.patchEdgeStart[q]);
+                    mC = std::max(mC, p.patchCellStart[q + 1] - p.patchCellStart[q]);
+                }
+                it = cache.emplace(std::make_pair(pBegin, pCount), std::make_pair(mE, mC)).first;
+            }
+            dev.maxOwnE = it->second.first; dev.maxOwnC = it->second.second;
+        }
+    }
     if (dev.nPatches <= 0) return hipSuccess;
     hipStream_t s = st->ctx->stream;
     const int v = st->ctx->variant;
