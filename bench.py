@@ -28,12 +28,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # measured float4 copy ceiling, same guide
 
 WORKLOADS = {
-    # name: (icosahedral frequency m, layers)  -- SURVEY.md section 8 size table
+    # name: (icosahedral frequency m, layers[, state bytes, Schmidt stretch])  -- SURVEY.md section 8 size table
     "config4_1M_x60": (320, 60),
     "config3_41k_x60": (64, 60),
     "exp_1M_x64": (320, 64),          # experiment: 512-byte rows (cache-line aligned)
     "config2_41k_x1": (64, 1),
     "small_10k_x60": (32, 60),
+    # BASELINE config 5: variable-resolution (~3-52 km) 3 696 642-cell sphere x 80 layers, fp32 state / fp64 arithmetic
+    "config5_3.7M_x80_f32": (608, 80, 4, 4.47),
+    "small_41k_x80_f32": (64, 80, 4, 4.47),
 }
 
 
@@ -51,10 +54,10 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def get_mesh(m):
+def get_mesh(m, stretch=1.0):
     from moka_hip import meshgen as mg
     t0 = time.time()
-    mesh = mg.icosahedral_mesh(m)
+    mesh = mg.icosahedral_mesh(m, stretch=stretch)
     log(f"[bench] mesh m={m}: {mesh.nCells} cells, {mesh.nEdges} edges built in {time.time() - t0:.1f}s")
     return mesh
 
@@ -72,14 +75,14 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MOKA_BENCH_THREADS", "16"))))
 
 
-def cpu_baseline(mesh, K, ssh, u, h, rest, dts, budget_s=25.0):
+def cpu_baseline(mesh, K, ssh, u, h, rest, dts, budget_s=25.0, mixed=False):
     """Oracle (C restatement of the reference loop nests) timed on this box's host cores: clean RK4 step,
     all cores (OpenMP), on the same mesh when one step fits the budget, else on a smaller sphere."""
     import oracle as orc
     cores = host_cores()
     orc.set_threads(cores)
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
-    st = orc.OracleState(om, ssh, u, h)
+    st = orc.OracleState(om, ssh, u, h, mixed=mixed)
     t0 = time.time()
     st.step_rk4(dts)                   # warm-up (page faults) and a size probe
     t_probe = time.time() - t0
@@ -90,14 +93,27 @@ def cpu_baseline(mesh, K, ssh, u, h, rest, dts, budget_s=25.0):
     for _ in range(n):
         st.step_rk4(dts)
     t = (time.time() - t0) / n if n else t_probe
+    out = {"value": mesh.nCells * K / t, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+           "sample": f"{max(n, 1)} RK4 step(s) on {mesh.nCells} cells x {K} layers, "
+                     f"oracle/moka_oracle.c with OpenMP on {cores} host threads",
+           "ms_per_step": t * 1e3}
+    if not mixed:
+        # the reference's live path: reference_compat Forward-Euler steps (time_integration.jl:150-193), same threads
+        fe = orc.OracleState(om, ssh, u, h)
+        flags = orc.FE_REFERENCE_COMPAT if K == 1 else (orc.FE_REFERENCE_COMPAT & ~4)
+        fe.step_fe(dts, flags)
+        t0 = time.time()
+        nf = 0
+        while nf < 8 and time.time() - t0 < budget_s / 3:
+            fe.step_fe(dts, flags)
+            nf += 1
+        out["forward_euler_compat"] = {"value": mesh.nCells * K / ((time.time() - t0) / nf), "unit": "cell-updates/s",
+                                       "sample": f"{nf} reference_compat FE steps, same mesh and threads"}
     orc.set_threads(1)
-    return {"value": mesh.nCells * K / t, "unit": "cell-updates/s", "cores": cores, "kind": "port",
-            "sample": f"{max(n, 1)} RK4 step(s) of the same workload ({mesh.nCells} cells x {K} layers), "
-                      f"oracle/moka_oracle.c with OpenMP on {cores} host threads",
-            "ms_per_step": t * 1e3}
+    return out
 
 
-def cpu_baseline_1t(K, budget_s=12.0):
+def cpu_baseline_1t(K, budget_s=12.0, mixed=False):
     """Single-thread figure (what `julia mpas_ocean.jl` gives with JULIA_NUM_THREADS=1), small sphere."""
     import oracle as orc
     from moka_hip import meshgen as mg
@@ -105,7 +121,7 @@ def cpu_baseline_1t(K, budget_s=12.0):
     ssh, u, h, rest, dts = mg.sphere_synthetic_state(mesh, K)
     orc.set_threads(1)
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
-    st = orc.OracleState(om, ssh, u, h)
+    st = orc.OracleState(om, ssh, u, h, mixed=mixed)
     st.step_rk4(dts)
     t0 = time.time()
     n = 0
@@ -154,8 +170,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group("gloo")
-    m, K = WORKLOADS[args.workload]
-    mesh = get_mesh(m)
+    m, K, sbytes, stretch = (tuple(WORKLOADS[args.workload]) + (8, 1.0))[:4]
+    mesh = get_mesh(m, stretch)
     ssh, u, h, rest, dts = mg.sphere_synthetic_state(mesh, K)
     cfg = {"time_management": {"config_start_time": dt.datetime(1, 1, 1), "config_run_duration": dt.timedelta(hours=1)},
            "time_integration": {"config_dt": dt.timedelta(seconds=dts), "config_number_of_time_levels": 2}}
@@ -168,7 +184,8 @@ def main():
         from moka_hip import parallel as mp
         t0 = time.time()
         model = mp.DistributedModel(mesh, ssh, u, h, rest, dts, backend, rank, world, ordering=args.ordering,
-                                    patch_cells=args.patch_cells, transport=args.transport, group=gloo_group)
+                                    patch_cells=args.patch_cells, transport=args.transport, group=gloo_group,
+                                    state_bytes=sbytes)
         log(f"[bench] rank {rank}: partition + local plan + upload: {time.time() - t0:.1f}s  {model.info()}")
         if args.transport == "nccl":
             # the overlapped form issues RCCL P2P on the library's comm stream (torch.cuda.ExternalStream); if this
@@ -186,7 +203,8 @@ def main():
     else:
         t0 = time.time()
         Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, cfg, backend, multilayer=True,
-                                                           ordering=args.ordering, patch_cells=args.patch_cells)
+                                                           ordering=args.ordering, patch_cells=args.patch_cells,
+                                                           state_bytes=sbytes)
         log(f"[bench] plan + upload: {time.time() - t0:.1f}s")
         info = Setup.mesh.info()
         step = lambda: mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)  # noqa: E731
@@ -214,7 +232,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = mesh.nCells * K / (elapsed / args.steps)
 
-    b_mesh, b_tend, b_step = algorithmic_bytes(mesh.nCells, mesh.nEdges, K)
+    b_mesh, b_tend, b_step = algorithmic_bytes(mesh.nCells, mesh.nEdges, K, S=sbytes)
     # dominant kernel = the fused RK-stage kernel k_stage: 4 launches per step, average launch time from HIP
     # events on the library's compute stream over the timed region; algorithmic bytes per launch = B_step / 4.
     launches = 4 * args.steps
@@ -236,8 +254,10 @@ def main():
 
     out = {"metric": "cell-updates/sec per RK4 step", "value": value, "unit": "cell-updates/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": args.workload, "mesh": f"icosahedral m={m}", "nCells": mesh.nCells,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64" if sbytes == 8 else "f64 arithmetic on f32-stored state", "data": "synthetic",
+           "config": {"workload": args.workload,
+                      "mesh": f"icosahedral m={m}" + (f", Schmidt stretch {stretch}" if stretch != 1.0 else ""), "nCells": mesh.nCells,
                       "nEdges": mesh.nEdges, "nVertLevels": K, "integrator": "RK4", "dt_s": dts,
                       "ordering": info.get("ordering"), "patch_cells": info.get("patch_cells"),
                       "kernel_variant": args.variant,
@@ -258,10 +278,29 @@ def main():
         out["tendency_kernel"] = {"avg_launch_ms": tms, "algorithmic_bytes": b_tend,
                                   "achieved_GBs": b_tend / (tms * 1e-3) / 1e9,
                                   "frac_of_peak": b_tend / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if sbytes == 8:
+            # the reference's live integrator: reference_compat Forward-Euler step (one fused launch), for the record
+            fe_flags = mk.REFERENCE_COMPAT if K == 1 else (mk.REFERENCE_COMPAT & ~4)
+            for _ in range(2):
+                mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=fe_flags)
+            backend.synchronize()
+            backend.timer_start()
+            for _ in range(args.tend_iters):
+                mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=fe_flags)
+            fms = backend.timer_stop() / args.tend_iters
+            out["forward_euler_compat"] = {"ms_per_step": fms, "value": mesh.nCells * K / (fms * 1e-3),
+                                           "unit": "cell-updates/s", "note": "moka_step_fe, reference_compat flags, all levels"}
     if rank == 0 and not args.no_cpu:
         t0 = time.time()
-        out["cpu_baseline"] = cpu_baseline(mesh, K, ssh, u, h, rest, dts)
-        out["cpu_baseline_1t"] = cpu_baseline_1t(K)
+        mixed = sbytes == 4
+        if mesh.nCells * K > 1.5e8:        # bounded sample: the same workload family on a quarter of the cells
+            from moka_hip import meshgen as mg
+            cm = get_mesh(m // 2, stretch)
+            cssh, cu, ch, crest, cdts = mg.sphere_synthetic_state(cm, K)
+            out["cpu_baseline"] = cpu_baseline(cm, K, cssh, cu, ch, crest, cdts, mixed=mixed)
+        else:
+            out["cpu_baseline"] = cpu_baseline(mesh, K, ssh, u, h, rest, dts, mixed=mixed)
+        out["cpu_baseline_1t"] = cpu_baseline_1t(K, mixed=mixed)
         out["cpu_baseline"]["host"] = _cpu_model()
         log(f"[bench] cpu baseline legs: {time.time() - t0:.1f}s")
     if rank == 0:

@@ -91,6 +91,11 @@ typedef struct moka_mesh_desc {
      * inside a class.  The multi-GPU layer passes 0 = owned & needed by another rank, 1 = owned interior,
      * 2 = halo, so that patch ranges [0,pb) / [pb,po) / [po,nPatches) are boundary / interior / halo. */
     const int32_t *cellClass;
+    /* bytes per real of the prognostic state this mesh will carry: 0 or 8 = Float64 (the reference,
+     * PrognosticVars.jl:91-93); 4 = fp32 STORAGE of ssh / normalVelocity / layerThickness (every time level and RK
+     * provisional state) with fp64 arithmetic and fp64 tendencies (BASELINE config 5; not a reference feature).
+     * It fixes the byte offsets baked into the gather records, so a mesh serves states of one storage type. */
+    int32_t stateBytes;
 } moka_mesh_desc;
 
 typedef struct moka_mesh_info {
@@ -179,6 +184,10 @@ int moka_interpolate_cell2edge(moka_mesh *mesh, const double *cellValue, double 
 /* ---- state ----------------------------------------------------------------------------- */
 /* PrognosticVars/DiagnosticVars/TendencyVars constructors with KA.zeros on the backend
  * (PrognosticVars.jl:59-106, DiagnosticVars.jl:75-99, TendencyVars.jl:51-67); nTimeLevels = 2 */
+/* A mesh created with stateBytes = 4 yields an fp32-STORAGE state: host arrays stay double (upload rounds to fp32,
+ * download widens), moka_tendencies / moka_step_rk4 / moka_run(RK4) / moka_sum_sq / the halo API work on it, the
+ * Forward-Euler sequence and DiagnosticVars do not (MOKA_ERR_UNSUPPORTED: the reference sequence is Float64).
+ * Needs nVertLevels % 4 == 0 and <= 128. */
 int  moka_state_create(moka_ctx *ctx, moka_mesh *mesh, moka_state **out);
 void moka_state_destroy(moka_state *st);
 /* Adapt.adapt(backend, array) / Adapt.adapt_structure(KA.CPU(), x) (OutPut.jl:122-124).
@@ -225,8 +234,10 @@ void moka_halo_destroy(moka_halo *h);
 int  moka_halo_buffer_elems(const moka_halo *h, int64_t *sendElems, int64_t *recvElems);
 /* what: 0 = current time level, 1..4 = output of RK4 stage `what`.  pack runs on the comm stream after the work
  * already queued on the compute stream; unpack makes later compute-stream work wait for it. */
-int  moka_halo_pack(moka_halo *h, int what, double *sendbuf_device);
-int  moka_halo_unpack(moka_halo *h, int what, const double *recvbuf_device);
+/* Buffers hold state reals: double, or float for an fp32-storage state (moka_mesh_desc.stateBytes = 4); sizes from
+ * moka_halo_buffer_elems are in elements either way. */
+int  moka_halo_pack(moka_halo *h, int what, void *sendbuf_device);
+int  moka_halo_unpack(moka_halo *h, int what, const void *recvbuf_device);
 /* distributed form of moka_step_rk4: begin; for stage 1..4 { stage(s,0) boundary patches; pack(s); stage(s,1)
  * interior patches (overlaps the transport); transport; unpack(s) }; end */
 int  moka_rk4_dist_begin(moka_halo *h, double dt);

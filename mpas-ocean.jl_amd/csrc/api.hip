@@ -63,6 +63,9 @@ struct moka_state {
     // results identical to computing them at the end of the step.
     bool diagDirty = false;
     bool tendDirty = false;           // stage-4 provisional state still sits in rk[0]
+    // fp32 storage of the prognostic fields (mesh stateBytes == 4): lev[] / rk[] then point at float arrays
+    // (the pointer type stays double* so that one StageArgs block serves both), Diag arrays do not exist.
+    bool f32 = false;
     std::vector<void *> allocs;
 };
 
@@ -117,12 +120,12 @@ int ensure_op_bufs(moka_mesh *m)
     return MOKA_OK;
 }
 
-int alloc_field(moka_state *st, double **out, size_t elems)
+int alloc_field(moka_state *st, double **out, size_t elems, size_t elemBytes = sizeof(double))
 {
     void *d = nullptr;
-    HIPCHK(st->ctx, hipMalloc(&d, std::max<size_t>(elems * sizeof(double), 16)));
+    HIPCHK(st->ctx, hipMalloc(&d, std::max<size_t>(elems * elemBytes, 16)));
     st->allocs.push_back(d);
-    HIPCHK(st->ctx, hipMemsetAsync(d, 0, elems * sizeof(double), st->ctx->stream));   // KA.zeros
+    HIPCHK(st->ctx, hipMemsetAsync(d, 0, elems * elemBytes, st->ctx->stream));   // KA.zeros
     *out = static_cast<double *>(d);
     return MOKA_OK;
 }
@@ -133,9 +136,10 @@ int ensure_rk_bufs(moka_state *st)
     const Plan &p = st->mesh->plan;
     for (auto &r : st->rk) {
         int rc;
-        if ((rc = alloc_field(st, &r.u, (size_t)p.K * p.nE))) return rc;
-        if ((rc = alloc_field(st, &r.h, (size_t)p.K * p.nC))) return rc;
-        if ((rc = alloc_field(st, &r.ssh, (size_t)p.nC))) return rc;
+        const size_t sb = st->f32 ? 4 : 8;
+        if ((rc = alloc_field(st, &r.u, (size_t)p.K * p.nE, sb))) return rc;
+        if ((rc = alloc_field(st, &r.h, (size_t)p.K * p.nC, sb))) return rc;
+        if ((rc = alloc_field(st, &r.ssh, (size_t)p.nC, sb))) return rc;
     }
     return MOKA_OK;
 }
@@ -145,6 +149,7 @@ struct FieldRef {
     int kind;     // MOKA_CELL / EDGE / VERTEX
     int64_t n;
     int K;
+    bool f32 = false;   // ptr is a float array (prognostic field of an fp32-storage state)
 };
 
 int field_ref(moka_state *st, int field, int level, FieldRef *r)
@@ -163,6 +168,8 @@ int field_ref(moka_state *st, int field, int level, FieldRef *r)
         case MOKA_F_TEND_LAYER_THICKNESS: *r = {st->tendH, MOKA_CELL, p.nC, p.K}; break;
         default: return fail(st->ctx, MOKA_ERR_ARG, "unknown field id");
     }
+    r->f32 = st->f32 && field <= MOKA_F_LAYER_THICKNESS;
+    if (!r->ptr) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "an fp32-storage state carries no DiagnosticVars arrays");
     return MOKA_OK;
 }
 
@@ -172,23 +179,25 @@ const int32_t *perm_of(const moka_mesh *m, int kind)
 }
 
 // host (caller numbering) -> device field (device numbering)
-int put_rows(moka_mesh *m, double *dst, const double *host, int kind, int64_t n, int K)
+int put_rows(moka_mesh *m, double *dst, const double *host, int kind, int64_t n, int K, bool f32 = false)
 {
     int rc = ensure_op_bufs(m);
     if (rc) return rc;
     hipStream_t s = m->ctx->stream;
     HIPCHK(m->ctx, hipMemcpyAsync(m->opBuf[2], host, (size_t)n * K * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(m->ctx, launch_permute_rows(dst, m->opBuf[2], perm_of(m, kind), n, K, 1, s));
+    if (f32) HIPCHK(m->ctx, launch_permute_rows_f32(dst, m->opBuf[2], perm_of(m, kind), n, K, 1, s));   // rounds to fp32
+    else HIPCHK(m->ctx, launch_permute_rows(dst, m->opBuf[2], perm_of(m, kind), n, K, 1, s));
     HIPCHK(m->ctx, hipStreamSynchronize(s));
     return MOKA_OK;
 }
 
-int get_rows(moka_mesh *m, double *host, const double *src, int kind, int64_t n, int K)
+int get_rows(moka_mesh *m, double *host, const double *src, int kind, int64_t n, int K, bool f32 = false)
 {
     int rc = ensure_op_bufs(m);
     if (rc) return rc;
     hipStream_t s = m->ctx->stream;
-    HIPCHK(m->ctx, launch_permute_rows(m->opBuf[2], src, perm_of(m, kind), n, K, 0, s));
+    if (f32) HIPCHK(m->ctx, launch_permute_rows_f32(m->opBuf[2], src, perm_of(m, kind), n, K, 0, s));
+    else HIPCHK(m->ctx, launch_permute_rows(m->opBuf[2], src, perm_of(m, kind), n, K, 0, s));
     HIPCHK(m->ctx, hipMemcpyAsync(host, m->opBuf[2], (size_t)n * K * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(m->ctx, hipStreamSynchronize(s));
     return MOKA_OK;
@@ -238,6 +247,7 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
     }
     if (dev.nPatches <= 0) return hipSuccess;
     hipStream_t s = st->ctx->stream;
+    if (st->f32) return launch_stage_rec2c_f32(dev, g, s);   // the one fp32-storage kernel (checked at state creation)
     const int v = st->ctx->variant;
     // 0 = auto (rec2c, then rec2, rec, col, generic as the mesh allows); 11 rec2c, 8 rec2, 7 rec, 1 colp, 4 col, 5/6 colx,
     // 2 LDS-tiled, 9 tile, 10 ptile, 3 generic
@@ -272,6 +282,7 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
 
 int flush_lazy(moka_state *st, bool diag, bool tend)
 {
+    if (st->f32) st->diagDirty = false;    // no DiagnosticVars on an fp32-storage state
     if (diag && st->diagDirty) {
         // clean diagnostics of the current state: hEdge = interp(h); F = u*hEdge; div; vort zeroed + curl
         FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE, 0, 0.0);
@@ -543,11 +554,22 @@ int moka_state_create(moka_ctx *ctx, moka_mesh *mesh, moka_state **out)
     const Plan &p = mesh->plan;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t nEK = (size_t)p.K * p.nE, nCK = (size_t)p.K * p.nC, nVK = (size_t)p.K * p.nV;
+    st->f32 = p.stateBytes == 4;
+    if (st->f32 && !stage_f32_supported(mesh->dev)) {
+        delete st;
+        return fail(ctx, MOKA_ERR_UNSUPPORTED,
+                    "fp32-storage state: needs nVertLevels % 4 == 0, nVertLevels <= 128, fields below 4 GiB and patches whose "
+                    "records + own u rows fit 64 KB of LDS (smaller patch_cells)");
+    }
+    const size_t sb = st->f32 ? 4 : 8;
     int rc = MOKA_OK;
-    auto A = [&](double **q, size_t n) { if (rc == MOKA_OK) rc = alloc_field(st, q, n); };
-    for (auto &l : st->lev) { A(&l.ssh, p.nC); A(&l.u, nEK); A(&l.h, nCK); }
-    A(&st->hEdge[0], nEK); A(&st->hEdge[1], nEK);
-    A(&st->F, nEK); A(&st->div, nCK); A(&st->vort, nVK); A(&st->tendU, nEK); A(&st->tendH, nCK);
+    auto A = [&](double **q, size_t n, size_t eb = 8) { if (rc == MOKA_OK) rc = alloc_field(st, q, n, eb); };
+    for (auto &l : st->lev) { A(&l.ssh, p.nC, sb); A(&l.u, nEK, sb); A(&l.h, nCK, sb); }
+    if (!st->f32) {
+        A(&st->hEdge[0], nEK); A(&st->hEdge[1], nEK);
+        A(&st->F, nEK); A(&st->div, nCK); A(&st->vort, nVK);
+    }
+    A(&st->tendU, nEK); A(&st->tendH, nCK);
     A(&st->scalar, 2);
     if (rc != MOKA_OK) { moka_state_destroy(st); return rc; }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -575,7 +597,7 @@ int moka_state_upload(moka_state *st, int field, int time_level, const double *h
     if ((rc = flush_lazy(st, prog1 || is_diag_field(field), prog1 || is_tend_field(field)))) return rc;
     if ((rc = field_ref(st, field, time_level, &r))) return rc;   // flush may have swapped buffers
     if (time_level == 1 && (field == MOKA_F_SSH || field == MOKA_F_LAYER_THICKNESS)) st->sshConsistent = false;
-    return put_rows(st->mesh, r.ptr, host, r.kind, r.n, r.K);
+    return put_rows(st->mesh, r.ptr, host, r.kind, r.n, r.K, r.f32);
 }
 
 int moka_state_download(moka_state *st, int field, int time_level, double *host)
@@ -587,7 +609,7 @@ int moka_state_download(moka_state *st, int field, int time_level, double *host)
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if ((rc = flush_lazy(st, is_diag_field(field), is_tend_field(field)))) return rc;
     if ((rc = field_ref(st, field, time_level, &r))) return rc;   // flush may have swapped buffers
-    return get_rows(st->mesh, host, r.ptr, r.kind, r.n, r.K);
+    return get_rows(st->mesh, host, r.ptr, r.kind, r.n, r.K, r.f32);
 }
 
 int moka_advance_time_levels(moka_state *st, int flags)
@@ -600,6 +622,12 @@ int moka_advance_time_levels(moka_state *st, int flags)
     // Level-1-only copies (K > 1) go through the FE kernel's carry-over path instead.
     if ((flags & MOKA_FE_LEVEL1_ONLY) && p.K > 1)
         return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "level-1-only advanceTimeLevels! is only available inside moka_step_fe");
+    if (st->f32) {   // float arrays: plain device copies
+        HIPCHK(st->ctx, hipMemcpyAsync(st->lev[0].ssh, st->lev[1].ssh, (size_t)p.nC * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(st->ctx, hipMemcpyAsync(st->lev[0].u, st->lev[1].u, (size_t)p.K * p.nE * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(st->ctx, hipMemcpyAsync(st->lev[0].h, st->lev[1].h, (size_t)p.K * p.nC * 4, hipMemcpyDeviceToDevice, s));
+        return MOKA_OK;
+    }
     HIPCHK(st->ctx, launch_copy(st->lev[0].ssh, st->lev[1].ssh, p.nC, s));
     HIPCHK(st->ctx, launch_copy(st->lev[0].u, st->lev[1].u, (int64_t)p.K * p.nE, s));
     HIPCHK(st->ctx, launch_copy(st->lev[0].h, st->lev[1].h, (int64_t)p.K * p.nC, s));
@@ -609,6 +637,7 @@ int moka_advance_time_levels(moka_state *st, int flags)
 int moka_diagnostic_compute(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rcl = flush_lazy(st, true, false)) return rcl;
     FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE, flags, 0.0);
@@ -620,6 +649,7 @@ int moka_diagnostic_compute(moka_state *st, int flags)
 int moka_compute_normal_velocity_tendency(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rcl = flush_lazy(st, false, true)) return rcl;
     FeArgs a = fe_args(st, FE_TENDU, flags, 0.0);
@@ -630,6 +660,7 @@ int moka_compute_normal_velocity_tendency(moka_state *st, int flags)
 int moka_compute_layer_thickness_tendency(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rcl = flush_lazy(st, true, true)) return rcl;
     FeArgs a = fe_args(st, FE_TENDH | FE_TENDH_FROM_F, flags, 0.0);
@@ -640,7 +671,11 @@ int moka_compute_layer_thickness_tendency(moka_state *st, int flags)
 static int make_ssh_consistent(moka_state *st, double *dst)
 {
     const Plan &p = st->mesh->plan;
-    HIPCHK(st->ctx, launch_update_ssh(st->mesh->dev, st->lev[1].h, dst, p.K, st->mesh->lpc, st->ctx->stream));
+    if (st->f32)
+        HIPCHK(st->ctx, launch_update_ssh_f32(st->mesh->dev, reinterpret_cast<const float *>(st->lev[1].h),
+                                              reinterpret_cast<float *>(dst), p.K, st->mesh->lpc, st->ctx->stream));
+    else
+        HIPCHK(st->ctx, launch_update_ssh(st->mesh->dev, st->lev[1].h, dst, p.K, st->mesh->lpc, st->ctx->stream));
     return MOKA_OK;
 }
 
@@ -664,6 +699,7 @@ int moka_tendencies(moka_state *st)
 int moka_step_fe(moka_state *st, double dt, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rcl = flush_lazy(st, true, true)) return rcl;
     // advanceTimeLevels! + diagnostic_compute! + both tendencies + updates (time_integration.jl:163-189)
@@ -797,7 +833,8 @@ int moka_sum_sq(moka_state *st, int field, int time_level, double *out)
     if ((rc = ensure_op_bufs(st->mesh))) return rc;
     hipStream_t s = st->ctx->stream;
     // caller's numbering, then the strictly serial order of sumArray (run_loop.jl:47-51)
-    HIPCHK(st->ctx, launch_permute_rows(st->mesh->opBuf[2], r.ptr, perm_of(st->mesh, r.kind), r.n, r.K, 0, s));
+    if (r.f32) HIPCHK(st->ctx, launch_permute_rows_f32(st->mesh->opBuf[2], r.ptr, perm_of(st->mesh, r.kind), r.n, r.K, 0, s));
+    else HIPCHK(st->ctx, launch_permute_rows(st->mesh->opBuf[2], r.ptr, perm_of(st->mesh, r.kind), r.n, r.K, 0, s));
     HIPCHK(st->ctx, launch_sum_sq_serial(st->mesh->opBuf[2], r.n * r.K, st->scalar, s));
     HIPCHK(st->ctx, hipMemcpyAsync(out, st->scalar, sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(st->ctx, hipStreamSynchronize(s));
@@ -896,7 +933,7 @@ int moka_halo_buffer_elems(const moka_halo *h, int64_t *sendElems, int64_t *recv
 }
 
 // what: 0 = the current time level, 1..4 = the output of RK4 stage `what` (valid between dist_begin and dist_end)
-int moka_halo_pack(moka_halo *h, int what, double *sendbuf)
+int moka_halo_pack(moka_halo *h, int what, void *sendbuf)
 {
     if (!h || (!sendbuf && h->nSend)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
     if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
@@ -907,11 +944,15 @@ int moka_halo_pack(moka_halo *h, int what, double *sendbuf)
     // the rows to send are produced by the boundary patches (or by whatever last ran on the compute stream)
     HIPCHK(c, hipEventRecord(c->evBoundary, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm, c->evBoundary, 0));
-    HIPCHK(c, launch_halo_map(sendbuf, o.h, o.ssh, o.u, h->sendMap, h->nSend, 0, c->comm));
+    if (st->f32)
+        HIPCHK(c, launch_halo_map_f32(static_cast<float *>(sendbuf), (float *)o.h, (float *)o.ssh, (float *)o.u, h->sendMap,
+                                      h->nSend, 0, c->comm));
+    else
+        HIPCHK(c, launch_halo_map(static_cast<double *>(sendbuf), o.h, o.ssh, o.u, h->sendMap, h->nSend, 0, c->comm));
     return MOKA_OK;
 }
 
-int moka_halo_unpack(moka_halo *h, int what, const double *recvbuf)
+int moka_halo_unpack(moka_halo *h, int what, const void *recvbuf)
 {
     if (!h || (!recvbuf && h->nRecv)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
     if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
@@ -922,7 +963,12 @@ int moka_halo_unpack(moka_halo *h, int what, const double *recvbuf)
     // the interior launch may still be writing the (to be overwritten) halo rows of a straddling patch
     HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
-    HIPCHK(c, launch_halo_map(const_cast<double *>(recvbuf), o.h, o.ssh, o.u, h->recvMap, h->nRecv, 1, c->comm));
+    if (st->f32)
+        HIPCHK(c, launch_halo_map_f32(static_cast<float *>(const_cast<void *>(recvbuf)), (float *)o.h, (float *)o.ssh,
+                                      (float *)o.u, h->recvMap, h->nRecv, 1, c->comm));
+    else
+        HIPCHK(c, launch_halo_map(static_cast<double *>(const_cast<void *>(recvbuf)), o.h, o.ssh, o.u, h->recvMap, h->nRecv, 1,
+                                  c->comm));
     HIPCHK(c, hipEventRecord(c->evHalo, c->comm));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->evHalo, 0));     // whatever comes next on the compute stream sees the halo
     return MOKA_OK;

@@ -1921,6 +1921,209 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c(const ColMesh m, const St
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32-state form of rec2c (BASELINE config 5: "fp32 state with fp64 tendency accumulation").
+// ssh / normalVelocity / layerThickness of every time level and RK provisional state are stored as fp32
+// (rows of K*4 bytes); a lane owns FOUR consecutive levels (one 16-byte load), a 32-lane half-wave one
+// entity (K <= 128, K % 4 == 0).  Every load widens to fp64, the arithmetic is that of k_stage_rec2c in the
+// same order, stores round to nearest fp32; tendencies (MODE 0) are written as fp64.  The StageArgs pointers
+// of state arrays are float arrays in disguise (the host keeps one argument block for both storage types).
+// The byte-offset records of such a mesh are built for K*4-byte rows (moka_mesh_desc.stateBytes = 4).
+// ssh column sum: oracle_ksum order -- lanes l and l^16 hold levels k and k^64, then k^32 ... k^4, and the four
+// levels of a lane combine as (x+z)+(y+w), i.e. k^2 then k^1.
+// ------------------------------------------------------------------------------------------------
+struct d4 {
+    double x, y, z, w;
+};
+__device__ __forceinline__ d4 widen4(float4 v) { return d4{(double)v.x, (double)v.y, (double)v.z, (double)v.w}; }
+__device__ __forceinline__ float4 narrow4(d4 v) { return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w); }
+__device__ __forceinline__ d4 gload4(const double *base, uint32_t off)
+{
+    return widen4(*reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off));
+}
+__device__ __forceinline__ void gstore4(double *base, uint32_t off, d4 v)
+{
+    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + off) = narrow4(v);
+}
+__device__ __forceinline__ d4 axpy4(d4 x, double a, d4 t)      // x + a*t, the reference's operand order
+{
+    return d4{x.x + a * t.x, x.y + a * t.y, x.z + a * t.z, x.w + a * t.w};
+}
+__device__ __forceinline__ d4 round4(d4 v) { return widen4(narrow4(v)); }
+
+template <int ME, int ME2, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_stage_rec2c_f32(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int pl_ = patch_of_block(m.nPatches);
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
+    constexpr int NG = BLOCK / 32;
+    const int tid = threadIdx.x;
+    const int grp = tid >> 5, l = tid & 31;
+    const int K = m.K, K4 = K >> 2;
+    const uint32_t voff = (uint32_t)l * 16u, rowB = (uint32_t)K * 4u;      // fp32 rows
+    const uint32_t voffD = (uint32_t)l * 32u, rowBD = (uint32_t)K * 8u;    // fp64 rows (tendency outputs)
+    const RecLds L = rec_carve(smem, m, ME, ME2, maxOwnE, maxOwnC);
+    const size_t recBytes = ((size_t)maxOwnE * (2 * ME2 + 1) * 8 + (size_t)maxOwnC * (ME + 2) * 8 +
+                             ((size_t)maxOwnE * m.EI + (size_t)maxOwnC * m.CI) * 4 + 15) & ~(size_t)15;
+    float4 *ubuf4 = reinterpret_cast<float4 *>(smem + recBytes);
+    const unsigned char *ubytes = reinterpret_cast<const unsigned char *>(ubuf4) + voff;
+    const int c0 = cptr(m.patchCellStart)[p], c1 = cptr(m.patchCellStart)[p + 1];
+    const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
+    const int nOwnC = c1 - c0, nOwnE = e1 - e0;
+    const uint32_t e0B = (uint32_t)e0 * rowB, nOwnB = (uint32_t)nOwnE * rowB;
+    const float *sshf = reinterpret_cast<const float *>(a.ssh);
+
+    for (int i = tid; i < nOwnE * m.EI; i += BLOCK) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
+    for (int i = tid; i < nOwnE * ME2; i += BLOCK) {
+        L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
+        L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
+    }
+    for (int i = tid; i < nOwnE; i += BLOCK) L.g[i] = m.gInvDc[e0 + i];
+    for (int i = tid; i < nOwnC * m.CI; i += BLOCK) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
+    for (int i = tid; i < nOwnC * ME; i += BLOCK) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
+    for (int i = tid; i < nOwnC; i += BLOCK) {
+        L.invA[i] = m.invArea[c0 + i];
+        L.rsum[i] = m.rsum[c0 + i];
+    }
+    {   // own u rows: one contiguous, fully coalesced copy
+        const float4 *src = reinterpret_cast<const float4 *>(a.pu) + (size_t)e0 * K4;
+        for (int i = tid; i < nOwnE * K4; i += BLOCK) ubuf4[i] = src[i];
+    }
+    __syncthreads();
+
+    const int k0 = 4 * l;
+    const bool act = k0 < K;
+    auto urow = [&](uint32_t off) -> d4 {                               // u row at global byte offset `off`
+        const uint32_t loc = off - e0B;
+        if (loc < nOwnB) return widen4(*reinterpret_cast<const float4 *>(ubytes + loc));
+        return gload4(a.pu, off + voff);
+    };
+    const d4 zero{0.0, 0.0, 0.0, 0.0};
+
+    // ---------------- cells ----------------
+    for (int ci = grp; ci < nOwnC; ci += NG) {
+        const int c = c0 + ci;
+        const uint32_t *r = L.cRec + (size_t)ci * m.CI;
+        const double *rs = L.sdv + (size_t)ci * ME;
+        const uint32_t mask = r[2 * ME], all = r[2 * ME + 1];
+        const double invA = L.invA[ci];
+        const uint32_t own = (uint32_t)c * rowB + voff;
+        d4 hc = zero, uv[ME], hv[ME], cur = zero, nin = zero;
+        if (act) {
+            hc = gload4(a.ph, own);
+#pragma unroll
+            for (int i = 0; i < ME; ++i) {
+                hv[i] = gload4(a.ph, r[ME + i] + voff);
+                uv[i] = urow(r[i]);
+            }
+            if constexpr (MODE == 2) cur = gload4(a.ch, own);
+            if constexpr (MODE >= 2) nin = gload4(a.nh_in, own);
+        }
+        d4 t = zero;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < ME; ++i) {
+                const int ml = all ? K : cptr(m.mltc)[(size_t)c * ME + i];
+                const bool on = (mask >> i) & 1u;
+                const double dx = uv[i].x * (0.5 * (hc.x + hv[i].x)) * rs[i] * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
+                const double dy = uv[i].y * (0.5 * (hc.y + hv[i].y)) * rs[i] * invA;   // horizontal_advection.jl:63
+                const double dz = uv[i].z * (0.5 * (hc.z + hv[i].z)) * rs[i] * invA;
+                const double dw = uv[i].w * (0.5 * (hc.w + hv[i].w)) * rs[i] * invA;
+                if (on && k0 < ml) t.x += dx;
+                if (on && k0 + 1 < ml) t.y += dy;
+                if (on && k0 + 2 < ml) t.z += dz;
+                if (on && k0 + 3 < ml) t.w += dw;
+            }
+        }
+        d4 hs = zero;
+        if (act) {
+            if constexpr (MODE == 0) {
+                const uint32_t ownD = (uint32_t)c * rowBD + voffD;
+                gstore2(a.tendH, ownD, make_double2(t.x, t.y));
+                gstore2(a.tendH, ownD + 16u, make_double2(t.z, t.w));
+            }
+            if constexpr (MODE == 1 || MODE == 2) {
+                const d4 hcur = MODE == 2 ? cur : hc;
+                const d4 nb = MODE == 2 ? nin : hcur;
+                hs = round4(axpy4(hcur, a.a, t));                                             // time_integration.jl:125
+                gstore4(a.ph_out, own, hs);
+                gstore4(a.nh_out, own, axpy4(nb, a.b, t));                                    // :135
+            }
+            if constexpr (MODE == 3) {
+                hs = round4(axpy4(nin, a.b, t));
+                gstore4(a.nh_out, own, hs);
+            }
+        }
+        if constexpr (MODE != 0) {
+#pragma unroll
+            for (int sft = 16; sft >= 1; sft >>= 1) {
+                hs = d4{hs.x + __shfl_xor(hs.x, sft, 32), hs.y + __shfl_xor(hs.y, sft, 32),
+                        hs.z + __shfl_xor(hs.z, sft, 32), hs.w + __shfl_xor(hs.w, sft, 32)};
+            }
+            if (l == 0)                                                                       // :209 (+N3), stored fp32
+                reinterpret_cast<float *>(a.ssh_out)[c] = (float)(((hs.x + hs.z) + (hs.y + hs.w)) - L.rsum[ci]);
+        }
+    }
+
+    // ---------------- edges ----------------
+    for (int ei = grp; ei < nOwnE; ei += NG) {
+        const int e = e0 + ei;
+        const uint32_t *r = L.eRec + (size_t)ei * m.EI;
+        const double *rw = L.woe + (size_t)ei * ME2;
+        const double *rf = L.feoe + (size_t)ei * ME2;
+        const uint32_t mask = r[ME2 + 2];
+        const int mlt = (int)r[ME2 + 3];
+        const double g = L.g[ei];
+        const uint32_t own = (uint32_t)e * rowB + voff;
+        double sA = 0.0, sB = 0.0;
+        if (l == 0) sA = (double)sshf[r[ME2]];
+        if (l == 1) sB = (double)sshf[r[ME2 + 1]];
+        d4 uv[ME2], cur = zero, nin = zero;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) uv[i] = urow(r[i]);
+            if constexpr (MODE == 2) cur = gload4(a.cu, own);
+            if constexpr (MODE >= 2) nin = gload4(a.nu_in, own);
+        }
+        const double ds = __shfl(sB, 1, 32) - __shfl(sA, 0, 32);       // ssh[c2] - ssh[c1]
+        if (act) {
+            const bool ax = k0 < mlt, ay = k0 + 1 < mlt, az = k0 + 2 < mlt, aw = k0 + 3 < mlt;
+            d4 t = zero;
+            if (ax) t.x -= g * ds;                                     // pressure_gradient.jl:63
+            if (ay) t.y -= g * ds;
+            if (az) t.z -= g * ds;
+            if (aw) t.w -= g * ds;
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) {
+                const bool on = (mask >> i) & 1u;
+                const double px = rw[i] * uv[i].x * rf[i], py = rw[i] * uv[i].y * rf[i];   // ...coriolis.jl:70-72
+                const double pz = rw[i] * uv[i].z * rf[i], pw = rw[i] * uv[i].w * rf[i];
+                if (on && ax) t.x += px;
+                if (on && ay) t.y += py;
+                if (on && az) t.z += pz;
+                if (on && aw) t.w += pw;
+            }
+            if constexpr (MODE == 0) {
+                const uint32_t ownD = (uint32_t)e * rowBD + voffD;
+                gstore2(a.tendU, ownD, make_double2(t.x, t.y));
+                gstore2(a.tendU, ownD + 16u, make_double2(t.z, t.w));
+            }
+            if constexpr (MODE == 1) {
+                const d4 up = widen4(ubuf4[(size_t)ei * K4 + l]);       // own row is in the cache
+                gstore4(a.pu_out, own, axpy4(up, a.a, t));              // time_integration.jl:124
+                gstore4(a.nu_out, own, axpy4(up, a.b, t));              // :134
+            }
+            if constexpr (MODE == 2) {
+                gstore4(a.pu_out, own, axpy4(cur, a.a, t));
+                gstore4(a.nu_out, own, axpy4(nin, a.b, t));
+            }
+            if constexpr (MODE == 3) gstore4(a.nu_out, own, axpy4(nin, a.b, t));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS patch-tiled variant of the fused tendency / RK-stage kernel (same arithmetic, same results).
 //
 // The direct kernel above re-reads every u-row ~12 times through the vector L1 (10 Coriolis
@@ -2306,8 +2509,8 @@ __global__ __launch_bounds__(BLOCK) void k_operator(const MeshDev m, const OpArg
 // ------------------------------------------------------------------------------------------------
 // ssh from layerThickness (Update_ssh!, time_integration.jl:205-211, N3 column sum)
 // ------------------------------------------------------------------------------------------------
-template <int LPC>
-__global__ __launch_bounds__(BLOCK) void k_update_ssh(const MeshDev m, const double *h, double *ssh, int nlev)
+template <int LPC, class T>
+__global__ __launch_bounds__(BLOCK) void k_update_ssh(const MeshDev m, const T *h, T *ssh, int nlev)
 {
     constexpr int NG = BLOCK / LPC;
     const int grp = threadIdx.x / LPC, l = threadIdx.x % LPC;
@@ -2317,12 +2520,12 @@ __global__ __launch_bounds__(BLOCK) void k_update_ssh(const MeshDev m, const dou
         double acc = 0.0;
         bool first = true;
         for (int k = l; k < Kc; k += LPC) {
-            const double v = k < nlev ? h[(size_t)c * K + k] : 0.0;
+            const double v = k < nlev ? (double)h[(size_t)c * K + k] : 0.0;
             acc = first ? v : acc + v;
             first = false;
         }
         const double s = group_sum<LPC>(acc);
-        if (l == 0) ssh[c] = s - m.rsum[c];
+        if (l == 0) ssh[c] = (T)(s - m.rsum[c]);        // fp32 state: stored rounded
     }
 }
 
@@ -2381,6 +2584,32 @@ __global__ __launch_bounds__(BLOCK) void k_halo_map(double *buf, double *h, doub
         const uint32_t mj = map[j];
         const uint32_t tag = mj >> 30, idx = mj & 0x3FFFFFFFu;
         double *f = tag == 0 ? h : tag == 1 ? ssh : u;
+        if (unpack) f[idx] = buf[j];
+        else buf[j] = f[idx];
+    }
+}
+
+// fp32-state forms: the caller's side (host order) is always double, the device field is float
+__global__ __launch_bounds__(BLOCK) void k_permute_rows_f32(void *dst, const void *src, const int32_t *n2o, int64_t n, int K,
+                                                           int to_device)
+{
+    const int64_t total = n * K;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+        const int64_t r = i / K;
+        const int k = (int)(i - r * K);
+        const int64_t o = (int64_t)n2o[r] * K + k;
+        if (to_device) static_cast<float *>(dst)[i] = (float)static_cast<const double *>(src)[o];
+        else static_cast<double *>(dst)[o] = (double)static_cast<const float *>(src)[i];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_halo_map_f32(float *buf, float *h, float *ssh, float *u, const uint32_t *map,
+                                                       int64_t n, int unpack)
+{
+    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * BLOCK) {
+        const uint32_t mj = map[j];
+        const uint32_t tag = mj >> 30, idx = mj & 0x3FFFFFFFu;
+        float *f = tag == 0 ? h : tag == 1 ? ssh : u;
         if (unpack) f[idx] = buf[j];
         else buf[j] = f[idx];
     }
@@ -2636,6 +2865,42 @@ hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t
     return ok ? hipGetLastError() : hipErrorNotSupported;
 }
 
+template <int ME, int ME2>
+static bool launch_rec2c_f32(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3 b, size_t lds, int mE, int mC, hipStream_t s)
+{
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 0>), g, b, lds, s, m, a, mE, mC); return true;
+        case 1: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 1>), g, b, lds, s, m, a, mE, mC); return true;
+        case 2: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 2>), g, b, lds, s, m, a, mE, mC); return true;
+        case 3: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 3>), g, b, lds, s, m, a, mE, mC); return true;
+    }
+    return false;
+}
+
+// fp32-state meshes: K % 4 == 0, K <= 128, byte-offset records, records + own u rows within 64 KB of LDS
+bool stage_f32_supported(const MeshDev &md)
+{
+    const size_t lds = ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 4 + 16;
+    const bool shape = (md.ME == 6 && md.ME2 == 10) || (md.ME == 8 && md.ME2 == 14) || (md.ME <= 6 && md.ME2 <= 14);
+    return md.cRec && md.eRec && md.K >= 4 && md.K <= 128 && (md.K & 3) == 0 && lds <= 64 * 1024 && md.maxOwnC >= 1 &&
+           md.maxOwnE >= 1 && shape;
+}
+
+hipError_t launch_stage_rec2c_f32(const MeshDev &md, const StageArgs &a, hipStream_t s)
+{
+    const dim3 g(patch_grid(md)), b(BLOCK);
+    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
+    const int mode = colp_mode(a);
+    if (mode < 0 || !stage_f32_supported(md)) return hipErrorNotSupported;
+    const size_t lds = ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 4 + 16;
+    bool ok = false;
+    if (md.ME == 6 && md.ME2 == 10) ok = launch_rec2c_f32<6, 10>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    else if (md.ME == 8 && md.ME2 == 14) ok = launch_rec2c_f32<8, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    else if (md.ME <= 6 && md.ME2 <= 14) ok = launch_rec2c_f32<6, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
+    return ok ? hipGetLastError() : hipErrorNotSupported;
+}
+
 hipError_t launch_stage_rec2(const MeshDev &md, const StageArgs &a, hipStream_t s)
 {
     const dim3 g(patch_grid(md)), b(BLOCK);
@@ -2747,19 +3012,26 @@ hipError_t launch_operator(const MeshDev &m, const OpArgs &a, int lpc, hipStream
 #undef CALL
 }
 
-template <int LPC>
-static hipError_t launch_update_ssh_lpc(const MeshDev &m, const double *h, double *ssh, int nlev, hipStream_t s)
+template <int LPC, class T>
+static hipError_t launch_update_ssh_lpc(const MeshDev &m, const T *h, T *ssh, int nlev, hipStream_t s)
 {
     const int ng = BLOCK / LPC;
     int grid = (m.nC + ng - 1) / ng;
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL((k_update_ssh<LPC>), dim3(grid), dim3(BLOCK), 0, s, m, h, ssh, nlev);
+    hipLaunchKernelGGL((k_update_ssh<LPC, T>), dim3(grid), dim3(BLOCK), 0, s, m, h, ssh, nlev);
     return hipGetLastError();
 }
 
 hipError_t launch_update_ssh(const MeshDev &m, const double *h, double *ssh, int nlev, int lpc, hipStream_t s)
 {
-#define CALL(L) launch_update_ssh_lpc<L>(m, h, ssh, nlev, s)
+#define CALL(L) launch_update_ssh_lpc<L, double>(m, h, ssh, nlev, s)
+    DISPATCH_LPC(lpc, CALL)
+#undef CALL
+}
+
+hipError_t launch_update_ssh_f32(const MeshDev &m, const float *h, float *ssh, int nlev, int lpc, hipStream_t s)
+{
+#define CALL(L) launch_update_ssh_lpc<L, float>(m, h, ssh, nlev, s)
     DISPATCH_LPC(lpc, CALL)
 #undef CALL
 }
@@ -2796,6 +3068,26 @@ hipError_t launch_halo_map(double *buf, double *h, double *ssh, double *u, const
     int64_t blocks = (n + BLOCK - 1) / BLOCK;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(k_halo_map, dim3((unsigned)blocks), dim3(BLOCK), 0, s, buf, h, ssh, u, map, n, unpack);
+    return hipGetLastError();
+}
+
+hipError_t launch_permute_rows_f32(void *dst, const void *src, const int32_t *n2o, int64_t n, int K, int to_device,
+                                   hipStream_t s)
+{
+    int64_t blocks = (n * K + BLOCK - 1) / BLOCK;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_permute_rows_f32, dim3((unsigned)blocks), dim3(BLOCK), 0, s, dst, src, n2o, n, K, to_device);
+    return hipGetLastError();
+}
+
+hipError_t launch_halo_map_f32(float *buf, float *h, float *ssh, float *u, const uint32_t *map, int64_t n, int unpack,
+                               hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + BLOCK - 1) / BLOCK;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_halo_map_f32, dim3((unsigned)blocks), dim3(BLOCK), 0, s, buf, h, ssh, u, map, n, unpack);
     return hipGetLastError();
 }
 

@@ -61,6 +61,14 @@ hipError_t prepare_stage_tile(const MeshDev &md);
 hipError_t launch_stage_tile(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_rec2c(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_rec2(const MeshDev &m, const StageArgs &a, hipStream_t s);
+// fp32-state form (state pointers of StageArgs are float arrays); stage_f32_supported: can this mesh carry one
+bool stage_f32_supported(const MeshDev &m);
+hipError_t launch_stage_rec2c_f32(const MeshDev &m, const StageArgs &a, hipStream_t s);
+hipError_t launch_update_ssh_f32(const MeshDev &m, const float *h, float *ssh, int nlev, int lpc, hipStream_t s);
+hipError_t launch_permute_rows_f32(void *dst, const void *src, const int32_t *n2o, int64_t n, int K, int to_device,
+                                   hipStream_t s);
+hipError_t launch_halo_map_f32(float *buf, float *h, float *ssh, float *u, const uint32_t *map, int64_t n, int unpack,
+                               hipStream_t s);
 hipError_t launch_stage_rec(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_colx(const MeshDev &m, const StageArgs &a, bool pipelined, hipStream_t s);
 hipError_t launch_stage_col(const MeshDev &m, const StageArgs &a, bool pipelined, hipStream_t s);

@@ -23,6 +23,7 @@ struct Plan {
     int32_t ME2 = 0;   // record width for edges  (>= max nEdgesOnEdge)
     int32_t VD = 3;
     int32_t ordering = 0, P = 0, nPatches = 0;
+    int32_t stateBytes = 8;           // bytes per real of the prognostic state (row offsets in cRec/eRec use it)
     int64_t cellBandwidth = 0;
 
     std::vector<int32_t> cellN2O, cellO2N, edgeN2O, edgeO2N, vertN2O, vertO2N;
@@ -51,7 +52,7 @@ struct Plan {
     std::vector<uint32_t> cRec, eRec;
     std::vector<double>   feoe;       // nE*ME2
     int32_t CI = 0, EI = 0;
-    bool colOk = false;               // K*8*nE < 4 GiB: offsets fit 32 bits
+    bool colOk = false;               // K*stateBytes*nE < 4 GiB: offsets fit 32 bits
     // patch-local view for the LDS-tiled kernel: the u-rows a patch needs are its own edges
     // [patchEdgeStart[p], patchEdgeStart[p+1]) followed by haloEdge[haloStart[p] .. haloStart[p+1]);
     // leoc / leoe hold, per cell slot / edgesOnEdge slot, the row index inside that list (0xFF = none).

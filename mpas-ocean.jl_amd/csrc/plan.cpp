@@ -205,7 +205,11 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     // 32 cells otherwise (generic / plain column kernels).
     {
         const int K = d->nVertLevels;
-        p.P = d->patch_cells > 0 ? d->patch_cells : ((K >= 34 && K <= 64 && !(K & 1)) ? 12 : 32);
+        REQUIRE(d->stateBytes == 0 || d->stateBytes == 4 || d->stateBytes == 8, "stateBytes must be 0, 4 or 8");
+        p.stateBytes = d->stateBytes == 4 ? 4 : 8;
+        // small patches where the stage kernel caches the patch's own u rows in LDS (k_stage_rec2c / _f32)
+        const bool cached = p.stateBytes == 8 ? (K >= 34 && K <= 64 && !(K & 1)) : (K >= 34 && K <= 128 && !(K & 3));
+        p.P = d->patch_cells > 0 ? d->patch_cells : (cached ? 12 : 32);
     }
     REQUIRE(p.P <= 4096, "patch_cells too large");
 
@@ -327,7 +331,7 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     }
     // ---- packed byte-offset records of the column kernel ----
     {
-        const uint64_t rowB = (uint64_t)p.K * 8;
+        const uint64_t rowB = (uint64_t)p.K * p.stateBytes;
         p.colOk = rowB * (uint64_t)std::max(nE, std::max(nC, nV)) < (1ull << 32) - 1024;
         p.CI = ((2 * ME + 2) + 3) & ~3;
         p.EI = ((ME2 + 4) + 3) & ~3;
@@ -431,7 +435,7 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     p.leOff.assign((size_t)nE * ME2, 0xFFFFFFFFu);
     p.patchRegular.assign(p.nPatches, 0);
     if (p.ldsOk) {
-        const uint32_t rowB = (uint32_t)p.K * 8u;
+        const uint32_t rowB = (uint32_t)p.K * (uint32_t)p.stateBytes;
         for (int c = 0; c < nC; ++c)
             for (int i = 0; i < ME; ++i)
                 if (p.leoc[(size_t)c * 8 + i] != 0xFF) p.lcOff[IX(i, c, ME)] = p.leoc[(size_t)c * 8 + i] * rowB;

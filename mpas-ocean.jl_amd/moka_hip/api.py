@@ -119,13 +119,16 @@ class Mesh:
     Adapt.adapt_structure(backend, mesh) (:26): the library reorders and uploads the mesh."""
 
     def __init__(self, horz: HorzMesh, vert: VerticalMesh, backend: MokaHIP | None = None,
-                 ordering: int = L.ORDER_DEFAULT, patch_cells: int = 0):
+                 ordering: int = L.ORDER_DEFAULT, patch_cells: int = 0, state_bytes: int = 8):
+        """state_bytes=4: the states on this mesh store ssh / normalVelocity / layerThickness as fp32 (fp64 arithmetic,
+        fp64 tendencies; RK4 only) -- BASELINE config 5, not a reference feature."""
         self.HorzMesh, self.VertMesh = horz, vert
         self.backend = backend
+        self.state_bytes = int(state_bytes)
         self._h = C.c_void_p()
         if backend is not None:
             desc, keep = L.make_desc(horz.data, vert.nVertLevels, vert.restingThicknessSum,
-                                     vert.maxLevelEdge.Top, ordering, patch_cells)
+                                     vert.maxLevelEdge.Top, ordering, patch_cells, state_bytes=state_bytes)
             L.check(L.lib().moka_mesh_create(backend._h, C.byref(desc), C.byref(self._h)), backend._h)
 
     def info(self) -> dict:
@@ -367,13 +370,13 @@ def ocn_run_loop(*args, backend=None, flags: int | None = None):
 
 def ocn_init_from_arrays(mesh_data, ssh, normalVelocity, layerThickness, restingThickness, config: dict,
                          backend: MokaHIP, multilayer: bool = False, ordering: int = L.ORDER_DEFAULT,
-                         patch_cells: int = 0):
+                         patch_cells: int = 0, state_bytes: int = 8):
     """ocn_init(config_fp; backend) (init.jl:3-30) with the NetCDF/YAML reads replaced by arrays:
     returns (Setup, Diag, Tend, Prog) like the reference."""
     K = np.asarray(normalVelocity).reshape(mesh_data.nEdges, -1).shape[1]
     h_mesh = HorzMesh(mesh_data)
     v_mesh = VerticalMesh(h_mesh, nVertLevels=K, restingThickness=restingThickness, multilayer=multilayer)
-    mesh = Mesh(h_mesh, v_mesh, backend=backend, ordering=ordering, patch_cells=patch_cells)
+    mesh = Mesh(h_mesh, v_mesh, backend=backend, ordering=ordering, patch_cells=patch_cells, state_bytes=state_bytes)
     clock = ocn_setup_clock(config)
     Setup = ModelSetup(config, mesh, clock)
     Prog = PrognosticVars(ssh, normalVelocity, layerThickness,

@@ -44,6 +44,7 @@ class MeshDesc(C.Structure):
         ("maxLevelEdgeTop", _i32p), ("restingThicknessSum", _f64p),
         ("ordering", C.c_int32), ("patch_cells", C.c_int32),
         ("cellClass", _i32p),
+        ("stateBytes", C.c_int32),
     ]
 
 
@@ -167,7 +168,7 @@ def i32(a):
 
 
 def make_desc(mesh, K, resting_thickness_sum=None, max_level_edge_top=None, ordering=ORDER_DEFAULT, patch_cells=0,
-              cell_class=None):
+              cell_class=None, state_bytes=8):
     """Build a moka_mesh_desc from reference-convention arrays.  Returns (desc, keepalive)."""
     keep = {}
 
@@ -199,6 +200,7 @@ def make_desc(mesh, K, resting_thickness_sum=None, max_level_edge_top=None, orde
     d.restingThicknessSum = f64(A("restingThicknessSum", np.float64, np.asarray(resting_thickness_sum).reshape(-1)))
     d.ordering, d.patch_cells = int(ordering), int(patch_cells)
     d.cellClass = i32(A("cellClass", np.int32, cell_class)) if cell_class is not None else None
+    d.stateBytes = int(state_bytes)
     return d, keep
 
 
@@ -217,10 +219,10 @@ class Plan:
     """Host-only reordered mesh (moka_plan_*): usable without a GPU."""
 
     def __init__(self, mesh, K, resting_thickness_sum=None, max_level_edge_top=None, ordering=ORDER_DEFAULT,
-                 patch_cells=0, cell_class=None):
+                 patch_cells=0, cell_class=None, state_bytes=8):
         self._h = C.c_void_p()
         desc, self._keep = make_desc(mesh, K, resting_thickness_sum, max_level_edge_top, ordering, patch_cells,
-                                     cell_class)
+                                     cell_class, state_bytes)
         check(lib().moka_plan_create(C.byref(desc), C.byref(self._h)))
         inf = MeshInfo()
         check(lib().moka_plan_info(self._h, C.byref(inf)))

@@ -350,11 +350,22 @@ def _flip_edges(T, nflips, seed):
 
 
 def icosahedral_mesh(m: int, radius: float = RADIUS_EARTH, omega: float = OMEGA_EARTH, flips: int = 0,
-                     seed: int = 0) -> MeshData:
+                     seed: int = 0, stretch: float = 1.0) -> MeshData:
     """Voronoi dual of the frequency-m geodesic triangulation: nCells = 10m^2+2, nEdges = 30m^2,
     nVertices = 20m^2 (sizes of SURVEY.md section 8: m=64 -> 40 962 cells, m=320 -> 1 024 002).
-    flips > 0 flips that many edges of the triangulation first (5/7-gon pairs, maxEdges = 7)."""
+    flips > 0 flips that many edges of the triangulation first (5/7-gon pairs, maxEdges = 7).
+    stretch = c > 1 gives a variable-resolution mesh: the generators are moved by the Schmidt transformation
+    sin(lat') = (D + sin(lat)) / (1 + D sin(lat)), D = (1 - c^2) / (1 + c^2) (longitude kept): a conformal (Moebius)
+    map of the sphere, so circumcircles stay circles and the triangulation stays Delaunay; cell spacing varies by
+    c^2 between the poles (c = 4.47: ~3 km to ~52 km at m = 608, BASELINE config 5's "3-60 km")."""
     P, T = _geodesic_points(m)
+    if stretch != 1.0:
+        c2 = float(stretch) ** 2
+        D = (1.0 - c2) / (1.0 + c2)
+        z = (D + P[:, 2]) / (1.0 + D * P[:, 2])
+        rxy = np.sqrt(np.maximum(1.0 - z * z, 0.0)) / np.maximum(np.hypot(P[:, 0], P[:, 1]), 1e-300)
+        P = np.stack([P[:, 0] * rxy, P[:, 1] * rxy, z], axis=1)
+        P = _unit(P)
     if flips:
         T = _flip_edges(T, flips, seed)
     nC, nV = P.shape[0], T.shape[0]

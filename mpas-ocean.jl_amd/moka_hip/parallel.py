@@ -187,7 +187,7 @@ class DistributedModel:
     (tests: two ranks may share one GPU)."""
 
     def __init__(self, mesh, ssh, u, h, rest, dt, backend, rank, world, ordering=0, patch_cells=0,
-                 transport="nccl", part=None, group=None):
+                 transport="nccl", part=None, group=None, state_bytes=8):
         import torch
         import torch.distributed as dist
         from . import api
@@ -205,7 +205,7 @@ class DistributedModel:
         self.mesh.HorzMesh, self.mesh.VertMesh, self.mesh.backend = h_mesh, v_mesh, backend
         self.mesh._h = C.c_void_p()
         desc, keep = L.make_desc(lm.mesh, K, v_mesh.restingThicknessSum, v_mesh.maxLevelEdge.Top, ordering,
-                                 patch_cells, cell_class=lm.cell_class)
+                                 patch_cells, cell_class=lm.cell_class, state_bytes=state_bytes)
         desc.cellsOnVertex = None
         desc.verticesOnEdge = None
         L.check(L.lib().moka_mesh_create(backend._h, C.byref(desc), C.byref(self.mesh._h)), backend._h)
@@ -231,15 +231,16 @@ class DistributedModel:
         ns, nr = C.c_int64(), C.c_int64()
         L.check(L.lib().moka_halo_buffer_elems(self._halo, C.byref(ns), C.byref(nr)))
         dev = torch.device("cuda", backend.device)
-        self.sendbuf = torch.zeros(max(ns.value, 1), dtype=torch.float64, device=dev)
-        self.recvbuf = torch.zeros(max(nr.value, 1), dtype=torch.float64, device=dev)
+        real = torch.float32 if state_bytes == 4 else torch.float64      # halo messages carry state reals
+        self.sendbuf = torch.zeros(max(ns.value, 1), dtype=real, device=dev)
+        self.recvbuf = torch.zeros(max(nr.value, 1), dtype=real, device=dev)
         self.send_slices = message_slices(lm, K, True)
         self.recv_slices = message_slices(lm, K, False)
         self._p2p = None                      # P2POp list of the nccl transport, built once
         cs, ms = C.c_void_p(), C.c_void_p()
         L.check(L.lib().moka_ctx_streams(backend._h, C.byref(cs), C.byref(ms)))
         self.comm_stream = torch.cuda.ExternalStream(ms.value, device=dev)
-        self.halo_bytes_per_stage = 8 * (ns.value + nr.value)
+        self.halo_bytes_per_stage = int(state_bytes) * (ns.value + nr.value)
 
     # ---- transport of the packed buffers ----
     def _transport(self):

@@ -328,6 +328,75 @@ void oracle_step_rk4(const oracle_mesh *m, oracle_state *s, double dt, double *w
     oracle_curl_on_vertex(m, s->vort, s->u[1]);
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * fp32 state / fp64 arithmetic ("mixed", BASELINE.json config 5).  Not a reference feature (the reference
+ * hard-codes Float64: PrognosticVars.jl:91-93): a storage option of this build, so PARITY UNPINNED beyond
+ * agreeing with the fp64 path to fp32 round-off.  Semantics: ssh, normalVelocity, layerThickness of every
+ * time level and RK provisional state are STORED as fp32; every load widens to fp64; all arithmetic is the
+ * fp64 arithmetic above, in the same order; a store rounds to nearest fp32.  Tendencies stay fp64.
+ * The oracle keeps double arrays whose values are fp32-representable (rnd32 at each store).
+ * --------------------------------------------------------------------------------------------- */
+static inline double rnd32(double x) { return (double)(float)x; }
+
+void oracle_round_f32(double *a, int64_t n)
+{
+    PFOR
+    for (int64_t i = 0; i < n; ++i) a[i] = rnd32(a[i]);
+}
+
+void oracle_tendencies_mixed(const oracle_mesh *m, double *tendU, double *tendH,
+                             const double *u, const double *h, double *ssh_out,
+                             double *hEdge, double *F)
+{
+    const int K = m->nVertLevels;
+    oracle_update_ssh(m, ssh_out, h, K);
+    oracle_round_f32(ssh_out, m->nCells);          /* ssh is stored fp32 before the pressure gradient reads it */
+    oracle_interpolate_cell2edge(m, hEdge, h, K);
+    oracle_thickness_flux(m, F, u, hEdge, K);
+    oracle_normal_velocity_tendency(m, tendU, ssh_out, u, K);
+    oracle_layer_thickness_tendency(m, tendH, F, K);
+}
+
+/* oracle_step_rk4 with fp32 storage of Provis / New (same sequence, time_integration.jl:61-148).
+ * Inputs must already be fp32-representable (oracle_round_f32).  No end-of-step diagnostics. */
+void oracle_step_rk4_mixed(const oracle_mesh *m, oracle_state *s, double dt, double *work)
+{
+    const int K = m->nVertLevels;
+    const int64_t nu = (int64_t)K * m->nEdges, nh = (int64_t)K * m->nCells;
+    double *newU = work, *newH = work + nu, *hEdge = s->hEdge, *F = s->F;
+    const double a[3] = {dt / 2., dt / 2., dt};
+    const double b[4] = {dt / 6., dt / 3., dt / 3., dt / 6.};
+    advance_levels(s->ssh[0], s->ssh[1], m->nCells, 1, 1);
+    advance_levels(s->u[0], s->u[1], m->nEdges, K, K);
+    advance_levels(s->h[0], s->h[1], m->nCells, K, K);
+    memcpy(newU, s->u[1], sizeof(double) * (size_t)nu);
+    memcpy(newH, s->h[1], sizeof(double) * (size_t)nh);
+    for (int st = 0; st < 4; ++st) {
+        oracle_tendencies_mixed(m, s->tendU, s->tendH, s->u[1], s->h[1], s->ssh[1], hEdge, F);
+        if (st < 3) {
+            const double as = a[st];
+            double *pu = s->u[1], *ph = s->h[1];
+            const double *cu = s->u[0], *ch = s->h[0], *tu = s->tendU, *th = s->tendH;
+            PFOR
+            for (int64_t i = 0; i < nu; ++i) pu[i] = rnd32(cu[i] + as * tu[i]);
+            PFOR
+            for (int64_t i = 0; i < nh; ++i) ph[i] = rnd32(ch[i] + as * th[i]);
+        }
+        {
+            const double bs = b[st];
+            const double *tu = s->tendU, *th = s->tendH;
+            PFOR
+            for (int64_t i = 0; i < nu; ++i) newU[i] = rnd32(newU[i] + bs * tu[i]);
+            PFOR
+            for (int64_t i = 0; i < nh; ++i) newH[i] = rnd32(newH[i] + bs * th[i]);
+        }
+    }
+    memcpy(s->u[1], newU, sizeof(double) * (size_t)nu);
+    memcpy(s->h[1], newH, sizeof(double) * (size_t)nh);
+    oracle_update_ssh(m, s->ssh[1], s->h[1], K);
+    oracle_round_f32(s->ssh[1], m->nCells);
+}
+
 /* K15 sumArray (serial, one work-item)                       src/forward/run_loop.jl:47-51
  *   sum = sum + a[j]*a[j] */
 double oracle_sum_sq(const double *a, int64_t n)

@@ -76,6 +76,9 @@ def lib():
         L.oracle_tendencies_clean.argtypes = [mp] + [_f64p] * 7
         L.oracle_step_fe.argtypes = [mp, sp, C.c_double, C.c_int]
         L.oracle_step_rk4.argtypes = [mp, sp, C.c_double, _f64p]
+        L.oracle_step_rk4_mixed.argtypes = [mp, sp, C.c_double, _f64p]
+        L.oracle_tendencies_mixed.argtypes = [mp] + [_f64p] * 7
+        L.oracle_round_f32.argtypes = [_f64p, C.c_int64]
         L.oracle_sum_sq.argtypes = [_f64p, C.c_int64]
         L.oracle_sum_sq.restype = C.c_double
         _lib = L
@@ -156,22 +159,27 @@ class OracleMesh:
         lib().oracle_update_ssh(self.ref, _p(ssh), _p(h), self.K if nlev is None else nlev)
         return ssh
 
-    def tendencies_clean(self, u, h):
-        u, h = _c(u, np.float64), _c(h, np.float64)
+    def tendencies_clean(self, u, h, mixed=False):
+        """mixed=True: fp32-stored state (u, h are rounded to fp32 first), fp64 arithmetic."""
+        dt = np.float32 if mixed else np.float64
+        u, h = _c(_c(u, dt), np.float64), _c(_c(h, dt), np.float64)
         tu, th = np.zeros_like(u), np.zeros_like(h)
         ssh = np.zeros(self.mesh.nCells)
         s1, s2 = np.zeros_like(u), np.zeros_like(u)
-        lib().oracle_tendencies_clean(self.ref, _p(tu), _p(th), _p(u), _p(h), _p(ssh), _p(s1), _p(s2))
+        fn = lib().oracle_tendencies_mixed if mixed else lib().oracle_tendencies_clean
+        fn(self.ref, _p(tu), _p(th), _p(u), _p(h), _p(ssh), _p(s1), _p(s2))
         return tu, th, ssh
 
 
 class OracleState:
     """Two time levels of PrognosticVars + DiagnosticVars + TendencyVars, reference layout."""
 
-    def __init__(self, om: OracleMesh, ssh, u, h):
+    def __init__(self, om: OracleMesh, ssh, u, h, mixed=False):
+        """mixed=True: fp32-stored state (inputs are rounded to fp32), fp64 arithmetic; RK4 only."""
         m, K = om.mesh, om.K
-        self.om = om
-        f = lambda a, shape: np.array(np.asarray(a, dtype=np.float64).reshape(shape), order="C", copy=True)
+        self.om, self.mixed = om, bool(mixed)
+        sd = np.float32 if mixed else np.float64
+        f = lambda a, shape: np.array(np.asarray(a, dtype=sd).astype(np.float64).reshape(shape), order="C", copy=True)
         # nTimeLevels = 2 deep copies (PrognosticVars.jl:44-55)
         self.ssh = [f(ssh, (m.nCells,)) for _ in range(2)]
         self.u = [f(u, (m.nEdges, K)) for _ in range(2)]
@@ -191,13 +199,16 @@ class OracleState:
             setattr(s, n, _p(getattr(self, n)))
 
     def step_fe(self, dt, flags=FE_REFERENCE_COMPAT):
+        if self.mixed:
+            raise ValueError("fp32-state oracle: RK4 only")
         lib().oracle_step_fe(self.om.ref, C.byref(self.c), float(dt), int(flags))
 
     def step_rk4(self, dt):
         if self._work is None:
             m, K = self.om.mesh, self.om.K
             self._work = np.zeros(2 * K * (m.nEdges + m.nCells) + m.nCells)
-        lib().oracle_step_rk4(self.om.ref, C.byref(self.c), float(dt), _p(self._work))
+        fn = lib().oracle_step_rk4_mixed if self.mixed else lib().oracle_step_rk4
+        fn(self.om.ref, C.byref(self.c), float(dt), _p(self._work))
 
     def sum_sq_ssh(self):
         return lib().oracle_sum_sq(_p(self.ssh[1]), self.ssh[1].size)

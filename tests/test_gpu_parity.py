@@ -281,6 +281,70 @@ def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
     Prog._state.close(); Setup.mesh.close()
 
 
+# ------------------------------------------------------------------------------------------------
+# fp32-storage state (BASELINE config 5: "fp32 state with fp64 tendency accumulation").  Not a reference
+# feature; the oracle emulates the storage (oracle_step_rk4_mixed) and the bar stays BIT-EXACT.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("meshname,K,P,nsteps", [("ico16", 80, 0, 3), ("ico16", 60, 12, 2), ("ico32", 80, 12, 2), ("ico16", 4, 0, 3),
+                                                  ("ico16", 128, 8, 2), ("planar", 8, 0, 4), ("ico12f", 80, 0, 2),
+                                                  ("ico16", 64, 32, 2), ("ico16", 36, 5, 2)])
+def test_fp32_state_tendency_and_rk4_bitwise(backend, meshname, K, P, nsteps):
+    mesh = get_mesh(meshname)
+    ssh, u, h, rest = random_state(mesh, K, 21 + K)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True,
+                                                       patch_cells=P, state_bytes=4)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    # upload rounds to fp32, download widens exactly
+    assert np.array_equal(Prog.normalVelocity[-1].get(), f32(u))
+    assert np.array_equal(Prog.layerThickness[-1].get(), f32(h))
+    tu, th, ossh = om.tendencies_clean(u, h, mixed=True)
+    mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
+    assert np.array_equal(Tend.tendNormalVelocity.get(), tu)
+    assert np.array_equal(Tend.tendLayerThickness.get(), th)
+    assert np.array_equal(Prog.ssh[-1].get(), ossh)
+    st = orc.OracleState(om, ssh, u, h, mixed=True)
+    dtv = 2.0 if meshname == "planar" else 20.0          # the 1 km planar mesh is unstable at 20 s
+    mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dtv))
+    for _ in range(nsteps):
+        mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)
+        st.step_rk4(dtv)
+    assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1])
+    assert np.array_equal(Prog.layerThickness[-1].get(), st.h[1])
+    assert np.array_equal(Prog.ssh[-1].get(), st.ssh[1])
+    assert np.array_equal(Prog.normalVelocity[0].get(), st.u[0]) and np.array_equal(Prog.layerThickness[0].get(), st.h[0])
+    # stage-4 tendencies, produced lazily from the fp32 provisional state
+    assert np.array_equal(Tend.tendNormalVelocity.get(), st.tendU) and np.array_equal(Tend.tendLayerThickness.get(), st.tendH)
+    # sum(ssh^2) in the reference's serial order over the widened values
+    tot = L.C.c_double()
+    L.check(L.lib().moka_sum_sq(Prog._state._h, L.F_SSH, 1, L.C.byref(tot)), backend._h)
+    assert tot.value == st.sum_sq_ssh()
+    # graph replay (moka_run) continues bit-identically
+    mk.run_steps(Prog, mk.RungeKutta4, dtv, 7)
+    for _ in range(7):
+        st.step_rk4(dtv)
+    assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.layerThickness[-1].get(), st.h[1])
+    # and it stays within fp32 round-off of the fp64 path
+    s64 = orc.OracleState(om, f32(ssh), f32(u), f32(h))
+    for _ in range(nsteps + 7):
+        s64.step_rk4(dtv)
+    assert np.abs(st.h[1] - s64.h[1]).max() <= 64 * np.finfo(np.float32).eps * np.abs(s64.h[1]).max()
+    # what the fp32 form does not carry fails loudly
+    with pytest.raises(mk.MokaError):
+        mk.ocn_timestep(np.array([dtv]), Prog, Diag, Tend, Setup, mk.ForwardEuler)
+    with pytest.raises(mk.MokaError):
+        Diag.layerThicknessEdge.get()
+    Prog._state.close(); Setup.mesh.close()
+
+
+def test_fp32_state_unsupported_shapes(backend):
+    mesh = get_mesh("ico16")
+    for K in (1, 6, 132):
+        ssh, u, h, rest = random_state(mesh, K, 3)
+        with pytest.raises(mk.MokaError):
+            mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True, state_bytes=4)
+
+
 def test_driver_replay_igw_forward_euler_and_rk4(backend):
     """Replays src/driver/mpas_ocean.jl:20-53: init -> ocn_init_alarms (dt override, init.jl:118) ->
     timestep[1] = dt -> ocn_run_loop until the simulation alarm rings -> download; RMS error vs the

@@ -109,3 +109,23 @@ def test_layer_split_invariance_N3():
         sK.step_rk4(400.0)
     assert np.abs(sK.ssh[1] - s1.ssh[1]).max() < 1e-9
     assert np.abs(sK.u[1] - s1.u[1]).max() < 1e-12
+
+
+def test_mixed_precision_oracle_tracks_fp64():
+    """fp32-storage emulation (config 5; not a reference feature): stored values are fp32-representable, the
+    IGW solution stays within fp32 round-off accumulation of the fp64 run and on the same error curve."""
+    mesh = mg.igw_mesh(200.0)
+    ssh, u, h, rest = mg.igw_initial_state(mesh)
+    om = orc.OracleMesh(mesh, 1, resting_thickness_sum=rest.reshape(mesh.nCells, -1).sum(1), max_level_edge_top=1)
+    a = orc.OracleState(om, ssh, u, h)
+    b = orc.OracleState(om, ssh, u, h, mixed=True)
+    for _ in range(30):
+        a.step_rk4(400.0)
+        b.step_rk4(400.0)
+    for arr in (b.u[1], b.h[1], b.ssh[1]):
+        assert np.array_equal(arr, arr.astype(np.float32).astype(np.float64))
+    # h ~ 1000 m stored in fp32: 6e-5 m resolution, so ssh differs by a few 1e-4 m after 30 steps
+    assert np.abs(a.h[1] - b.h[1]).max() < 5e-3
+    assert np.abs(a.u[1] - b.u[1]).max() < 5e-5
+    with pytest.raises(ValueError):
+        b.step_fe(400.0)

@@ -159,3 +159,21 @@ def test_zero_entries_in_edges_on_edge_are_skipped():
     tu, th, ssh = om.tendencies_clean(u, h)
     tU, tH = plan_tendency_numpy(plan, 1, u[eperm], h[cperm], ssh[cperm])
     assert np.array_equal(tU, tu[eperm]) and np.array_equal(tH, th[cperm])
+
+
+def test_state_bytes_scales_the_gather_records():
+    """moka_mesh_desc.stateBytes = 4 (fp32-storage state, config 5): same numbering, byte-offset records for K*4-byte rows."""
+    m = mg.icosahedral_mesh(8)
+    K = 80
+    p8 = L.Plan(m, K, max_level_edge_top=K, patch_cells=12)
+    p4 = L.Plan(m, K, max_level_edge_top=K, patch_cells=12, state_bytes=4)
+    assert np.array_equal(p8.permutation(L.CELL), p4.permutation(L.CELL))
+    assert np.array_equal(p8.permutation(L.EDGE), p4.permutation(L.EDGE))
+    c8, c4 = p8.array("cRec").reshape(m.nCells, -1), p4.array("cRec").reshape(m.nCells, -1)
+    e8, e4 = p8.array("eRec").reshape(m.nEdges, -1), p4.array("eRec").reshape(m.nEdges, -1)
+    ME, ME2 = p8.info["maxEdgesUsed"], p8.info["maxEdges2Used"]
+    assert np.array_equal(c8[:, :2 * ME], 2 * c4[:, :2 * ME]) and np.array_equal(c8[:, 2 * ME:], c4[:, 2 * ME:])
+    assert np.array_equal(e8[:, :ME2], 2 * e4[:, :ME2]) and np.array_equal(e8[:, ME2:], e4[:, ME2:])
+    assert p4.info["patch_cells"] == 12 == L.Plan(m, K, max_level_edge_top=K, state_bytes=4).info["patch_cells"]
+    with pytest.raises(L.MokaError):
+        L.Plan(m, K, state_bytes=2)
