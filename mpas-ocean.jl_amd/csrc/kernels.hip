@@ -1759,6 +1759,97 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
     }
 }
 
+typedef const __attribute__((address_space(3))) unsigned char *lds_bytes_t;
+typedef const __attribute__((address_space(1))) unsigned char *glb_bytes_t;
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+// N 16-byte LDS reads issued back to back, one wait.  Inline assembly because a plain LDS load next to a global
+// load of the other branch is merged by the compiler into ONE flat_load from a selected pointer (a flat load of an LDS
+// address still occupies the texture-address unit), and a volatile LDS load is waited for individually.
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+template <int N>
+__device__ __forceinline__ void lds_burst(v4u_t (&v)[N], const uint32_t (&ad)[N]);
+template <>
+__device__ __forceinline__ void lds_burst<6>(v4u_t (&v)[6], const uint32_t (&ad)[6])
+{
+    asm volatile("ds_read_b128 %[o0], %[a0]\n\t"
+                 "ds_read_b128 %[o1], %[a1]\n\t"
+                 "ds_read_b128 %[o2], %[a2]\n\t"
+                 "ds_read_b128 %[o3], %[a3]\n\t"
+                 "ds_read_b128 %[o4], %[a4]\n\t"
+                 "ds_read_b128 %[o5], %[a5]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [o0] "=&v"(v[0]), [o1] "=&v"(v[1]), [o2] "=&v"(v[2]), [o3] "=&v"(v[3]), [o4] "=&v"(v[4]), [o5] "=&v"(v[5])
+                 : [a0] "v"(ad[0]), [a1] "v"(ad[1]), [a2] "v"(ad[2]), [a3] "v"(ad[3]), [a4] "v"(ad[4]), [a5] "v"(ad[5])
+                 : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_burst<8>(v4u_t (&v)[8], const uint32_t (&ad)[8])
+{
+    asm volatile("ds_read_b128 %[o0], %[a0]\n\t"
+                 "ds_read_b128 %[o1], %[a1]\n\t"
+                 "ds_read_b128 %[o2], %[a2]\n\t"
+                 "ds_read_b128 %[o3], %[a3]\n\t"
+                 "ds_read_b128 %[o4], %[a4]\n\t"
+                 "ds_read_b128 %[o5], %[a5]\n\t"
+                 "ds_read_b128 %[o6], %[a6]\n\t"
+                 "ds_read_b128 %[o7], %[a7]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [o0] "=&v"(v[0]), [o1] "=&v"(v[1]), [o2] "=&v"(v[2]), [o3] "=&v"(v[3]), [o4] "=&v"(v[4]), [o5] "=&v"(v[5]), [o6] "=&v"(v[6]), [o7] "=&v"(v[7])
+                 : [a0] "v"(ad[0]), [a1] "v"(ad[1]), [a2] "v"(ad[2]), [a3] "v"(ad[3]), [a4] "v"(ad[4]), [a5] "v"(ad[5]), [a6] "v"(ad[6]), [a7] "v"(ad[7])
+                 : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_burst<10>(v4u_t (&v)[10], const uint32_t (&ad)[10])
+{
+    asm volatile("ds_read_b128 %[o0], %[a0]\n\t"
+                 "ds_read_b128 %[o1], %[a1]\n\t"
+                 "ds_read_b128 %[o2], %[a2]\n\t"
+                 "ds_read_b128 %[o3], %[a3]\n\t"
+                 "ds_read_b128 %[o4], %[a4]\n\t"
+                 "ds_read_b128 %[o5], %[a5]\n\t"
+                 "ds_read_b128 %[o6], %[a6]\n\t"
+                 "ds_read_b128 %[o7], %[a7]\n\t"
+                 "ds_read_b128 %[o8], %[a8]\n\t"
+                 "ds_read_b128 %[o9], %[a9]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [o0] "=&v"(v[0]), [o1] "=&v"(v[1]), [o2] "=&v"(v[2]), [o3] "=&v"(v[3]), [o4] "=&v"(v[4]), [o5] "=&v"(v[5]), [o6] "=&v"(v[6]), [o7] "=&v"(v[7]), [o8] "=&v"(v[8]), [o9] "=&v"(v[9])
+                 : [a0] "v"(ad[0]), [a1] "v"(ad[1]), [a2] "v"(ad[2]), [a3] "v"(ad[3]), [a4] "v"(ad[4]), [a5] "v"(ad[5]), [a6] "v"(ad[6]), [a7] "v"(ad[7]), [a8] "v"(ad[8]), [a9] "v"(ad[9])
+                 : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_burst<14>(v4u_t (&v)[14], const uint32_t (&ad)[14])
+{
+    asm volatile("ds_read_b128 %[o0], %[a0]\n\t"
+                 "ds_read_b128 %[o1], %[a1]\n\t"
+                 "ds_read_b128 %[o2], %[a2]\n\t"
+                 "ds_read_b128 %[o3], %[a3]\n\t"
+                 "ds_read_b128 %[o4], %[a4]\n\t"
+                 "ds_read_b128 %[o5], %[a5]\n\t"
+                 "ds_read_b128 %[o6], %[a6]\n\t"
+                 "ds_read_b128 %[o7], %[a7]\n\t"
+                 "ds_read_b128 %[o8], %[a8]\n\t"
+                 "ds_read_b128 %[o9], %[a9]\n\t"
+                 "ds_read_b128 %[o10], %[a10]\n\t"
+                 "ds_read_b128 %[o11], %[a11]\n\t"
+                 "ds_read_b128 %[o12], %[a12]\n\t"
+                 "ds_read_b128 %[o13], %[a13]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [o0] "=&v"(v[0]), [o1] "=&v"(v[1]), [o2] "=&v"(v[2]), [o3] "=&v"(v[3]), [o4] "=&v"(v[4]), [o5] "=&v"(v[5]), [o6] "=&v"(v[6]), [o7] "=&v"(v[7]), [o8] "=&v"(v[8]), [o9] "=&v"(v[9]), [o10] "=&v"(v[10]), [o11] "=&v"(v[11]), [o12] "=&v"(v[12]), [o13] "=&v"(v[13])
+                 : [a0] "v"(ad[0]), [a1] "v"(ad[1]), [a2] "v"(ad[2]), [a3] "v"(ad[3]), [a4] "v"(ad[4]), [a5] "v"(ad[5]), [a6] "v"(ad[6]), [a7] "v"(ad[7]), [a8] "v"(ad[8]), [a9] "v"(ad[9]), [a10] "v"(ad[10]), [a11] "v"(ad[11]), [a12] "v"(ad[12]), [a13] "v"(ad[13])
+                 : "memory");
+}
+__device__ __forceinline__ double2 glb_row2(glb_bytes_t p)
+{
+    const v2d_t v = *(const __attribute__((address_space(1))) v2d_t *)p;
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ float4 glb_row4f(glb_bytes_t p)
+{
+    const v4f_t v = *(const __attribute__((address_space(1))) v4f_t *)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // ------------------------------------------------------------------------------------------------
 // rec2 + own-edge cache ("rec2c"): k_stage_rec2 with the u-rows of the patch's OWN edges copied once into LDS
 // (a contiguous range: one coalesced copy, no halo list).  ~65 % of all u gathers of a compact patch refer to
@@ -1767,14 +1858,14 @@ __global__ __launch_bounds__(PBLOCK, 2) void k_stage_ptile(const MeshDev m, cons
 // Not pipelined: loads sit behind per-lane branches, so the compiler waits with vmcnt(0) at first use; 12+
 // waves per CU cover the latency instead.
 // ------------------------------------------------------------------------------------------------
-template <int ME, int ME2, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_stage_rec2c(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
+template <int ME, int ME2, int MODE, int NT = BLOCK>
+__global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int pl_ = patch_of_block(m.nPatches);
     if (pl_ >= m.nPatches) return;
     const int p = pl_ + m.patchBegin;
-    constexpr int NG = BLOCK / 32;
+    constexpr int NG = NT / 32;
     const int tid = threadIdx.x;
     const int grp = tid >> 5, l = tid & 31;
     const int K = m.K, K2 = K >> 1;
@@ -1790,31 +1881,39 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c(const ColMesh m, const St
     const int nOwnC = c1 - c0, nOwnE = e1 - e0;
     const uint32_t e0B = (uint32_t)e0 * rowB, nOwnB = (uint32_t)nOwnE * rowB;
 
-    for (int i = tid; i < nOwnE * m.EI; i += BLOCK) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
-    for (int i = tid; i < nOwnE * ME2; i += BLOCK) {
+    for (int i = tid; i < nOwnE * m.EI; i += NT) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
+    for (int i = tid; i < nOwnE * ME2; i += NT) {
         L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
         L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
     }
-    for (int i = tid; i < nOwnE; i += BLOCK) L.g[i] = m.gInvDc[e0 + i];
-    for (int i = tid; i < nOwnC * m.CI; i += BLOCK) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
-    for (int i = tid; i < nOwnC * ME; i += BLOCK) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
-    for (int i = tid; i < nOwnC; i += BLOCK) {
+    for (int i = tid; i < nOwnE; i += NT) L.g[i] = m.gInvDc[e0 + i];
+    for (int i = tid; i < nOwnC * m.CI; i += NT) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
+    for (int i = tid; i < nOwnC * ME; i += NT) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
+    for (int i = tid; i < nOwnC; i += NT) {
         L.invA[i] = m.invArea[c0 + i];
         L.rsum[i] = m.rsum[c0 + i];
     }
     {   // own u rows: one contiguous, fully coalesced copy
         const double2 *src = reinterpret_cast<const double2 *>(a.pu) + (size_t)e0 * K2;
-        for (int i = tid; i < nOwnE * K2; i += BLOCK) ubuf2[i] = src[i];
+        for (int i = tid; i < nOwnE * K2; i += NT) ubuf2[i] = src[i];
     }
     __syncthreads();
 
     const int k0 = 2 * l;
     const bool act = k0 < K;
-    auto urow = [&](uint32_t off) -> double2 {                         // u row at global byte offset `off`
+    // Explicit address spaces: with generic pointers the compiler folds the two branches into ONE flat_load from a
+    // selected pointer, and a flat load of an LDS address still goes through the texture-address unit.
+    const lds_bytes_t ubytesL = (lds_bytes_t)ubytes;
+    const glb_bytes_t puG = (glb_bytes_t)a.pu;
+    // u rows in two phases so that nothing serialises: every lane reads the cache (lds_burst; a lane whose row is not
+    // cached reads row 0), then only those lanes overwrite the value with an exec-masked global_load_dwordx4.
+    const uint32_t ldsU = (uint32_t)(size_t)ubytesL;
+    auto urow_addr = [&](uint32_t off, bool &cached) -> uint32_t {
         const uint32_t loc = off - e0B;
-        if (loc < nOwnB) return *reinterpret_cast<const double2 *>(ubytes + loc);
-        return gload2(a.pu, off + voff);
+        cached = loc < nOwnB;
+        return ldsU + (cached ? loc : 0u);
     };
+    auto urow_glb = [&](uint32_t off) -> double2 { return glb_row2(puG + (off + voff)); };
 
     // ---------------- cells ----------------
     for (int ci = grp; ci < nOwnC; ci += NG) {
@@ -1826,11 +1925,20 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c(const ColMesh m, const St
         const uint32_t own = (uint32_t)c * rowB + voff;
         double2 hc = make_double2(0.0, 0.0), uv[ME], hv[ME], cur = hc, nin = hc;
         if (act) {
+            bool cached[ME];
+            uint32_t ad[ME];
+            v4u_t raw[ME];
             hc = gload2(a.ph, own);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
                 hv[i] = gload2(a.ph, r[ME + i] + voff);
-                uv[i] = urow(r[i]);
+                ad[i] = urow_addr(r[i], cached[i]);
+            }
+            lds_burst<ME>(raw, ad);
+#pragma unroll
+            for (int i = 0; i < ME; ++i) {
+                uv[i] = __builtin_bit_cast(double2, raw[i]);
+                if (!cached[i]) uv[i] = urow_glb(r[i]);
             }
             if constexpr (MODE == 2) cur = gload2(a.ch, own);
             if constexpr (MODE >= 2) nin = gload2(a.nh_in, own);
@@ -1887,8 +1995,17 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c(const ColMesh m, const St
         if (l == 1) sB = a.ssh[r[ME2 + 1]];
         double2 uv[ME2], cur = make_double2(0.0, 0.0), nin = cur;
         if (act) {
+            bool cached[ME2];
+            uint32_t ad[ME2];
+            v4u_t raw[ME2];
 #pragma unroll
-            for (int i = 0; i < ME2; ++i) uv[i] = urow(r[i]);
+            for (int i = 0; i < ME2; ++i) ad[i] = urow_addr(r[i], cached[i]);
+            lds_burst<ME2>(raw, ad);
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) {
+                uv[i] = __builtin_bit_cast(double2, raw[i]);
+                if (!cached[i]) uv[i] = urow_glb(r[i]);
+            }
             if constexpr (MODE == 2) cur = gload2(a.cu, own);
             if constexpr (MODE >= 2) nin = gload2(a.nu_in, own);
         }
@@ -1994,11 +2111,15 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c_f32(const ColMesh m, cons
 
     const int k0 = 4 * l;
     const bool act = k0 < K;
-    auto urow = [&](uint32_t off) -> d4 {                               // u row at global byte offset `off`
+    const lds_bytes_t ubytesL = (lds_bytes_t)ubytes;                    // explicit address spaces: see k_stage_rec2c
+    const glb_bytes_t puG = (glb_bytes_t)a.pu;
+    const uint32_t ldsU = (uint32_t)(size_t)ubytesL;                    // two-phase gather: see k_stage_rec2c
+    auto urow_addr = [&](uint32_t off, bool &cached) -> uint32_t {
         const uint32_t loc = off - e0B;
-        if (loc < nOwnB) return widen4(*reinterpret_cast<const float4 *>(ubytes + loc));
-        return gload4(a.pu, off + voff);
+        cached = loc < nOwnB;
+        return ldsU + (cached ? loc : 0u);
     };
+    auto urow_glb = [&](uint32_t off) -> float4 { return glb_row4f(puG + (off + voff)); };
     const d4 zero{0.0, 0.0, 0.0, 0.0};
 
     // ---------------- cells ----------------
@@ -2011,14 +2132,26 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c_f32(const ColMesh m, cons
         const uint32_t own = (uint32_t)c * rowB + voff;
         d4 hc = zero, uv[ME], hv[ME], cur = zero, nin = zero;
         if (act) {
+            bool cached[ME];
+            uint32_t ad[ME];
+            v4u_t raw[ME];
+            float4 uf[ME];
             hc = gload4(a.ph, own);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
                 hv[i] = gload4(a.ph, r[ME + i] + voff);
-                uv[i] = urow(r[i]);
+                ad[i] = urow_addr(r[i], cached[i]);
+            }
+            lds_burst<ME>(raw, ad);
+#pragma unroll
+            for (int i = 0; i < ME; ++i) {
+                uf[i] = __builtin_bit_cast(float4, raw[i]);
+                if (!cached[i]) uf[i] = urow_glb(r[i]);
             }
             if constexpr (MODE == 2) cur = gload4(a.ch, own);
             if constexpr (MODE >= 2) nin = gload4(a.nh_in, own);
+#pragma unroll
+            for (int i = 0; i < ME; ++i) uv[i] = widen4(uf[i]);
         }
         d4 t = zero;
         if (act) {
@@ -2081,10 +2214,22 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c_f32(const ColMesh m, cons
         if (l == 1) sB = (double)sshf[r[ME2 + 1]];
         d4 uv[ME2], cur = zero, nin = zero;
         if (act) {
+            bool cached[ME2];
+            uint32_t ad[ME2];
+            v4u_t raw[ME2];
+            float4 uf[ME2];
 #pragma unroll
-            for (int i = 0; i < ME2; ++i) uv[i] = urow(r[i]);
+            for (int i = 0; i < ME2; ++i) ad[i] = urow_addr(r[i], cached[i]);
+            lds_burst<ME2>(raw, ad);
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) {
+                uf[i] = __builtin_bit_cast(float4, raw[i]);
+                if (!cached[i]) uf[i] = urow_glb(r[i]);
+            }
             if constexpr (MODE == 2) cur = gload4(a.cu, own);
             if constexpr (MODE >= 2) nin = gload4(a.nu_in, own);
+#pragma unroll
+            for (int i = 0; i < ME2; ++i) uv[i] = widen4(uf[i]);
         }
         const double ds = __shfl(sB, 1, 32) - __shfl(sA, 0, 32);       // ssh[c2] - ssh[c1]
         if (act) {
