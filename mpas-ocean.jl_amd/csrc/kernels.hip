@@ -1944,7 +1944,17 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (MODE >= 2) nin = gload2(a.nh_in, own);
         }
         double2 t = make_double2(0.0, 0.0);
-        if (act) {
+        // regular entity (every slot valid, every level active) in BOTH half-waves: no per-slot masks (wave-uniform branch)
+        const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME) - 1u && all)) == 0;
+        if (plain) {
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < ME; ++i) {
+                    t.x += uv[i].x * (0.5 * (hc.x + hv[i].x)) * rs[i] * invA;
+                    t.y += uv[i].y * (0.5 * (hc.y + hv[i].y)) * rs[i] * invA;
+                }
+            }
+        } else if (act) {
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
                 const int ml = all ? K : cptr(m.mltc)[(size_t)c * ME + i];
@@ -2010,17 +2020,28 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (MODE >= 2) nin = gload2(a.nu_in, own);
         }
         const double ds = __shfl(sB, 1, 32) - __shfl(sA, 0, 32);       // ssh[c2] - ssh[c1]
+        const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME2) - 1u && mlt >= K)) == 0;   // wave-uniform
         if (act) {
             const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
             double2 t = make_double2(0.0, 0.0);
-            if (ax) t.x -= g * ds;                                     // pressure_gradient.jl:63
-            if (ay) t.y -= g * ds;
+            if (plain) {                                               // all 2*ME2/2 slots valid, all levels active
+                t.x -= g * ds;
+                t.y -= g * ds;
 #pragma unroll
-            for (int i = 0; i < ME2; ++i) {
-                const bool on = (mask >> i) & 1u;
-                const double px = rw[i] * uv[i].x * rf[i], py = rw[i] * uv[i].y * rf[i];   // ...coriolis.jl:70-72
-                if (on && ax) t.x += px;
-                if (on && ay) t.y += py;
+                for (int i = 0; i < ME2; ++i) {
+                    t.x += rw[i] * uv[i].x * rf[i];
+                    t.y += rw[i] * uv[i].y * rf[i];
+                }
+            } else {
+                if (ax) t.x -= g * ds;                                 // pressure_gradient.jl:63
+                if (ay) t.y -= g * ds;
+#pragma unroll
+                for (int i = 0; i < ME2; ++i) {
+                    const bool on = (mask >> i) & 1u;
+                    const double px = rw[i] * uv[i].x * rf[i], py = rw[i] * uv[i].y * rf[i];   // ...coriolis.jl:70-72
+                    if (on && ax) t.x += px;
+                    if (on && ay) t.y += py;
+                }
             }
             if constexpr (MODE == 0) gstore2(a.tendU, own, t);
             if constexpr (MODE == 1) {
@@ -2068,7 +2089,7 @@ __device__ __forceinline__ d4 axpy4(d4 x, double a, d4 t)      // x + a*t, the r
 __device__ __forceinline__ d4 round4(d4 v) { return widen4(narrow4(v)); }
 
 template <int ME, int ME2, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_stage_rec2c_f32(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
+__global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int pl_ = patch_of_block(m.nPatches);
@@ -2154,7 +2175,18 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c_f32(const ColMesh m, cons
             for (int i = 0; i < ME; ++i) uv[i] = widen4(uf[i]);
         }
         d4 t = zero;
-        if (act) {
+        const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME) - 1u && all)) == 0;   // see k_stage_rec2c
+        if (plain) {
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < ME; ++i) {
+                    t.x += uv[i].x * (0.5 * (hc.x + hv[i].x)) * rs[i] * invA;
+                    t.y += uv[i].y * (0.5 * (hc.y + hv[i].y)) * rs[i] * invA;
+                    t.z += uv[i].z * (0.5 * (hc.z + hv[i].z)) * rs[i] * invA;
+                    t.w += uv[i].w * (0.5 * (hc.w + hv[i].w)) * rs[i] * invA;
+                }
+            }
+        } else if (act) {
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
                 const int ml = all ? K : cptr(m.mltc)[(size_t)c * ME + i];
@@ -2232,22 +2264,34 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rec2c_f32(const ColMesh m, cons
             for (int i = 0; i < ME2; ++i) uv[i] = widen4(uf[i]);
         }
         const double ds = __shfl(sB, 1, 32) - __shfl(sA, 0, 32);       // ssh[c2] - ssh[c1]
+        const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME2) - 1u && mlt >= K)) == 0;   // wave-uniform
         if (act) {
             const bool ax = k0 < mlt, ay = k0 + 1 < mlt, az = k0 + 2 < mlt, aw = k0 + 3 < mlt;
             d4 t = zero;
-            if (ax) t.x -= g * ds;                                     // pressure_gradient.jl:63
-            if (ay) t.y -= g * ds;
-            if (az) t.z -= g * ds;
-            if (aw) t.w -= g * ds;
+            if (plain) {
+                t.x -= g * ds; t.y -= g * ds; t.z -= g * ds; t.w -= g * ds;
 #pragma unroll
-            for (int i = 0; i < ME2; ++i) {
-                const bool on = (mask >> i) & 1u;
-                const double px = rw[i] * uv[i].x * rf[i], py = rw[i] * uv[i].y * rf[i];   // ...coriolis.jl:70-72
-                const double pz = rw[i] * uv[i].z * rf[i], pw = rw[i] * uv[i].w * rf[i];
-                if (on && ax) t.x += px;
-                if (on && ay) t.y += py;
-                if (on && az) t.z += pz;
-                if (on && aw) t.w += pw;
+                for (int i = 0; i < ME2; ++i) {
+                    t.x += rw[i] * uv[i].x * rf[i];
+                    t.y += rw[i] * uv[i].y * rf[i];
+                    t.z += rw[i] * uv[i].z * rf[i];
+                    t.w += rw[i] * uv[i].w * rf[i];
+                }
+            } else {
+                if (ax) t.x -= g * ds;                                 // pressure_gradient.jl:63
+                if (ay) t.y -= g * ds;
+                if (az) t.z -= g * ds;
+                if (aw) t.w -= g * ds;
+#pragma unroll
+                for (int i = 0; i < ME2; ++i) {
+                    const bool on = (mask >> i) & 1u;
+                    const double px = rw[i] * uv[i].x * rf[i], py = rw[i] * uv[i].y * rf[i];   // ...coriolis.jl:70-72
+                    const double pz = rw[i] * uv[i].z * rf[i], pw = rw[i] * uv[i].w * rf[i];
+                    if (on && ax) t.x += px;
+                    if (on && ay) t.y += py;
+                    if (on && az) t.z += pz;
+                    if (on && aw) t.w += pw;
+                }
             }
             if constexpr (MODE == 0) {
                 const uint32_t ownD = (uint32_t)e * rowBD + voffD;
