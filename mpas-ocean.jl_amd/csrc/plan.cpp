@@ -200,16 +200,18 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     p.ME = maxEoC <= 6 ? 6 : (maxEoC <= 8 ? 8 : maxEoC);
     p.ME2 = maxEoE <= 10 ? 10 : (maxEoE <= 14 ? 14 : maxEoE);
     if (p.ME == 8 && p.ME2 < 14) p.ME2 = 14;   // kernels are instantiated for (6,10), (6,14), (8,14)
-    // default patch size (bench sweeps in profiles/r01_variants.txt): 12 cells for even 34 <= K <= 64, where the
-    // default stage kernel (k_stage_rec2c) keeps the patch's own u rows in LDS and four workgroups must fit a CU;
+    // default patch size (bench sweeps in profiles/r01_variants.txt): where the default stage kernel keeps the patch's own
+    // u rows in LDS (k_stage_rec2c: even 34 <= K <= 64; k_stage_rec2c_f32: K % 4 == 0, 34 <= K <= 128) the largest patch
+    // that still lets four (fp64: 16 cells, ~51 edges, 38 KB) or three (fp32: 24 cells) workgroups share a CU;
     // 32 cells otherwise (generic / plain column kernels).
     {
         const int K = d->nVertLevels;
         REQUIRE(d->stateBytes == 0 || d->stateBytes == 4 || d->stateBytes == 8, "stateBytes must be 0, 4 or 8");
         p.stateBytes = d->stateBytes == 4 ? 4 : 8;
-        // small patches where the stage kernel caches the patch's own u rows in LDS (k_stage_rec2c / _f32)
-        const bool cached = p.stateBytes == 8 ? (K >= 34 && K <= 64 && !(K & 1)) : (K >= 34 && K <= 128 && !(K & 3));
-        p.P = d->patch_cells > 0 ? d->patch_cells : (cached ? 12 : 32);
+        int def = 32;
+        if (p.stateBytes == 8 && K >= 34 && K <= 64 && !(K & 1)) def = 16;
+        if (p.stateBytes == 4 && K >= 34 && K <= 128 && !(K & 3)) def = 24;
+        p.P = d->patch_cells > 0 ? d->patch_cells : def;
     }
     REQUIRE(p.P <= 4096, "patch_cells too large");
 
@@ -228,7 +230,7 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     p.cellO2N.assign(nC, -1);
     for (int i = 0; i < nC; ++i) p.cellO2N[p.cellN2O[i]] = i;
 
-    // ---- edges / vertices numbered by their lowest-numbered (new) cell: counting sort by owner ----
+    // ---- edges / vertices numbered by their owner cell (new numbering): counting sort by owner ----
     auto renumber = [&](int n, auto owner_of, std::vector<int32_t> &n2o, std::vector<int32_t> &o2n) {
         std::vector<int32_t> owner(n), cnt(nC + 1, 0);
         for (int i = 0; i < n; ++i) { owner[i] = owner_of(i); ++cnt[owner[i] + 1]; }
@@ -237,9 +239,44 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
         for (int i = 0; i < n; ++i) { int pos = cnt[owner[i]]++; n2o[pos] = i; o2n[i] = pos; }
         return owner;
     };
-    auto edgeOwner = renumber(nE, [&](int e) {
-        return std::min(p.cellO2N[d->cellsOnEdge[2 * (int64_t)e] - 1], p.cellO2N[d->cellsOnEdge[2 * (int64_t)e + 1] - 1]);
-    }, p.edgeN2O, p.edgeO2N);
+    // Edge ownership.  An edge whose two cells sit in one patch belongs to it.  An edge between two patches goes to the
+    // cell of lower class when the classes differ (multi-GPU: the boundary launch must own every edge another rank needs,
+    // and no computed edge may belong to a halo patch), otherwise to whichever patch owns fewer edges so far, followed by
+    // a few balancing sweeps: the LDS carve of the record-staging kernels is sized by the LARGEST patch, and
+    // "lowest-numbered cell owns the edge" gives early patches up to 1.7x the average (61 vs 36 edges at P = 12).
+    std::vector<int32_t> ownerCell(nE);
+    {
+        const int P = p.P, nP = (nC + P - 1) / P;
+        std::vector<int32_t> cnt(nP, 0), flex;
+        auto cls = [&](int cn) { return d->cellClass ? d->cellClass[p.cellN2O[cn]] : 0; };
+        std::vector<int32_t> lo(nE), hi(nE);
+        for (int e = 0; e < nE; ++e) {
+            const int a = p.cellO2N[d->cellsOnEdge[2 * (int64_t)e] - 1], b = p.cellO2N[d->cellsOnEdge[2 * (int64_t)e + 1] - 1];
+            lo[e] = std::min(a, b); hi[e] = std::max(a, b);
+            if (lo[e] / P == hi[e] / P || cls(lo[e]) != cls(hi[e])) {   // class order == numbering order: lower class = lo
+                ownerCell[e] = lo[e];
+                ++cnt[lo[e] / P];
+            } else {
+                ownerCell[e] = -1;
+                flex.push_back(e);
+            }
+        }
+        std::stable_sort(flex.begin(), flex.end(), [&](int x, int y) { return lo[x] < lo[y]; });
+        for (int e : flex) {
+            const int pa = lo[e] / P, pb = hi[e] / P;
+            if (cnt[pa] <= cnt[pb]) { ownerCell[e] = lo[e]; ++cnt[pa]; }
+            else { ownerCell[e] = hi[e]; ++cnt[pb]; }
+        }
+        for (int sweep = 0; sweep < 8; ++sweep) {
+            int moved = 0;
+            for (int e : flex) {
+                const int cur = ownerCell[e], oth = cur == lo[e] ? hi[e] : lo[e];
+                if (cnt[cur / P] > cnt[oth / P] + 1) { ownerCell[e] = oth; --cnt[cur / P]; ++cnt[oth / P]; ++moved; }
+            }
+            if (!moved) break;
+        }
+    }
+    auto edgeOwner = renumber(nE, [&](int e) { return ownerCell[e]; }, p.edgeN2O, p.edgeO2N);
     auto vertOwner = renumber(nV, [&](int v) {
         int best = nC;
         for (int j = 0; j < VD; ++j) {

@@ -95,11 +95,14 @@ def test_plan_is_a_faithful_renumbering(mesh, ordering, K, P):
     assert cs[0] == es[0] == vs[0] == 0
     assert (cs[-1], es[-1], vs[-1]) == (mesh.nCells, mesh.nEdges, mesh.nVertices)
     assert np.all(np.diff(cs) > 0) and np.all(np.diff(cs)[:-1] == P) and np.all(np.diff(es) >= 0)
-    # every edge lies in the patch of its lowest-numbered (new) cell
+    # every edge lies in the patch of one of its two cells, and the patches own balanced numbers of edges
     ehdr = plan.array("ehdr").reshape(mesh.nEdges, 4)
-    owner = np.minimum(ehdr[:, 0], ehdr[:, 1])
     patch_of_edge = np.searchsorted(es, np.arange(mesh.nEdges), side="right") - 1
-    assert np.array_equal(owner // P, patch_of_edge)
+    assert np.all((ehdr[:, 0] // P == patch_of_edge) | (ehdr[:, 1] // P == patch_of_edge))
+    full = np.diff(cs) == P
+    own = np.diff(es)[full]
+    if own.size > 4 and mesh.maxEdges <= 6:
+        assert own.max() - np.median(own) <= max(3, 0.12 * np.median(own)), (own.max(), np.median(own))
     # tendency from the records == oracle in the caller's numbering, bit for bit
     u = rng.uniform(-1, 1, (mesh.nEdges, K))
     h = 1000.0 / K + rng.uniform(-1, 1, (mesh.nCells, K))
@@ -174,6 +177,7 @@ def test_state_bytes_scales_the_gather_records():
     ME, ME2 = p8.info["maxEdgesUsed"], p8.info["maxEdges2Used"]
     assert np.array_equal(c8[:, :2 * ME], 2 * c4[:, :2 * ME]) and np.array_equal(c8[:, 2 * ME:], c4[:, 2 * ME:])
     assert np.array_equal(e8[:, :ME2], 2 * e4[:, :ME2]) and np.array_equal(e8[:, ME2:], e4[:, ME2:])
-    assert p4.info["patch_cells"] == 12 == L.Plan(m, K, max_level_edge_top=K, state_bytes=4).info["patch_cells"]
+    assert p4.info["patch_cells"] == 12 and L.Plan(m, K, max_level_edge_top=K, state_bytes=4).info["patch_cells"] == 24
+    assert L.Plan(m, 60, max_level_edge_top=60).info["patch_cells"] == 16
     with pytest.raises(L.MokaError):
         L.Plan(m, K, state_bytes=2)

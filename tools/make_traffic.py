@@ -12,8 +12,8 @@ import sys
 src, workload = sys.argv[1], sys.argv[2]
 vals = {}
 for line in open(src):
-    m = re.match(r"(k_stage_\w+)<[^>]*?(\d)>\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+avg=([\d.e+]+)", line)
-    if m:
+    m = re.match(r"(k_stage_\w+)<\d+, \d+, (\d+)[^>]*>\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+avg=([\d.e+]+)", line)
+    if m:                                      # template arguments: <ME, ME2, MODE[, threads]>
         vals[(int(m.group(2)), m.group(3))] = float(m.group(4))
         kernel = m.group(1)
 modes = [1, 2, 2, 3]  # the four stage launches of one RK4 step
