@@ -14,6 +14,10 @@ import math
 import numpy as np
 
 from . import lib as L
+from . import mpasio
+from .config import ConfigGet, ConfigRead, GlobalConfig, yaml_config
+from .timemanager import (Alarm, Clock, OneTimeAlarm, PeriodicAlarm, Second, advance, attachAlarm, changeTimeStep, isRinging,
+                          mpas_create_clock, period_seconds, reset, setCurrentTime, stop)
 
 __all__ = [
     "MokaHIP", "MokaError", "ForwardEuler", "RungeKutta4", "HorzMesh", "VerticalMesh", "Mesh", "ModelSetup",
@@ -21,8 +25,9 @@ __all__ = [
     "GradientOnEdge", "DivergenceOnCell", "CurlOnVertex", "interpolateCell2Edge",
     "advanceTimeLevels", "diagnostic_compute", "computeNormalVelocityTendency", "computeLayerThicknessTendency",
     "computeTendency", "ocn_timestep", "ocn_run_loop", "run_steps", "ocn_init_from_arrays", "ocn_init_alarms",
-    "Clock", "OneTimeAlarm", "PeriodicAlarm", "advance", "isRinging", "reset", "changeTimeStep",
-    "REFERENCE_COMPAT",
+    "Clock", "OneTimeAlarm", "PeriodicAlarm", "Alarm", "advance", "isRinging", "reset", "stop", "changeTimeStep",
+    "attachAlarm", "setCurrentTime", "ocn_setup_clock", "ocn_setup_mesh", "ocn_init", "write_netcdf",
+    "ConfigRead", "ConfigGet", "GlobalConfig", "REFERENCE_COMPAT",
 ]
 
 MokaError = L.MokaError
@@ -387,79 +392,88 @@ def ocn_init_from_arrays(mesh_data, ssh, normalVelocity, layerThickness, resting
 
 
 # ---------------------------------------------------------------------------------------------
-# minimal clock / alarms  (src/infra/TimeManager.jl) -- host-only, enough to replay the driver
+# model initialisation from a configuration  (src/forward/init.jl); clock / alarms live in timemanager.py,
+# the YAML configuration in config.py, the MPAS file readers / writer in mpasio.py
 # ---------------------------------------------------------------------------------------------
-class _Alarm:
-    def __init__(self, name):
-        self.name, self.clock = name, None
+def _cfg_get(section, key, default="none"):
+    """ConfigGet on a yaml_config, or a plain dict (the array-driven tests pass already-parsed dicts)."""
+    d = section.dict if isinstance(section, yaml_config) else section
+    return d.get(key, default)
 
 
-class OneTimeAlarm(_Alarm):      # TimeManager.jl:54
-    def __init__(self, name, ringTime):
-        super().__init__(name)
-        self.ringTime = ringTime
-
-
-class PeriodicAlarm(_Alarm):     # TimeManager.jl:80
-    def __init__(self, name, interval, startTime):
-        super().__init__(name)
-        self.interval, self.ringTime = interval, startTime + interval
-
-
-class Clock:                     # TimeManager.jl:5
-    def __init__(self, startTime, timeStep):
-        self.startTime = self.currTime = startTime
-        self.timeStep = timeStep
-        self.alarms = {}
-
-
-def attachAlarm(clock, alarm):
-    alarm.clock = clock
-    clock.alarms[alarm.name] = alarm
-
-
-def advance(clock):              # advance!(clock)  TimeManager.jl:150
-    clock.currTime = clock.currTime + clock.timeStep
-
-
-def isRinging(alarm):            # rings only on equality for one-time alarms (TimeManager.jl:127-129)
-    if isinstance(alarm, OneTimeAlarm):
-        return alarm.clock.currTime == alarm.ringTime
-    return alarm.clock.currTime >= alarm.ringTime
-
-
-def reset(alarm):                # reset!(alarm)  TimeManager.jl:173
-    while alarm.ringTime <= alarm.clock.currTime:
-        alarm.ringTime = alarm.ringTime + alarm.interval
-
-
-def changeTimeStep(clock, timeStep):
-    clock.timeStep = timeStep
-
-
-def ocn_setup_clock(config: dict) -> Clock:
-    """ocn_setup_clock (init.jl:57-108) on an already-parsed config dict (datetime / timedelta values)."""
-    tm = config["time_management"]
-    ti = config["time_integration"]
-    out = config.get("output", {})
-    start = tm.get("config_start_time", _dt.datetime(1, 1, 1))
-    dt = ti.get("config_dt", _dt.timedelta(seconds=1))
-    run_duration, stop_time = tm.get("config_run_duration", "none"), tm.get("config_stop_time", "none")
-    if run_duration != "none":
+def ocn_setup_clock(config) -> Clock:
+    """ocn_setup_clock(Config) (init.jl:57-108): `config` is a GlobalConfig, or a dict
+    {"time_management": ..., "time_integration": ..., "output": ...} holding datetimes / periods."""
+    if isinstance(config, GlobalConfig):
+        tm, ti = ConfigGet(config.namelist, "time_management"), ConfigGet(config.namelist, "time_integration")
+        out = ConfigGet(config.streams, "output")
+    else:
+        tm, ti, out = config["time_management"], config["time_integration"], config.get("output", {})
+    start = _cfg_get(tm, "config_start_time", _dt.datetime(1, 1, 1))
+    dt = _cfg_get(ti, "config_dt", _dt.timedelta(seconds=1))
+    run_duration, stop_time = _cfg_get(tm, "config_run_duration"), _cfg_get(tm, "config_stop_time")
+    if not isinstance(run_duration, str) or run_duration != "none":
+        clock = mpas_create_clock(dt, start, runDuration=run_duration)
+        if not isinstance(stop_time, str) or stop_time != "none":
+            if start + run_duration != stop_time:                                  # init.jl:85
+                print("Warning: config_run_duration and config_stop_time are inconsitent: using config_run_duration.")
         stop_time = start + run_duration
-    elif stop_time == "none":
+    elif not isinstance(stop_time, str) or stop_time != "none":
+        clock = mpas_create_clock(dt, start, stopTime=stop_time)
+    else:
         raise MokaError(L.ERR_ARG, "Error: Neither config_run_duration nor config_stop_time were specified.")  # :94
-    clock = Clock(start, dt)
     attachAlarm(clock, OneTimeAlarm("simulation_end", stop_time))
-    attachAlarm(clock, PeriodicAlarm("outputAlarm", out.get("output_interval", _dt.timedelta(days=1)),
-                                     out.get("reference_time", start)))
+    attachAlarm(clock, PeriodicAlarm("outputAlarm", _cfg_get(out, "output_interval", _dt.timedelta(days=1)),
+                                     _cfg_get(out, "reference_time", start)))
     return clock
+
+
+def ocn_setup_mesh(Config: GlobalConfig, backend=None, multilayer: bool = True, **layout) -> Mesh:
+    """ocn_setup_mesh(Config; backend) (init.jl:41-55): the `mesh` stream names the MPAS file; ReadHorzMesh +
+    VerticalMesh(mesh_fp, h_mesh) (mpasio.read_mesh / read_vertical_mesh), then onto the backend."""
+    mesh_fp = ConfigGet(ConfigGet(Config.streams, "mesh"), "filename_template")
+    data = mpasio.read_mesh(mesh_fp)
+    vm = mpasio.read_vertical_mesh(mesh_fp, data)
+    h_mesh = HorzMesh(data)
+    v_mesh = VerticalMesh(h_mesh, nVertLevels=vm["nVertLevels"], restingThickness=vm["restingThickness"],
+                          multilayer=multilayer)
+    v_mesh.minLevelCell, v_mesh.maxLevelCell = vm["minLevelCell"], vm["maxLevelCell"]
+    return Mesh(h_mesh, v_mesh, backend=backend, **layout)
+
+
+def ocn_init(Config_filepath, backend=None, multilayer: bool = True, **layout):
+    """ocn_init(config_fp; backend) (init.jl:3-30): returns (Setup, Diag, Tend, Prog).  The initial state is the first
+    time record of the `input` stream's file (PrognosticVars.jl:59-106; restarts are not supported there either)."""
+    Config = ConfigRead(Config_filepath)
+    mesh = ocn_setup_mesh(Config, backend=backend, multilayer=multilayer, **layout)
+    clock = ocn_setup_clock(Config)
+    Setup = ModelSetup(Config, mesh, clock)
+    if ConfigGet(ConfigGet(Config.namelist, "time_management"), "config_do_restart"):
+        raise MokaError(L.ERR_UNSUPPORTED, "restart not yet supported")            # PrognosticVars.jl:64-66
+    input_fp = ConfigGet(ConfigGet(Config.streams, "input"), "filename_template")
+    nT = ConfigGet(ConfigGet(Config.namelist, "time_integration"), "config_number_of_time_levels")
+    K = mesh.VertMesh.nVertLevels
+    ssh, u, h = mpasio.read_initial_state(input_fp, mesh.HorzMesh.data, K)
+    Prog = PrognosticVars(ssh, u, h, nT, mesh)
+    Diag = DiagnosticVars(Config, mesh, Prog._state)
+    Tend = TendencyVars(Config, mesh, Prog._state)
+    return Setup, Diag, Tend, Prog
+
+
+def write_netcdf(Setup: ModelSetup, Diag, Prog):
+    """write_netcdf(Setup, Diag, Prog) (OutPut.jl:117-215): the current time level to the `output` stream's file."""
+    out_fp = ConfigGet(ConfigGet(Setup.config.streams, "output"), "filename_template")
+    clock, mesh = Setup.timeManager, Setup.mesh
+    mpasio.write_output(out_fp, mesh.HorzMesh.data, mesh.VertMesh.nVertLevels, period_seconds(clock.timeStep),
+                        (clock.currTime - clock.startTime).total_seconds(), Prog.ssh[-1].get(),
+                        Prog.layerThickness[-1].get(), Prog.normalVelocity[-1].get())
+    return out_fp
 
 
 def ocn_init_alarms(Setup: ModelSetup):
     """ocn_init_alarms (init.jl:111-127): dt := floor(2*(mean dcEdge/1e3)*mean dcEdge/200e3) seconds."""
     dc = Setup.mesh.HorzMesh.data.dcEdge
     dt = math.floor(2 * (float(np.mean(dc)) / 1e3) * float(np.mean(dc)) / 200e3)
-    changeTimeStep(Setup.timeManager, _dt.timedelta(seconds=dt))
+    changeTimeStep(Setup.timeManager, Second(dt))
     clock = Setup.timeManager
     return clock, clock.alarms["simulation_end"], clock.alarms["outputAlarm"]

@@ -447,3 +447,52 @@ def test_full_size_properties(backend):
     assert np.abs(P1.ssh[-1].get() - sshK).max() < 1e-8
     assert np.abs(P1.normalVelocity[-1].get()[:, 0] - uK[:, 0]).max() < 1e-12
     P1._state.close(); S1.mesh.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# the driver end to end: YAML config + MPAS files -> ocn_init -> alarm-driven loop
+# -> write_netcdf, against the oracle replaying the same sequence (src/driver/mpas_ocean.jl:20-53)
+# ------------------------------------------------------------------------------------------------
+def test_driver_from_yaml_and_mpas_files(tmp_path):
+    from moka_hip import driver, mpasio
+    mesh = get_mesh("igw200")
+    ssh, u, h, rest = mg.igw_initial_state(mesh)
+    mesh_fp, out_fp, cfg_fp = tmp_path / "igw_mesh.nc", tmp_path / "output.nc", tmp_path / "config.yml"
+    mpasio.write_mesh(mesh_fp, mesh, restingThickness=np.asarray(rest).reshape(mesh.nCells, 1),
+                      state=(ssh, u.reshape(mesh.nEdges, 1), h.reshape(mesh.nCells, 1)))
+    cfg_fp.write_text(f"""omega:
+  time_management:
+    config_do_restart: false
+    config_restart_timestamp_name: Restart_timestamp
+    config_start_time: 0001-01-01_00:00:00
+    config_stop_time: none
+    config_run_duration: 0000-00-00_02:00:00
+  time_integration:
+    config_dt: 0000-00-00_00:05:00
+    config_number_of_time_levels: 2
+  streams:
+    mesh:
+      filename_template: {mesh_fp}
+    input:
+      filename_template: {mesh_fp}
+    output:
+      filename_template: {out_fp}
+      reference_time: 0001-01-01_00:00:00
+      output_interval: 0000-00-00_01:00:00
+""")
+    assert driver.ocn_run(str(cfg_fp)) == str(out_fp)
+    dts = float(mg.igw_dt(mesh))                    # ocn_init_alarms overrides config_dt (init.jl:118): 400 s at 200 km
+    assert dts == 400.0
+    nsteps = int(2 * 3600 / dts)
+    om = orc.OracleMesh(mesh, 1, resting_thickness_sum=np.asarray(rest).reshape(mesh.nCells, -1).sum(1))
+    st = orc.OracleState(om, ssh, u, h)
+    for _ in range(nsteps):
+        st.step_fe(dts)
+    ds = mpasio.open_dataset(out_fp)
+    try:
+        assert ds.attr("dt") == dts and ds.var("time")[0] == nsteps * dts
+        assert np.array_equal(ds.var("ssh"), st.ssh[1])
+        assert np.array_equal(ds.var("layerThickness")[0], st.h[1][:, 0])
+        assert np.array_equal(ds.var("normalVelocity")[0], st.u[1][:, 0])
+    finally:
+        ds.close()
