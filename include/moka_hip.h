@@ -250,6 +250,23 @@ int  moka_rk4_dist_end(moka_halo *h);
  * 2 = LDS patch-tiled; 9 = tiled, two-burst prefetch; 10 = persistent double-buffered tile; 3 = generic index kernel. */
 int moka_set_kernel_variant(moka_ctx *ctx, int variant);
 
+/* ---- reverse mode of the Forward-Euler loop ----------------------------------------------------------------
+ * The reference gets d sum(ssh^2) / d (initial normalVelocity, layerThickness) from Enzyme over ocn_run_loop
+ * (ext/MPASEnzymeExt.jl, test/enzyme/test_Enzyme_end2end.jl:62-96; on CUDA it yields NaNs there, :183-186).
+ * Here: a tape of the forward values each step's transpose needs, and hand-written transposed kernels in gather
+ * form (no atomics).  Float64 states on whole (unpartitioned) meshes; flags without MOKA_FE_LEVEL1_ONLY unless
+ * nVertLevels = 1.  Usage: tape_create -> n x step_fe_taped -> seed -> sweep -> download. */
+typedef struct moka_tape moka_tape;
+int  moka_tape_create(moka_state *st, int64_t capacity_steps, moka_tape **out);   /* 2*K*nEdges doubles per step */
+void moka_tape_destroy(moka_tape *t);
+int  moka_step_fe_taped(moka_tape *t, double dt, int flags);                        /* records, then moka_step_fe */
+/* lambda := d sum(ssh^2) / d state at the current state (the objective of run_loop.jl:26-45) */
+int  moka_adjoint_seed_sum_sq_ssh(moka_tape *t);
+int  moka_adjoint_sweep(moka_tape *t);                                              /* reverse over (and pop) every recorded step */
+/* field: MOKA_F_SSH, MOKA_F_NORMAL_VELOCITY, MOKA_F_LAYER_THICKNESS (d_Prog of the reference test) or
+ * MOKA_F_LAYER_THICKNESS_EDGE (the carried diagnostic of the reference_compat sequence); caller's numbering */
+int  moka_adjoint_download(moka_tape *t, int field, double *host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1006,4 +1006,206 @@ int moka_rk4_dist_end(moka_halo *h)
     return MOKA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// reverse mode of the Forward-Euler loop.  The reference differentiates
+// ocn_run_loop with Enzyme (ext/MPASEnzymeExt.jl; test/enzyme/test_Enzyme_end2end.jl: d sum(ssh^2) / d initial
+// layerThickness, normalVelocity); here the tape and the transposed kernels are written by hand.
+// ---------------------------------------------------------------------------------------------
+struct moka_tape {
+    moka_state *st = nullptr;
+    int64_t capacity = 0, n = 0;
+    double *uTape = nullptr, *hTape = nullptr;      // capacity x (K, nE): u_n and the hEdge the flux of step n used
+    std::vector<double> dts;
+    std::vector<int> flags;
+    double *lamU[2] = {nullptr, nullptr}, *lamH[2] = {nullptr, nullptr}, *lamS[2] = {nullptr, nullptr}, *lamE[2] = {nullptr, nullptr};
+    double *Enew = nullptr, *csum = nullptr;
+    int cur = 0;                                     // index of the adjoint state that is current
+    bool seeded = false;
+    moka::AdjMesh am{};
+    std::vector<void *> allocs;
+};
+
+static int tape_alloc(moka_tape *t, void **out, size_t bytes)
+{
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, std::max<size_t>(bytes, 16));
+    if (e != hipSuccess)
+        return fail(t->st->ctx, MOKA_ERR_ALLOC, std::string("tape: hipMalloc of ") + std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
+    t->allocs.push_back(d);
+    HIPCHK(t->st->ctx, hipMemsetAsync(d, 0, bytes, t->st->ctx->stream));
+    *out = d;
+    return MOKA_OK;
+}
+
+extern "C++" {
+template <class T>
+static int tape_upload(moka_tape *t, const std::vector<T> &v, const T **out)
+{
+    void *d = nullptr;
+    int rc = tape_alloc(t, &d, v.size() * sizeof(T));
+    if (rc) return rc;
+    if (!v.empty()) HIPCHK(t->st->ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(d);
+    return MOKA_OK;
+}
+}  // extern "C++"
+
+int moka_tape_create(moka_state *st, int64_t capacity_steps, moka_tape **out)
+{
+    if (!st || !out || capacity_steps < 0) return fail(st ? st->ctx : nullptr, MOKA_ERR_ARG, "bad argument");
+    *out = nullptr;
+    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode: Float64 states only");
+    const Plan &p = st->mesh->plan;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    // transposed Coriolis stencil, sources sorted by (caller's edge id, slot): the oracle's summation order
+    const int nE = p.nE, nC = p.nC, ME = p.ME, ME2 = p.ME2;
+    std::vector<std::vector<std::pair<std::pair<int32_t, int32_t>, int32_t>>> lists(nE);   // ((orig src, slot), new src)
+    for (int s = 0; s < nE; ++s)
+        for (int i = 0; i < ME2; ++i) {
+            const int tgt = p.eoe[(size_t)s * ME2 + i];
+            if (tgt >= 0) lists[tgt].push_back({{p.edgeN2O[s], i}, s});
+        }
+    int W = 1;
+    for (auto &l : lists) { std::sort(l.begin(), l.end()); W = std::max(W, (int)l.size()); }
+    std::vector<int32_t> teoe((size_t)nE * W, -1), csgn((size_t)nC * ME, 0);
+    std::vector<double> tw((size_t)nE * W, 0.0), sd((size_t)nE * 2, 0.0);
+    for (int e = 0; e < nE; ++e)
+        for (size_t j = 0; j < lists[e].size(); ++j) {
+            const int s = lists[e][j].second, i = lists[e][j].first.second;
+            teoe[(size_t)e * W + j] = s;
+            tw[(size_t)e * W + j] = p.woe[(size_t)s * ME2 + i];
+        }
+    for (int c = 0; c < nC; ++c)
+        for (int i = 0; i < ME; ++i)
+            if (p.eoc[(size_t)c * ME + i] >= 0) csgn[(size_t)c * ME + i] = p.sdv[(size_t)c * ME + i] < 0.0 ? -1 : 1;
+    for (int e = 0; e < nE; ++e) {
+        const int cc[2] = {p.ehdr[(size_t)e * 4], p.ehdr[(size_t)e * 4 + 1]};
+        if (cc[0] == cc[1]) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode: rank-local (partitioned) meshes are not supported");
+        for (int q = 0; q < 2; ++q) {
+            double sgn = 0.0;
+            for (int i = 0; i < ME; ++i)
+                if (p.eoc[(size_t)cc[q] * ME + i] == e) { sgn = (double)csgn[(size_t)cc[q] * ME + i]; break; }
+            sd[(size_t)e * 2 + q] = p.dvEdge[e] * sgn * p.invArea[cc[q]];
+        }
+    }
+    moka_tape *t = new (std::nothrow) moka_tape();
+    if (!t) return fail(st->ctx, MOKA_ERR_ALLOC, "out of host memory");
+    t->st = st;
+    t->capacity = capacity_steps;
+    const size_t nEK = (size_t)p.K * nE, nCK = (size_t)p.K * nC;
+    int rc = MOKA_OK;
+    auto A = [&](double **q, size_t n) { if (rc == MOKA_OK) { void *d = nullptr; rc = tape_alloc(t, &d, n * sizeof(double)); *q = static_cast<double *>(d); } };
+    A(&t->uTape, nEK * (size_t)capacity_steps); A(&t->hTape, nEK * (size_t)capacity_steps);
+    for (int b = 0; b < 2; ++b) { A(&t->lamU[b], nEK); A(&t->lamH[b], nCK); A(&t->lamS[b], nC); A(&t->lamE[b], nEK); }
+    A(&t->Enew, nEK); A(&t->csum, nE);
+    moka::AdjMesh &am = t->am;
+    am.nC = nC; am.nE = nE; am.K = p.K; am.ME = ME; am.W = W;
+    am.eoc = st->mesh->dev.eoc; am.ehdr = st->mesh->dev.ehdr; am.fEdge = st->mesh->dev.fEdge; am.gInvDc = st->mesh->dev.gInvDc;
+    if (rc == MOKA_OK) rc = tape_upload(t, teoe, &am.teoe);
+    if (rc == MOKA_OK) rc = tape_upload(t, tw, &am.tw);
+    if (rc == MOKA_OK) rc = tape_upload(t, sd, &am.sd);
+    if (rc == MOKA_OK) rc = tape_upload(t, csgn, &am.csgn);
+    if (rc != MOKA_OK) { moka_tape_destroy(t); return rc; }
+    HIPCHK(st->ctx, hipStreamSynchronize(st->ctx->stream));
+    *out = t;
+    return MOKA_OK;
+}
+
+void moka_tape_destroy(moka_tape *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->st->ctx->device);
+    (void)hipStreamSynchronize(t->st->ctx->stream);
+    for (void *q : t->allocs) (void)hipFree(q);
+    delete t;
+}
+
+int moka_step_fe_taped(moka_tape *t, double dt, int flags)
+{
+    if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
+    moka_state *st = t->st;
+    const Plan &p = st->mesh->plan;
+    if (t->n >= t->capacity) return fail(st->ctx, MOKA_ERR_ARG, "tape is full");
+    if ((flags & MOKA_FE_LEVEL1_ONLY) && p.K != 1)
+        return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode: level-1-only stepping is supported for nVertLevels = 1 only");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    int rc = flush_lazy(st, true, true);
+    if (rc) return rc;
+    hipStream_t s = st->ctx->stream;
+    const size_t nEK = (size_t)p.K * p.nE, bytes = nEK * sizeof(double);
+    HIPCHK(st->ctx, hipMemcpyAsync(t->uTape + nEK * t->n, st->lev[1].u, bytes, hipMemcpyDeviceToDevice, s));
+    const bool stale = flags & MOKA_FE_STALE_HEDGE;
+    if (stale) HIPCHK(st->ctx, hipMemcpyAsync(t->hTape + nEK * t->n, st->hEdge[0], bytes, hipMemcpyDeviceToDevice, s));
+    if ((rc = moka_step_fe(st, dt, flags))) return rc;
+    // a refreshed layerThicknessEdge (= interp of the pre-step thickness) is what the flux used: it is Diag's after the step
+    if (!stale) HIPCHK(st->ctx, hipMemcpyAsync(t->hTape + nEK * t->n, st->hEdge[0], bytes, hipMemcpyDeviceToDevice, s));
+    t->dts.push_back(dt);
+    t->flags.push_back(flags);
+    ++t->n;
+    t->seeded = false;
+    return MOKA_OK;
+}
+
+int moka_adjoint_seed_sum_sq_ssh(moka_tape *t)
+{
+    if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
+    moka_state *st = t->st;
+    const Plan &p = st->mesh->plan;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    hipStream_t s = st->ctx->stream;
+    const size_t nEK = (size_t)p.K * p.nE, nCK = (size_t)p.K * p.nC;
+    t->cur = 0;
+    HIPCHK(st->ctx, hipMemsetAsync(t->lamU[0], 0, nEK * sizeof(double), s));
+    HIPCHK(st->ctx, hipMemsetAsync(t->lamH[0], 0, nCK * sizeof(double), s));
+    HIPCHK(st->ctx, hipMemsetAsync(t->lamE[0], 0, nEK * sizeof(double), s));
+    HIPCHK(st->ctx, launch_scale_copy(t->lamS[0], st->lev[1].ssh, 2.0, p.nC, s));      // d sum(ssh^2) = 2 ssh
+    t->seeded = true;
+    return MOKA_OK;
+}
+
+int moka_adjoint_sweep(moka_tape *t)
+{
+    if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
+    moka_state *st = t->st;
+    if (!t->seeded) return fail(st->ctx, MOKA_ERR_ARG, "seed the adjoint first (moka_adjoint_seed_sum_sq_ssh)");
+    const Plan &p = st->mesh->plan;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    hipStream_t s = st->ctx->stream;
+    const size_t nEK = (size_t)p.K * p.nE;
+    while (t->n > 0) {
+        const int64_t i = t->n - 1;
+        const int in = t->cur, o = 1 - t->cur;
+        moka::AdjArgs a{};
+        a.dt = t->dts[i];
+        a.stale = (t->flags[i] & MOKA_FE_STALE_HEDGE) ? 1 : 0;
+        a.u = t->uTape + nEK * i; a.hEuse = t->hTape + nEK * i;
+        a.lamU1 = t->lamU[in]; a.lamH1 = t->lamH[in]; a.lamS1 = t->lamS[in]; a.lamE1 = t->lamE[in];
+        a.lamU0 = t->lamU[o]; a.lamH0 = t->lamH[o]; a.lamS0 = t->lamS[o];
+        a.Enew = a.stale ? t->lamE[o] : t->Enew;        // stale: u*Fbar IS the adjoint of the carried hEdge
+        a.csum = t->csum;
+        HIPCHK(st->ctx, launch_adj_edge(t->am, a, st->mesh->lpc, s));
+        HIPCHK(st->ctx, launch_adj_cell(t->am, a, st->mesh->lpc, s));
+        if (!a.stale) HIPCHK(st->ctx, hipMemsetAsync(t->lamE[o], 0, nEK * sizeof(double), s));
+        t->cur = o;
+        t->dts.pop_back(); t->flags.pop_back();
+        --t->n;
+    }
+    return MOKA_OK;
+}
+
+int moka_adjoint_download(moka_tape *t, int field, double *host)
+{
+    if (!t || !host) return fail(t ? t->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    moka_state *st = t->st;
+    const Plan &p = st->mesh->plan;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    switch (field) {
+        case MOKA_F_SSH: return get_rows(st->mesh, host, t->lamS[t->cur], MOKA_CELL, p.nC, 1);
+        case MOKA_F_NORMAL_VELOCITY: return get_rows(st->mesh, host, t->lamU[t->cur], MOKA_EDGE, p.nE, p.K);
+        case MOKA_F_LAYER_THICKNESS: return get_rows(st->mesh, host, t->lamH[t->cur], MOKA_CELL, p.nC, p.K);
+        case MOKA_F_LAYER_THICKNESS_EDGE: return get_rows(st->mesh, host, t->lamE[t->cur], MOKA_EDGE, p.nE, p.K);
+        default: return fail(st->ctx, MOKA_ERR_ARG, "adjoint fields: ssh, normalVelocity, layerThickness, layerThicknessEdge");
+    }
+}
+
 }  // extern "C"

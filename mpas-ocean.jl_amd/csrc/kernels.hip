@@ -2810,6 +2810,91 @@ __global__ __launch_bounds__(BLOCK) void k_copy(double *dst, const double *src, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Reverse mode of one Forward-Euler step (reference: Enzyme over ocn_run_loop, ext/MPASEnzymeExt.jl and
+// test/enzyme/test_Enzyme_end2end.jl; here the hand transposition, see oracle_step_fe_adjoint for the algebra).
+// Gather form -- no atomics: an edge gathers the cell adjoints of its two cells and the velocity adjoints of the
+// edges whose Coriolis stencil contains it (transposed lists built at tape creation); a cell gathers from its edges.
+// LPC lanes span a column; every sum runs in the oracle's order, so the results are bit-identical to it.
+// ------------------------------------------------------------------------------------------------
+template <int LPC>
+__global__ __launch_bounds__(BLOCK) void k_adj_edge(const AdjMesh m, const AdjArgs a)
+{
+    constexpr int NG = BLOCK / LPC;
+    const int grp = threadIdx.x / LPC, l = threadIdx.x % LPC;
+    const int K = m.K;
+    const int Kc = ((K + LPC - 1) / LPC) * LPC;
+    for (int e = blockIdx.x * NG + grp; e < m.nE; e += gridDim.x * NG) {
+        const int c1 = m.ehdr[(size_t)e * 4], c2 = m.ehdr[(size_t)e * 4 + 1], mlt = m.ehdr[(size_t)e * 4 + 3];
+        const double sd1 = m.sd[(size_t)e * 2], sd2 = m.sd[(size_t)e * 2 + 1];
+        const double fe = m.fEdge[e];
+        const double s1 = a.lamS1[c1], s2 = a.lamS1[c2];
+        double acc = 0.0;
+        bool first = true;
+        for (int k = l; k < Kc; k += LPC) {
+            double tu = 0.0;
+            if (k < K) {
+                const size_t off = (size_t)e * K + k;
+                double Fbar = 0.0;
+                if (k < mlt) {
+                    const double tH1 = a.dt * (a.lamH1[(size_t)c1 * K + k] + s1);
+                    const double tH2 = a.dt * (a.lamH1[(size_t)c2 * K + k] + s2);
+                    Fbar = sd1 * tH1 + sd2 * tH2;
+                }
+                double cor = 0.0;
+                for (int j = 0; j < m.W; ++j) {
+                    const int s = m.teoe[(size_t)e * m.W + j];
+                    if (s < 0 || k >= m.ehdr[(size_t)s * 4 + 3]) continue;
+                    cor += (m.tw[(size_t)e * m.W + j] * fe) * (a.dt * a.lamU1[(size_t)s * K + k]);
+                }
+                const double lu = a.lamU1[off];
+                a.lamU0[off] = (lu + a.hEuse[off] * Fbar) + cor;
+                a.Enew[off] = a.u[off] * Fbar;
+                if (k < mlt) tu = a.dt * lu;
+            }
+            acc = first ? tu : acc + tu;                  // oracle_ksum: lane partial sums, then the butterfly
+            first = false;
+        }
+        const double cs = group_sum<LPC>(acc);
+        if (l == 0) a.csum[e] = cs;
+    }
+}
+
+template <int LPC>
+__global__ __launch_bounds__(BLOCK) void k_adj_cell(const AdjMesh m, const AdjArgs a)
+{
+    constexpr int NG = BLOCK / LPC;
+    const int grp = threadIdx.x / LPC, l = threadIdx.x % LPC;
+    const int K = m.K, ME = m.ME;
+    const double *Eread = a.stale ? a.lamE1 : a.Enew;
+    for (int c = blockIdx.x * NG + grp; c < m.nC; c += gridDim.x * NG) {
+        const int32_t *re = m.eoc + (size_t)c * ME;
+        const double s1 = a.lamS1[c];
+        if (l == 0) {
+            double ls = 0.0;
+            for (int i = 0; i < ME; ++i) {
+                const int e = re[i];
+                if (e < 0) continue;
+                ls += (-(double)m.csgn[(size_t)c * ME + i]) * m.gInvDc[e] * a.csum[e];
+            }
+            a.lamS0[c] = ls;
+        }
+        for (int k = l; k < K; k += LPC) {
+            double acc = 0.0;
+            for (int i = 0; i < ME; ++i) {
+                const int e = re[i];
+                if (e >= 0) acc += Eread[(size_t)e * K + k];
+            }
+            a.lamH0[(size_t)c * K + k] = (a.lamH1[(size_t)c * K + k] + s1) + 0.5 * acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scale_copy(double *dst, const double *src, double f, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = f * src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline int patch_grid(const MeshDev &m) { return 8 * ((m.nPatches + 7) / 8); }
@@ -3286,6 +3371,49 @@ hipError_t launch_copy(double *dst, const double *src, int64_t n, hipStream_t s)
     if (blocks > 65536) blocks = 65536;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_copy, dim3((unsigned)blocks), dim3(BLOCK), 0, s, dst, src, n);
+    return hipGetLastError();
+}
+
+template <int LPC>
+static hipError_t launch_adj_edge_lpc(const AdjMesh &m, const AdjArgs &a, hipStream_t s)
+{
+    const int ng = BLOCK / LPC;
+    int grid = (m.nE + ng - 1) / ng;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL((k_adj_edge<LPC>), dim3(grid), dim3(BLOCK), 0, s, m, a);
+    return hipGetLastError();
+}
+
+template <int LPC>
+static hipError_t launch_adj_cell_lpc(const AdjMesh &m, const AdjArgs &a, hipStream_t s)
+{
+    const int ng = BLOCK / LPC;
+    int grid = (m.nC + ng - 1) / ng;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL((k_adj_cell<LPC>), dim3(grid), dim3(BLOCK), 0, s, m, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s)
+{
+#define CALL(L) launch_adj_edge_lpc<L>(m, a, s)
+    DISPATCH_LPC(lpc, CALL)
+#undef CALL
+}
+
+hipError_t launch_adj_cell(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s)
+{
+#define CALL(L) launch_adj_cell_lpc<L>(m, a, s)
+    DISPATCH_LPC(lpc, CALL)
+#undef CALL
+}
+
+hipError_t launch_scale_copy(double *dst, const double *src, double f, int64_t n, hipStream_t s)
+{
+    int64_t blocks = (n + BLOCK - 1) / BLOCK;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)blocks), dim3(BLOCK), 0, s, dst, src, f, n);
     return hipGetLastError();
 }
 

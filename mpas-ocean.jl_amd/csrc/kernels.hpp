@@ -86,4 +86,27 @@ hipError_t launch_halo_map(double *buf, double *h, double *ssh, double *u, const
                            hipStream_t s);
 hipError_t launch_pack_rows(double *buf, const double *field, const int32_t *rows, int64_t n, int K, int unpack, hipStream_t s);
 
+// ---- reverse mode of one Forward-Euler step: gather form, the oracle's summation order ----
+struct AdjMesh {
+    int32_t nC, nE, K, ME, W;          // W = width of the transposed Coriolis lists
+    const int32_t *eoc;                // (ME, nC) edges of a cell, -1 = none
+    const int32_t *csgn;               // (ME, nC) edgeSignOnCell
+    const int32_t *ehdr;               // (4, nE) c1, c2, -, maxLevelEdgeTop
+    const int32_t *teoe;               // (W, nE) source edges s with edgesOnEdge[i,s] == e, sorted by (original s, i); -1 = none
+    const double *tw;                  // (W, nE) weightsOnEdge[i,s]
+    const double *sd;                  // (2, nE) dvEdge*edgeSign*invArea for c1, c2
+    const double *fEdge, *gInvDc;      // (nE)
+};
+struct AdjArgs {
+    double dt;
+    int stale;                         // MOKA_FE_STALE_HEDGE
+    const double *u, *hEuse;           // forward values of the step (tape)
+    const double *lamU1, *lamH1, *lamS1, *lamE1;
+    double *lamU0, *lamH0, *lamS0;
+    double *Enew, *csum;               // u*Fbar (K, nE); ksum_k dt*lamU1 (nE)
+};
+hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s);
+hipError_t launch_adj_cell(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s);
+hipError_t launch_scale_copy(double *dst, const double *src, double f, int64_t n, hipStream_t s);   // dst = f*src
+
 }  // namespace moka

@@ -27,7 +27,7 @@ __all__ = [
     "computeTendency", "ocn_timestep", "ocn_run_loop", "run_steps", "ocn_init_from_arrays", "ocn_init_alarms",
     "Clock", "OneTimeAlarm", "PeriodicAlarm", "Alarm", "advance", "isRinging", "reset", "stop", "changeTimeStep",
     "attachAlarm", "setCurrentTime", "ocn_setup_clock", "ocn_setup_mesh", "ocn_init", "write_netcdf",
-    "ConfigRead", "ConfigGet", "GlobalConfig", "REFERENCE_COMPAT",
+    "ConfigRead", "ConfigGet", "GlobalConfig", "AdjointTape", "REFERENCE_COMPAT",
 ]
 
 MokaError = L.MokaError
@@ -389,6 +389,48 @@ def ocn_init_from_arrays(mesh_data, ssh, normalVelocity, layerThickness, resting
     Diag = DiagnosticVars(config, mesh, Prog._state)
     Tend = TendencyVars(config, mesh, Prog._state)
     return Setup, Diag, Tend, Prog
+
+
+# ---------------------------------------------------------------------------------------------
+# reverse mode (the reference: Enzyme.autodiff(Reverse, ocn_run_loop, ...), test/enzyme/test_Enzyme_end2end.jl:62-96)
+# ---------------------------------------------------------------------------------------------
+class AdjointTape:
+    """Tape of a Forward-Euler run plus the reverse sweep: d sum(ssh^2) / d initial state, the quantity the reference's
+    end-to-end AD test differentiates.  `d_Prog` of that test = (gradient()["ssh"], ["normalVelocity"], ["layerThickness"])."""
+
+    def __init__(self, Prog: "PrognosticVars", capacity_steps: int):
+        self._state = Prog._state
+        self._ctx = self._state.mesh.backend._h
+        m, K = self._state.mesh.HorzMesh.data, self._state.mesh.VertMesh.nVertLevels
+        self._shapes = {"ssh": (m.nCells,), "normalVelocity": (m.nEdges, K), "layerThickness": (m.nCells, K),
+                        "layerThicknessEdge": (m.nEdges, K)}
+        self._h = C.c_void_p()
+        L.check(L.lib().moka_tape_create(self._state._h, int(capacity_steps), C.byref(self._h)), self._ctx)
+
+    def step(self, timestep, flags: int = REFERENCE_COMPAT):
+        """ocn_timestep(timestep, ..., ForwardEuler) with the step recorded."""
+        dt = float(np.asarray(timestep).reshape(-1)[0])
+        L.check(L.lib().moka_step_fe_taped(self._h, dt, int(flags)), self._ctx)
+
+    def gradient(self) -> dict:
+        """Seeds with d sum(ssh^2) at the current state, sweeps the tape backwards (consuming it) and returns the gradient
+        with respect to the state the tape started from: ssh, normalVelocity, layerThickness (d_Prog) and the carried
+        layerThicknessEdge of the reference_compat sequence."""
+        lib = L.lib()
+        L.check(lib.moka_adjoint_seed_sum_sq_ssh(self._h), self._ctx)
+        L.check(lib.moka_adjoint_sweep(self._h), self._ctx)
+        out = {}
+        for name, fid in (("ssh", L.F_SSH), ("normalVelocity", L.F_NORMAL_VELOCITY), ("layerThickness", L.F_LAYER_THICKNESS),
+                          ("layerThicknessEdge", L.F_LAYER_THICKNESS_EDGE)):
+            a = np.empty(self._shapes[name], dtype=np.float64)
+            L.check(lib.moka_adjoint_download(self._h, fid, L.f64(a)), self._ctx)
+            out[name] = a
+        return out
+
+    def close(self):
+        if self._h:
+            L.lib().moka_tape_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -397,6 +397,82 @@ void oracle_step_rk4_mixed(const oracle_mesh *m, oracle_state *s, double dt, dou
     oracle_round_f32(s->ssh[1], m->nCells);
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Reverse mode of one Forward-Euler step.  The reference obtains it from Enzyme
+ * (ext/MPASEnzymeExt.jl; test/enzyme/test_Enzyme_end2end.jl differentiates sum(ssh^2) after ocn_run_loop with
+ * respect to the initial layerThickness / normalVelocity and checks one entry against central differences); this is
+ * the hand transposition of oracle_step_fe, written in GATHER form with a fixed summation order so that the HIP
+ * kernels can match it bit for bit.  Pinned like the reference's own AD test: against finite differences of the
+ * forward oracle (tests/test_oracle_adjoint.py) -- no independent values exist.
+ *
+ * State of the FE map: (u, h, ssh, hE) with hE = DiagnosticVars.layerThicknessEdge carried between steps when
+ * ORACLE_FE_STALE_HEDGE is set.  Forward, all levels (LEVEL1_ONLY is supported for K = 1 only):
+ *   hEuse = stale ? hE : interp(h);  F = u*hEuse;  tendH = sum_i F*dv*sign/area;  tendU = -g*(ssh2-ssh1)/dc + Coriolis(u)
+ *   u' = u + dt*tendU;  h' = h + dt*tendH;  ssh' = ksum_k h' - rsum;  hE' = interp(h)
+ * Inputs: adjoints after the step (lamU1, lamH1, lamS1, lamE1), the forward u and hEuse of the step.
+ * teoe/tw (tWidth, nEdges): for edge e the j-th (source edge s, weightsOnEdge[i,s]) with edgesOnEdge[i,s] == e,
+ * sorted by (s, i) -- the transpose of the Coriolis stencil; 0 = no entry.
+ * --------------------------------------------------------------------------------------------- */
+static double cell_sign_of_edge(const oracle_mesh *m, int32_t c, int64_t e)
+{
+    for (int i = 1; i <= m->nEdgesOnCell[c - 1]; ++i)
+        if (m->edgesOnCell[IX(i, c, m->maxEdges)] == e) return (double)m->edgeSignOnCell[IX(i, c, m->maxEdges)];
+    return 0.0;
+}
+
+void oracle_step_fe_adjoint(const oracle_mesh *m, const int32_t *teoe, const double *tw, int tWidth, double dt, int flags,
+                            const double *u, const double *hEuse,
+                            const double *lamU1, const double *lamH1, const double *lamS1, const double *lamE1,
+                            double *lamU0, double *lamH0, double *lamS0, double *lamE0, double *Enew, double *csum)
+{
+    const int K = m->nVertLevels;
+    const int stale = (flags & ORACLE_FE_STALE_HEDGE) != 0;
+    PFOR
+    for (int64_t e = 1; e <= m->nEdges; ++e) {
+        const int32_t c1 = m->cellsOnEdge[IX(1, e, 2)], c2 = m->cellsOnEdge[IX(2, e, 2)];
+        const int mlt = m->maxLevelEdgeTop[e - 1];
+        const double sd1 = m->dvEdge[e - 1] * cell_sign_of_edge(m, c1, e) * (1. / m->areaCell[c1 - 1]);
+        const double sd2 = m->dvEdge[e - 1] * cell_sign_of_edge(m, c2, e) * (1. / m->areaCell[c2 - 1]);
+        double col[ORACLE_MAX_LEVELS];
+        for (int k = 1; k <= K; ++k) {
+            double Fbar = 0.0;
+            if (k <= mlt) {
+                const double tH1 = dt * (lamH1[IX(k, c1, K)] + lamS1[c1 - 1]);
+                const double tH2 = dt * (lamH1[IX(k, c2, K)] + lamS1[c2 - 1]);
+                Fbar = sd1 * tH1 + sd2 * tH2;
+            }
+            double cor = 0.0;
+            for (int j = 1; j <= tWidth; ++j) {
+                const int32_t s = teoe[IX(j, e, tWidth)];
+                if (s == 0 || k > m->maxLevelEdgeTop[s - 1]) continue;
+                cor += (tw[IX(j, e, tWidth)] * m->fEdge[e - 1]) * (dt * lamU1[IX(k, s, K)]);
+            }
+            lamU0[IX(k, e, K)] = (lamU1[IX(k, e, K)] + hEuse[IX(k, e, K)] * Fbar) + cor;
+            Enew[IX(k, e, K)] = u[IX(k, e, K)] * Fbar;
+            col[k - 1] = k <= mlt ? dt * lamU1[IX(k, e, K)] : 0.0;
+        }
+        csum[e - 1] = oracle_ksum(col, K);
+    }
+    const double *Eread = stale ? lamE1 : Enew;
+    PFOR
+    for (int64_t c = 1; c <= m->nCells; ++c) {
+        double ls = 0.0;
+        for (int i = 1; i <= m->nEdgesOnCell[c - 1]; ++i) {
+            const int32_t e = m->edgesOnCell[IX(i, c, m->maxEdges)];
+            ls += (-(double)m->edgeSignOnCell[IX(i, c, m->maxEdges)]) * (9.80616 * (1. / m->dcEdge[e - 1])) * csum[e - 1];
+        }
+        lamS0[c - 1] = ls;
+        for (int k = 1; k <= K; ++k) {
+            double acc = 0.0;
+            for (int i = 1; i <= m->nEdgesOnCell[c - 1]; ++i)
+                acc += Eread[IX(k, m->edgesOnCell[IX(i, c, m->maxEdges)], K)];
+            lamH0[IX(k, c, K)] = (lamH1[IX(k, c, K)] + lamS1[c - 1]) + 0.5 * acc;
+        }
+    }
+    PFOR
+    for (int64_t i = 0; i < (int64_t)K * m->nEdges; ++i) lamE0[i] = stale ? Enew[i] : 0.0;
+}
+
 /* K15 sumArray (serial, one work-item)                       src/forward/run_loop.jl:47-51
  *   sum = sum + a[j]*a[j] */
 double oracle_sum_sq(const double *a, int64_t n)

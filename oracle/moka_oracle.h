@@ -96,6 +96,13 @@ void oracle_tendencies_mixed(const oracle_mesh *m, double *tendU, double *tendH,
 void oracle_step_rk4_mixed(const oracle_mesh *m, oracle_state *s, double dt, double *work);
 double oracle_sum_sq(const double *a, int64_t n);   /* sumArray, run_loop.jl:47-51 */
 
+/* reverse mode of one Forward-Euler step (gather form, fixed order); see moka_oracle.c */
+#define ORACLE_MAX_LEVELS 512
+void oracle_step_fe_adjoint(const oracle_mesh *m, const int32_t *teoe, const double *tw, int tWidth, double dt, int flags,
+                            const double *u, const double *hEuse,
+                            const double *lamU1, const double *lamH1, const double *lamS1, const double *lamE1,
+                            double *lamU0, double *lamH0, double *lamS0, double *lamE0, double *Enew, double *csum);
+
 #ifdef __cplusplus
 }
 #endif

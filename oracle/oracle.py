@@ -80,6 +80,7 @@ def lib():
         L.oracle_tendencies_mixed.argtypes = [mp] + [_f64p] * 7
         L.oracle_round_f32.argtypes = [_f64p, C.c_int64]
         L.oracle_sum_sq.argtypes = [_f64p, C.c_int64]
+        L.oracle_step_fe_adjoint.argtypes = [mp, _i32p, _f64p, C.c_int, C.c_double, C.c_int] + [_f64p] * 12
         L.oracle_sum_sq.restype = C.c_double
         _lib = L
     return _lib
@@ -221,3 +222,69 @@ def set_threads(n: int):
 def ksum(col):
     col = _c(col, np.float64)
     return lib().oracle_ksum(_p(col), col.size)
+
+
+# ------------------------------------------------------------------------------------------------
+# reverse mode of the Forward-Euler loop (reference: Enzyme over ocn_run_loop,
+# test/enzyme/test_Enzyme_end2end.jl).  Test infrastructure like the rest of this file.
+# ------------------------------------------------------------------------------------------------
+def transpose_coriolis(mesh):
+    """(teoe, tw), both (nEdges, W): for edge e the (source edge s [1-based], weightsOnEdge[i, s]) pairs with
+    edgesOnEdge[i, s] == e, sorted by (s, i); 0 / 0.0 pad.  The transpose of the Coriolis stencil."""
+    eoe = np.asarray(mesh.edgesOnEdge)
+    neoe = np.asarray(mesh.nEdgesOnEdge)
+    w = np.asarray(mesh.weightsOnEdge)
+    nE, M = eoe.shape
+    src = np.repeat(np.arange(1, nE + 1), M)
+    slot = np.tile(np.arange(M), nE)
+    tgt = eoe.reshape(-1)
+    ok = (slot < np.repeat(neoe, M)) & (tgt > 0)
+    src, slot, tgt, ww = src[ok], slot[ok], tgt[ok], w.reshape(-1)[ok]
+    order = np.lexsort((slot, src, tgt))
+    src, tgt, ww = src[order], tgt[order], ww[order]
+    cnt = np.bincount(tgt - 1, minlength=nE)
+    W = int(cnt.max()) if cnt.size else 0
+    start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    pos = np.arange(tgt.size) - start[tgt - 1]
+    teoe = np.zeros((nE, max(W, 1)), dtype=np.int32)
+    tw = np.zeros((nE, max(W, 1)))
+    teoe[tgt - 1, pos] = src
+    tw[tgt - 1, pos] = ww
+    return teoe, tw
+
+
+class OracleAdjoint:
+    """Tape + reverse sweep for Forward-Euler runs of an OracleState (flags without LEVEL1_ONLY unless K == 1)."""
+
+    def __init__(self, st: OracleState):
+        self.st, self.om = st, st.om
+        self.teoe, self.tw = transpose_coriolis(self.om.mesh)
+        self.tape = []
+
+    def step_fe(self, dt, flags=FE_REFERENCE_COMPAT):
+        st, om = self.st, self.om
+        if (flags & FE_LEVEL1_ONLY) and om.K != 1:
+            raise ValueError("adjoint: level-1-only stepping is supported for K = 1 only")
+        u = st.u[1].copy()
+        if flags & FE_STALE_HEDGE:
+            hE = st.hEdge.copy()                               # DiagnosticVars.layerThicknessEdge of the previous step
+        else:
+            hE = np.zeros_like(st.hEdge)
+            lib().oracle_interpolate_cell2edge(om.ref, _p(hE), _p(st.h[1]), om.K)
+        self.tape.append((u, hE, float(dt), int(flags)))
+        st.step_fe(dt, flags)
+
+    def gradient_sum_sq_ssh(self):
+        """d sum(ssh_N^2) / d (ssh_0, u_0, h_0, hEdge_0): the reverse sweep over the tape."""
+        st, om = self.st, self.om
+        m, K = om.mesh, om.K
+        lamS = 2.0 * st.ssh[1]
+        lamU, lamH, lamE = np.zeros((m.nEdges, K)), np.zeros((m.nCells, K)), np.zeros((m.nEdges, K))
+        Enew, csum = np.zeros((m.nEdges, K)), np.zeros(m.nEdges)
+        for u, hE, dt, flags in reversed(self.tape):
+            oU, oH, oS, oE = np.zeros_like(lamU), np.zeros_like(lamH), np.zeros_like(lamS), np.zeros_like(lamE)
+            lib().oracle_step_fe_adjoint(om.ref, _p(self.teoe), _p(self.tw), self.teoe.shape[1], dt, flags, _p(u), _p(hE),
+                                         _p(lamU), _p(lamH), _p(lamS), _p(lamE), _p(oU), _p(oH), _p(oS), _p(oE),
+                                         _p(Enew), _p(csum))
+            lamU, lamH, lamS, lamE = oU, oH, oS, oE
+        return lamS, lamU, lamH, lamE

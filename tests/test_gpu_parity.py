@@ -496,3 +496,91 @@ def test_driver_from_yaml_and_mpas_files(tmp_path):
         assert np.array_equal(ds.var("normalVelocity")[0], st.u[1][:, 0])
     finally:
         ds.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# reverse mode of the Forward-Euler loop: gradients of sum(ssh^2) from the HIP tape +
+# transposed kernels, bit for bit against the oracle's adjoint, whose own pin is finite differences
+# (tests/test_oracle_adjoint.py, the reference's test/enzyme/test_Enzyme_end2end.jl check)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("meshname,K,flags,nsteps", [("igw200", 1, 7, 12), ("igw200", 1, 0, 12), ("ico16", 1, 7, 6), ("ico16", 3, 3, 5),
+                                                       ("ico16", 60, 0, 3), ("ico12f", 5, 1, 4), ("ico16", 70, 3, 2)])
+def test_fe_adjoint_bitwise(backend, meshname, K, flags, nsteps):
+    mesh = get_mesh(meshname)
+    if meshname == "igw200":
+        ssh, u, h, rest = mg.igw_initial_state(mesh)
+        u, h, rest = u.reshape(mesh.nEdges, 1), h.reshape(mesh.nCells, 1), np.asarray(rest).reshape(mesh.nCells, 1)
+        dtv = 400.0
+    else:
+        ssh, u, h, rest = random_state(mesh, K, 31 + K)
+        dtv = 20.0
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    tape = mk.AdjointTape(Prog, nsteps)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    adj = orc.OracleAdjoint(st)
+    for _ in range(nsteps):
+        tape.step(np.array([dtv]), flags)
+        adj.step_fe(dtv, flags)
+    assert np.array_equal(Prog.ssh[-1].get(), st.ssh[1])           # the taped step is the ordinary step
+    with pytest.raises(mk.MokaError):
+        tape.step(dtv, flags)                                      # tape is full
+    g = tape.gradient()
+    gS, gU, gH, gE = adj.gradient_sum_sq_ssh()
+    assert np.array_equal(g["ssh"], gS)
+    assert np.array_equal(g["normalVelocity"], gU)
+    assert np.array_equal(g["layerThickness"], gH)
+    assert np.array_equal(g["layerThicknessEdge"], gE)
+    assert np.abs(gU).max() > 0 and np.abs(gH).max() > 0
+    # the tape is consumed: it can record again, and the state keeps stepping
+    tape.step(dtv, flags)
+    adj2 = orc.OracleAdjoint(st)
+    adj2.step_fe(dtv, flags)
+    g2, o2 = tape.gradient(), adj2.gradient_sum_sq_ssh()
+    assert np.array_equal(g2["normalVelocity"], o2[1]) and np.array_equal(g2["layerThickness"], o2[2])
+    tape.close(); Prog._state.close(); Setup.mesh.close()
+
+
+def test_fe_adjoint_central_difference_through_the_c_abi(backend):
+    """The reference's own check (test_Enzyme_end2end.jl:128-176), on the GPU path: perturb one entry of the initial
+    layerThickness / normalVelocity, rerun, compare (J+ - J-)/dist with the adjoint entry (atol 1e-4 / 1e-2)."""
+    mesh = get_mesh("igw200")
+    ssh, u, h, rest = mg.igw_initial_state(mesh)
+    u, h, rest = u.reshape(mesh.nEdges, 1), h.reshape(mesh.nCells, 1), np.asarray(rest).reshape(mesh.nCells, 1)
+    dtv, nsteps, k = 400.0, 15, 4
+
+    def run(uu, hh, want_grad=False):
+        Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, uu, hh, rest, CONFIG, backend, multilayer=True)
+        tape = mk.AdjointTape(Prog, nsteps)
+        for _ in range(nsteps):
+            tape.step(dtv)
+        tot = L.C.c_double()
+        L.check(L.lib().moka_sum_sq(Prog._state._h, L.F_SSH, 1, L.C.byref(tot)), backend._h)
+        g = tape.gradient() if want_grad else None
+        tape.close(); Prog._state.close(); Setup.mesh.close()
+        return tot.value, g
+
+    _, g = run(u, h, True)
+    for arr, name, atol in ((h, "layerThickness", 1e-4), (u, "normalVelocity", 1e-2)):
+        eps = abs(arr[k, 0]) * 1e-6
+        p, m_ = arr.copy(), arr.copy()
+        p[k, 0] += eps
+        m_[k, 0] -= eps
+        Jp, _ = run(*( (u, p) if arr is h else (p, h) ))
+        Jm, _ = run(*( (u, m_) if arr is h else (m_, h) ))
+        fd = (Jp - Jm) / (p[k, 0] - m_[k, 0])
+        assert abs(fd - g[name][k, 0]) <= atol, (name, fd, g[name][k, 0])
+
+
+def test_adjoint_refuses_what_it_does_not_cover(backend):
+    mesh = get_mesh("ico16")
+    ssh, u, h, rest = random_state(mesh, 4, 2)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    tape = mk.AdjointTape(Prog, 2)
+    with pytest.raises(mk.MokaError):
+        tape.step(10.0, 7)                          # level-1-only stepping with K > 1
+    tape.close(); Prog._state.close(); Setup.mesh.close()
+    S2, D2, T2, P2 = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True, state_bytes=4)
+    with pytest.raises(mk.MokaError):
+        mk.AdjointTape(P2, 2)                       # fp32-storage state
+    P2._state.close(); S2.mesh.close()
