@@ -167,7 +167,8 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(device_index)
         if args.transport.startswith("nccl"):
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            # a wedged exchange should surface within minutes, not after the default 10-minute watchdog
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=dt.timedelta(seconds=300))
         else:
             dist.init_process_group("gloo")
     m, K, sbytes, stretch = (tuple(WORKLOADS[args.workload]) + (8, 1.0))[:4]
