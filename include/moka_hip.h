@@ -260,6 +260,9 @@ typedef struct moka_tape moka_tape;
 int  moka_tape_create(moka_state *st, int64_t capacity_steps, moka_tape **out);   /* 2*K*nEdges doubles per step */
 void moka_tape_destroy(moka_tape *t);
 int  moka_step_fe_taped(moka_tape *t, double dt, int flags);                        /* records, then moka_step_fe */
+/* RK4 (time_integration.jl:61-148): records the four provisional states, 4*K*(nEdges+nCells) doubles per step.
+ * One integrator per tape.  The RK4 map's state is (normalVelocity, layerThickness): the ssh gradient is zero. */
+int  moka_step_rk4_taped(moka_tape *t, double dt);
 /* lambda := d sum(ssh^2) / d state at the current state (the objective of run_loop.jl:26-45) */
 int  moka_adjoint_seed_sum_sq_ssh(moka_tape *t);
 int  moka_adjoint_sweep(moka_tape *t);                                              /* reverse over (and pop) every recorded step */

@@ -1019,6 +1019,10 @@ struct moka_tape {
     std::vector<int> flags;
     double *lamU[2] = {nullptr, nullptr}, *lamH[2] = {nullptr, nullptr}, *lamS[2] = {nullptr, nullptr}, *lamE[2] = {nullptr, nullptr};
     double *Enew = nullptr, *csum = nullptr;
+    // RK4: per step the four provisional states the tendencies were evaluated at; work arrays of the reverse step
+    double *rkU = nullptr, *rkH = nullptr;          // capacity x 4 x (K, nE) / (K, nC), allocated at the first RK4 step
+    double *kbU = nullptr, *kbH = nullptr, *pbU = nullptr, *pbH = nullptr;
+    int kind = -1;                                   // -1 empty, 0 Forward Euler, 1 RK4 (one integrator per tape)
     int cur = 0;                                     // index of the adjoint state that is current
     bool seeded = false;
     moka::AdjMesh am{};
@@ -1128,6 +1132,8 @@ int moka_step_fe_taped(moka_tape *t, double dt, int flags)
     if (t->n >= t->capacity) return fail(st->ctx, MOKA_ERR_ARG, "tape is full");
     if ((flags & MOKA_FE_LEVEL1_ONLY) && p.K != 1)
         return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode: level-1-only stepping is supported for nVertLevels = 1 only");
+    if (t->n > 0 && t->kind != 0) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode: one integrator per tape");
+    t->kind = 0;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     int rc = flush_lazy(st, true, true);
     if (rc) return rc;
@@ -1146,6 +1152,43 @@ int moka_step_fe_taped(moka_tape *t, double dt, int flags)
     return MOKA_OK;
 }
 
+int moka_step_rk4_taped(moka_tape *t, double dt)
+{
+    if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
+    moka_state *st = t->st;
+    const Plan &p = st->mesh->plan;
+    if (t->n >= t->capacity) return fail(st->ctx, MOKA_ERR_ARG, "tape is full");
+    if (t->n > 0 && t->kind != 1) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode: one integrator per tape");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    const size_t nEK = (size_t)p.K * p.nE, nCK = (size_t)p.K * p.nC;
+    int rc = MOKA_OK;
+    if (!t->rkU) {
+        auto A = [&](double **q, size_t n) { if (rc == MOKA_OK) { void *d = nullptr; rc = tape_alloc(t, &d, n * sizeof(double)); *q = static_cast<double *>(d); } };
+        A(&t->rkU, nEK * 4 * (size_t)t->capacity); A(&t->rkH, nCK * 4 * (size_t)t->capacity);
+        A(&t->kbU, nEK); A(&t->kbH, nCK); A(&t->pbU, nEK); A(&t->pbH, nCK);
+        if (rc) return rc;
+    }
+    if ((rc = flush_lazy(st, true, true))) return rc;
+    const double *ssh0 = nullptr;
+    if ((rc = rk4_begin(st, &ssh0))) return rc;
+    hipStream_t s = st->ctx->stream;
+    double *tu = t->rkU + nEK * 4 * t->n, *th = t->rkH + nCK * 4 * t->n;
+    for (int sg = 1; sg <= 4; ++sg) {
+        const StageArgs g = rk4_stage_args(st, sg, dt, ssh0);
+        // the provisional state this stage's tendency is evaluated at
+        HIPCHK(st->ctx, hipMemcpyAsync(tu + nEK * (sg - 1), g.pu, nEK * sizeof(double), hipMemcpyDeviceToDevice, s));
+        HIPCHK(st->ctx, hipMemcpyAsync(th + nCK * (sg - 1), g.ph, nCK * sizeof(double), hipMemcpyDeviceToDevice, s));
+        HIPCHK(st->ctx, run_stage(st, g));
+    }
+    rk4_end(st);
+    t->kind = 1;
+    t->dts.push_back(dt);
+    t->flags.push_back(0);
+    ++t->n;
+    t->seeded = false;
+    return MOKA_OK;
+}
+
 int moka_adjoint_seed_sum_sq_ssh(moka_tape *t)
 {
     if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
@@ -1158,7 +1201,16 @@ int moka_adjoint_seed_sum_sq_ssh(moka_tape *t)
     HIPCHK(st->ctx, hipMemsetAsync(t->lamU[0], 0, nEK * sizeof(double), s));
     HIPCHK(st->ctx, hipMemsetAsync(t->lamH[0], 0, nCK * sizeof(double), s));
     HIPCHK(st->ctx, hipMemsetAsync(t->lamE[0], 0, nEK * sizeof(double), s));
-    HIPCHK(st->ctx, launch_scale_copy(t->lamS[0], st->lev[1].ssh, 2.0, p.nC, s));      // d sum(ssh^2) = 2 ssh
+    if (t->kind == 1) {
+        // RK4: ssh is recomputed from layerThickness inside every tendency, so the objective lives on h: every level gets 2 ssh
+        for (int b = 0; b < 2; ++b) {   // the RK4 sweep never writes the ssh / layerThicknessEdge adjoints: both stay zero
+            HIPCHK(st->ctx, hipMemsetAsync(t->lamS[b], 0, (size_t)p.nC * sizeof(double), s));
+            HIPCHK(st->ctx, hipMemsetAsync(t->lamE[b], 0, nEK * sizeof(double), s));
+        }
+        HIPCHK(st->ctx, launch_bcast_rows(t->lamH[0], st->lev[1].ssh, 2.0, p.nC, p.K, s));
+    } else {
+        HIPCHK(st->ctx, launch_scale_copy(t->lamS[0], st->lev[1].ssh, 2.0, p.nC, s));      // d sum(ssh^2) = 2 ssh
+    }
     t->seeded = true;
     return MOKA_OK;
 }
@@ -1171,7 +1223,39 @@ int moka_adjoint_sweep(moka_tape *t)
     const Plan &p = st->mesh->plan;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     hipStream_t s = st->ctx->stream;
-    const size_t nEK = (size_t)p.K * p.nE;
+    const size_t nEK = (size_t)p.K * p.nE, nCK = (size_t)p.K * p.nC;
+    while (t->n > 0 && t->kind == 1) {
+        // one RK4 step backwards (time_integration.jl:61-148 transposed):
+        //   kb4 = b4*X; Pb = T'(P4)^T kb4; acc = X + Pb;  for s = 3,2,1: kb = b_s*X + a_s*Pb; Pb = T'(P_s)^T kb; acc += Pb;  X = acc
+        const int64_t i = t->n - 1;
+        const double dt = t->dts[i];
+        const double ca[3] = {dt / 2., dt / 2., dt}, cb[4] = {dt / 6., dt / 3., dt / 3., dt / 6.};
+        const int in = t->cur, o = 1 - t->cur;
+        const double *XU = t->lamU[in], *XH = t->lamH[in];
+        double *accU = t->lamU[o], *accH = t->lamH[o];
+        for (int sg = 4; sg >= 1; --sg) {
+            if (sg == 4) {
+                HIPCHK(st->ctx, launch_scale_copy(t->kbU, XU, cb[3], (int64_t)nEK, s));
+                HIPCHK(st->ctx, launch_scale_copy(t->kbH, XH, cb[3], (int64_t)nCK, s));
+            } else {
+                HIPCHK(st->ctx, launch_axpby(t->kbU, cb[sg - 1], XU, ca[sg - 1], t->pbU, (int64_t)nEK, s));
+                HIPCHK(st->ctx, launch_axpby(t->kbH, cb[sg - 1], XH, ca[sg - 1], t->pbH, (int64_t)nCK, s));
+            }
+            moka::AdjArgs a{};
+            a.tt = 1; a.dt = 1.0;
+            a.u = t->rkU + nEK * (4 * i + (sg - 1)); a.h = t->rkH + nCK * (4 * i + (sg - 1));
+            a.lamU1 = t->kbU; a.lamH1 = t->kbH;
+            a.lamU0 = t->pbU; a.lamH0 = t->pbH;
+            a.Enew = t->Enew; a.csum = t->csum;
+            HIPCHK(st->ctx, launch_adj_edge(t->am, a, st->mesh->lpc, s));
+            HIPCHK(st->ctx, launch_adj_cell(t->am, a, st->mesh->lpc, s));
+            HIPCHK(st->ctx, launch_add(accU, sg == 4 ? XU : accU, t->pbU, (int64_t)nEK, s));
+            HIPCHK(st->ctx, launch_add(accH, sg == 4 ? XH : accH, t->pbH, (int64_t)nCK, s));
+        }
+        t->cur = o;
+        t->dts.pop_back(); t->flags.pop_back();
+        --t->n;
+    }
     while (t->n > 0) {
         const int64_t i = t->n - 1;
         const int in = t->cur, o = 1 - t->cur;

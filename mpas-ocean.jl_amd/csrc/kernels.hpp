@@ -100,7 +100,9 @@ struct AdjMesh {
 struct AdjArgs {
     double dt;
     int stale;                         // MOKA_FE_STALE_HEDGE
+    int tt;                            // 1: transpose of the tendency evaluation only (RK4 stages); 0: of a Forward-Euler step
     const double *u, *hEuse;           // forward values of the step (tape)
+    const double *h;                   // tt: layerThickness of the stage (layerThicknessEdge is recomputed from it)
     const double *lamU1, *lamH1, *lamS1, *lamE1;
     double *lamU0, *lamH0, *lamS0;
     double *Enew, *csum;               // u*Fbar (K, nE); ksum_k dt*lamU1 (nE)
@@ -108,5 +110,8 @@ struct AdjArgs {
 hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s);
 hipError_t launch_adj_cell(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s);
 hipError_t launch_scale_copy(double *dst, const double *src, double f, int64_t n, hipStream_t s);   // dst = f*src
+hipError_t launch_axpby(double *dst, double a, const double *x, double b, const double *y, int64_t n, hipStream_t s);
+hipError_t launch_add(double *dst, const double *x, const double *y, int64_t n, hipStream_t s);       // dst = x + y
+hipError_t launch_bcast_rows(double *dst, const double *src, double f, int64_t n, int K, hipStream_t s);   // dst[c][k] = f*src[c]
 
 }  // namespace moka

@@ -407,10 +407,14 @@ class AdjointTape:
         self._h = C.c_void_p()
         L.check(L.lib().moka_tape_create(self._state._h, int(capacity_steps), C.byref(self._h)), self._ctx)
 
-    def step(self, timestep, flags: int = REFERENCE_COMPAT):
-        """ocn_timestep(timestep, ..., ForwardEuler) with the step recorded."""
+    def step(self, timestep, flags: int = REFERENCE_COMPAT, method=None):
+        """ocn_timestep(timestep, ..., ForwardEuler) -- or RungeKutta4 with method=RungeKutta4 -- with the step recorded.
+        One integrator per tape."""
         dt = float(np.asarray(timestep).reshape(-1)[0])
-        L.check(L.lib().moka_step_fe_taped(self._h, dt, int(flags)), self._ctx)
+        if method is RungeKutta4:
+            L.check(L.lib().moka_step_rk4_taped(self._h, dt), self._ctx)
+        else:
+            L.check(L.lib().moka_step_fe_taped(self._h, dt, int(flags)), self._ctx)
 
     def gradient(self) -> dict:
         """Seeds with d sum(ssh^2) at the current state, sweeps the tape backwards (consuming it) and returns the gradient

@@ -75,7 +75,7 @@ EXPORTS = [
     "moka_sum_sq", "moka_set_kernel_variant",
     "moka_ctx_streams", "moka_halo_create", "moka_halo_destroy", "moka_halo_buffer_elems", "moka_halo_pack",
     "moka_halo_unpack", "moka_rk4_dist_begin", "moka_rk4_dist_stage", "moka_rk4_dist_end",
-    "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
+    "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
     "moka_adjoint_download",
 ]
 
@@ -155,6 +155,7 @@ def lib():
     L.moka_tape_destroy.argtypes = [vp]
     L.moka_tape_destroy.restype = None
     L.moka_step_fe_taped.argtypes = [vp, C.c_double, C.c_int]
+    L.moka_step_rk4_taped.argtypes = [vp, C.c_double]
     L.moka_adjoint_seed_sum_sq_ssh.argtypes = [vp]
     L.moka_adjoint_sweep.argtypes = [vp]
     L.moka_adjoint_download.argtypes = [vp, C.c_int, _f64p]

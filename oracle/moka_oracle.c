@@ -473,6 +473,54 @@ void oracle_step_fe_adjoint(const oracle_mesh *m, const int32_t *teoe, const dou
     for (int64_t i = 0; i < (int64_t)K * m->nEdges; ++i) lamE0[i] = stale ? Enew[i] : 0.0;
 }
 
+/* Transpose of the tendency evaluation T(u,h) = (tendU, tendH) of oracle_tendencies_clean at the point (u,h):
+ *   (outU, outH) = T'(u,h)^T (kU, kH)
+ * -- the building block of the RK4 reverse sweep (each stage applies T to a provisional state).  ssh is computed
+ * inside T from h, so its adjoint flows into every level of outH.  Gather form, fixed order, like the FE transpose. */
+void oracle_tendency_transpose(const oracle_mesh *m, const int32_t *teoe, const double *tw, int tWidth,
+                               const double *u, const double *h, const double *kU, const double *kH,
+                               double *outU, double *outH, double *Enew, double *csum)
+{
+    const int K = m->nVertLevels;
+    PFOR
+    for (int64_t e = 1; e <= m->nEdges; ++e) {
+        const int32_t c1 = m->cellsOnEdge[IX(1, e, 2)], c2 = m->cellsOnEdge[IX(2, e, 2)];
+        const int mlt = m->maxLevelEdgeTop[e - 1];
+        const double sd1 = m->dvEdge[e - 1] * cell_sign_of_edge(m, c1, e) * (1. / m->areaCell[c1 - 1]);
+        const double sd2 = m->dvEdge[e - 1] * cell_sign_of_edge(m, c2, e) * (1. / m->areaCell[c2 - 1]);
+        double col[ORACLE_MAX_LEVELS];
+        for (int k = 1; k <= K; ++k) {
+            const double hI = 0.5 * (h[IX(k, c1, K)] + h[IX(k, c2, K)]);
+            double Fbar = 0.0;
+            if (k <= mlt) Fbar = sd1 * kH[IX(k, c1, K)] + sd2 * kH[IX(k, c2, K)];
+            double cor = 0.0;
+            for (int j = 1; j <= tWidth; ++j) {
+                const int32_t s = teoe[IX(j, e, tWidth)];
+                if (s == 0 || k > m->maxLevelEdgeTop[s - 1]) continue;
+                cor += (tw[IX(j, e, tWidth)] * m->fEdge[e - 1]) * kU[IX(k, s, K)];
+            }
+            outU[IX(k, e, K)] = hI * Fbar + cor;
+            Enew[IX(k, e, K)] = u[IX(k, e, K)] * Fbar;
+            col[k - 1] = k <= mlt ? kU[IX(k, e, K)] : 0.0;
+        }
+        csum[e - 1] = oracle_ksum(col, K);
+    }
+    PFOR
+    for (int64_t c = 1; c <= m->nCells; ++c) {
+        double ls = 0.0;
+        for (int i = 1; i <= m->nEdgesOnCell[c - 1]; ++i) {
+            const int32_t e = m->edgesOnCell[IX(i, c, m->maxEdges)];
+            ls += (-(double)m->edgeSignOnCell[IX(i, c, m->maxEdges)]) * (9.80616 * (1. / m->dcEdge[e - 1])) * csum[e - 1];
+        }
+        for (int k = 1; k <= K; ++k) {
+            double acc = 0.0;
+            for (int i = 1; i <= m->nEdgesOnCell[c - 1]; ++i)
+                acc += Enew[IX(k, m->edgesOnCell[IX(i, c, m->maxEdges)], K)];
+            outH[IX(k, c, K)] = 0.5 * acc + ls;
+        }
+    }
+}
+
 /* K15 sumArray (serial, one work-item)                       src/forward/run_loop.jl:47-51
  *   sum = sum + a[j]*a[j] */
 double oracle_sum_sq(const double *a, int64_t n)

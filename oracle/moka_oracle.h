@@ -102,6 +102,10 @@ void oracle_step_fe_adjoint(const oracle_mesh *m, const int32_t *teoe, const dou
                             const double *u, const double *hEuse,
                             const double *lamU1, const double *lamH1, const double *lamS1, const double *lamE1,
                             double *lamU0, double *lamH0, double *lamS0, double *lamE0, double *Enew, double *csum);
+/* (outU, outH) = T'(u,h)^T (kU, kH): transpose of oracle_tendencies_clean, the building block of the RK4 reverse sweep */
+void oracle_tendency_transpose(const oracle_mesh *m, const int32_t *teoe, const double *tw, int tWidth,
+                               const double *u, const double *h, const double *kU, const double *kH,
+                               double *outU, double *outH, double *Enew, double *csum);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,7 @@ def lib():
         L.oracle_round_f32.argtypes = [_f64p, C.c_int64]
         L.oracle_sum_sq.argtypes = [_f64p, C.c_int64]
         L.oracle_step_fe_adjoint.argtypes = [mp, _i32p, _f64p, C.c_int, C.c_double, C.c_int] + [_f64p] * 12
+        L.oracle_tendency_transpose.argtypes = [mp, _i32p, _f64p, C.c_int] + [_f64p] * 8
         L.oracle_sum_sq.restype = C.c_double
         _lib = L
     return _lib
@@ -288,3 +289,59 @@ class OracleAdjoint:
                                          _p(Enew), _p(csum))
             lamU, lamH, lamS, lamE = oU, oH, oS, oE
         return lamS, lamU, lamH, lamE
+
+
+class OracleAdjointRK4:
+    """Tape + reverse sweep for RK4 runs (oracle_step_rk4, time_integration.jl:61-148).  The state of the RK4 map is
+    (u, h): ssh is recomputed from h inside every tendency evaluation.  Per step the tape holds the four provisional
+    states P1..P4 the tendencies were evaluated at; the reverse step is
+        kb4 = b4*X;          Pb4 = T'(P4)^T kb4;   kb3 = b3*X + a3*Pb4;  Pb3 = T'(P3)^T kb3;
+        kb2 = b2*X + a2*Pb3; Pb2 = T'(P2)^T kb2;   kb1 = b1*X + a1*Pb2;  Pb1 = T'(P1)^T kb1;
+        X   = (((X + Pb4) + Pb3) + Pb2) + Pb1."""
+
+    def __init__(self, st: OracleState):
+        self.st, self.om = st, st.om
+        self.teoe, self.tw = transpose_coriolis(self.om.mesh)
+        self.tape = []
+
+    def step_rk4(self, dt):
+        st, om = self.st, self.om
+        K = om.K
+        a = (dt / 2., dt / 2., dt)
+        u0, h0 = st.u[1].copy(), st.h[1].copy()
+        P = [(u0, h0)]
+        pu, ph = u0, h0
+        for s in range(3):                                     # provisional states, exactly as the forward step forms them
+            tu, th, _ = om.tendencies_clean(pu, ph)
+            pu, ph = u0 + a[s] * tu, h0 + a[s] * th
+            P.append((pu, ph))
+        self.tape.append((P, float(dt)))
+        st.step_rk4(dt)
+
+    def _tt(self, u, h, kU, kH):
+        m, K = self.om.mesh, self.om.K
+        oU, oH = np.zeros((m.nEdges, K)), np.zeros((m.nCells, K))
+        En, cs = np.zeros((m.nEdges, K)), np.zeros(m.nEdges)
+        lib().oracle_tendency_transpose(self.om.ref, _p(self.teoe), _p(self.tw), self.teoe.shape[1], _p(_c(u, np.float64)),
+                                        _p(_c(h, np.float64)), _p(_c(kU, np.float64)), _p(_c(kH, np.float64)), _p(oU), _p(oH),
+                                        _p(En), _p(cs))
+        return oU, oH
+
+    def gradient_sum_sq_ssh(self):
+        """d sum(ssh_N^2) / d (u_0, h_0)."""
+        st, om = self.st, self.om
+        m, K = om.mesh, om.K
+        XU = np.zeros((m.nEdges, K))
+        XH = np.repeat((2.0 * st.ssh[1])[:, None], K, axis=1)          # ssh_N = ksum_k h_N - rsum
+        for P, dt in reversed(self.tape):
+            a = (dt / 2., dt / 2., dt)
+            b = (dt / 6., dt / 3., dt / 3., dt / 6.)
+            kU, kH = b[3] * XU, b[3] * XH
+            PU, PH = self._tt(P[3][0], P[3][1], kU, kH)
+            accU, accH = XU + PU, XH + PH
+            for s in (2, 1, 0):
+                kU, kH = b[s] * XU + a[s] * PU, b[s] * XH + a[s] * PH
+                PU, PH = self._tt(P[s][0], P[s][1], kU, kH)
+                accU, accH = accU + PU, accH + PH
+            XU, XH = accU, accH
+        return XU, XH

@@ -584,3 +584,38 @@ def test_adjoint_refuses_what_it_does_not_cover(backend):
     with pytest.raises(mk.MokaError):
         mk.AdjointTape(P2, 2)                       # fp32-storage state
     P2._state.close(); S2.mesh.close()
+
+
+@pytest.mark.parametrize("meshname,K,nsteps", [("igw200", 1, 6), ("ico16", 3, 4), ("ico16", 60, 2), ("ico12f", 5, 3), ("ico16", 70, 2)])
+def test_rk4_adjoint_bitwise(backend, meshname, K, nsteps):
+    mesh = get_mesh(meshname)
+    if meshname == "igw200":
+        ssh, u, h, rest = mg.igw_initial_state(mesh)
+        u, h, rest = u.reshape(mesh.nEdges, 1), h.reshape(mesh.nCells, 1), np.asarray(rest).reshape(mesh.nCells, 1)
+        dtv = 400.0
+    else:
+        ssh, u, h, rest = random_state(mesh, K, 41 + K)
+        dtv = 20.0
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    tape = mk.AdjointTape(Prog, nsteps)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    adj = orc.OracleAdjointRK4(st)
+    for _ in range(nsteps):
+        tape.step(dtv, method=mk.RungeKutta4)
+        adj.step_rk4(dtv)
+    assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.ssh[-1].get(), st.ssh[1])
+    with pytest.raises(mk.MokaError):
+        tape.step(dtv)                                             # one integrator per tape (and it is full)
+    g = tape.gradient()
+    gU, gH = adj.gradient_sum_sq_ssh()
+    assert np.array_equal(g["normalVelocity"], gU)
+    assert np.array_equal(g["layerThickness"], gH)
+    assert not g["ssh"].any() and not g["layerThicknessEdge"].any()
+    assert np.abs(gU).max() > 0 and np.abs(gH).max() > 0
+    # an emptied tape may switch integrator
+    tape.step(dtv, 0)
+    a2 = orc.OracleAdjoint(st)
+    a2.step_fe(dtv, 0)
+    assert np.array_equal(tape.gradient()["layerThickness"], a2.gradient_sum_sq_ssh()[2])
+    tape.close(); Prog._state.close(); Setup.mesh.close()

@@ -93,3 +93,66 @@ def test_transposed_coriolis_stencil_is_the_transpose():
     assert np.array_equal(B, A.T)
     srcs = [list(teoe[e][teoe[e] > 0]) for e in range(nE)]
     assert all(s == sorted(s) for s in srcs)
+
+
+@pytest.mark.parametrize("meshname,K", [("ico", 3), ("planar", 1), ("ico5", 2)])
+def test_rk4_directional_derivative_identity(meshname, K):
+    mesh = {"ico": lambda: mg.icosahedral_mesh(5), "planar": lambda: mg.planar_hex_mesh(10, 8, 50e3, f0=1e-4),
+            "ico5": lambda: mg.icosahedral_mesh(6, flips=5, seed=2)}[meshname]()
+    rng = np.random.default_rng(15 + K)
+    rest = np.full((mesh.nCells, K), 1000.0 / K)
+    h = rest + rng.uniform(-1, 1, (mesh.nCells, K))
+    u = rng.uniform(-1, 1, (mesh.nEdges, K))
+    ssh = h.sum(1) - rest.sum(1)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    dt = 0.5 * float(mesh.dcEdge.min()) / np.sqrt(9.80616 * 1000.0)
+    nsteps = 5
+
+    def J(uu, hh):
+        st = orc.OracleState(om, ssh, uu, hh)
+        for _ in range(nsteps):
+            st.step_rk4(dt)
+        return st.sum_sq_ssh()
+
+    st = orc.OracleState(om, ssh, u, h)
+    adj = orc.OracleAdjointRK4(st)
+    for _ in range(nsteps):
+        adj.step_rk4(dt)
+    ref = orc.OracleState(om, ssh, u, h)
+    for _ in range(nsteps):
+        ref.step_rk4(dt)
+    assert np.array_equal(st.u[1], ref.u[1]) and np.array_equal(st.h[1], ref.h[1])     # taping does not change the run
+    gU, gH = adj.gradient_sum_sq_ssh()
+    for trial in range(3):
+        dU, dH = rng.standard_normal(u.shape), rng.standard_normal(h.shape)
+        lhs = (gU * dU).sum() + (gH * dH).sum()
+        eps = 1e-5
+        fd = (J(u + eps * dU, h + eps * dH) - J(u - eps * dU, h - eps * dH)) / (2 * eps)
+        assert abs(fd - lhs) <= 2e-6 * max(abs(fd), abs(lhs), 1.0), (trial, fd, lhs)
+
+
+def test_rk4_igw_gradient_vs_central_differences():
+    mesh = mg.igw_mesh(200.0)
+    ssh, u, h, rest = mg.igw_initial_state(mesh)
+    u, h = u.reshape(mesh.nEdges, 1), h.reshape(mesh.nCells, 1)
+    om = orc.OracleMesh(mesh, 1, resting_thickness_sum=np.asarray(rest).reshape(mesh.nCells, -1).sum(1))
+    dt, nsteps = 400.0, 10
+    st = orc.OracleState(om, ssh, u, h)
+    adj = orc.OracleAdjointRK4(st)
+    for _ in range(nsteps):
+        adj.step_rk4(dt)
+    gU, gH = adj.gradient_sum_sq_ssh()
+
+    def J(uu, hh):
+        s2 = orc.OracleState(om, ssh, uu, hh)
+        for _ in range(nsteps):
+            s2.step_rk4(dt)
+        return s2.sum_sq_ssh()
+    for k in (4, 999):
+        for arr, g, atol in ((h, gH, 1e-4), (u, gU, 1e-2)):
+            eps = abs(arr[k, 0]) * 1e-6 + 1e-9
+            p, m_ = arr.copy(), arr.copy()
+            p[k, 0] += eps
+            m_[k, 0] -= eps
+            fd = (J(u, p) - J(u, m_)) / (2 * eps) if arr is h else (J(p, h) - J(m_, h)) / (2 * eps)
+            assert abs(fd - g[k, 0]) <= atol + 1e-5 * abs(fd), (k, fd, g[k, 0])
