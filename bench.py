@@ -168,7 +168,18 @@ def main():
         torch.cuda.set_device(device_index)
         if args.transport.startswith("nccl"):
             # a wedged exchange should surface within minutes, not after the default 10-minute watchdog
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=dt.timedelta(seconds=300))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device_index),
+                                        timeout=dt.timedelta(seconds=300))
+                gloo_group = dist.new_group(backend="gloo")     # control messages + last-resort halo transport
+            except Exception as exc:                 # noqa: BLE001  e.g. several ranks on one GPU in a rehearsal
+                log(f"[bench] rank {rank}: RCCL process group unavailable ({str(exc).splitlines()[0]}); host-staged gloo instead")
+                try:
+                    dist.destroy_process_group()
+                except Exception:                    # noqa: BLE001
+                    pass
+                dist.init_process_group("gloo")
+                args.transport = "gloo"
         else:
             dist.init_process_group("gloo")
     m, K, sbytes, stretch = (tuple(WORKLOADS[args.workload]) + (8, 1.0))[:4]
@@ -189,15 +200,28 @@ def main():
                                     state_bytes=sbytes)
         log(f"[bench] rank {rank}: partition + local plan + upload: {time.time() - t0:.1f}s  {model.info()}")
         if args.transport == "nccl":
-            # the overlapped form issues RCCL P2P on the library's comm stream (torch.cuda.ExternalStream); if this
-            # torch build rejects that, fall back to the same P2P on the default stream rather than lose the run
-            try:
-                model.step_rk4()
-                backend.synchronize(); torch.cuda.synchronize()
-            except Exception as exc:             # noqa: BLE001
-                log(f"[bench] rank {rank}: overlapped nccl transport failed ({exc!r}); using nccl-default-stream")
-                model.transport = "nccl-default-stream"
-                args.transport = "nccl-default-stream"
+            # The overlapped form issues RCCL P2P on the library's comm stream (torch.cuda.ExternalStream).  If this torch /
+            # RCCL build rejects that, fall back to the same P2P on the default stream, then to host-staged gloo, rather
+            # than lose the run; the ranks agree on the outcome over the gloo group so nobody is left waiting.
+            for cand in ("nccl", "nccl-default-stream", "gloo"):
+                model.transport = cand
+                ok = 1.0
+                try:
+                    model.step_rk4()
+                    backend.synchronize(); torch.cuda.synchronize()
+                except Exception as exc:             # noqa: BLE001
+                    log(f"[bench] rank {rank}: halo transport {cand} failed: {exc!r}")
+                    ok = 0.0
+                flag = torch.tensor([ok], dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=gloo_group)
+                if float(flag[0]) == 1.0:
+                    break
+            else:
+                raise RuntimeError("no halo transport works on this node")
+            if cand != "nccl":
+                log(f"[bench] rank {rank}: using halo transport {cand}")
+                model.exchange_state()               # a failed attempt may have left halos behind: refresh them
+            args.transport = cand
         step = model.step_rk4
         sync = backend.synchronize
         info = model.info()
@@ -227,7 +251,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed, ev_ms], device="cuda" if args.transport.startswith("nccl") else "cpu", dtype=torch.float64)
+        tt = torch.tensor([elapsed, ev_ms], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(tt[0]), float(tt[1])
     ms_per_step = elapsed / args.steps * 1e3
