@@ -96,6 +96,10 @@ typedef struct moka_mesh_desc {
      * provisional state) with fp64 arithmetic and fp64 tendencies (BASELINE config 5; not a reference feature).
      * It fixes the byte offsets baked into the gather records, so a mesh serves states of one storage type. */
     int32_t stateBytes;
+    /* (opt) only for the optional nonlinear terms (moka_set_nonlinear): MPAS mesh files carry both, the reference
+     * reads neither.  With them verticesOnEdge and cellsOnVertex are required too. */
+    const double *kiteAreasOnVertex;                 /* (vertexDegree, nVertices) */
+    const double *fVertex;                           /* (nVertices)               */
 } moka_mesh_desc;
 
 typedef struct moka_mesh_info {
@@ -249,6 +253,15 @@ int  moka_rk4_dist_end(moka_halo *h);
  * without the row cache; 7 = record-staged 8-byte lanes; 1/4 = column kernel pipelined/plain; 5/6 = 16-byte-lane column;
  * 2 = LDS patch-tiled; 9 = tiled, two-burst prefetch; 10 = persistent double-buffered tile; 3 = generic index kernel. */
 int moka_set_kernel_variant(moka_ctx *ctx, int variant);
+
+/* ---- optional nonlinear terms (extension; NOT in the reference, parity unpinned) ---------------------------------
+ * north_star names potential-vorticity Coriolis over edgesOnEdge, the KE + ssh gradient over cellsOnEdge and vertex
+ * relativeVorticity; the reference has only the linear f*u_perp term (horizontal_advection_and_coriolis.jl:61-73,
+ * SURVEY.md N4).  on = 1 switches moka_tendencies / moka_step_rk4 / moka_run(RK4) of this state to the
+ * vector-invariant TRiSK form (Ringler et al. 2010):  q = (fVertex + zeta)/h_vertex at vertices, averaged to edges;
+ *   tendU = sum_i w[i,e] F[eoe_i] (q_e + q_eoe_i)/2 - g grad(ssh) - grad(KE),  KE = sum_e dc dv u^2 / (4 areaCell).
+ * Default off.  Needs the optional mesh arrays above; Float64 states on whole meshes; no Forward Euler, no tape. */
+int  moka_set_nonlinear(moka_state *st, int on);
 
 /* ---- reverse mode of the Forward-Euler loop ----------------------------------------------------------------
  * The reference gets d sum(ssh^2) / d (initial normalVelocity, layerThickness) from Enzyme over ocn_run_loop

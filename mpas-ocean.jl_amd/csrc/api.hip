@@ -66,6 +66,9 @@ struct moka_state {
     // fp32 storage of the prognostic fields (mesh stateBytes == 4): lev[] / rk[] then point at float arrays
     // (the pointer type stays double* so that one StageArgs block serves both), Diag arrays do not exist.
     bool f32 = false;
+    // optional nonlinear terms (moka_set_nonlinear): scratch of the three preparation passes
+    bool nonlinear = false;
+    double *nlQv = nullptr, *nlQe = nullptr, *nlKe = nullptr;
     std::vector<void *> allocs;
 };
 
@@ -247,6 +250,15 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
     }
     if (dev.nPatches <= 0) return hipSuccess;
     hipStream_t s = st->ctx->stream;
+    if (st->nonlinear) {
+        // vector-invariant form: potential vorticity at vertices -> edges, kinetic energy at cells, thickness flux at edges
+        // (whole mesh: the stencil of the edge pass reaches two cells deep), then the generic stage kernel's nonlinear twin
+        if (pCount >= 0) return hipErrorNotSupported;
+        const NlArgs nl{st->nlQv, st->nlQe, st->nlKe, st->F};
+        hipError_t e = launch_nl_prepare(dev, g.pu, g.ph, nl, m->lpc, s);
+        if (e != hipSuccess) return e;
+        return launch_stage_nl(dev, g, nl, m->lpc, s);
+    }
     if (st->f32) return launch_stage_rec2c_f32(dev, g, s);   // the one fp32-storage kernel (checked at state creation)
     const int v = st->ctx->variant;
     // 0 = auto (rec2c, then rec2, rec, col, generic as the mesh allows); 11 rec2c, 8 rec2, 7 rec, 1 colp, 4 col, 5/6 colx,
@@ -441,6 +453,7 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     UP(ehdr) UP(eoe) UP(woe) UP(gInvDc) UP(dcEdge) UP(dvEdge) UP(fEdge)
     UP(eov) UP(cv) UP(cellN2O) UP(edgeN2O) UP(vertN2O)
     UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(lcOff) UP(leOff) UP(patchRegular) UP(rowStart) UP(rowEdge)
+    if (p.nlOk) { UP(voe) UP(cov) UP(kite) UP(invAreaTri) UP(fVertex) UP(keCoef) UP(invDc) }
 #undef UP
     d.CI = p.CI; d.EI = p.EI;
     m->colOk = p.colOk;
@@ -637,6 +650,7 @@ int moka_advance_time_levels(moka_state *st, int flags)
 int moka_diagnostic_compute(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms: moka_tendencies / RK4 only");
     if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rcl = flush_lazy(st, true, false)) return rcl;
@@ -649,6 +663,7 @@ int moka_diagnostic_compute(moka_state *st, int flags)
 int moka_compute_normal_velocity_tendency(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms: moka_tendencies / RK4 only");
     if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rcl = flush_lazy(st, false, true)) return rcl;
@@ -660,6 +675,7 @@ int moka_compute_normal_velocity_tendency(moka_state *st, int flags)
 int moka_compute_layer_thickness_tendency(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms: moka_tendencies / RK4 only");
     if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rcl = flush_lazy(st, true, true)) return rcl;
@@ -699,6 +715,7 @@ int moka_tendencies(moka_state *st)
 int moka_step_fe(moka_state *st, double dt, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms: moka_tendencies / RK4 only");
     if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rcl = flush_lazy(st, true, true)) return rcl;
@@ -993,6 +1010,7 @@ int moka_rk4_dist_stage(moka_halo *h, int stage, int part)
     if (stage < 1 || stage > 4 || part < 0 || part > 1) return fail(h->st->ctx, MOKA_ERR_ARG, "stage must be 1..4, part 0 or 1");
     moka_state *st = h->st;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms are not available on partitioned meshes");
     const StageArgs g = rk4_stage_args(st, stage, h->dt, h->ssh0);
     const int p0 = part == 0 ? 0 : h->pBoundary, cnt = part == 0 ? h->pBoundary : h->pOwned - h->pBoundary;
     HIPCHK(st->ctx, run_stage(st, g, p0, cnt));
@@ -1003,6 +1021,30 @@ int moka_rk4_dist_end(moka_halo *h)
 {
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
     rk4_end(h->st);
+    return MOKA_OK;
+}
+
+int moka_set_nonlinear(moka_state *st, int on)
+{
+    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    if (!on) { st->nonlinear = false; return MOKA_OK; }
+    const Plan &p = st->mesh->plan;
+    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms: Float64 states only");
+    if (!p.nlOk)
+        return fail(st->ctx, MOKA_ERR_UNSUPPORTED,
+                    "nonlinear terms need kiteAreasOnVertex, fVertex, verticesOnEdge and cellsOnVertex in the mesh descriptor");
+    for (int e = 0; e < p.nE; ++e)
+        if (p.ehdr[(size_t)e * 4] == p.ehdr[(size_t)e * 4 + 1])
+            return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms are not available on partitioned (rank-local) meshes");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    int rc = flush_lazy(st, true, true);
+    if (rc) return rc;
+    if (!st->nlQv) {
+        if ((rc = alloc_field(st, &st->nlQv, (size_t)p.K * p.nV))) return rc;
+        if ((rc = alloc_field(st, &st->nlQe, (size_t)p.K * p.nE))) return rc;
+        if ((rc = alloc_field(st, &st->nlKe, (size_t)p.K * p.nC))) return rc;
+    }
+    st->nonlinear = true;
     return MOKA_OK;
 }
 
@@ -1059,6 +1101,7 @@ int moka_tape_create(moka_state *st, int64_t capacity_steps, moka_tape **out)
     if (!st || !out || capacity_steps < 0) return fail(st ? st->ctx : nullptr, MOKA_ERR_ARG, "bad argument");
     *out = nullptr;
     if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode: Float64 states only");
+    if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode covers the reference's linear terms only");
     const Plan &p = st->mesh->plan;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     // transposed Coriolis stencil, sources sorted by (caller's edge id, slot): the oracle's summation order

@@ -86,6 +86,16 @@ hipError_t launch_halo_map(double *buf, double *h, double *ssh, double *u, const
                            hipStream_t s);
 hipError_t launch_pack_rows(double *buf, const double *field, const int32_t *rows, int64_t n, int K, int unpack, hipStream_t s);
 
+// ---- optional nonlinear terms (not in the reference): scratch arrays of the preparation passes ----
+struct NlArgs {
+    double *qv;     // (K, nV) potential vorticity at vertices
+    double *qe;     // (K, nE) ... averaged to edges
+    double *ke;     // (K, nC) kinetic energy at cells
+    double *F;      // (K, nE) thickness flux u * layerThicknessEdge
+};
+hipError_t launch_nl_prepare(const MeshDev &m, const double *u, const double *h, const NlArgs &nl, int lpc, hipStream_t s);
+hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &nl, int lpc, hipStream_t s);
+
 // ---- reverse mode of one Forward-Euler step: gather form, the oracle's summation order ----
 struct AdjMesh {
     int32_t nC, nE, K, ME, W;          // W = width of the transposed Coriolis lists

@@ -72,6 +72,13 @@ struct Plan {
     // vertices
     std::vector<int32_t> eov;      // nV*VD  edgesOnVertex
     std::vector<double>  cv;       // nV*VD  (dcEdge[e]*(1/areaTriangle[v]))*sign  (Operators.jl:137-146)
+    // optional nonlinear terms (moka_set_nonlinear): present when the mesh brought kiteAreasOnVertex and fVertex
+    bool nlOk = false;
+    std::vector<int32_t> voe;      // nE*2   verticesOnEdge
+    std::vector<int32_t> cov;      // nV*VD  cellsOnVertex
+    std::vector<double>  kite;     // nV*VD  kiteAreasOnVertex
+    std::vector<double>  invAreaTri, fVertex;   // nV
+    std::vector<double>  keCoef, invDc;         // nE  0.25*dcEdge*dvEdge ; 1/dcEdge
 };
 
 int build_plan(const moka_mesh_desc *d, Plan &out);   // returns moka_status
@@ -100,6 +107,9 @@ struct MeshDev {
     const uint32_t *lcOff, *leOff;
     const int32_t *patchRegular;
     int32_t maxRows, maxOwnE, maxOwnC;
+    // optional nonlinear terms (nullptr when the mesh did not bring them)
+    const int32_t *voe, *cov;
+    const double *kite, *invAreaTri, *fVertex, *keCoef, *invDc;
 };
 
 // Dynamic LDS the LDS-tiled stage kernel carves up (same formula on host and device):

@@ -366,6 +366,34 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
             p.cv[IX(j, vn, VD)] = (d->dcEdge[eo] * invA) * (double)d->edgeSignOnVertex[IX(j, vo, ldSV)];
         }
     }
+    // ---- optional nonlinear terms: vertex-side connectivity and metric factors ----
+    p.nlOk = d->kiteAreasOnVertex && d->fVertex && d->verticesOnEdge && d->cellsOnVertex;
+    if (p.nlOk) {
+        p.voe.resize((size_t)nE * 2); p.cov.resize((size_t)nV * VD); p.kite.resize((size_t)nV * VD);
+        p.invAreaTri.resize(nV); p.fVertex.resize(nV); p.keCoef.resize(nE); p.invDc.resize(nE);
+        for (int en = 0; en < nE; ++en) {
+            const int eo = p.edgeN2O[en];
+            for (int q = 0; q < 2; ++q) {
+                const int v = d->verticesOnEdge[2 * (int64_t)eo + q];
+                REQUIRE(v >= 1 && v <= nV, "verticesOnEdge out of range");
+                p.voe[(size_t)en * 2 + q] = p.vertO2N[v - 1];
+            }
+            p.keCoef[en] = 0.25 * d->dcEdge[eo] * d->dvEdge[eo];
+            p.invDc[en] = 1. / d->dcEdge[eo];
+        }
+        for (int vn = 0; vn < nV; ++vn) {
+            const int vo = p.vertN2O[vn];
+            p.invAreaTri[vn] = 1.0 / d->areaTriangle[vo];
+            p.fVertex[vn] = d->fVertex[vo];
+            for (int j = 0; j < VD; ++j) {
+                const int c = d->cellsOnVertex[IX(j, vo, VD)];
+                REQUIRE(c >= 1 && c <= nC, "cellsOnVertex out of range");
+                p.cov[IX(j, vn, VD)] = p.cellO2N[c - 1];
+                p.kite[IX(j, vn, VD)] = d->kiteAreasOnVertex[IX(j, vo, VD)];
+            }
+        }
+    }
+
     // ---- packed byte-offset records of the column kernel ----
     {
         const uint64_t rowB = (uint64_t)p.K * p.stateBytes;

@@ -54,6 +54,7 @@ struct MeshDesc
     ordering::Int32; patch_cells::Int32
     cellClass::Ptr{Int32}          # C_NULL on one GPU; 0/1/2 per local cell in the multi-GPU layer
     stateBytes::Int32              # 0/8 = Float64 state (the reference); 4 = fp32 storage, fp64 arithmetic (RK4 only)
+    kiteAreasOnVertex::Ptr{Float64}; fVertex::Ptr{Float64}   # C_NULL unless the optional nonlinear terms are wanted
 end
 
 struct DeviceMesh{HM,VM}           # what Adapt returns: the host Mesh plus the library handle
@@ -73,7 +74,7 @@ function Adapt.adapt_structure(b::Backend, m::Mesh)
                      pointer(E.cellsOnEdge), pointer(E.verticesOnEdge), pointer(E.nEdgesOnEdge), pointer(E.edgesOnEdge),
                      pointer(E.weightsOnEdge), pointer(E.dvEdge), pointer(E.dcEdge), pointer(E.fᵉ),
                      pointer(D.edgesOnVertex), pointer(D.cellsOnVertex), pointer(D.edgeSignOnVertex), pointer(D.areaTriangle),
-                     pointer(V.maxLevelEdge.Top), pointer(rsum), 0, 0, C_NULL, 0)
+                     pointer(V.maxLevelEdge.Top), pointer(rsum), 0, 0, C_NULL, 0, C_NULL, C_NULL)
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:moka_mesh_create, lib), Cint, (Ptr{Cvoid}, Ref{MeshDesc}, Ref{Ptr{Cvoid}}), b.ctx, d, ref), b.ctx)
         return DeviceMesh(m, ref[], b)

@@ -27,7 +27,7 @@ __all__ = [
     "computeTendency", "ocn_timestep", "ocn_run_loop", "run_steps", "ocn_init_from_arrays", "ocn_init_alarms",
     "Clock", "OneTimeAlarm", "PeriodicAlarm", "Alarm", "advance", "isRinging", "reset", "stop", "changeTimeStep",
     "attachAlarm", "setCurrentTime", "ocn_setup_clock", "ocn_setup_mesh", "ocn_init", "write_netcdf",
-    "ConfigRead", "ConfigGet", "GlobalConfig", "AdjointTape", "REFERENCE_COMPAT",
+    "ConfigRead", "ConfigGet", "GlobalConfig", "AdjointTape", "set_nonlinear", "REFERENCE_COMPAT",
 ]
 
 MokaError = L.MokaError
@@ -389,6 +389,12 @@ def ocn_init_from_arrays(mesh_data, ssh, normalVelocity, layerThickness, resting
     Diag = DiagnosticVars(config, mesh, Prog._state)
     Tend = TendencyVars(config, mesh, Prog._state)
     return Setup, Diag, Tend, Prog
+
+
+def set_nonlinear(Prog: "PrognosticVars", on: bool = True):
+    """Switch the optional nonlinear terms (potential-vorticity Coriolis, kinetic-energy gradient) of this model's
+    tendencies / RK4 steps on or off.  An extension: the reference has only the linear terms; default off."""
+    L.check(L.lib().moka_set_nonlinear(Prog._state._h, 1 if on else 0), Prog._state.mesh.backend._h)
 
 
 # ---------------------------------------------------------------------------------------------

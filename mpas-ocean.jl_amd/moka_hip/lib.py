@@ -45,6 +45,7 @@ class MeshDesc(C.Structure):
         ("ordering", C.c_int32), ("patch_cells", C.c_int32),
         ("cellClass", _i32p),
         ("stateBytes", C.c_int32),
+        ("kiteAreasOnVertex", _f64p), ("fVertex", _f64p),
     ]
 
 
@@ -75,7 +76,7 @@ EXPORTS = [
     "moka_sum_sq", "moka_set_kernel_variant",
     "moka_ctx_streams", "moka_halo_create", "moka_halo_destroy", "moka_halo_buffer_elems", "moka_halo_pack",
     "moka_halo_unpack", "moka_rk4_dist_begin", "moka_rk4_dist_stage", "moka_rk4_dist_end",
-    "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
+    "moka_set_nonlinear", "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
     "moka_adjoint_download",
 ]
 
@@ -151,6 +152,7 @@ def lib():
     L.moka_rk4_dist_begin.argtypes = [vp, C.c_double]
     L.moka_rk4_dist_stage.argtypes = [vp, C.c_int, C.c_int]
     L.moka_rk4_dist_end.argtypes = [vp]
+    L.moka_set_nonlinear.argtypes = [vp, C.c_int]
     L.moka_tape_create.argtypes = [vp, C.c_int64, C.POINTER(vp)]
     L.moka_tape_destroy.argtypes = [vp]
     L.moka_tape_destroy.restype = None
@@ -211,6 +213,10 @@ def make_desc(mesh, K, resting_thickness_sum=None, max_level_edge_top=None, orde
     d.ordering, d.patch_cells = int(ordering), int(patch_cells)
     d.cellClass = i32(A("cellClass", np.int32, cell_class)) if cell_class is not None else None
     d.stateBytes = int(state_bytes)
+    kite = getattr(mesh, "kiteAreasOnVertex", None)          # only the optional nonlinear terms read these two
+    if kite is not None:
+        d.kiteAreasOnVertex = f64(A("kiteAreasOnVertex", np.float64, kite))
+        d.fVertex = f64(A("fVertex", np.float64))
     return d, keep
 
 

@@ -78,6 +78,9 @@ class MeshData:
     sphere_radius: float = 0.0
     is_periodic: bool = True
     meta: dict = field(default_factory=dict)
+    # (nVertices, vertexDegree) area of the kite shared by vertex v and cellsOnVertex[v, j]: MPAS mesh files carry it;
+    # only the optional nonlinear (potential-vorticity) terms read it -- the reference never does
+    kiteAreasOnVertex: np.ndarray | None = None
 
 
 def sign_index_fields(cellsOnEdge, verticesOnEdge, nEdgesOnCell, edgesOnCell, edgesOnVertex,
@@ -220,6 +223,7 @@ def planar_hex_mesh(nx: int, ny: int, dc: float, f0: float = 0.0) -> MeshData:
         edgesOnVertex=edgesOnVertex, cellsOnVertex=(cellsOnVertex0 + 1).astype(I32),
         edgeSignOnVertex=esv, on_sphere=False, is_periodic=True,
         meta={"kind": "planar_hex", "nx": nx, "ny": ny, "dc": dc},
+        kiteAreasOnVertex=np.full((nV, 3), math.sqrt(3.0) / 12.0 * dc * dc),      # a third of the triangle each
     )
 
 
@@ -468,6 +472,14 @@ def icosahedral_mesh(m: int, radius: float = RADIUS_EARTH, omega: float = OMEGA_
         kite = np.where(act, kite, 0.0)
         kiteR[:, i] = kite
         areaCell += kite
+    kiteAreasOnVertex = np.zeros((nV, 3))
+    for i in range(maxEdges):
+        act = i < cnt
+        cc = np.nonzero(act)[0]
+        vv = vertAfter0[cc, i]
+        for j in range(3):
+            hit = cellsOnVertex0[vv, j] == cc
+            kiteAreasOnVertex[vv[hit], j] = kiteR[cc[hit], i] * radius * radius
     kiteR /= areaCell[:, None]
     areaCell *= radius * radius
     assert abs(areaCell.sum() / (4 * np.pi * radius * radius) - 1.0) < (1e-9 if not flips else 1e-2)
@@ -529,7 +541,7 @@ def icosahedral_mesh(m: int, radius: float = RADIUS_EARTH, omega: float = OMEGA_
         fVertex=2 * omega * np.sin(latV), areaTriangle=areaTriangle,
         edgesOnVertex=edgesOnVertex, cellsOnVertex=(cellsOnVertex0 + 1).astype(I32),
         edgeSignOnVertex=esv, on_sphere=True, sphere_radius=radius, is_periodic=True,
-        meta={"kind": "icosahedral", "m": m, "radius": radius},
+        meta={"kind": "icosahedral", "m": m, "radius": radius}, kiteAreasOnVertex=kiteAreasOnVertex,
     )
 
 

@@ -259,7 +259,9 @@ def read_mesh(path) -> MeshData:
             fVertex=_f64(ds, "fVertex", nV, True), areaTriangle=_f64(ds, "areaTriangle", nV), edgesOnVertex=eov,
             cellsOnVertex=_i32(ds, "cellsOnVertex"), edgeSignOnVertex=esv, on_sphere=on_sphere,
             sphere_radius=float(radius) if radius is not None else 0.0, is_periodic=periodic,
-            meta={"source": os.fspath(path)})
+            meta={"source": os.fspath(path)},
+            kiteAreasOnVertex=(np.ascontiguousarray(ds.var("kiteAreasOnVertex"), dtype=np.float64)
+                               if ds.has("kiteAreasOnVertex") else None))
     finally:
         ds.close()
 
@@ -344,6 +346,8 @@ def write_mesh(path, mesh: MeshData, restingThickness=None, state=None):
     _put(f, "weightsOnEdge", "d", ("nEdges", "maxEdges2"), mesh.weightsOnEdge)
     for n in ("edgesOnVertex", "cellsOnVertex"):
         _put(f, n, "i", ("nVertices", "vertexDegree"), getattr(mesh, n))
+    if mesh.kiteAreasOnVertex is not None:
+        _put(f, "kiteAreasOnVertex", "d", ("nVertices", "vertexDegree"), mesh.kiteAreasOnVertex)
     if restingThickness is not None:
         rest = np.asarray(restingThickness, dtype=np.float64).reshape(mesh.nCells, -1)
         K = rest.shape[1]

@@ -521,6 +521,125 @@ void oracle_tendency_transpose(const oracle_mesh *m, const int32_t *teoe, const 
     }
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Nonlinear shallow-water tendencies (SURVEY.md section 8(f) rank 4 / note N4): the vector-invariant TRiSK form of
+ * MPAS-Ocean (Ringler et al. 2010) that north_star names -- potential-vorticity flux over edgesOnEdge, gradient of
+ * kinetic energy + ssh over cellsOnEdge, vertex relativeVorticity.  The REFERENCE HAS NO SUCH TERMS (its Coriolis
+ * term is the linear f*u_perp, horizontal_advection_and_coriolis.jl:61-73; relativeVorticity is computed and never
+ * used), so PARITY IS UNPINNED: this is an optional extension, off by default, pinned only by its own properties
+ * (steady solid-body rotation = Williamson test case 2, linear limit) in tests/test_oracle_nonlinear.py.
+ *   hEdge = 1/2 (h[c1]+h[c2]);  F = u hEdge
+ *   zeta[v] = sum_j dc*invA_v*u*sign;  hv[v] = (sum_j kite[j,v] h[c_j]) invA_v;  q_v = (fVertex + zeta)/hv
+ *   q_e = 1/2 (q_v[v1] + q_v[v2]);  KE[c] = (sum_i (1/4 dc dv) u u) invArea_c
+ *   tendH = as the linear form;  tendU = -g (ssh2-ssh1)/dc - (KE2-KE1)/dc + sum_i w[i,e] F[eoe_i] 1/2 (q_e[e] + q_e[eoe_i])
+ * Extra mesh arrays (1-based, reference conventions): verticesOnEdge (2,nE), cellsOnVertex (VD,nV),
+ * kiteAreasOnVertex (VD,nV), fVertex (nV).
+ * --------------------------------------------------------------------------------------------- */
+void oracle_tendencies_nonlinear(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
+                                 const double *kiteAreasOnVertex, const double *fVertex,
+                                 double *tendU, double *tendH, const double *u, const double *h, double *ssh_out,
+                                 double *hEdge, double *F, double *qv, double *qe, double *ke)
+{
+    const int K = m->nVertLevels, VD = m->vertexDegree;
+    oracle_update_ssh(m, ssh_out, h, K);
+    oracle_interpolate_cell2edge(m, hEdge, h, K);
+    oracle_thickness_flux(m, F, u, hEdge, K);
+    oracle_layer_thickness_tendency(m, tendH, F, K);
+    PFOR
+    for (int64_t v = 1; v <= m->nVertices; ++v) {
+        const double invA = 1.0 / m->areaTriangle[v - 1];
+        for (int k = 1; k <= K; ++k) {
+            double zeta = 0.0, hv = 0.0;
+            for (int j = 1; j <= VD; ++j) {
+                const int32_t e = m->edgesOnVertex[IX(j, v, VD)];
+                zeta += m->dcEdge[e - 1] * invA * u[IX(k, e, K)] * (double)m->edgeSignOnVertex[IX(j, v, m->edgeSignOnVertexLD)];
+                hv += kiteAreasOnVertex[IX(j, v, VD)] * h[IX(k, cellsOnVertex[IX(j, v, VD)], K)];
+            }
+            hv = hv * invA;
+            qv[IX(k, v, K)] = (fVertex[v - 1] + zeta) / hv;
+        }
+    }
+    PFOR
+    for (int64_t e = 1; e <= m->nEdges; ++e) {
+        const int32_t v1 = verticesOnEdge[IX(1, e, 2)], v2 = verticesOnEdge[IX(2, e, 2)];
+        for (int k = 1; k <= K; ++k) qe[IX(k, e, K)] = 0.5 * (qv[IX(k, v1, K)] + qv[IX(k, v2, K)]);
+    }
+    PFOR
+    for (int64_t c = 1; c <= m->nCells; ++c) {
+        const double invA = 1.0 / m->areaCell[c - 1];
+        for (int k = 1; k <= K; ++k) {
+            double acc = 0.0;
+            for (int i = 1; i <= m->nEdgesOnCell[c - 1]; ++i) {
+                const int32_t e = m->edgesOnCell[IX(i, c, m->maxEdges)];
+                acc += (0.25 * m->dcEdge[e - 1] * m->dvEdge[e - 1]) * u[IX(k, e, K)] * u[IX(k, e, K)];
+            }
+            ke[IX(k, c, K)] = acc * invA;
+        }
+    }
+    PFOR
+    for (int64_t e = 1; e <= m->nEdges; ++e) {
+        const int32_t c1 = m->cellsOnEdge[IX(1, e, 2)], c2 = m->cellsOnEdge[IX(2, e, 2)];
+        const double invDc = 1. / m->dcEdge[e - 1];
+        for (int k = 1; k <= K; ++k) {
+            double t = 0.0;
+            if (k <= m->maxLevelEdgeTop[e - 1]) {
+                t -= 9.80616 * invDc * (ssh_out[c2 - 1] - ssh_out[c1 - 1]);
+                t -= invDc * (ke[IX(k, c2, K)] - ke[IX(k, c1, K)]);
+                for (int i = 1; i <= m->nEdgesOnEdge[e - 1]; ++i) {
+                    const int32_t eoe = m->edgesOnEdge[IX(i, e, m->maxEdges2)];
+                    if (eoe == 0) continue;
+                    t += m->weightsOnEdge[IX(i, e, m->maxEdges2)] * F[IX(k, eoe, K)] *
+                         (0.5 * (qe[IX(k, e, K)] + qe[IX(k, eoe, K)]));
+                }
+            }
+            tendU[IX(k, e, K)] = t;
+        }
+    }
+}
+
+/* oracle_step_rk4 with the nonlinear tendencies (no end-of-step diagnostics); work = 2*K*(nE+nC) doubles,
+ * scratch = 4*K*nE + K*nV + K*nC doubles */
+void oracle_step_rk4_nonlinear(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
+                               const double *kiteAreasOnVertex, const double *fVertex, oracle_state *s, double dt,
+                               double *work, double *scratch)
+{
+    const int K = m->nVertLevels;
+    const int64_t nu = (int64_t)K * m->nEdges, nh = (int64_t)K * m->nCells;
+    double *newU = work, *newH = work + nu;
+    double *qe = scratch, *qv = scratch + nu, *ke = qv + (int64_t)K * m->nVertices;
+    const double a[3] = {dt / 2., dt / 2., dt};
+    const double b[4] = {dt / 6., dt / 3., dt / 3., dt / 6.};
+    advance_levels(s->ssh[0], s->ssh[1], m->nCells, 1, 1);
+    advance_levels(s->u[0], s->u[1], m->nEdges, K, K);
+    advance_levels(s->h[0], s->h[1], m->nCells, K, K);
+    memcpy(newU, s->u[1], sizeof(double) * (size_t)nu);
+    memcpy(newH, s->h[1], sizeof(double) * (size_t)nh);
+    for (int st = 0; st < 4; ++st) {
+        oracle_tendencies_nonlinear(m, verticesOnEdge, cellsOnVertex, kiteAreasOnVertex, fVertex, s->tendU, s->tendH,
+                                    s->u[1], s->h[1], s->ssh[1], s->hEdge, s->F, qv, qe, ke);
+        if (st < 3) {
+            const double as = a[st];
+            double *pu = s->u[1], *ph = s->h[1];
+            const double *cu = s->u[0], *ch = s->h[0], *tu = s->tendU, *th = s->tendH;
+            PFOR
+            for (int64_t i = 0; i < nu; ++i) pu[i] = cu[i] + as * tu[i];
+            PFOR
+            for (int64_t i = 0; i < nh; ++i) ph[i] = ch[i] + as * th[i];
+        }
+        {
+            const double bs = b[st];
+            const double *tu = s->tendU, *th = s->tendH;
+            PFOR
+            for (int64_t i = 0; i < nu; ++i) newU[i] = newU[i] + bs * tu[i];
+            PFOR
+            for (int64_t i = 0; i < nh; ++i) newH[i] = newH[i] + bs * th[i];
+        }
+    }
+    memcpy(s->u[1], newU, sizeof(double) * (size_t)nu);
+    memcpy(s->h[1], newH, sizeof(double) * (size_t)nh);
+    oracle_update_ssh(m, s->ssh[1], s->h[1], K);
+}
+
 /* K15 sumArray (serial, one work-item)                       src/forward/run_loop.jl:47-51
  *   sum = sum + a[j]*a[j] */
 double oracle_sum_sq(const double *a, int64_t n)

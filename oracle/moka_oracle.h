@@ -96,6 +96,15 @@ void oracle_tendencies_mixed(const oracle_mesh *m, double *tendU, double *tendH,
 void oracle_step_rk4_mixed(const oracle_mesh *m, oracle_state *s, double dt, double *work);
 double oracle_sum_sq(const double *a, int64_t n);   /* sumArray, run_loop.jl:47-51 */
 
+/* nonlinear (vector-invariant TRiSK) tendencies and RK4 step: an extension, NOT in the reference -- parity unpinned */
+void oracle_tendencies_nonlinear(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
+                                 const double *kiteAreasOnVertex, const double *fVertex,
+                                 double *tendU, double *tendH, const double *u, const double *h, double *ssh_out,
+                                 double *hEdge, double *F, double *qv, double *qe, double *ke);
+void oracle_step_rk4_nonlinear(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
+                               const double *kiteAreasOnVertex, const double *fVertex, oracle_state *s, double dt,
+                               double *work, double *scratch);
+
 /* reverse mode of one Forward-Euler step (gather form, fixed order); see moka_oracle.c */
 #define ORACLE_MAX_LEVELS 512
 void oracle_step_fe_adjoint(const oracle_mesh *m, const int32_t *teoe, const double *tw, int tWidth, double dt, int flags,

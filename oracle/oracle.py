@@ -82,6 +82,8 @@ def lib():
         L.oracle_sum_sq.argtypes = [_f64p, C.c_int64]
         L.oracle_step_fe_adjoint.argtypes = [mp, _i32p, _f64p, C.c_int, C.c_double, C.c_int] + [_f64p] * 12
         L.oracle_tendency_transpose.argtypes = [mp, _i32p, _f64p, C.c_int] + [_f64p] * 8
+        L.oracle_tendencies_nonlinear.argtypes = [mp, _i32p, _i32p, _f64p, _f64p] + [_f64p] * 10
+        L.oracle_step_rk4_nonlinear.argtypes = [mp, _i32p, _i32p, _f64p, _f64p, sp, C.c_double, _f64p, _f64p]
         L.oracle_sum_sq.restype = C.c_double
         _lib = L
     return _lib
@@ -345,3 +347,37 @@ class OracleAdjointRK4:
                 accU, accH = accU + PU, accH + PH
             XU, XH = accU, accH
         return XU, XH
+
+
+class OracleNonlinear:
+    """The optional nonlinear (potential-vorticity + kinetic-energy) tendencies -- an extension that the reference does
+    not have: parity unpinned, pinned by its own properties only."""
+
+    def __init__(self, om: OracleMesh):
+        m = om.mesh
+        if m.kiteAreasOnVertex is None:
+            raise ValueError("the nonlinear terms need kiteAreasOnVertex")
+        self.om = om
+        self.voe = _c(m.verticesOnEdge, np.int32)
+        self.cov = _c(m.cellsOnVertex, np.int32)
+        self.kite = _c(m.kiteAreasOnVertex, np.float64)
+        self.fv = _c(m.fVertex, np.float64)
+
+    def tendencies(self, u, h):
+        m, K = self.om.mesh, self.om.K
+        u, h = _c(u, np.float64).reshape(m.nEdges, K), _c(h, np.float64).reshape(m.nCells, K)
+        tu, th, ssh = np.zeros_like(u), np.zeros_like(h), np.zeros(m.nCells)
+        hE, F, qe = np.zeros_like(u), np.zeros_like(u), np.zeros_like(u)
+        qv, ke = np.zeros((m.nVertices, K)), np.zeros_like(h)
+        lib().oracle_tendencies_nonlinear(self.om.ref, _p(self.voe), _p(self.cov), _p(self.kite), _p(self.fv), _p(tu), _p(th),
+                                          _p(u), _p(h), _p(ssh), _p(hE), _p(F), _p(qv), _p(qe), _p(ke))
+        return tu, th, ssh, {"pv_vertex": qv, "pv_edge": qe, "ke": ke}
+
+    def step_rk4(self, st: OracleState, dt):
+        m, K = self.om.mesh, self.om.K
+        if st._work is None:
+            st._work = np.zeros(2 * K * (m.nEdges + m.nCells) + m.nCells)
+        if getattr(st, "_nl_scratch", None) is None:
+            st._nl_scratch = np.zeros(4 * K * m.nEdges + K * m.nVertices + K * m.nCells)
+        lib().oracle_step_rk4_nonlinear(self.om.ref, _p(self.voe), _p(self.cov), _p(self.kite), _p(self.fv), C.byref(st.c),
+                                        float(dt), _p(st._work), _p(st._nl_scratch))

@@ -14,7 +14,7 @@ from moka_hip import mpasio as io
 MESH_VARS = ["xCell", "yCell", "zCell", "fCell", "areaCell", "nEdgesOnCell", "edgesOnCell", "verticesOnCell",
              "cellsOnCell", "xEdge", "yEdge", "zEdge", "fEdge", "dvEdge", "dcEdge", "angleEdge", "nEdgesOnEdge",
              "cellsOnEdge", "verticesOnEdge", "edgesOnEdge", "weightsOnEdge", "xVertex", "yVertex", "zVertex",
-             "fVertex", "areaTriangle", "edgesOnVertex", "cellsOnVertex"]
+             "fVertex", "areaTriangle", "edgesOnVertex", "cellsOnVertex", "kiteAreasOnVertex"]
 
 
 def same_mesh(a, b):
@@ -61,11 +61,12 @@ def test_missing_coriolis_defaults_to_zero_and_missing_variable_raises(tmp_path,
     mesh = case[0]
     if io.hdf5() is None:
         pytest.skip("no libhdf5 on this machine")
-    arrays = {n: getattr(mesh, n) for n in MESH_VARS if n not in ("fCell", "fEdge", "fVertex")}
+    arrays = {n: getattr(mesh, n) for n in MESH_VARS if n not in ("fCell", "fEdge", "fVertex", "kiteAreasOnVertex")}
     p = tmp_path / "nof.h5"
     io.write_hdf5(p, arrays, {"is_periodic": "YES", "on_a_sphere": "NO"})
     got = io.read_mesh(p)
     assert not got.fEdge.any() and not got.fCell.any() and not got.fVertex.any()    # HorzMesh.jl:177-182,220-225,257-262
+    assert got.kiteAreasOnVertex is None                                            # optional: the reference never reads it
     del arrays["weightsOnEdge"]
     io.write_hdf5(p, arrays, {"is_periodic": "YES"})
     with pytest.raises(io.MpasIOError):
