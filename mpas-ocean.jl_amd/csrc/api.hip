@@ -254,7 +254,7 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
         // vector-invariant form: potential vorticity at vertices -> edges, kinetic energy at cells, thickness flux at edges
         // (whole mesh: the stencil of the edge pass reaches two cells deep), then the generic stage kernel's nonlinear twin
         if (pCount >= 0) return hipErrorNotSupported;
-        const NlArgs nl{st->nlQv, st->nlQe, st->nlKe, st->F};
+        const NlArgs nl{st->nlQv, st->nlQe, st->nlKe};
         hipError_t e = launch_nl_prepare(dev, g.pu, g.ph, nl, m->lpc, s);
         if (e != hipSuccess) return e;
         return launch_stage_nl(dev, g, nl, m->lpc, s);
@@ -1041,7 +1041,7 @@ int moka_set_nonlinear(moka_state *st, int on)
     if (rc) return rc;
     if (!st->nlQv) {
         if ((rc = alloc_field(st, &st->nlQv, (size_t)p.K * p.nV))) return rc;
-        if ((rc = alloc_field(st, &st->nlQe, (size_t)p.K * p.nE))) return rc;
+        if ((rc = alloc_field(st, &st->nlQe, 2 * (size_t)p.K * p.nE))) return rc;   // {F, q_e} pairs
         if ((rc = alloc_field(st, &st->nlKe, (size_t)p.K * p.nC))) return rc;
     }
     st->nonlinear = true;

@@ -2819,15 +2819,15 @@ template <int LPC>
 __global__ __launch_bounds__(BLOCK) void k_nl_vertex(const MeshDev m, const double *u, const double *h, double *qv)
 {
     constexpr int NG = BLOCK / LPC;
-    const int grp = threadIdx.x / LPC, l = threadIdx.x % LPC;
+    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;   // LPC = 64: records come through scalar loads
     const int K = m.K, VD = m.VD;
     for (int v = blockIdx.x * NG + grp; v < m.nV; v += gridDim.x * NG) {
-        const double invA = m.invAreaTri[v], fv = m.fVertex[v];
+        const double invA = cptr(m.invAreaTri)[v], fv = cptr(m.fVertex)[v];
         for (int k = l; k < K; k += LPC) {
             double zeta = 0.0, hv = 0.0;
             for (int j = 0; j < VD; ++j) {
-                zeta += m.cv[(size_t)v * VD + j] * u[(size_t)m.eov[(size_t)v * VD + j] * K + k];    // (dc*invA*sign)*u, sign = +-1
-                hv += m.kite[(size_t)v * VD + j] * h[(size_t)m.cov[(size_t)v * VD + j] * K + k];
+                zeta += cptr(m.cv)[(size_t)v * VD + j] * u[(size_t)cptr(m.eov)[(size_t)v * VD + j] * K + k];   // (dc*invA*sign)*u, sign = +-1
+                hv += cptr(m.kite)[(size_t)v * VD + j] * h[(size_t)cptr(m.cov)[(size_t)v * VD + j] * K + k];
             }
             hv = hv * invA;
             qv[(size_t)v * K + k] = (fv + zeta) / hv;
@@ -2835,20 +2835,22 @@ __global__ __launch_bounds__(BLOCK) void k_nl_vertex(const MeshDev m, const doub
     }
 }
 
+// F and q_e are stored interleaved, (K, nE) pairs {F, q_e}: the stage kernel fetches both of a neighbour edge in one 16-byte load
 template <int LPC>
 __global__ __launch_bounds__(BLOCK) void k_nl_edge(const MeshDev m, const double *u, const double *h, const NlArgs nl)
 {
     constexpr int NG = BLOCK / LPC;
-    const int grp = threadIdx.x / LPC, l = threadIdx.x % LPC;
+    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;
     const int K = m.K;
+    double2 *fq = reinterpret_cast<double2 *>(nl.fq);
     for (int e = blockIdx.x * NG + grp; e < m.nE; e += gridDim.x * NG) {
-        const int c1 = m.ehdr[(size_t)e * 4], c2 = m.ehdr[(size_t)e * 4 + 1];
-        const int v1 = m.voe[(size_t)e * 2], v2 = m.voe[(size_t)e * 2 + 1];
+        const int c1 = cptr(m.ehdr)[(size_t)e * 4], c2 = cptr(m.ehdr)[(size_t)e * 4 + 1];
+        const int v1 = cptr(m.voe)[(size_t)e * 2], v2 = cptr(m.voe)[(size_t)e * 2 + 1];
         for (int k = l; k < K; k += LPC) {
             const size_t off = (size_t)e * K + k;
             const double hE = 0.5 * (h[(size_t)c1 * K + k] + h[(size_t)c2 * K + k]);      // Operators.jl:217
-            nl.F[off] = u[off] * hE;                                                      // DiagnosticVars.jl:165
-            nl.qe[off] = 0.5 * (nl.qv[(size_t)v1 * K + k] + nl.qv[(size_t)v2 * K + k]);
+            fq[off] = make_double2(u[off] * hE,                                           // DiagnosticVars.jl:165
+                                   0.5 * (nl.qv[(size_t)v1 * K + k] + nl.qv[(size_t)v2 * K + k]));
         }
     }
 }
@@ -2857,17 +2859,17 @@ template <int LPC>
 __global__ __launch_bounds__(BLOCK) void k_nl_cell(const MeshDev m, const double *u, double *ke)
 {
     constexpr int NG = BLOCK / LPC;
-    const int grp = threadIdx.x / LPC, l = threadIdx.x % LPC;
+    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;
     const int K = m.K, ME = m.ME;
     for (int c = blockIdx.x * NG + grp; c < m.nC; c += gridDim.x * NG) {
-        const double invA = m.invArea[c];
+        const double invA = cptr(m.invArea)[c];
         for (int k = l; k < K; k += LPC) {
             double acc = 0.0;
             for (int i = 0; i < ME; ++i) {
-                const int e = m.eoc[(size_t)c * ME + i];
+                const int e = cptr(m.eoc)[(size_t)c * ME + i];
                 if (e < 0) continue;
                 const double ue = u[(size_t)e * K + k];
-                acc += m.keCoef[e] * ue * ue;
+                acc += cptr(m.keCoef)[e] * ue * ue;
             }
             ke[(size_t)c * K + k] = acc * invA;
         }
@@ -2879,11 +2881,12 @@ template <int LPC>
 __global__ __launch_bounds__(BLOCK) void k_stage_nl(const MeshDev m, const StageArgs a, const NlArgs nl)
 {
     constexpr int NG = BLOCK / LPC;
-    const int grp = threadIdx.x / LPC, l = threadIdx.x % LPC;
+    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;
     const int K = m.K, ME = m.ME, ME2 = m.ME2;
     const int Kc = ((K + LPC - 1) / LPC) * LPC;
+    const double2 *fq = reinterpret_cast<const double2 *>(nl.fq);
     for (int c = blockIdx.x * NG + grp; c < m.nC; c += gridDim.x * NG) {
-        const double invA = m.invArea[c];
+        const double invA = cptr(m.invArea)[c];
         double sshAcc = 0.0;
         bool first = true;
         for (int k = l; k < Kc; k += LPC) {
@@ -2893,11 +2896,11 @@ __global__ __launch_bounds__(BLOCK) void k_stage_nl(const MeshDev m, const Stage
             if (act) {
                 hc = a.ph[off];
                 for (int i = 0; i < ME; ++i) {
-                    const int e = m.eoc[(size_t)c * ME + i];
-                    if (e < 0 || k >= m.mltc[(size_t)c * ME + i]) continue;
-                    const double hE = 0.5 * (hc + a.ph[(size_t)m.coc[(size_t)c * ME + i] * K + k]);
+                    const int e = cptr(m.eoc)[(size_t)c * ME + i];
+                    if (e < 0 || k >= cptr(m.mltc)[(size_t)c * ME + i]) continue;
+                    const double hE = 0.5 * (hc + a.ph[(size_t)cptr(m.coc)[(size_t)c * ME + i] * K + k]);
                     const double F = a.pu[(size_t)e * K + k] * hE;
-                    t += F * m.sdv[(size_t)c * ME + i] * invA;                          // horizontal_advection.jl:63-64
+                    t += F * cptr(m.sdv)[(size_t)c * ME + i] * invA;                    // horizontal_advection.jl:63-64
                 }
                 if (a.tendH) a.tendH[off] = t;
                 const double hcur = a.ch ? a.ch[off] : hc;
@@ -2917,12 +2920,12 @@ __global__ __launch_bounds__(BLOCK) void k_stage_nl(const MeshDev m, const Stage
         }
         if (a.ssh_out) {
             const double s = group_sum<LPC>(sshAcc);
-            if (l == 0) a.ssh_out[c] = s - m.rsum[c];
+            if (l == 0) a.ssh_out[c] = s - cptr(m.rsum)[c];
         }
     }
     for (int e = blockIdx.x * NG + grp; e < m.nE; e += gridDim.x * NG) {
-        const int c1 = m.ehdr[(size_t)e * 4], c2 = m.ehdr[(size_t)e * 4 + 1], mlt = m.ehdr[(size_t)e * 4 + 3];
-        const double g = m.gInvDc[e], invDc = m.invDc[e];
+        const int c1 = cptr(m.ehdr)[(size_t)e * 4], c2 = cptr(m.ehdr)[(size_t)e * 4 + 1], mlt = cptr(m.ehdr)[(size_t)e * 4 + 3];
+        const double g = cptr(m.gInvDc)[e], invDc = cptr(m.invDc)[e];
         const double ds = a.ssh[c2] - a.ssh[c1];
         for (int k = l; k < K; k += LPC) {
             const size_t off = (size_t)e * K + k;
@@ -2930,11 +2933,12 @@ __global__ __launch_bounds__(BLOCK) void k_stage_nl(const MeshDev m, const Stage
             if (k < mlt) {
                 t -= g * ds;
                 t -= invDc * (nl.ke[(size_t)c2 * K + k] - nl.ke[(size_t)c1 * K + k]);
-                const double qe = nl.qe[off];
+                const double qe = fq[off].y;
                 for (int i = 0; i < ME2; ++i) {
-                    const int x = m.eoe[(size_t)e * ME2 + i];
+                    const int x = cptr(m.eoe)[(size_t)e * ME2 + i];
                     if (x < 0) continue;
-                    t += m.woe[(size_t)e * ME2 + i] * nl.F[(size_t)x * K + k] * (0.5 * (qe + nl.qe[(size_t)x * K + k]));
+                    const double2 n = fq[(size_t)x * K + k];                            // {F, q_e} of the neighbour edge
+                    t += cptr(m.woe)[(size_t)e * ME2 + i] * n.x * (0.5 * (qe + n.y));
                 }
             }
             if (a.tendU) a.tendU[off] = t;
@@ -2959,13 +2963,13 @@ template <int LPC, bool TT>
 __global__ __launch_bounds__(BLOCK) void k_adj_edge(const AdjMesh m, const AdjArgs a)
 {
     constexpr int NG = BLOCK / LPC;
-    const int grp = threadIdx.x / LPC, l = threadIdx.x % LPC;
+    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;
     const int K = m.K;
     const int Kc = ((K + LPC - 1) / LPC) * LPC;
     for (int e = blockIdx.x * NG + grp; e < m.nE; e += gridDim.x * NG) {
-        const int c1 = m.ehdr[(size_t)e * 4], c2 = m.ehdr[(size_t)e * 4 + 1], mlt = m.ehdr[(size_t)e * 4 + 3];
-        const double sd1 = m.sd[(size_t)e * 2], sd2 = m.sd[(size_t)e * 2 + 1];
-        const double fe = m.fEdge[e];
+        const int c1 = cptr(m.ehdr)[(size_t)e * 4], c2 = cptr(m.ehdr)[(size_t)e * 4 + 1], mlt = cptr(m.ehdr)[(size_t)e * 4 + 3];
+        const double sd1 = cptr(m.sd)[(size_t)e * 2], sd2 = cptr(m.sd)[(size_t)e * 2 + 1];
+        const double fe = cptr(m.fEdge)[e];
         double s1 = 0.0, s2 = 0.0;
         if constexpr (!TT) { s1 = a.lamS1[c1]; s2 = a.lamS1[c2]; }
         double acc = 0.0;
@@ -2986,10 +2990,10 @@ __global__ __launch_bounds__(BLOCK) void k_adj_edge(const AdjMesh m, const AdjAr
                 }
                 double cor = 0.0;
                 for (int j = 0; j < m.W; ++j) {
-                    const int s = m.teoe[(size_t)e * m.W + j];
-                    if (s < 0 || k >= m.ehdr[(size_t)s * 4 + 3]) continue;
-                    if constexpr (TT) cor += (m.tw[(size_t)e * m.W + j] * fe) * a.lamU1[(size_t)s * K + k];
-                    else cor += (m.tw[(size_t)e * m.W + j] * fe) * (a.dt * a.lamU1[(size_t)s * K + k]);
+                    const int s = cptr(m.teoe)[(size_t)e * m.W + j];
+                    if (s < 0 || k >= cptr(m.ehdr)[(size_t)s * 4 + 3]) continue;
+                    if constexpr (TT) cor += (cptr(m.tw)[(size_t)e * m.W + j] * fe) * a.lamU1[(size_t)s * K + k];
+                    else cor += (cptr(m.tw)[(size_t)e * m.W + j] * fe) * (a.dt * a.lamU1[(size_t)s * K + k]);
                 }
                 const double lu = a.lamU1[off];
                 if constexpr (TT) {
@@ -3013,16 +3017,16 @@ template <int LPC, bool TT>
 __global__ __launch_bounds__(BLOCK) void k_adj_cell(const AdjMesh m, const AdjArgs a)
 {
     constexpr int NG = BLOCK / LPC;
-    const int grp = threadIdx.x / LPC, l = threadIdx.x % LPC;
+    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;
     const int K = m.K, ME = m.ME;
     const double *Eread = (TT || !a.stale) ? a.Enew : a.lamE1;
     for (int c = blockIdx.x * NG + grp; c < m.nC; c += gridDim.x * NG) {
-        const int32_t *re = m.eoc + (size_t)c * ME;
+        CP<int32_t> re = cptr(m.eoc) + (size_t)c * ME;
         double ls = 0.0;                                  // every lane: TT adds it to each level
         for (int i = 0; i < ME; ++i) {
             const int e = re[i];
             if (e < 0) continue;
-            ls += (-(double)m.csgn[(size_t)c * ME + i]) * m.gInvDc[e] * a.csum[e];
+            ls += (-(double)cptr(m.csgn)[(size_t)c * ME + i]) * cptr(m.gInvDc)[e] * a.csum[e];
         }
         double s1 = 0.0;
         if constexpr (!TT) {
@@ -3552,7 +3556,7 @@ static hipError_t launch_nl_prepare_lpc(const MeshDev &m, const double *u, const
     auto grid = [&](int n) { return dim3((unsigned)std::min(std::max((n + ng - 1) / ng, 1), 65536)); };
     hipLaunchKernelGGL((k_nl_vertex<LPC>), grid(m.nV), dim3(BLOCK), 0, s, m, u, h, nl.qv);
     hipLaunchKernelGGL((k_nl_cell<LPC>), grid(m.nC), dim3(BLOCK), 0, s, m, u, nl.ke);
-    hipLaunchKernelGGL((k_nl_edge<LPC>), grid(m.nE), dim3(BLOCK), 0, s, m, u, h, nl);
+    hipLaunchKernelGGL((k_nl_edge<LPC>), grid(m.nE), dim3(BLOCK), 0, s, m, u, h, nl);   // after k_nl_vertex (same stream)
     return hipGetLastError();
 }
 

@@ -89,9 +89,8 @@ hipError_t launch_pack_rows(double *buf, const double *field, const int32_t *row
 // ---- optional nonlinear terms (not in the reference): scratch arrays of the preparation passes ----
 struct NlArgs {
     double *qv;     // (K, nV) potential vorticity at vertices
-    double *qe;     // (K, nE) ... averaged to edges
+    double *fq;     // (K, nE) pairs {thickness flux u * layerThicknessEdge, potential vorticity averaged to the edge}
     double *ke;     // (K, nC) kinetic energy at cells
-    double *F;      // (K, nE) thickness flux u * layerThicknessEdge
 };
 hipError_t launch_nl_prepare(const MeshDev &m, const double *u, const double *h, const NlArgs &nl, int lpc, hipStream_t s);
 hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &nl, int lpc, hipStream_t s);
