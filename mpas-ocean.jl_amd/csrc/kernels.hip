@@ -2062,8 +2062,8 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
 // ------------------------------------------------------------------------------------------------
 // fp32-state form of rec2c (BASELINE config 5: "fp32 state with fp64 tendency accumulation").
 // ssh / normalVelocity / layerThickness of every time level and RK provisional state are stored as fp32
-// (rows of K*4 bytes); a lane owns FOUR consecutive levels (one 16-byte load), a 32-lane half-wave one
-// entity (K <= 128, K % 4 == 0).  Every load widens to fp64, the arithmetic is that of k_stage_rec2c in the
+// (rows of K*4 bytes); a lane owns FOUR consecutive levels (one 16-byte load), K/4 lanes one entity and a wave
+// 64/(K/4) entities (K <= 128, K % 4 == 0).  Every load widens to fp64, the arithmetic is that of k_stage_rec2c in the
 // same order, stores round to nearest fp32; tendencies (MODE 0) are written as fp64.  The StageArgs pointers
 // of state arrays are float arrays in disguise (the host keeps one argument block for both storage types).
 // The byte-offset records of such a mesh are built for K*4-byte rows (moka_mesh_desc.stateBytes = 4).
@@ -2096,10 +2096,20 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
     const int pl_ = patch_of_block(m.nPatches);
     if (pl_ >= m.nPatches) return;
     const int p = pl_ + m.patchBegin;
-    constexpr int NG = BLOCK / 32;
+    // K/4 lanes carry one entity, so a wave carries 64 / (K/4) of them (3 at K = 80, 4 at K = 60 or 64, 2 at K = 128):
+    // lanes beyond the last whole group idle.  Shuffles address lanes of the own group only.
     const int tid = threadIdx.x;
-    const int grp = tid >> 5, l = tid & 31;
     const int K = m.K, K4 = K >> 2;
+    const int EPW = 64 / K4, NG = (BLOCK / 64) * EPW;
+    const int lane = tid & 63, sub = lane / K4;
+    const int l = lane - sub * K4, gbase = sub * K4;
+    const bool lane_on = sub < EPW;
+    const int grp = lane_on ? (tid >> 6) * EPW + sub : (1 << 28);          // idle lanes never enter the entity loops
+    auto gxor = [&](double v, int sft) -> double {                          // v of lane l^sft of the group, 0 beyond it
+        const int pl = l ^ sft;
+        const double o = __shfl(v, gbase + (pl < K4 ? pl : l), 64);
+        return pl < K4 ? o : 0.0;
+    };
     const uint32_t voff = (uint32_t)l * 16u, rowB = (uint32_t)K * 4u;      // fp32 rows
     const uint32_t voffD = (uint32_t)l * 32u, rowBD = (uint32_t)K * 8u;    // fp64 rows (tendency outputs)
     const RecLds L = rec_carve(smem, m, ME, ME2, maxOwnE, maxOwnC);
@@ -2132,7 +2142,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
     __syncthreads();
 
     const int k0 = 4 * l;
-    const bool act = k0 < K;
+    const bool act = lane_on;
     const lds_bytes_t ubytesL = (lds_bytes_t)ubytes;                    // explicit address spaces: see k_stage_rec2c
     const glb_bytes_t puG = (glb_bytes_t)a.pu;
     const uint32_t ldsU = (uint32_t)(size_t)ubytesL;                    // two-phase gather: see k_stage_rec2c
@@ -2224,8 +2234,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         if constexpr (MODE != 0) {
 #pragma unroll
             for (int sft = 16; sft >= 1; sft >>= 1) {
-                hs = d4{hs.x + __shfl_xor(hs.x, sft, 32), hs.y + __shfl_xor(hs.y, sft, 32),
-                        hs.z + __shfl_xor(hs.z, sft, 32), hs.w + __shfl_xor(hs.w, sft, 32)};
+                hs = d4{hs.x + gxor(hs.x, sft), hs.y + gxor(hs.y, sft), hs.z + gxor(hs.z, sft), hs.w + gxor(hs.w, sft)};
             }
             if (l == 0)                                                                       // :209 (+N3), stored fp32
                 reinterpret_cast<float *>(a.ssh_out)[c] = (float)(((hs.x + hs.z) + (hs.y + hs.w)) - L.rsum[ci]);
@@ -2242,9 +2251,8 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         const int mlt = (int)r[ME2 + 3];
         const double g = L.g[ei];
         const uint32_t own = (uint32_t)e * rowB + voff;
-        double sA = 0.0, sB = 0.0;
-        if (l == 0) sA = (double)sshf[r[ME2]];
-        if (l == 1) sB = (double)sshf[r[ME2 + 1]];
+        double ds0 = 0.0;
+        if (l == 0) ds0 = (double)sshf[r[ME2 + 1]] - (double)sshf[r[ME2]];     // ssh[c2] - ssh[c1], in the group's first lane
         d4 uv[ME2], cur = zero, nin = zero;
         if (act) {
             bool cached[ME2];
@@ -2264,7 +2272,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
 #pragma unroll
             for (int i = 0; i < ME2; ++i) uv[i] = widen4(uf[i]);
         }
-        const double ds = __shfl(sB, 1, 32) - __shfl(sA, 0, 32);       // ssh[c2] - ssh[c1]
+        const double ds = __shfl(ds0, gbase, 64);
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME2) - 1u && mlt >= K)) == 0;   // wave-uniform
         if (act) {
             const bool ax = k0 < mlt, ay = k0 + 1 < mlt, az = k0 + 2 < mlt, aw = k0 + 3 < mlt;
