@@ -13,48 +13,9 @@
 // Arithmetic.  Compiled with -ffp-contract=off and written in the reference's operand order
 // (each expression cites the reference line), so results are bit-identical to the CPU oracle.
 // Memory-bound indirect stencil: no MFMA by design.
-#include <algorithm>
-#include <hip/hip_runtime.h>
-
-#include "kernels.hpp"
+#include "kernels_common.hpp"
 
 namespace moka {
-
-constexpr int BLOCK = 256;
-
-// ------------------------------------------------------------------------------------------------
-// helpers
-// ------------------------------------------------------------------------------------------------
-template <int LPC>
-__device__ __forceinline__ double group_sum(double v)
-{
-    // XOR butterfly over the LPC lanes of a group: the summation order fixed by the oracle
-    // (oracle_ksum).  fp add is commutative, so every lane ends with the same bits.
-#pragma unroll
-    for (int s = LPC / 2; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
-    return v;
-}
-
-// Mesh records and other kernel-invariant data are read through the constant address space: with a
-// wave-uniform address (LPC = 64) the compiler then emits scalar loads (s_load_dwordx4/x8/x16 into SGPRs)
-// instead of 64 identical vector loads, which frees the vector memory pipe and ~50 VGPRs per lane.
-template <class T> using CP = const T __attribute__((address_space(4))) *;
-template <class T> __device__ __forceinline__ CP<T> cptr(const T *p) { return (CP<T>)(uintptr_t)p; }
-
-template <int LPC>
-__device__ __forceinline__ int uniform_if_wave(int x)
-{
-    if constexpr (LPC == 64) return __builtin_amdgcn_readfirstlane(x);
-    else return x;
-}
-
-// blockIdx -> patch: XCD x (= blockIdx % 8 by the observed round-robin dispatch; speed only)
-// walks the contiguous patch range [x*chunk, (x+1)*chunk).
-__device__ __forceinline__ int patch_of_block(int nPatches)
-{
-    const int chunk = (nPatches + 7) >> 3;
-    return (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-}
 
 // experiment (MOKA_DBG 16 / 32): 16 = identity map (consecutive patches on different XCDs); 32 = tiles of 64
 // consecutive patches per XCD, tiles dealt round-robin, so the 8 XCDs sweep memory together
@@ -2819,265 +2780,6 @@ __global__ __launch_bounds__(BLOCK) void k_copy(double *dst, const double *src, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Optional nonlinear terms (moka_set_nonlinear; NOT in the reference, see oracle_tendencies_nonlinear for the
-// algebra and the operand order these kernels reproduce bit for bit).  Generic column kernels: LPC lanes span a
-// column, one entity per lane group.  Three preparation passes over the whole mesh, then the stage kernel.
-// ------------------------------------------------------------------------------------------------
-template <int LPC>
-__global__ __launch_bounds__(BLOCK) void k_nl_vertex(const MeshDev m, const double *u, const double *h, double *qv)
-{
-    constexpr int NG = BLOCK / LPC;
-    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;   // LPC = 64: records come through scalar loads
-    const int K = m.K, VD = m.VD;
-    for (int v = blockIdx.x * NG + grp; v < m.nV; v += gridDim.x * NG) {
-        const double invA = cptr(m.invAreaTri)[v], fv = cptr(m.fVertex)[v];
-        for (int k = l; k < K; k += LPC) {
-            double zeta = 0.0, hv = 0.0;
-            for (int j = 0; j < VD; ++j) {
-                zeta += cptr(m.cv)[(size_t)v * VD + j] * u[(size_t)cptr(m.eov)[(size_t)v * VD + j] * K + k];   // (dc*invA*sign)*u, sign = +-1
-                hv += cptr(m.kite)[(size_t)v * VD + j] * h[(size_t)cptr(m.cov)[(size_t)v * VD + j] * K + k];
-            }
-            hv = hv * invA;
-            qv[(size_t)v * K + k] = (fv + zeta) / hv;
-        }
-    }
-}
-
-// F and q_e are stored interleaved, (K, nE) pairs {F, q_e}: the stage kernel fetches both of a neighbour edge in one 16-byte load
-template <int LPC>
-__global__ __launch_bounds__(BLOCK) void k_nl_edge(const MeshDev m, const double *u, const double *h, const NlArgs nl)
-{
-    constexpr int NG = BLOCK / LPC;
-    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;
-    const int K = m.K;
-    double2 *fq = reinterpret_cast<double2 *>(nl.fq);
-    for (int e = blockIdx.x * NG + grp; e < m.nE; e += gridDim.x * NG) {
-        const int c1 = cptr(m.ehdr)[(size_t)e * 4], c2 = cptr(m.ehdr)[(size_t)e * 4 + 1];
-        const int v1 = cptr(m.voe)[(size_t)e * 2], v2 = cptr(m.voe)[(size_t)e * 2 + 1];
-        for (int k = l; k < K; k += LPC) {
-            const size_t off = (size_t)e * K + k;
-            const double hE = 0.5 * (h[(size_t)c1 * K + k] + h[(size_t)c2 * K + k]);      // Operators.jl:217
-            fq[off] = make_double2(u[off] * hE,                                           // DiagnosticVars.jl:165
-                                   0.5 * (nl.qv[(size_t)v1 * K + k] + nl.qv[(size_t)v2 * K + k]));
-        }
-    }
-}
-
-template <int LPC>
-__global__ __launch_bounds__(BLOCK) void k_nl_cell(const MeshDev m, const double *u, double *ke)
-{
-    constexpr int NG = BLOCK / LPC;
-    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;
-    const int K = m.K, ME = m.ME;
-    for (int c = blockIdx.x * NG + grp; c < m.nC; c += gridDim.x * NG) {
-        const double invA = cptr(m.invArea)[c];
-        for (int k = l; k < K; k += LPC) {
-            double acc = 0.0;
-            for (int i = 0; i < ME; ++i) {
-                const int e = cptr(m.eoc)[(size_t)c * ME + i];
-                if (e < 0) continue;
-                const double ue = u[(size_t)e * K + k];
-                acc += cptr(m.keCoef)[e] * ue * ue;
-            }
-            ke[(size_t)c * K + k] = acc * invA;
-        }
-    }
-}
-
-// the stage kernel with the nonlinear velocity tendency; the thickness part is that of k_stage
-template <int LPC>
-__global__ __launch_bounds__(BLOCK) void k_stage_nl(const MeshDev m, const StageArgs a, const NlArgs nl)
-{
-    constexpr int NG = BLOCK / LPC;
-    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;
-    const int K = m.K, ME = m.ME, ME2 = m.ME2;
-    const int Kc = ((K + LPC - 1) / LPC) * LPC;
-    const double2 *fq = reinterpret_cast<const double2 *>(nl.fq);
-    for (int c = blockIdx.x * NG + grp; c < m.nC; c += gridDim.x * NG) {
-        const double invA = cptr(m.invArea)[c];
-        double sshAcc = 0.0;
-        bool first = true;
-        for (int k = l; k < Kc; k += LPC) {
-            const bool act = k < K;
-            const size_t off = (size_t)c * K + k;
-            double t = 0.0, hc = 0.0, hs = 0.0;
-            if (act) {
-                hc = a.ph[off];
-                for (int i = 0; i < ME; ++i) {
-                    const int e = cptr(m.eoc)[(size_t)c * ME + i];
-                    if (e < 0 || k >= cptr(m.mltc)[(size_t)c * ME + i]) continue;
-                    const double hE = 0.5 * (hc + a.ph[(size_t)cptr(m.coc)[(size_t)c * ME + i] * K + k]);
-                    const double F = a.pu[(size_t)e * K + k] * hE;
-                    t += F * cptr(m.sdv)[(size_t)c * ME + i] * invA;                    // horizontal_advection.jl:63-64
-                }
-                if (a.tendH) a.tendH[off] = t;
-                const double hcur = a.ch ? a.ch[off] : hc;
-                if (a.ph_out) {
-                    const double hp = hcur + a.a * t;
-                    a.ph_out[off] = hp;
-                    hs = hp;
-                }
-                if (a.nh_out) {
-                    const double hn = (a.nh_in ? a.nh_in[off] : hcur) + a.b * t;
-                    a.nh_out[off] = hn;
-                    if (!a.ph_out) hs = hn;
-                }
-            }
-            sshAcc = first ? hs : sshAcc + hs;
-            first = false;
-        }
-        if (a.ssh_out) {
-            const double s = group_sum<LPC>(sshAcc);
-            if (l == 0) a.ssh_out[c] = s - cptr(m.rsum)[c];
-        }
-    }
-    for (int e = blockIdx.x * NG + grp; e < m.nE; e += gridDim.x * NG) {
-        const int c1 = cptr(m.ehdr)[(size_t)e * 4], c2 = cptr(m.ehdr)[(size_t)e * 4 + 1], mlt = cptr(m.ehdr)[(size_t)e * 4 + 3];
-        const double g = cptr(m.gInvDc)[e], invDc = cptr(m.invDc)[e];
-        const double ds = a.ssh[c2] - a.ssh[c1];
-        for (int k = l; k < K; k += LPC) {
-            const size_t off = (size_t)e * K + k;
-            double t = 0.0;
-            if (k < mlt) {
-                t -= g * ds;
-                t -= invDc * (nl.ke[(size_t)c2 * K + k] - nl.ke[(size_t)c1 * K + k]);
-                const double qe = fq[off].y;
-                for (int i = 0; i < ME2; ++i) {
-                    const int x = cptr(m.eoe)[(size_t)e * ME2 + i];
-                    if (x < 0) continue;
-                    const double2 n = fq[(size_t)x * K + k];                            // {F, q_e} of the neighbour edge
-                    t += cptr(m.woe)[(size_t)e * ME2 + i] * n.x * (0.5 * (qe + n.y));
-                }
-            }
-            if (a.tendU) a.tendU[off] = t;
-            const double ucur = a.cu ? a.cu[off] : a.pu[off];
-            if (a.pu_out) a.pu_out[off] = ucur + a.a * t;
-            if (a.nu_out) a.nu_out[off] = (a.nu_in ? a.nu_in[off] : ucur) + a.b * t;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Reverse mode of one Forward-Euler step (reference: Enzyme over ocn_run_loop, ext/MPASEnzymeExt.jl and
-// test/enzyme/test_Enzyme_end2end.jl; here the hand transposition, see oracle_step_fe_adjoint for the algebra).
-// Gather form -- no atomics: an edge gathers the cell adjoints of its two cells and the velocity adjoints of the
-// edges whose Coriolis stencil contains it (transposed lists built at tape creation); a cell gathers from its edges.
-// LPC lanes span a column; every sum runs in the oracle's order, so the results are bit-identical to it.
-// ------------------------------------------------------------------------------------------------
-// TT = false: transpose of one Forward-Euler step (identity parts included, dt folded in, ssh a state variable);
-// TT = true : transpose of the tendency evaluation alone, (outU, outH) = T'(u,h)^T (kU, kH) -- the RK4 building block
-//             (kU = lamU1, kH = lamH1; layerThicknessEdge is recomputed from the stage's h; ssh's adjoint goes into h).
-template <int LPC, bool TT>
-__global__ __launch_bounds__(BLOCK) void k_adj_edge(const AdjMesh m, const AdjArgs a)
-{
-    constexpr int NG = BLOCK / LPC;
-    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;
-    const int K = m.K;
-    const int Kc = ((K + LPC - 1) / LPC) * LPC;
-    for (int e = blockIdx.x * NG + grp; e < m.nE; e += gridDim.x * NG) {
-        const int c1 = cptr(m.ehdr)[(size_t)e * 4], c2 = cptr(m.ehdr)[(size_t)e * 4 + 1], mlt = cptr(m.ehdr)[(size_t)e * 4 + 3];
-        const double sd1 = cptr(m.sd)[(size_t)e * 2], sd2 = cptr(m.sd)[(size_t)e * 2 + 1];
-        const double fe = cptr(m.fEdge)[e];
-        double s1 = 0.0, s2 = 0.0;
-        if constexpr (!TT) { s1 = a.lamS1[c1]; s2 = a.lamS1[c2]; }
-        double acc = 0.0;
-        bool first = true;
-        for (int k = l; k < Kc; k += LPC) {
-            double tu = 0.0;
-            if (k < K) {
-                const size_t off = (size_t)e * K + k;
-                double Fbar = 0.0;
-                if (k < mlt) {
-                    if constexpr (TT) {
-                        Fbar = sd1 * a.lamH1[(size_t)c1 * K + k] + sd2 * a.lamH1[(size_t)c2 * K + k];
-                    } else {
-                        const double tH1 = a.dt * (a.lamH1[(size_t)c1 * K + k] + s1);
-                        const double tH2 = a.dt * (a.lamH1[(size_t)c2 * K + k] + s2);
-                        Fbar = sd1 * tH1 + sd2 * tH2;
-                    }
-                }
-                double cor = 0.0;
-                for (int j = 0; j < m.W; ++j) {
-                    const int s = cptr(m.teoe)[(size_t)e * m.W + j];
-                    if (s < 0 || k >= cptr(m.ehdr)[(size_t)s * 4 + 3]) continue;
-                    if constexpr (TT) cor += (cptr(m.tw)[(size_t)e * m.W + j] * fe) * a.lamU1[(size_t)s * K + k];
-                    else cor += (cptr(m.tw)[(size_t)e * m.W + j] * fe) * (a.dt * a.lamU1[(size_t)s * K + k]);
-                }
-                const double lu = a.lamU1[off];
-                if constexpr (TT) {
-                    const double hI = 0.5 * (a.h[(size_t)c1 * K + k] + a.h[(size_t)c2 * K + k]);    // Operators.jl:217
-                    a.lamU0[off] = hI * Fbar + cor;
-                } else {
-                    a.lamU0[off] = (lu + a.hEuse[off] * Fbar) + cor;
-                }
-                a.Enew[off] = a.u[off] * Fbar;
-                if (k < mlt) tu = TT ? lu : a.dt * lu;
-            }
-            acc = first ? tu : acc + tu;                  // oracle_ksum: lane partial sums, then the butterfly
-            first = false;
-        }
-        const double cs = group_sum<LPC>(acc);
-        if (l == 0) a.csum[e] = cs;
-    }
-}
-
-template <int LPC, bool TT>
-__global__ __launch_bounds__(BLOCK) void k_adj_cell(const AdjMesh m, const AdjArgs a)
-{
-    constexpr int NG = BLOCK / LPC;
-    const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;
-    const int K = m.K, ME = m.ME;
-    const double *Eread = (TT || !a.stale) ? a.Enew : a.lamE1;
-    for (int c = blockIdx.x * NG + grp; c < m.nC; c += gridDim.x * NG) {
-        CP<int32_t> re = cptr(m.eoc) + (size_t)c * ME;
-        double ls = 0.0;                                  // every lane: TT adds it to each level
-        for (int i = 0; i < ME; ++i) {
-            const int e = re[i];
-            if (e < 0) continue;
-            ls += (-(double)cptr(m.csgn)[(size_t)c * ME + i]) * cptr(m.gInvDc)[e] * a.csum[e];
-        }
-        double s1 = 0.0;
-        if constexpr (!TT) {
-            s1 = a.lamS1[c];
-            if (l == 0) a.lamS0[c] = ls;
-        }
-        for (int k = l; k < K; k += LPC) {
-            double acc = 0.0;
-            for (int i = 0; i < ME; ++i) {
-                const int e = re[i];
-                if (e >= 0) acc += Eread[(size_t)e * K + k];
-            }
-            if constexpr (TT) a.lamH0[(size_t)c * K + k] = 0.5 * acc + ls;
-            else a.lamH0[(size_t)c * K + k] = (a.lamH1[(size_t)c * K + k] + s1) + 0.5 * acc;
-        }
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_scale_copy(double *dst, const double *src, double f, int64_t n)
-{
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = f * src[i];
-}
-
-// dst = a*x + b*y (y == nullptr: dst = a*x; a == 1 and x == dst: dst += ... is written as dst = x + y by k_add)
-__global__ __launch_bounds__(BLOCK) void k_axpby(double *dst, double a, const double *x, double b, const double *y, int64_t n)
-{
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
-        dst[i] = a * x[i] + b * y[i];
-}
-
-__global__ __launch_bounds__(BLOCK) void k_add(double *dst, const double *x, const double *y, int64_t n)
-{
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = x[i] + y[i];
-}
-
-// dst[c][k] = f * src[c] for every level k
-__global__ __launch_bounds__(BLOCK) void k_bcast_rows(double *dst, const double *src, double f, int64_t n, int K)
-{
-    const int64_t total = n * K;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) dst[i] = f * src[i / K];
-}
-
-// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline int patch_grid(const MeshDev &m) { return 8 * ((m.nPatches + 7) / 8); }
@@ -3103,17 +2805,6 @@ static hipError_t launch_fe_lpc(const MeshDev &m, const FeArgs &a, hipStream_t s
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-
-#define DISPATCH_LPC(lpc, CALL)                 \
-    switch (lpc) {                              \
-        case 1: return CALL(1);                 \
-        case 2: return CALL(2);                 \
-        case 4: return CALL(4);                 \
-        case 8: return CALL(8);                 \
-        case 16: return CALL(16);               \
-        case 32: return CALL(32);               \
-        default: return CALL(64);               \
-    }
 
 hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream_t s)
 {
@@ -3554,109 +3245,6 @@ hipError_t launch_copy(double *dst, const double *src, int64_t n, hipStream_t s)
     if (blocks > 65536) blocks = 65536;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_copy, dim3((unsigned)blocks), dim3(BLOCK), 0, s, dst, src, n);
-    return hipGetLastError();
-}
-
-template <int LPC>
-static hipError_t launch_nl_prepare_lpc(const MeshDev &m, const double *u, const double *h, const NlArgs &nl, hipStream_t s)
-{
-    const int ng = BLOCK / LPC;
-    auto grid = [&](int n) { return dim3((unsigned)std::min(std::max((n + ng - 1) / ng, 1), 65536)); };
-    hipLaunchKernelGGL((k_nl_vertex<LPC>), grid(m.nV), dim3(BLOCK), 0, s, m, u, h, nl.qv);
-    hipLaunchKernelGGL((k_nl_cell<LPC>), grid(m.nC), dim3(BLOCK), 0, s, m, u, nl.ke);
-    hipLaunchKernelGGL((k_nl_edge<LPC>), grid(m.nE), dim3(BLOCK), 0, s, m, u, h, nl);   // after k_nl_vertex (same stream)
-    return hipGetLastError();
-}
-
-template <int LPC>
-static hipError_t launch_stage_nl_lpc(const MeshDev &m, const StageArgs &a, const NlArgs &nl, hipStream_t s)
-{
-    const int ng = BLOCK / LPC;
-    const int grid = std::min(std::max((std::max(m.nE, m.nC) + ng - 1) / ng, 1), 65536);
-    hipLaunchKernelGGL((k_stage_nl<LPC>), dim3(grid), dim3(BLOCK), 0, s, m, a, nl);
-    return hipGetLastError();
-}
-
-hipError_t launch_nl_prepare(const MeshDev &m, const double *u, const double *h, const NlArgs &nl, int lpc, hipStream_t s)
-{
-#define CALL(L) launch_nl_prepare_lpc<L>(m, u, h, nl, s)
-    DISPATCH_LPC(lpc, CALL)
-#undef CALL
-}
-
-hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &nl, int lpc, hipStream_t s)
-{
-#define CALL(L) launch_stage_nl_lpc<L>(m, a, nl, s)
-    DISPATCH_LPC(lpc, CALL)
-#undef CALL
-}
-
-template <int LPC>
-static hipError_t launch_adj_edge_lpc(const AdjMesh &m, const AdjArgs &a, hipStream_t s)
-{
-    const int ng = BLOCK / LPC;
-    int grid = (m.nE + ng - 1) / ng;
-    if (grid > 65536) grid = 65536;
-    if (a.tt) hipLaunchKernelGGL((k_adj_edge<LPC, true>), dim3(grid), dim3(BLOCK), 0, s, m, a);
-    else hipLaunchKernelGGL((k_adj_edge<LPC, false>), dim3(grid), dim3(BLOCK), 0, s, m, a);
-    return hipGetLastError();
-}
-
-template <int LPC>
-static hipError_t launch_adj_cell_lpc(const AdjMesh &m, const AdjArgs &a, hipStream_t s)
-{
-    const int ng = BLOCK / LPC;
-    int grid = (m.nC + ng - 1) / ng;
-    if (grid > 65536) grid = 65536;
-    if (a.tt) hipLaunchKernelGGL((k_adj_cell<LPC, true>), dim3(grid), dim3(BLOCK), 0, s, m, a);
-    else hipLaunchKernelGGL((k_adj_cell<LPC, false>), dim3(grid), dim3(BLOCK), 0, s, m, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s)
-{
-#define CALL(L) launch_adj_edge_lpc<L>(m, a, s)
-    DISPATCH_LPC(lpc, CALL)
-#undef CALL
-}
-
-hipError_t launch_adj_cell(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s)
-{
-#define CALL(L) launch_adj_cell_lpc<L>(m, a, s)
-    DISPATCH_LPC(lpc, CALL)
-#undef CALL
-}
-
-static unsigned ew_blocks(int64_t n)
-{
-    int64_t blocks = (n + BLOCK - 1) / BLOCK;
-    return (unsigned)std::min<int64_t>(std::max<int64_t>(blocks, 1), 65536);
-}
-
-hipError_t launch_axpby(double *dst, double a, const double *x, double b, const double *y, int64_t n, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_axpby, dim3(ew_blocks(n)), dim3(BLOCK), 0, s, dst, a, x, b, y, n);
-    return hipGetLastError();
-}
-
-hipError_t launch_add(double *dst, const double *x, const double *y, int64_t n, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_add, dim3(ew_blocks(n)), dim3(BLOCK), 0, s, dst, x, y, n);
-    return hipGetLastError();
-}
-
-hipError_t launch_bcast_rows(double *dst, const double *src, double f, int64_t n, int K, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_bcast_rows, dim3(ew_blocks(n * K)), dim3(BLOCK), 0, s, dst, src, f, n, K);
-    return hipGetLastError();
-}
-
-hipError_t launch_scale_copy(double *dst, const double *src, double f, int64_t n, hipStream_t s)
-{
-    int64_t blocks = (n + BLOCK - 1) / BLOCK;
-    if (blocks > 65536) blocks = 65536;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)blocks), dim3(BLOCK), 0, s, dst, src, f, n);
     return hipGetLastError();
 }
 
