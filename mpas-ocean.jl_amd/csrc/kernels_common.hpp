@@ -44,6 +44,109 @@ __device__ __forceinline__ int patch_of_block(int nPatches)
     return (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
 }
 
+// ---- small device helpers shared by the stage kernels ----
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ double bload(rsrc_t r, int voff, uint32_t soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, (int)soff, 0));
+}
+
+__device__ __forceinline__ void bstore(rsrc_t r, int voff, uint32_t soff, double x)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, voff, (int)soff, 0);
+}
+
+__device__ __forceinline__ double gload(const double *base, uint32_t off)
+{
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + off);
+}
+
+__device__ __forceinline__ void gstore(double *base, uint32_t off, double x)
+{
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + off) = x;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double2 bload2(rsrc_t r, int voff, uint32_t soff)
+{
+    return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, (int)soff, 0));
+}
+
+__device__ __forceinline__ double2 gload2(const double *base, uint32_t off)
+{
+    return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + off);
+}
+
+__device__ __forceinline__ void gstore2(double *base, uint32_t off, double2 x)
+{
+    *reinterpret_cast<double2 *>(reinterpret_cast<char *>(base) + off) = x;
+}
+
+struct RecLds {
+    uint32_t *eRec, *cRec;
+    double *woe, *feoe, *g, *sdv, *invA, *rsum;
+};
+
+__device__ __forceinline__ RecLds rec_carve(unsigned char *smem, const ColMesh &m, int ME, int ME2, int maxOwnE, int maxOwnC)
+{
+    RecLds L;
+    L.woe = reinterpret_cast<double *>(smem);
+    L.feoe = L.woe + (size_t)maxOwnE * ME2;
+    L.g = L.feoe + (size_t)maxOwnE * ME2;
+    L.sdv = L.g + maxOwnE;
+    L.invA = L.sdv + (size_t)maxOwnC * ME;
+    L.rsum = L.invA + maxOwnC;
+    L.eRec = reinterpret_cast<uint32_t *>(L.rsum + maxOwnC);
+    L.cRec = L.eRec + (size_t)maxOwnE * m.EI;
+    return L;
+}
+
+// experiment (MOKA_DBG 16 / 32): 16 = identity map (consecutive patches on different XCDs); 32 = tiles of 64
+// consecutive patches per XCD, tiles dealt round-robin, so the 8 XCDs sweep memory together
+__device__ __forceinline__ int patch_of_block_dbg(int nPatches, int dbg)
+{
+    if (dbg & 16) return (int)blockIdx.x;
+    if (dbg & 32) {
+        const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+        return ((j >> 6) * 8 + x) * 64 + (j & 63);
+    }
+    return patch_of_block(nPatches);
+}
+
+// ---- host-side helpers of the launchers ----
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline int patch_grid(const MeshDev &m) { return 8 * ((m.nPatches + 7) / 8); }
+
+// which pipelined specialisation serves this argument block (-1: none, use the plain column kernel)
+inline int colp_mode(const StageArgs &a)
+{
+    const bool outs = a.pu_out || a.ph_out || a.nu_out || a.nh_out;
+    if (a.tendU && a.tendH && !outs && !a.ssh_out) return 0;
+    if (a.tendU || a.tendH) return -1;
+    if (!a.cu && !a.ch && !a.nu_in && !a.nh_in && a.pu_out && a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 1;
+    if (a.cu && a.ch && a.nu_in && a.nh_in && a.pu_out && a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 2;
+    if (a.nu_in && a.nh_in && !a.pu_out && !a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 3;
+    return -1;
+}
+
+inline size_t rec_lds_bytes(const MeshDev &md)
+{
+    return (size_t)md.maxOwnE * (2 * md.ME2 + 1) * 8 + (size_t)md.maxOwnC * (md.ME + 2) * 8 +
+           ((size_t)md.maxOwnE * md.EI + (size_t)md.maxOwnC * md.CI) * 4 + 16;
+}
+
+
 // lanes-per-column dispatch of the generic column kernels (LPC = smallest power of two >= nVertLevels, capped at 64)
 #define DISPATCH_LPC(lpc, CALL)                 \
     switch (lpc) {                              \
