@@ -173,7 +173,6 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         cached = loc < nOwnB;
         return ldsU + (cached ? loc : 0u);
     };
-    auto urow_glb = [&](uint32_t off) -> double2 { return glb_row2(puG + (off + voff)); };
 
     // ---------------- cells ----------------
     for (int ci = grp; ci < nOwnC; ci += NG) {
@@ -186,19 +185,22 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         double2 hc = make_double2(0.0, 0.0), uv[ME], hv[ME], cur = hc, nin = hc;
         if (act) {
             bool cached[ME];
-            uint32_t ad[ME];
+            uint32_t ad[ME], goff[ME];
             v4u_t raw[ME];
             hc = gload2(a.ph, own);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
                 hv[i] = gload2(a.ph, r[ME + i] + voff);
-                ad[i] = urow_addr(r[i], cached[i]);
+                const uint32_t off = r[i];
+                ad[i] = urow_addr(off, cached[i]);
+                goff[i] = off + voff;
+                asm volatile("" : "+v"(goff[i]));      // stays in a VGPR (see the edge loop)
             }
             lds_burst<ME>(raw, ad);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
                 uv[i] = __builtin_bit_cast(double2, raw[i]);
-                if (!cached[i]) uv[i] = urow_glb(r[i]);
+                if (!cached[i]) uv[i] = glb_row2(puG + goff[i]);
             }
             if constexpr (MODE == 2) cur = gload2(a.ch, own);
             if constexpr (MODE >= 2) nin = gload2(a.nh_in, own);
@@ -266,15 +268,20 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         double2 uv[ME2], cur = make_double2(0.0, 0.0), nin = cur;
         if (act) {
             bool cached[ME2];
-            uint32_t ad[ME2];
+            uint32_t ad[ME2], goff[ME2];
             v4u_t raw[ME2];
 #pragma unroll
-            for (int i = 0; i < ME2; ++i) ad[i] = urow_addr(r[i], cached[i]);
+            for (int i = 0; i < ME2; ++i) {
+                const uint32_t off = r[i];
+                ad[i] = urow_addr(off, cached[i]);
+                goff[i] = off + voff;
+                asm volatile("" : "+v"(goff[i]));      // keep it in a VGPR: otherwise each masked load re-reads r[i] from LDS first
+            }
             lds_burst<ME2>(raw, ad);
 #pragma unroll
             for (int i = 0; i < ME2; ++i) {
                 uv[i] = __builtin_bit_cast(double2, raw[i]);
-                if (!cached[i]) uv[i] = urow_glb(r[i]);
+                if (!cached[i]) uv[i] = glb_row2(puG + goff[i]);
             }
             if constexpr (MODE == 2) cur = gload2(a.cu, own);
             if constexpr (MODE >= 2) nin = gload2(a.nu_in, own);
@@ -410,7 +417,6 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         cached = loc < nOwnB;
         return ldsU + (cached ? loc : 0u);
     };
-    auto urow_glb = [&](uint32_t off) -> float4 { return glb_row4f(puG + (off + voff)); };
     const d4 zero{0.0, 0.0, 0.0, 0.0};
 
     // ---------------- cells ----------------
@@ -427,17 +433,21 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
             uint32_t ad[ME];
             v4u_t raw[ME];
             float4 uf[ME];
+            uint32_t goff[ME];
             hc = gload4(a.ph, own);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
                 hv[i] = gload4(a.ph, r[ME + i] + voff);
-                ad[i] = urow_addr(r[i], cached[i]);
+                const uint32_t off = r[i];
+                ad[i] = urow_addr(off, cached[i]);
+                goff[i] = off + voff;
+                asm volatile("" : "+v"(goff[i]));      // stays in a VGPR (see k_stage_rec2c)
             }
             lds_burst<ME>(raw, ad);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
                 uf[i] = __builtin_bit_cast(float4, raw[i]);
-                if (!cached[i]) uf[i] = urow_glb(r[i]);
+                if (!cached[i]) uf[i] = glb_row4f(puG + goff[i]);
             }
             if constexpr (MODE == 2) cur = gload4(a.ch, own);
             if constexpr (MODE >= 2) nin = gload4(a.nh_in, own);
@@ -518,13 +528,19 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
             uint32_t ad[ME2];
             v4u_t raw[ME2];
             float4 uf[ME2];
+            uint32_t goff[ME2];
 #pragma unroll
-            for (int i = 0; i < ME2; ++i) ad[i] = urow_addr(r[i], cached[i]);
+            for (int i = 0; i < ME2; ++i) {
+                const uint32_t off = r[i];
+                ad[i] = urow_addr(off, cached[i]);
+                goff[i] = off + voff;
+                asm volatile("" : "+v"(goff[i]));
+            }
             lds_burst<ME2>(raw, ad);
 #pragma unroll
             for (int i = 0; i < ME2; ++i) {
                 uf[i] = __builtin_bit_cast(float4, raw[i]);
-                if (!cached[i]) uf[i] = urow_glb(r[i]);
+                if (!cached[i]) uf[i] = glb_row4f(puG + goff[i]);
             }
             if constexpr (MODE == 2) cur = gload4(a.cu, own);
             if constexpr (MODE >= 2) nin = gload4(a.nu_in, own);
