@@ -57,6 +57,22 @@ def test_partition_and_local_mesh_properties():
             assert np.all(np.diff(cls) >= 0)                                     # class-major ordering
             cs, es, _ = plan.patch_ranges()      # the record-staging kernels size their LDS from these maxima
             assert plan.info["maxPatchEdges"] == np.diff(es).max() and plan.info["maxPatchCells"] == np.diff(cs).max()
+            # launch ranges: patches [0, pB) are computed before the halo is packed, [pB, pO) while it travels, the rest never.
+            # Whatever the balancing of edge ownership does, every sent edge must be produced by the boundary launch and
+            # every edge with an owned cell by a launched patch.
+            P = plan.info["patch_cells"]
+            nB, nO = int((lm.cell_class == 0).sum()), int((lm.cell_class <= 1).sum())
+            pB, pO = -(-nB // P), -(-nO // P)
+            eperm = plan.permutation(L.EDGE)
+            patch_of_edge = np.empty(lm.mesh.nEdges, dtype=np.int64)
+            patch_of_edge[eperm] = np.searchsorted(es, np.arange(lm.mesh.nEdges), side="right") - 1
+            assert np.all(patch_of_edge[lm.send_edges] < pB)
+            coe = lm.mesh.cellsOnEdge - 1
+            has_owned = lm.owned_cell_mask[coe[:, 0]] | lm.owned_cell_mask[coe[:, 1]]
+            assert np.all(patch_of_edge[has_owned] < pO)
+            cpos = np.empty(lm.mesh.nCells, dtype=np.int64)
+            cpos[cperm] = np.arange(lm.mesh.nCells)
+            assert np.all(cpos[lm.send_cells] // P < pB)
             for i, q in enumerate(lm.neighbors):
                 sent[(r, q)] = (lm.cells_g[lm.send_cells[lm.send_cell_off[i]:lm.send_cell_off[i + 1]]],
                                 lm.edges_g[lm.send_edges[lm.send_edge_off[i]:lm.send_edge_off[i + 1]]])
