@@ -172,4 +172,33 @@ function sum_sq_ssh(Prog)
 end
 # ocn_run_loop itself (run_loop.jl:8-22) needs no change: it only calls advance!, ocn_timestep, isRinging, reset!.
 
+# ---- beyond the reference's GPU path (all optional) ------------------------------------------------
+# nonlinear terms (potential-vorticity Coriolis + kinetic-energy gradient); the mesh descriptor must carry
+# kiteAreasOnVertex / fVertex.  Off by default: the reference has only the linear terms.
+set_nonlinear!(Prog, on::Bool = true) =
+    check(ccall((:moka_set_nonlinear, lib), Cint, (Ptr{Cvoid}, Cint), Prog.state.handle, on ? 1 : 0), Prog.state.mesh.backend.ctx)
+
+# reverse mode: what an EnzymeRules rule for ocn_run_loop on this backend calls (ext/MPASEnzymeExt.jl registers such
+# rules for mycopyto! already, :13-38).  d sum(ssh^2) / d initial state, test/enzyme/test_Enzyme_end2end.jl.
+mutable struct Tape; handle::Ptr{Cvoid}; state::State; end
+function Tape(Prog, capacity::Integer)
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:moka_tape_create, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), Prog.state.handle, capacity, ref), Prog.state.mesh.backend.ctx)
+    t = Tape(ref[], Prog.state)
+    finalizer(x -> ccall((:moka_tape_destroy, lib), Cvoid, (Ptr{Cvoid},), x.handle), t)
+    t
+end
+step_fe!(t::Tape, dt; flags = REFERENCE_COMPAT) =
+    check(ccall((:moka_step_fe_taped, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint), t.handle, dt, flags), t.state.mesh.backend.ctx)
+step_rk4!(t::Tape, dt) =
+    check(ccall((:moka_step_rk4_taped, lib), Cint, (Ptr{Cvoid}, Cdouble), t.handle, dt), t.state.mesh.backend.ctx)
+function gradient!(t::Tape, d_ssh::Vector{Float64}, d_u::Matrix{Float64}, d_h::Matrix{Float64})   # d_Prog of the reference test
+    ctx = t.state.mesh.backend.ctx
+    check(ccall((:moka_adjoint_seed_sum_sq_ssh, lib), Cint, (Ptr{Cvoid},), t.handle), ctx)
+    check(ccall((:moka_adjoint_sweep, lib), Cint, (Ptr{Cvoid},), t.handle), ctx)
+    for (f, a) in ((F_SSH, d_ssh), (F_U, d_u), (F_H, d_h))
+        check(ccall((:moka_adjoint_download, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), t.handle, f, a), ctx)
+    end
+end
+
 end # module
