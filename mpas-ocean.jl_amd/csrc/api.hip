@@ -1211,17 +1211,26 @@ int moka_step_rk4_taped(moka_tape *t, double dt)
         A(&t->kbU, nEK); A(&t->kbH, nCK); A(&t->pbU, nEK); A(&t->pbH, nCK);
         if (rc) return rc;
     }
-    if ((rc = flush_lazy(st, true, true))) return rc;
-    const double *ssh0 = nullptr;
+    const double *ssh0 = nullptr;       // like moka_step_rk4: pending lazy diagnostics / tendencies of the previous step are simply superseded
     if ((rc = rk4_begin(st, &ssh0))) return rc;
     hipStream_t s = st->ctx->stream;
     double *tu = t->rkU + nEK * 4 * t->n, *th = t->rkH + nCK * 4 * t->n;
+    // The tape needs the provisional states P1..P4 the four tendencies are evaluated at.  P1 (the current level) and P4
+    // (stage 3's output, which also has to stay in the RK buffer for the lazily produced stage-4 tendencies) are copied;
+    // P2 and P3 are written by stages 1 and 2 straight into their tape slots and read from there by stages 2 and 3.
+    auto slotU = [&](int i) { return tu + nEK * i; };
+    auto slotH = [&](int i) { return th + nCK * i; };
+    HIPCHK(st->ctx, hipMemcpyAsync(slotU(0), st->lev[1].u, nEK * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(st->ctx, hipMemcpyAsync(slotH(0), st->lev[1].h, nCK * sizeof(double), hipMemcpyDeviceToDevice, s));
     for (int sg = 1; sg <= 4; ++sg) {
-        const StageArgs g = rk4_stage_args(st, sg, dt, ssh0);
-        // the provisional state this stage's tendency is evaluated at
-        HIPCHK(st->ctx, hipMemcpyAsync(tu + nEK * (sg - 1), g.pu, nEK * sizeof(double), hipMemcpyDeviceToDevice, s));
-        HIPCHK(st->ctx, hipMemcpyAsync(th + nCK * (sg - 1), g.ph, nCK * sizeof(double), hipMemcpyDeviceToDevice, s));
+        StageArgs g = rk4_stage_args(st, sg, dt, ssh0);
+        if (sg == 2 || sg == 3) { g.pu = slotU(sg - 1); g.ph = slotH(sg - 1); }
+        if (sg == 1 || sg == 2) { g.pu_out = slotU(sg); g.ph_out = slotH(sg); }
         HIPCHK(st->ctx, run_stage(st, g));
+        if (sg == 3) {
+            HIPCHK(st->ctx, hipMemcpyAsync(slotU(3), g.pu_out, nEK * sizeof(double), hipMemcpyDeviceToDevice, s));
+            HIPCHK(st->ctx, hipMemcpyAsync(slotH(3), g.ph_out, nCK * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
     }
     rk4_end(st);
     t->kind = 1;
