@@ -224,7 +224,7 @@ FeArgs fe_args(moka_state *st, int ops, int flags, double dt)
 }
 
 // variant 0 (auto): LDS-tiled kernel when it fits two workgroups per CU, else the direct kernel
-hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int pCount = -1)
+hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int pCount = -1, hipStream_t on = nullptr)
 {
     StageArgs g = g_in;
     static const int dbg = [] { const char *e = std::getenv("MOKA_DBG"); return e ? std::atoi(e) : 0; }();
@@ -249,7 +249,7 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
         }
     }
     if (dev.nPatches <= 0) return hipSuccess;
-    hipStream_t s = st->ctx->stream;
+    hipStream_t s = on ? on : st->ctx->stream;
     if (st->nonlinear) {
         // vector-invariant form: potential vorticity at vertices -> edges, kinetic energy at cells, thickness flux at edges
         // (whole mesh: the stencil of the edge pass reaches two cells deep), then the generic stage kernel's nonlinear twin
@@ -1013,7 +1013,18 @@ int moka_rk4_dist_stage(moka_halo *h, int stage, int part)
     if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms are not available on partitioned meshes");
     const StageArgs g = rk4_stage_args(st, stage, h->dt, h->ssh0);
     const int p0 = part == 0 ? 0 : h->pBoundary, cnt = part == 0 ? h->pBoundary : h->pOwned - h->pBoundary;
-    HIPCHK(st->ctx, run_stage(st, g, p0, cnt));
+    moka_ctx *c = st->ctx;
+    if (part == 0) {
+        // The boundary patches run on the COMM stream, concurrently with the interior launch of the same stage on the
+        // compute stream (disjoint outputs, same read-only inputs): the few boundary workgroups no longer hold back the
+        // interior launch, and the pack that follows needs no cross-stream event.  Everything they read or overwrite was
+        // last touched by work already queued on the compute stream (previous interior launch) or earlier on this stream.
+        HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
+        HIPCHK(c, run_stage(st, g, p0, cnt, c->comm));
+    } else {
+        HIPCHK(c, run_stage(st, g, p0, cnt));
+    }
     return MOKA_OK;
 }
 
