@@ -223,7 +223,9 @@ FeArgs fe_args(moka_state *st, int ops, int flags, double dt)
     return a;
 }
 
-// variant 0 (auto): LDS-tiled kernel when it fits two workgroups per CU, else the direct kernel
+// One fused tendency / RK-stage launch over patches [pBegin, pBegin + pCount) (default: all) on the compute stream (or `on`).
+// variant 0 (auto): k_stage_rec2c, then rec2 / rec / col / generic as the mesh allows; fp32-storage and nonlinear states have
+// their own kernels.
 hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int pCount = -1, hipStream_t on = nullptr)
 {
     StageArgs g = g_in;
