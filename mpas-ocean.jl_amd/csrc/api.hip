@@ -979,9 +979,13 @@ int moka_halo_unpack(moka_halo *h, int what, const void *recvbuf)
     moka_ctx *c = st->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     const LevelBufs &o = rk4_stage_output(st, what);
-    // the interior launch may still be writing the (to be overwritten) halo rows of a straddling patch
-    HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
+    // Inside an RK4 step (what >= 1) every row this overwrites was last written on this stream (moka_rk4_dist_stage part 0
+    // carries the straddling patch), so the exchange and the unpack overlap the interior launch completely.  For the
+    // current time level (what == 0) anything may have run on the compute stream before: wait for it.
+    if (what == 0) {
+        HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
+    }
     if (st->f32)
         HIPCHK(c, launch_halo_map_f32(static_cast<float *>(const_cast<void *>(recvbuf)), (float *)o.h, (float *)o.ssh,
                                       (float *)o.u, h->recvMap, h->nRecv, 1, c->comm));
@@ -1014,7 +1018,11 @@ int moka_rk4_dist_stage(moka_halo *h, int stage, int part)
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms are not available on partitioned meshes");
     const StageArgs g = rk4_stage_args(st, stage, h->dt, h->ssh0);
-    const int p0 = part == 0 ? 0 : h->pBoundary, cnt = part == 0 ? h->pBoundary : h->pOwned - h->pBoundary;
+    // The last owned patch may straddle into the halo cells (patches are P consecutive cells): it writes rows that
+    // moka_halo_unpack overwrites, so it travels with the boundary group on the comm stream -- the interior launch then
+    // touches no received row and the unpack of a stage does not have to wait for it.
+    const int pTail = h->pOwned - 1 >= h->pBoundary ? h->pOwned - 1 : h->pOwned;      // == pOwned: no separate tail patch
+    const int p0 = part == 0 ? 0 : h->pBoundary, cnt = part == 0 ? h->pBoundary : pTail - h->pBoundary;
     moka_ctx *c = st->ctx;
     if (part == 0) {
         // The boundary patches run on the COMM stream, concurrently with the interior launch of the same stage on the
@@ -1024,6 +1032,7 @@ int moka_rk4_dist_stage(moka_halo *h, int stage, int part)
         HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
         HIPCHK(c, run_stage(st, g, p0, cnt, c->comm));
+        if (pTail < h->pOwned) HIPCHK(c, run_stage(st, g, pTail, 1, c->comm));
     } else {
         HIPCHK(c, run_stage(st, g, p0, cnt));
     }

@@ -262,6 +262,8 @@ class DistributedModel:
                     [dist.P2POp(dist.isend, self.sendbuf[a:b], q) for q, a, b in self.send_slices if b > a]):
                 w.wait()
             torch.cuda.synchronize()
+        elif self.transport == "local":
+            raise RuntimeError("transport 'local' is driven by LocalCluster.step_rk4")
         else:                                    # gloo: through the host
             self.backend.synchronize()
             send_cpu, recv_cpu = self.sendbuf.cpu(), torch.empty_like(self.recvbuf, device="cpu")
@@ -303,3 +305,86 @@ class DistributedModel:
                   "neighbors": len(self.lm.neighbors), "halo_bytes_per_stage": self.halo_bytes_per_stage,
                   "patches_boundary": self.p_boundary, "patches_owned": self.p_owned})
         return d
+
+
+class LocalCluster:
+    """All ranks of a partition inside ONE process on ONE GPU: every rank is a DistributedModel with its own context
+    (two HIP streams each), and the halo messages are device-to-device copies issued on the receiver's comm stream
+    behind an event of the sender's comm stream -- stream-ordered end to end, never synchronised with the host, which
+    is the ordering an RCCL send/recv pair gives.  A test harness for the stream / event choreography of the
+    distributed RK4 step (RCCL itself refuses several ranks on one device)."""
+
+    def __init__(self, mesh, ssh, u, h, rest, dt, world, device=0, ordering=0, patch_cells=0, state_bytes=8):
+        import torch
+        from . import api
+        self.torch, self.world = torch, world
+        self.backends = [api.MokaHIP(device) for _ in range(world)]
+        part = partition_cells(mesh, world)
+        self.models = [DistributedModel(mesh, ssh, u, h, rest, dt, self.backends[r], r, world, ordering=ordering,
+                                        patch_cells=patch_cells, transport="local", part=part, state_bytes=state_bytes)
+                       for r in range(world)]
+        self.events = [torch.cuda.Event() for _ in range(world)]
+        # (receiver, a, b) <- (sender, c, d): slices of the packed buffers, matched by construction (message_slices)
+        self.moves = []
+        for r, mr in enumerate(self.models):
+            send_of = {}
+            for q in range(world):
+                send_of[q] = {dst: (a, b) for dst, a, b in self.models[q].send_slices}
+            for src, a, b in mr.recv_slices:
+                c, d = send_of[src][r]
+                assert b - a == d - c
+                if b > a:
+                    self.moves.append((r, a, b, src, c, d))
+
+    def _exchange(self, what, pack=True):
+        """pack (optional) -> copies on the receivers' comm streams behind the senders' pack -> unpack; all stream-ordered."""
+        torch = self.torch
+        lib = L.lib()
+        if pack:
+            for m in self.models:
+                L.check(lib.moka_halo_pack(m._halo, what, m.sendbuf.data_ptr()), m.backend._h)
+        for r, m in enumerate(self.models):
+            self.events[r].record(m.comm_stream)                    # "send posted": the sender's pack is queued before it
+        for r, a, b, src, c, d in self.moves:
+            mr, ms = self.models[r], self.models[src]
+            mr.comm_stream.wait_event(self.events[src])
+            with torch.cuda.stream(mr.comm_stream):
+                mr.recvbuf[a:b].copy_(ms.sendbuf[c:d], non_blocking=True)
+        # a sender may not repack before its data was read: its comm stream waits for the receivers' copies
+        done = [torch.cuda.Event() for _ in self.models]
+        for r, m in enumerate(self.models):
+            done[r].record(m.comm_stream)
+        for r, a, b, src, c, d in self.moves:
+            self.models[src].comm_stream.wait_event(done[r])
+        for m in self.models:
+            L.check(lib.moka_halo_unpack(m._halo, what, m.recvbuf.data_ptr()), m.backend._h)
+
+    def exchange_state(self):
+        self._exchange(0)
+
+    def step_rk4(self):
+        lib = L.lib()
+        for m in self.models:
+            L.check(lib.moka_rk4_dist_begin(m._halo, m.dt), m.backend._h)
+        for s in (1, 2, 3, 4):
+            for m in self.models:
+                L.check(lib.moka_rk4_dist_stage(m._halo, s, 0), m.backend._h)     # boundary patches (comm stream)
+            for m in self.models:
+                L.check(lib.moka_halo_pack(m._halo, s, m.sendbuf.data_ptr()), m.backend._h)
+            for m in self.models:
+                L.check(lib.moka_rk4_dist_stage(m._halo, s, 1), m.backend._h)     # interior overlaps the exchange
+            self._exchange(s, pack=False)
+        for m in self.models:
+            L.check(lib.moka_rk4_dist_end(m._halo), m.backend._h)
+
+    def gather_owned(self, nCells, nEdges, K):
+        """(ssh, u, h) of the whole mesh assembled from the ranks' owned entities (synchronises)."""
+        ssh, u, h = np.full(nCells, np.nan), np.full((nEdges, K), np.nan), np.full((nCells, K), np.nan)
+        for m in self.models:
+            (cg, s, hh), (eg, uu) = m.owned_state()
+            ssh[cg], h[cg], u[eg] = s, hh, uu
+        return ssh, u, h
+
+    def close(self):
+        for b in self.backends:
+            b.synchronize()
