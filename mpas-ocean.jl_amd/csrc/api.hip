@@ -1002,8 +1002,7 @@ int moka_rk4_dist_begin(moka_halo *h, double dt)
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
     moka_state *st = h->st;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
-    int rc = flush_lazy(st, true, true);
-    if (rc) return rc;
+    // like moka_step_rk4: lazily pending diagnostics / stage-4 tendencies of the previous step are superseded, not computed
     h->dt = dt;
     return rk4_begin(st, &h->ssh0);
 }

@@ -99,6 +99,12 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise MokaError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: build it with `make -C {PKG_DIR}` "
                                        "(there is no CPU fallback for the HIP path)")
+    try:
+        # PyTorch bundles its own libamdhip64; if it is going to be used in this process (halo buffers, torch.distributed)
+        # it has to be loaded first, or two HIP runtimes end up side by side and torch finds no device.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.moka_version.restype = C.c_char_p
