@@ -21,7 +21,7 @@ struct moka_ctx {
     hipStream_t stream = nullptr;
     hipStream_t comm = nullptr;                       // halo pack / transport / unpack
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t evBoundary = nullptr, evInterior = nullptr, evHalo = nullptr;
+    hipEvent_t evBoundary = nullptr, evInterior = nullptr, evHalo = nullptr, evBoundaryDone = nullptr;
     int variant = 0;
     int nCUs = 256;
     std::string err;
@@ -226,13 +226,34 @@ FeArgs fe_args(moka_state *st, int ops, int flags, double dt)
 // One fused tendency / RK-stage launch over patches [pBegin, pBegin + pCount) (default: all) on the compute stream (or `on`).
 // variant 0 (auto): k_stage_rec2c, then rec2 / rec / col / generic as the mesh allows; fp32-storage and nonlinear states have
 // their own kernels.
-hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int pCount = -1, hipStream_t on = nullptr)
+hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int pCount = -1, hipStream_t on = nullptr, int tail = -1)
 {
     StageArgs g = g_in;
     static const int dbg = [] { const char *e = std::getenv("MOKA_DBG"); return e ? std::atoi(e) : 0; }();
     g.dbg = dbg;   // diagnostics only; 0 in normal operation
     const moka_mesh *m = st->mesh;
-    MeshDev dev = m->dev;                 // the launch covers patches [pBegin, pBegin + pCount)
+    MeshDev dev = m->dev;                 // the launch covers patches [pBegin, pBegin + pCount) (+ the patch `tail`)
+    dev.tailPatch = -1;
+    hipStream_t s = on ? on : st->ctx->stream;
+    if (tail >= 0) {
+        // One extra, non-adjacent patch in the same launch: only the default kernels can carry it.  Anything else
+        // (explicit variants, fallbacks for other K, the nonlinear path) gets a launch of its own for it.
+        hipError_t e = hipErrorNotSupported;
+        if (pCount > 0 && !st->nonlinear && (st->f32 || ((st->ctx->variant == 0 || st->ctx->variant == 11) && m->lpc == 64 && m->colOk))) {
+            const moka::Plan &p = m->plan;
+            dev.patchBegin = pBegin; dev.nPatches = pCount; dev.tailPatch = tail;
+            int mE = p.patchEdgeStart[tail + 1] - p.patchEdgeStart[tail], mC = p.patchCellStart[tail + 1] - p.patchCellStart[tail];
+            for (int q = pBegin; q < pBegin + pCount; ++q) {
+                mE = std::max(mE, p.patchEdgeStart[q + 1] - p.patchEdgeStart[q]);
+                mC = std::max(mC, p.patchCellStart[q + 1] - p.patchCellStart[q]);
+            }
+            dev.maxOwnE = mE; dev.maxOwnC = mC;
+            e = st->f32 ? launch_stage_rec2c_f32(dev, g, s) : launch_stage_rec2c(dev, g, s);
+        }
+        if (e != hipErrorNotSupported) return e;
+        e = run_stage(st, g_in, pBegin, pCount, on);
+        return e != hipSuccess ? e : run_stage(st, g_in, tail, 1, on);
+    }
     if (pCount >= 0) {
         dev.patchBegin = pBegin; dev.nPatches = pCount;
         if (pCount > 0) {
@@ -251,7 +272,6 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
         }
     }
     if (dev.nPatches <= 0) return hipSuccess;
-    hipStream_t s = on ? on : st->ctx->stream;
     if (st->nonlinear) {
         // vector-invariant form: potential vorticity at vertices -> edges, kinetic energy at cells, thickness flux at edges
         // (whole mesh: the stencil of the edge pass reaches two cells deep), then the generic stage kernel's nonlinear twin
@@ -350,10 +370,17 @@ int moka_ctx_create(int device, moka_ctx **out)
     hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     hipError_t e2 = hipEventCreate(&c->ev0);
     hipError_t e3 = hipEventCreate(&c->ev1);
-    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking);
+    if (e1 == hipSuccess) {
+        // the comm stream carries the boundary patches, pack / unpack and the halo transport: highest priority, so that its
+        // few workgroups are dispatched ahead of the thousands the interior launch has queued
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e1 = hipStreamCreateWithPriority(&c->comm, hipStreamNonBlocking, hi);
+    }
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->evBoundary, hipEventDisableTiming);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->evInterior, hipEventDisableTiming);
     if (e3 == hipSuccess) e3 = hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming);
+    if (e3 == hipSuccess) e3 = hipEventCreateWithFlags(&c->evBoundaryDone, hipEventDisableTiming);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         delete c;
         return fail(nullptr, MOKA_ERR_HIP, "failed to create stream/events");
@@ -368,7 +395,7 @@ void moka_ctx_destroy(moka_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) { (void)hipStreamSynchronize(ctx->comm); (void)hipStreamDestroy(ctx->comm); }
-    for (hipEvent_t e : {ctx->evBoundary, ctx->evInterior, ctx->evHalo}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ctx->evBoundary, ctx->evInterior, ctx->evHalo, ctx->evBoundaryDone}) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1024,15 +1051,19 @@ int moka_rk4_dist_stage(moka_halo *h, int stage, int part)
     const int p0 = part == 0 ? 0 : h->pBoundary, cnt = part == 0 ? h->pBoundary : pTail - h->pBoundary;
     moka_ctx *c = st->ctx;
     if (part == 0) {
-        // The boundary patches run on the COMM stream, concurrently with the interior launch of the same stage on the
-        // compute stream (disjoint outputs, same read-only inputs): the few boundary workgroups no longer hold back the
-        // interior launch, and the pack that follows needs no cross-stream event.  Everything they read or overwrite was
-        // last touched by work already queued on the compute stream (previous interior launch) or earlier on this stream.
+        // The boundary patches (and the last owned patch, see above) run on the COMM stream, so that pack, transport and
+        // unpack follow them in stream order while the interior launch runs on the compute stream.  Everything they read
+        // or overwrite was last touched by work already queued on the compute stream (previous interior launch) or
+        // earlier on this stream.
         HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
-        HIPCHK(c, run_stage(st, g, p0, cnt, c->comm));
-        if (pTail < h->pOwned) HIPCHK(c, run_stage(st, g, pTail, 1, c->comm));
+        HIPCHK(c, run_stage(st, g, p0, cnt, c->comm, pTail < h->pOwned ? pTail : -1));
+        HIPCHK(c, hipEventRecord(c->evBoundaryDone, c->comm));
     } else {
+        // Launched together the two kernels share the CUs and the ~130 boundary workgroups finish no earlier than the
+        // thousands of interior ones (measured: 290 us instead of 35 us), which would push pack and transport behind the
+        // interior compute they are meant to hide under.  So the interior launch waits for the boundary group.
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->evBoundaryDone, 0));
         HIPCHK(c, run_stage(st, g, p0, cnt));
     }
     return MOKA_OK;

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     extern __shared__ __align__(16) unsigned char smem[];
     const int pl_ = patch_of_block(m.nPatches);
     if (pl_ >= m.nPatches) return;
-    const int p = pl_ + m.patchBegin;
+    const int p = (m.tailPlus1 && pl_ == m.nPatches - 1) ? m.tailPlus1 - 1 : pl_ + m.patchBegin;
     constexpr int NG = NT / 32;
     const int tid = threadIdx.x;
     const int grp = tid >> 5, l = tid & 31;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
     extern __shared__ __align__(16) unsigned char smem[];
     const int pl_ = patch_of_block(m.nPatches);
     if (pl_ >= m.nPatches) return;
-    const int p = pl_ + m.patchBegin;
+    const int p = (m.tailPlus1 && pl_ == m.nPatches - 1) ? m.tailPlus1 - 1 : pl_ + m.patchBegin;
     // K/4 lanes carry one entity, so a wave carries 64 / (K/4) of them (3 at K = 80, 4 at K = 60 or 64, 2 at K = 128):
     // lanes beyond the last whole group idle.  Shuffles address lanes of the own group only.
     const int tid = threadIdx.x;
@@ -926,9 +926,10 @@ size_t rec2c_lds_bytes(const MeshDev &md)
 
 hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t s)
 {
-    const dim3 g(patch_grid(md)), b(BLOCK);
-    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
-                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
+    const int nLaunch = md.nPatches + (md.tailPatch >= 0 ? 1 : 0);
+    const dim3 g(8 * ((nLaunch + 7) / 8)), b(BLOCK);
+    const ColMesh m{md.nC, md.nE, md.K, nLaunch, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc, md.tailPatch >= 0 ? md.tailPatch + 1 : 0};
     const int mode = colp_mode(a);
     const size_t lds = rec2c_lds_bytes(md);
     if (mode < 0 || md.K > 64 || (md.K & 1) || lds > 64 * 1024 || md.maxOwnC < 1 || md.maxOwnE < 1) return hipErrorNotSupported;
@@ -962,9 +963,10 @@ bool stage_f32_supported(const MeshDev &md)
 
 hipError_t launch_stage_rec2c_f32(const MeshDev &md, const StageArgs &a, hipStream_t s)
 {
-    const dim3 g(patch_grid(md)), b(BLOCK);
-    const ColMesh m{md.nC, md.nE, md.K, md.nPatches, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
-                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc};
+    const int nLaunch = md.nPatches + (md.tailPatch >= 0 ? 1 : 0);
+    const dim3 g(8 * ((nLaunch + 7) / 8)), b(BLOCK);
+    const ColMesh m{md.nC, md.nE, md.K, nLaunch, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc, md.tailPatch >= 0 ? md.tailPatch + 1 : 0};
     const int mode = colp_mode(a);
     if (mode < 0 || !stage_f32_supported(md)) return hipErrorNotSupported;
     const size_t lds = ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 4 + 16;

@@ -27,6 +27,7 @@ struct ColMesh {
     const uint32_t *cRec, *eRec;
     const int32_t *mltc;
     const double *sdv, *invArea, *rsum, *woe, *feoe, *gInvDc;
+    int32_t tailPlus1;   // != 0: the launch's last workgroup takes patch tailPlus1 - 1 instead of patchBegin + nPatches - 1
 };
 
 enum : int {

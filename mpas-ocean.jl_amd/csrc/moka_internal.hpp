@@ -110,6 +110,7 @@ struct MeshDev {
     // optional nonlinear terms (nullptr when the mesh did not bring them)
     const int32_t *voe, *cov;
     const double *kite, *invAreaTri, *fVertex, *keCoef, *invDc;
+    int32_t tailPatch;    // >= 0: one extra, non-adjacent patch rides in this launch (default stage kernels only)
 };
 
 // Dynamic LDS the LDS-tiled stage kernel carves up (same formula on host and device):
