@@ -1051,19 +1051,13 @@ int moka_rk4_dist_stage(moka_halo *h, int stage, int part)
     const int p0 = part == 0 ? 0 : h->pBoundary, cnt = part == 0 ? h->pBoundary : pTail - h->pBoundary;
     moka_ctx *c = st->ctx;
     if (part == 0) {
-        // The boundary patches (and the last owned patch, see above) run on the COMM stream, so that pack, transport and
-        // unpack follow them in stream order while the interior launch runs on the compute stream.  Everything they read
-        // or overwrite was last touched by work already queued on the compute stream (previous interior launch) or
-        // earlier on this stream.
-        HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
-        HIPCHK(c, run_stage(st, g, p0, cnt, c->comm, pTail < h->pOwned ? pTail : -1));
-        HIPCHK(c, hipEventRecord(c->evBoundaryDone, c->comm));
+        // Boundary group first, interior right behind it on the same (compute) stream: in-order, no cross-queue wait in the
+        // compute chain.  Launched concurrently the two kernels share the CUs and the ~130 boundary workgroups finish no
+        // earlier than the thousands of interior ones (measured 290 us instead of 35 us), which would push pack and
+        // transport behind the interior compute they are meant to hide under.  moka_halo_pack then makes the comm stream
+        // wait for the boundary group only (it records its event before the interior launch is queued).
+        HIPCHK(c, run_stage(st, g, p0, cnt, nullptr, pTail < h->pOwned ? pTail : -1));
     } else {
-        // Launched together the two kernels share the CUs and the ~130 boundary workgroups finish no earlier than the
-        // thousands of interior ones (measured: 290 us instead of 35 us), which would push pack and transport behind the
-        // interior compute they are meant to hide under.  So the interior launch waits for the boundary group.
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->evBoundaryDone, 0));
         HIPCHK(c, run_stage(st, g, p0, cnt));
     }
     return MOKA_OK;
