@@ -21,7 +21,7 @@ struct moka_ctx {
     hipStream_t stream = nullptr;
     hipStream_t comm = nullptr;                       // halo pack / transport / unpack
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t evBoundary = nullptr, evInterior = nullptr, evHalo = nullptr, evBoundaryDone = nullptr;
+    hipEvent_t evBoundary = nullptr, evInterior = nullptr, evHalo = nullptr;
     int variant = 0;
     int nCUs = 256;
     std::string err;
@@ -380,7 +380,6 @@ int moka_ctx_create(int device, moka_ctx **out)
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->evBoundary, hipEventDisableTiming);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->evInterior, hipEventDisableTiming);
     if (e3 == hipSuccess) e3 = hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming);
-    if (e3 == hipSuccess) e3 = hipEventCreateWithFlags(&c->evBoundaryDone, hipEventDisableTiming);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         delete c;
         return fail(nullptr, MOKA_ERR_HIP, "failed to create stream/events");
@@ -395,7 +394,7 @@ void moka_ctx_destroy(moka_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) { (void)hipStreamSynchronize(ctx->comm); (void)hipStreamDestroy(ctx->comm); }
-    for (hipEvent_t e : {ctx->evBoundary, ctx->evInterior, ctx->evHalo, ctx->evBoundaryDone}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ctx->evBoundary, ctx->evInterior, ctx->evHalo}) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
