@@ -281,7 +281,14 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
         if (e != hipSuccess) return e;
         return launch_stage_nl(dev, g, nl, m->lpc, s);
     }
-    if (st->f32) return launch_stage_rec2c_f32(dev, g, s);   // the one fp32-storage kernel (checked at state creation)
+    if (st->f32) {   // the one fp32-storage kernel (checked at state creation against the patches that are ever launched)
+        if (pCount < 0 && m->plan.nPatchesLaunch < m->plan.nPatches) {
+            // whole-mesh launch on a partitioned mesh: the halo-only patches are skipped (their rows arrive by exchange)
+            dev.nPatches = m->plan.nPatchesLaunch;
+            dev.maxOwnE = std::max(m->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(m->plan.maxOwnCLaunch, 1);
+        }
+        return launch_stage_rec2c_f32(dev, g, s);
+    }
     const int v = st->ctx->variant;
     // 0 = auto (rec2c, then rec2, rec, col, generic as the mesh allows); 11 rec2c, 8 rec2, 7 rec, 1 colp, 4 col, 5/6 colx,
     // 2 LDS-tiled, 9 tile, 10 ptile, 3 generic
@@ -596,7 +603,9 @@ int moka_state_create(moka_ctx *ctx, moka_mesh *mesh, moka_state **out)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t nEK = (size_t)p.K * p.nE, nCK = (size_t)p.K * p.nC, nVK = (size_t)p.K * p.nV;
     st->f32 = p.stateBytes == 4;
-    if (st->f32 && !stage_f32_supported(mesh->dev)) {
+    MeshDev launchDev = mesh->dev;        // what the stage launches will see: maxima over the patches that are ever computed
+    launchDev.maxOwnE = std::max(p.maxOwnELaunch, 1); launchDev.maxOwnC = std::max(p.maxOwnCLaunch, 1);
+    if (st->f32 && !stage_f32_supported(launchDev)) {
         delete st;
         return fail(ctx, MOKA_ERR_UNSUPPORTED,
                     "fp32-storage state: needs nVertLevels % 4 == 0, nVertLevels <= 128, fields below 4 GiB and patches whose "

@@ -943,6 +943,16 @@ hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t
 template <int ME, int ME2>
 static bool launch_rec2c_f32(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3 b, size_t lds, int mE, int mC, hipStream_t s)
 {
+    // a launch that carries a halo-straddling patch of a partitioned mesh (up to 6 own edges per cell) may need more than
+    // the default 64 KB of dynamic LDS; such launches are small (the boundary group), occupancy does not matter there
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
     switch (mode) {
         case 0: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 0>), g, b, lds, s, m, a, mE, mC); return true;
         case 1: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 1>), g, b, lds, s, m, a, mE, mC); return true;
@@ -952,12 +962,13 @@ static bool launch_rec2c_f32(const ColMesh &m, const StageArgs &a, int mode, dim
     return false;
 }
 
-// fp32-state meshes: K % 4 == 0, K <= 128, byte-offset records, records + own u rows within 64 KB of LDS
+// fp32-state meshes: K % 4 == 0, K <= 128, byte-offset records, records + own u rows of the largest launched patch within
+// the 160 KB of LDS a workgroup can have (64 KB without raising the kernel attribute: every whole-mesh launch stays below)
 bool stage_f32_supported(const MeshDev &md)
 {
     const size_t lds = ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 4 + 16;
     const bool shape = (md.ME == 6 && md.ME2 == 10) || (md.ME == 8 && md.ME2 == 14) || (md.ME <= 6 && md.ME2 <= 14);
-    return md.cRec && md.eRec && md.K >= 4 && md.K <= 128 && (md.K & 3) == 0 && lds <= 64 * 1024 && md.maxOwnC >= 1 &&
+    return md.cRec && md.eRec && md.K >= 4 && md.K <= 128 && (md.K & 3) == 0 && lds <= 160 * 1024 && md.maxOwnC >= 1 &&
            md.maxOwnE >= 1 && shape;
 }
 

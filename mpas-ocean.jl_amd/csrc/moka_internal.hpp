@@ -68,6 +68,9 @@ struct Plan {
     std::vector<uint32_t> leOff;      // nE*ME2
     std::vector<int32_t>  patchRegular;   // nPatches
     int32_t maxRows = 0, maxOwnE = 0, maxOwnC = 0;
+    // the same maxima over the patches that are ever launched (those starting with a cell of class < 2: halo-only
+    // patches of a partitioned mesh own up to 6 edges per cell and are never computed)
+    int32_t maxOwnELaunch = 0, maxOwnCLaunch = 0, nPatchesLaunch = 0;   // launchable patches are a prefix (class-major order)
     bool ldsOk = false;               // every patch has <= 254 rows
     // vertices
     std::vector<int32_t> eov;      // nV*VD  edgesOnVertex

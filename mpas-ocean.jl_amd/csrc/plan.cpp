@@ -450,9 +450,17 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     p.leoc.assign((size_t)nC * 8, 0xFF);
     p.leoe.assign((size_t)nE * 16, 0xFF);
     p.maxRows = p.maxOwnE = p.maxOwnC = 0;
+    p.maxOwnELaunch = p.maxOwnCLaunch = 0;
     for (int q = 0; q < p.nPatches; ++q) {   // needed by every LDS-staging kernel: must cover ALL patches
-        p.maxOwnE = std::max(p.maxOwnE, p.patchEdgeStart[q + 1] - p.patchEdgeStart[q]);
-        p.maxOwnC = std::max(p.maxOwnC, p.patchCellStart[q + 1] - p.patchCellStart[q]);
+        const int nE_q = p.patchEdgeStart[q + 1] - p.patchEdgeStart[q], nC_q = p.patchCellStart[q + 1] - p.patchCellStart[q];
+        p.maxOwnE = std::max(p.maxOwnE, nE_q);
+        p.maxOwnC = std::max(p.maxOwnC, nC_q);
+        const bool launched = !d->cellClass || d->cellClass[p.cellN2O[p.patchCellStart[q]]] < 2;
+        if (launched) {
+            p.nPatchesLaunch = q + 1;
+            p.maxOwnELaunch = std::max(p.maxOwnELaunch, nE_q);
+            p.maxOwnCLaunch = std::max(p.maxOwnCLaunch, nC_q);
+        }
     }
     p.ldsOk = (ME <= 8 && ME2 <= 16);
     {

@@ -90,8 +90,9 @@ def test_distributed_rk4_hip_two_ranks_one_gpu(K, variant):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,K,P,nsteps", [(2, 60, 0, 4), (4, 60, 0, 4), (8, 60, 0, 3), (3, 1, 0, 5), (4, 60, 8, 3), (5, 80, 0, 2)])
-def test_stream_ordered_exchange_in_one_process(world, K, P, nsteps):
+@pytest.mark.parametrize("world,K,P,nsteps,sbytes", [(2, 60, 0, 4, 8), (4, 60, 0, 4, 8), (8, 60, 0, 3, 8), (3, 1, 0, 5, 8), (4, 60, 8, 3, 8),
+                                                     (5, 80, 0, 2, 8), (4, 80, 0, 3, 4), (3, 60, 0, 2, 4)])
+def test_stream_ordered_exchange_in_one_process(world, K, P, nsteps, sbytes):
     """All ranks in one process on one GPU, halo messages as stream-ordered device copies with no host synchronisation
     anywhere in the step -- the ordering RCCL gives.  Exercises the two-stream / event choreography of the distributed
     RK4 step (boundary patches + pack on the comm stream, interior on the compute stream, unpack overlapping it): any
@@ -105,8 +106,8 @@ def test_stream_ordered_exchange_in_one_process(world, K, P, nsteps):
     ssh = h.sum(1) - rest.sum(1)
     dt = 20.0
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
-    ref = orc.OracleState(om, ssh, u, h)
-    cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, world, patch_cells=P)
+    ref = orc.OracleState(om, ssh, u, h, mixed=sbytes == 4)          # fp32-storage states exchange fp32 halos
+    cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, world, patch_cells=P, state_bytes=sbytes)
     cl.exchange_state()
     for rep in range(3):                      # several rounds: timing-dependent races get more than one chance to show
         for _ in range(nsteps):
