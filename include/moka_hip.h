@@ -262,6 +262,12 @@ int moka_set_kernel_variant(moka_ctx *ctx, int variant);
  *   tendU = sum_i w[i,e] F[eoe_i] (q_e + q_eoe_i)/2 - g grad(ssh) - grad(KE),  KE = sum_e dc dv u^2 / (4 areaCell).
  * Default off.  Needs the optional mesh arrays above; Float64 states on whole meshes; no Forward Euler, no tape. */
 int  moka_set_nonlinear(moka_state *st, int on);
+/* Del2 momentum mixing on top of the nonlinear terms -- the reference's sketch (never called there, and not runnable:
+ * src/ocn/Tendencies/normalVelocity/horizontal_momentum_mixing.jl:53-80, with viscDel2 hard-wired to 1.0 at :30):
+ *   tendU[k,e] += ((div[k,c2] - div[k,c1]) / dcEdge[e] - (relVort[k,v2] - relVort[k,v1]) / dvEdge[e]) * viscDel2
+ * with div = velocityDivCell and relVort = relativeVorticity of the stage's provisional velocity.  0 (default) = off.
+ * MOKA_ERR_UNSUPPORTED unless moka_set_nonlinear(st, 1) came first. */
+int  moka_set_viscosity_del2(moka_state *st, double viscDel2);
 
 /* ---- reverse mode of the Forward-Euler loop ----------------------------------------------------------------
  * The reference gets d sum(ssh^2) / d (initial normalVelocity, layerThickness) from Enzyme over ocn_run_loop

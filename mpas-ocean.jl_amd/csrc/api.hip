@@ -69,6 +69,8 @@ struct moka_state {
     // optional nonlinear terms (moka_set_nonlinear): scratch of the three preparation passes
     bool nonlinear = false;
     double *nlQv = nullptr, *nlQe = nullptr, *nlKe = nullptr;
+    double *nlZv = nullptr, *nlDiv = nullptr;   // Del2 mixing (moka_set_viscosity_del2)
+    double viscDel2 = 0.0;
     std::vector<void *> allocs;
 };
 
@@ -276,7 +278,8 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
         // vector-invariant form: potential vorticity at vertices -> edges, kinetic energy at cells, thickness flux at edges
         // (whole mesh: the stencil of the edge pass reaches two cells deep), then the generic stage kernel's nonlinear twin
         if (pCount >= 0) return hipErrorNotSupported;
-        const NlArgs nl{st->nlQv, st->nlQe, st->nlKe};
+        const bool del2 = st->viscDel2 != 0.0;
+        const NlArgs nl{st->nlQv, st->nlQe, st->nlKe, del2 ? st->nlZv : nullptr, del2 ? st->nlDiv : nullptr, st->viscDel2};
         hipError_t e = launch_nl_prepare(dev, g.pu, g.ph, nl, m->lpc, s);
         if (e != hipSuccess) return e;
         return launch_stage_nl(dev, g, nl, m->lpc, s);
@@ -1099,6 +1102,23 @@ int moka_set_nonlinear(moka_state *st, int on)
         if ((rc = alloc_field(st, &st->nlKe, (size_t)p.K * p.nC))) return rc;
     }
     st->nonlinear = true;
+    return MOKA_OK;
+}
+
+int moka_set_viscosity_del2(moka_state *st, double viscDel2)
+{
+    if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
+    if (!(viscDel2 >= 0.0)) return fail(st->ctx, MOKA_ERR_ARG, "viscDel2 must be >= 0");
+    if (viscDel2 != 0.0 && !st->nonlinear)
+        return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "Del2 mixing rides on the nonlinear tendencies: call moka_set_nonlinear first");
+    if (viscDel2 != 0.0 && !st->nlZv) {
+        const Plan &p = st->mesh->plan;
+        HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+        int rc;
+        if ((rc = alloc_field(st, &st->nlZv, (size_t)p.K * p.nV))) return rc;
+        if ((rc = alloc_field(st, &st->nlDiv, (size_t)p.K * p.nC))) return rc;
+    }
+    st->viscDel2 = viscDel2;
     return MOKA_OK;
 }
 

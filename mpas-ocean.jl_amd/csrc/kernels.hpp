@@ -92,6 +92,10 @@ struct NlArgs {
     double *qv;     // (K, nV) potential vorticity at vertices
     double *fq;     // (K, nE) pairs {thickness flux u * layerThicknessEdge, potential vorticity averaged to the edge}
     double *ke;     // (K, nC) kinetic energy at cells
+    // Del2 momentum mixing (moka_set_viscosity_del2; horizontal_momentum_mixing.jl:53-80): nullptr / 0 = term absent
+    double *zv;     // (K, nV) relativeVorticity
+    double *divc;   // (K, nC) velocityDivCell
+    double visc;
 };
 hipError_t launch_nl_prepare(const MeshDev &m, const double *u, const double *h, const NlArgs &nl, int lpc, hipStream_t s);
 hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &nl, int lpc, hipStream_t s);

@@ -9,7 +9,7 @@ namespace moka {
 // column, one entity per lane group.  Three preparation passes over the whole mesh, then the stage kernel.
 // ------------------------------------------------------------------------------------------------
 template <int LPC>
-__global__ __launch_bounds__(BLOCK) void k_nl_vertex(const MeshDev m, const double *u, const double *h, double *qv)
+__global__ __launch_bounds__(BLOCK) void k_nl_vertex(const MeshDev m, const double *u, const double *h, double *qv, double *zv)
 {
     constexpr int NG = BLOCK / LPC;
     const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;   // LPC = 64: records come through scalar loads
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(BLOCK) void k_nl_vertex(const MeshDev m, const doub
             }
             hv = hv * invA;
             qv[(size_t)v * K + k] = (fv + zeta) / hv;
+            if (zv) zv[(size_t)v * K + k] = zeta;                                                      // relativeVorticity, Operators.jl:137-146
         }
     }
 }
@@ -49,22 +50,24 @@ __global__ __launch_bounds__(BLOCK) void k_nl_edge(const MeshDev m, const double
 }
 
 template <int LPC>
-__global__ __launch_bounds__(BLOCK) void k_nl_cell(const MeshDev m, const double *u, double *ke)
+__global__ __launch_bounds__(BLOCK) void k_nl_cell(const MeshDev m, const double *u, double *ke, double *divc)
 {
     constexpr int NG = BLOCK / LPC;
     const int grp = uniform_if_wave<LPC>(threadIdx.x / LPC), l = threadIdx.x % LPC;
     const int K = m.K, ME = m.ME;
     for (int c = blockIdx.x * NG + grp; c < m.nC; c += gridDim.x * NG) {
-        const double invA = cptr(m.invArea)[c];
+        const double invA = cptr(m.invArea)[c], area = cptr(m.areaCell)[c];
         for (int k = l; k < K; k += LPC) {
-            double acc = 0.0;
+            double acc = 0.0, d = 0.0;
             for (int i = 0; i < ME; ++i) {
                 const int e = cptr(m.eoc)[(size_t)c * ME + i];
                 if (e < 0) continue;
                 const double ue = u[(size_t)e * K + k];
                 acc += cptr(m.keCoef)[e] * ue * ue;
+                d -= ue * cptr(m.sdv)[(size_t)c * ME + i];                                              // (u*dvEdge)*sign, Operators.jl:18,36
             }
             ke[(size_t)c * K + k] = acc * invA;
+            if (divc) divc[(size_t)c * K + k] = d / area;                                               // velocityDivCell, Operators.jl:41
         }
     }
 }
@@ -120,6 +123,9 @@ __global__ __launch_bounds__(BLOCK) void k_stage_nl(const MeshDev m, const Stage
         const int c1 = cptr(m.ehdr)[(size_t)e * 4], c2 = cptr(m.ehdr)[(size_t)e * 4 + 1], mlt = cptr(m.ehdr)[(size_t)e * 4 + 3];
         const double g = cptr(m.gInvDc)[e], invDc = cptr(m.invDc)[e];
         const double ds = a.ssh[c2] - a.ssh[c1];
+        const bool del2 = nl.zv != nullptr;
+        const double invDv = del2 ? 1.0 / cptr(m.dvEdge)[e] : 0.0;
+        const int v1 = del2 ? cptr(m.voe)[(size_t)e * 2] : 0, v2 = del2 ? cptr(m.voe)[(size_t)e * 2 + 1] : 0;
         for (int k = l; k < K; k += LPC) {
             const size_t off = (size_t)e * K + k;
             double t = 0.0;
@@ -133,6 +139,9 @@ __global__ __launch_bounds__(BLOCK) void k_stage_nl(const MeshDev m, const Stage
                     const double2 n = fq[(size_t)x * K + k];                            // {F, q_e} of the neighbour edge
                     t += cptr(m.woe)[(size_t)e * ME2 + i] * n.x * (0.5 * (qe + n.y));
                 }
+                if (del2)                                                               // horizontal_momentum_mixing.jl:75-78
+                    t += ((nl.divc[(size_t)c2 * K + k] - nl.divc[(size_t)c1 * K + k]) * invDc -
+                          (nl.zv[(size_t)v2 * K + k] - nl.zv[(size_t)v1 * K + k]) * invDv) * nl.visc;
             }
             if (a.tendU) a.tendU[off] = t;
             const double ucur = a.cu ? a.cu[off] : a.pu[off];
@@ -147,8 +156,8 @@ static hipError_t launch_nl_prepare_lpc(const MeshDev &m, const double *u, const
 {
     const int ng = BLOCK / LPC;
     auto grid = [&](int n) { return dim3((unsigned)std::min(std::max((n + ng - 1) / ng, 1), 65536)); };
-    hipLaunchKernelGGL((k_nl_vertex<LPC>), grid(m.nV), dim3(BLOCK), 0, s, m, u, h, nl.qv);
-    hipLaunchKernelGGL((k_nl_cell<LPC>), grid(m.nC), dim3(BLOCK), 0, s, m, u, nl.ke);
+    hipLaunchKernelGGL((k_nl_vertex<LPC>), grid(m.nV), dim3(BLOCK), 0, s, m, u, h, nl.qv, nl.zv);
+    hipLaunchKernelGGL((k_nl_cell<LPC>), grid(m.nC), dim3(BLOCK), 0, s, m, u, nl.ke, nl.divc);
     hipLaunchKernelGGL((k_nl_edge<LPC>), grid(m.nE), dim3(BLOCK), 0, s, m, u, h, nl);   // after k_nl_vertex (same stream)
     return hipGetLastError();
 }

@@ -177,6 +177,9 @@ end
 # kiteAreasOnVertex / fVertex.  Off by default: the reference has only the linear terms.
 set_nonlinear!(Prog, on::Bool = true) =
     check(ccall((:moka_set_nonlinear, lib), Cint, (Ptr{Cvoid}, Cint), Prog.state.handle, on ? 1 : 0), Prog.state.mesh.backend.ctx)
+# Del2 momentum mixing on top of them (what horizontal_momentum_mixing.jl:53-80 sketches); 0 = off
+set_viscosity_del2!(Prog, viscDel2::Float64) =
+    check(ccall((:moka_set_viscosity_del2, lib), Cint, (Ptr{Cvoid}, Cdouble), Prog.state.handle, viscDel2), Prog.state.mesh.backend.ctx)
 
 # reverse mode: what an EnzymeRules rule for ocn_run_loop on this backend calls (ext/MPASEnzymeExt.jl registers such
 # rules for mycopyto! already, :13-38).  d sum(ssh^2) / d initial state, test/enzyme/test_Enzyme_end2end.jl.

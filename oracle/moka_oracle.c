@@ -540,6 +540,23 @@ void oracle_tendencies_nonlinear(const oracle_mesh *m, const int32_t *verticesOn
                                  double *tendU, double *tendH, const double *u, const double *h, double *ssh_out,
                                  double *hEdge, double *F, double *qv, double *qe, double *ke)
 {
+    oracle_tendencies_nonlinear_del2(m, verticesOnEdge, cellsOnVertex, kiteAreasOnVertex, fVertex, tendU, tendH, u, h,
+                                     ssh_out, hEdge, F, qv, qe, ke, 0.0, NULL, NULL);
+}
+
+/* ... plus the Del2 momentum mixing of the reference's (never called, not runnable) sketch
+ *   src/ocn/Tendencies/normalVelocity/horizontal_momentum_mixing.jl:53-80
+ *   tendency[k,e] += ((div[k,c2] - div[k,c1]) * (1/dcEdge[e]) - (relVort[k,v2] - relVort[k,v1]) * (1/dvEdge[e])) * viscDel2
+ * with div = velocityDivCell as DivergenceOnCell forms it (Operators.jl:18,34-42: -= (u*dvEdge)*sign, / areaCell) and
+ * relVort = relativeVorticity as CurlOnVertex forms it from zero (Operators.jl:137-146).  viscDel2 = 0 (or zv NULL)
+ * leaves the term out altogether; zv (K,nV) and divc (K,nC) receive the two diagnostics. */
+void oracle_tendencies_nonlinear_del2(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
+                                      const double *kiteAreasOnVertex, const double *fVertex,
+                                      double *tendU, double *tendH, const double *u, const double *h, double *ssh_out,
+                                      double *hEdge, double *F, double *qv, double *qe, double *ke,
+                                      double viscDel2, double *zv, double *divc)
+{
+    const int del2 = viscDel2 != 0.0 && zv && divc;
     const int K = m->nVertLevels, VD = m->vertexDegree;
     oracle_update_ssh(m, ssh_out, h, K);
     oracle_interpolate_cell2edge(m, hEdge, h, K);
@@ -557,6 +574,7 @@ void oracle_tendencies_nonlinear(const oracle_mesh *m, const int32_t *verticesOn
             }
             hv = hv * invA;
             qv[IX(k, v, K)] = (fVertex[v - 1] + zeta) / hv;
+            if (del2) zv[IX(k, v, K)] = zeta;
         }
     }
     PFOR
@@ -568,18 +586,21 @@ void oracle_tendencies_nonlinear(const oracle_mesh *m, const int32_t *verticesOn
     for (int64_t c = 1; c <= m->nCells; ++c) {
         const double invA = 1.0 / m->areaCell[c - 1];
         for (int k = 1; k <= K; ++k) {
-            double acc = 0.0;
+            double acc = 0.0, d = 0.0;
             for (int i = 1; i <= m->nEdgesOnCell[c - 1]; ++i) {
                 const int32_t e = m->edgesOnCell[IX(i, c, m->maxEdges)];
                 acc += (0.25 * m->dcEdge[e - 1] * m->dvEdge[e - 1]) * u[IX(k, e, K)] * u[IX(k, e, K)];
+                d -= (u[IX(k, e, K)] * m->dvEdge[e - 1]) * (double)m->edgeSignOnCell[IX(i, c, m->maxEdges)];
             }
             ke[IX(k, c, K)] = acc * invA;
+            if (del2) divc[IX(k, c, K)] = d / m->areaCell[c - 1];
         }
     }
     PFOR
     for (int64_t e = 1; e <= m->nEdges; ++e) {
         const int32_t c1 = m->cellsOnEdge[IX(1, e, 2)], c2 = m->cellsOnEdge[IX(2, e, 2)];
-        const double invDc = 1. / m->dcEdge[e - 1];
+        const double invDc = 1. / m->dcEdge[e - 1], invDv = 1. / m->dvEdge[e - 1];
+        const int32_t v1 = verticesOnEdge[IX(1, e, 2)], v2 = verticesOnEdge[IX(2, e, 2)];
         for (int k = 1; k <= K; ++k) {
             double t = 0.0;
             if (k <= m->maxLevelEdgeTop[e - 1]) {
@@ -591,6 +612,9 @@ void oracle_tendencies_nonlinear(const oracle_mesh *m, const int32_t *verticesOn
                     t += m->weightsOnEdge[IX(i, e, m->maxEdges2)] * F[IX(k, eoe, K)] *
                          (0.5 * (qe[IX(k, e, K)] + qe[IX(k, eoe, K)]));
                 }
+                if (del2)
+                    t += ((divc[IX(k, c2, K)] - divc[IX(k, c1, K)]) * invDc -
+                          (zv[IX(k, v2, K)] - zv[IX(k, v1, K)]) * invDv) * viscDel2;
             }
             tendU[IX(k, e, K)] = t;
         }
@@ -603,10 +627,20 @@ void oracle_step_rk4_nonlinear(const oracle_mesh *m, const int32_t *verticesOnEd
                                const double *kiteAreasOnVertex, const double *fVertex, oracle_state *s, double dt,
                                double *work, double *scratch)
 {
+    oracle_step_rk4_nonlinear_del2(m, verticesOnEdge, cellsOnVertex, kiteAreasOnVertex, fVertex, s, dt, work, scratch, 0.0);
+}
+
+/* the same with Del2 mixing; scratch then holds K*nV + K*nC doubles more (4*K*nE + 2*K*nV + 2*K*nC) */
+void oracle_step_rk4_nonlinear_del2(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
+                                    const double *kiteAreasOnVertex, const double *fVertex, oracle_state *s, double dt,
+                                    double *work, double *scratch, double viscDel2)
+{
     const int K = m->nVertLevels;
     const int64_t nu = (int64_t)K * m->nEdges, nh = (int64_t)K * m->nCells;
     double *newU = work, *newH = work + nu;
     double *qe = scratch, *qv = scratch + nu, *ke = qv + (int64_t)K * m->nVertices;
+    double *zv = viscDel2 != 0.0 ? scratch + 4 * nu + (int64_t)K * m->nVertices + nh : NULL;
+    double *divc = zv ? zv + (int64_t)K * m->nVertices : NULL;
     const double a[3] = {dt / 2., dt / 2., dt};
     const double b[4] = {dt / 6., dt / 3., dt / 3., dt / 6.};
     advance_levels(s->ssh[0], s->ssh[1], m->nCells, 1, 1);
@@ -615,8 +649,8 @@ void oracle_step_rk4_nonlinear(const oracle_mesh *m, const int32_t *verticesOnEd
     memcpy(newU, s->u[1], sizeof(double) * (size_t)nu);
     memcpy(newH, s->h[1], sizeof(double) * (size_t)nh);
     for (int st = 0; st < 4; ++st) {
-        oracle_tendencies_nonlinear(m, verticesOnEdge, cellsOnVertex, kiteAreasOnVertex, fVertex, s->tendU, s->tendH,
-                                    s->u[1], s->h[1], s->ssh[1], s->hEdge, s->F, qv, qe, ke);
+        oracle_tendencies_nonlinear_del2(m, verticesOnEdge, cellsOnVertex, kiteAreasOnVertex, fVertex, s->tendU, s->tendH,
+                                         s->u[1], s->h[1], s->ssh[1], s->hEdge, s->F, qv, qe, ke, viscDel2, zv, divc);
         if (st < 3) {
             const double as = a[st];
             double *pu = s->u[1], *ph = s->h[1];

@@ -101,6 +101,15 @@ void oracle_tendencies_nonlinear(const oracle_mesh *m, const int32_t *verticesOn
                                  const double *kiteAreasOnVertex, const double *fVertex,
                                  double *tendU, double *tendH, const double *u, const double *h, double *ssh_out,
                                  double *hEdge, double *F, double *qv, double *qe, double *ke);
+/* ... with the Del2 momentum mixing of horizontal_momentum_mixing.jl:53-80 (a sketch the reference never calls) */
+void oracle_tendencies_nonlinear_del2(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
+                                      const double *kiteAreasOnVertex, const double *fVertex,
+                                      double *tendU, double *tendH, const double *u, const double *h, double *ssh_out,
+                                      double *hEdge, double *F, double *qv, double *qe, double *ke,
+                                      double viscDel2, double *zv, double *divc);
+void oracle_step_rk4_nonlinear_del2(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
+                                    const double *kiteAreasOnVertex, const double *fVertex, oracle_state *s, double dt,
+                                    double *work, double *scratch, double viscDel2);
 void oracle_step_rk4_nonlinear(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
                                const double *kiteAreasOnVertex, const double *fVertex, oracle_state *s, double dt,
                                double *work, double *scratch);

@@ -84,6 +84,8 @@ def lib():
         L.oracle_tendency_transpose.argtypes = [mp, _i32p, _f64p, C.c_int] + [_f64p] * 8
         L.oracle_tendencies_nonlinear.argtypes = [mp, _i32p, _i32p, _f64p, _f64p] + [_f64p] * 10
         L.oracle_step_rk4_nonlinear.argtypes = [mp, _i32p, _i32p, _f64p, _f64p, sp, C.c_double, _f64p, _f64p]
+        L.oracle_tendencies_nonlinear_del2.argtypes = [mp, _i32p, _i32p, _f64p, _f64p] + [_f64p] * 10 + [C.c_double, _f64p, _f64p]
+        L.oracle_step_rk4_nonlinear_del2.argtypes = [mp, _i32p, _i32p, _f64p, _f64p, sp, C.c_double, _f64p, _f64p, C.c_double]
         L.oracle_sum_sq.restype = C.c_double
         _lib = L
     return _lib
@@ -351,10 +353,12 @@ class OracleAdjointRK4:
 
 class OracleNonlinear:
     """The optional nonlinear (potential-vorticity + kinetic-energy) tendencies -- an extension that the reference does
-    not have: parity unpinned, pinned by its own properties only."""
+    not have: parity unpinned, pinned by its own properties only.  `visc_del2` != 0 adds the Del2
+    momentum mixing of the reference's uncalled sketch (horizontal_momentum_mixing.jl:53-80)."""
 
-    def __init__(self, om: OracleMesh):
+    def __init__(self, om: OracleMesh, visc_del2: float = 0.0):
         m = om.mesh
+        self.visc_del2 = float(visc_del2)
         if m.kiteAreasOnVertex is None:
             raise ValueError("the nonlinear terms need kiteAreasOnVertex")
         self.om = om
@@ -369,15 +373,17 @@ class OracleNonlinear:
         tu, th, ssh = np.zeros_like(u), np.zeros_like(h), np.zeros(m.nCells)
         hE, F, qe = np.zeros_like(u), np.zeros_like(u), np.zeros_like(u)
         qv, ke = np.zeros((m.nVertices, K)), np.zeros_like(h)
-        lib().oracle_tendencies_nonlinear(self.om.ref, _p(self.voe), _p(self.cov), _p(self.kite), _p(self.fv), _p(tu), _p(th),
-                                          _p(u), _p(h), _p(ssh), _p(hE), _p(F), _p(qv), _p(qe), _p(ke))
-        return tu, th, ssh, {"pv_vertex": qv, "pv_edge": qe, "ke": ke}
+        zv, divc = np.zeros_like(qv), np.zeros_like(h)
+        lib().oracle_tendencies_nonlinear_del2(self.om.ref, _p(self.voe), _p(self.cov), _p(self.kite), _p(self.fv), _p(tu),
+                                               _p(th), _p(u), _p(h), _p(ssh), _p(hE), _p(F), _p(qv), _p(qe), _p(ke),
+                                               self.visc_del2, _p(zv), _p(divc))
+        return tu, th, ssh, {"pv_vertex": qv, "pv_edge": qe, "ke": ke, "relativeVorticity": zv, "velocityDivCell": divc}
 
     def step_rk4(self, st: OracleState, dt):
         m, K = self.om.mesh, self.om.K
         if st._work is None:
             st._work = np.zeros(2 * K * (m.nEdges + m.nCells) + m.nCells)
         if getattr(st, "_nl_scratch", None) is None:
-            st._nl_scratch = np.zeros(4 * K * m.nEdges + K * m.nVertices + K * m.nCells)
-        lib().oracle_step_rk4_nonlinear(self.om.ref, _p(self.voe), _p(self.cov), _p(self.kite), _p(self.fv), C.byref(st.c),
-                                        float(dt), _p(st._work), _p(st._nl_scratch))
+            st._nl_scratch = np.zeros(4 * K * m.nEdges + 2 * K * m.nVertices + 2 * K * m.nCells)
+        lib().oracle_step_rk4_nonlinear_del2(self.om.ref, _p(self.voe), _p(self.cov), _p(self.kite), _p(self.fv),
+                                             C.byref(st.c), float(dt), _p(st._work), _p(st._nl_scratch), self.visc_del2)

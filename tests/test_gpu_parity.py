@@ -668,6 +668,45 @@ def test_nonlinear_tendency_and_rk4_bitwise(backend, meshname, K, nsteps):
     Prog._state.close(); Setup.mesh.close()
 
 
+@pytest.mark.parametrize("meshname,K,nsteps", [("ico16", 1, 3), ("ico16", 60, 2), ("planar", 4, 3), ("ico12f", 5, 2), ("ico16", 70, 2)])
+def test_del2_mixing_bitwise(backend, meshname, K, nsteps):
+    """Del2 momentum mixing (the reference's uncalled sketch, horizontal_momentum_mixing.jl:53-80) on top of the nonlinear
+    terms: tendencies, RK4 steps and graph replay against the oracle's restatement, bit for bit."""
+    mesh = get_mesh(meshname)
+    ssh, u, h, rest = random_state(mesh, K, 77 + K)
+    dtv = 2.0 if meshname == "planar" else 20.0
+    visc = 0.01 * float(mesh.dcEdge.min()) ** 2 / dtv
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    with pytest.raises(mk.MokaError, match="moka_set_nonlinear"):
+        L.check(L.lib().moka_set_viscosity_del2(Prog._state._h, visc), Prog._state.mesh.backend._h)
+    mk.set_nonlinear(Prog, True, visc_del2=visc)
+    nl = orc.OracleNonlinear(om, visc_del2=visc)
+    tu, th, ossh, _ = nl.tendencies(u, h)
+    mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
+    assert np.array_equal(Tend.tendNormalVelocity.get(), tu)
+    assert not np.array_equal(tu, orc.OracleNonlinear(om).tendencies(u, h)[0])
+    assert np.array_equal(Tend.tendLayerThickness.get(), th) and np.array_equal(Prog.ssh[-1].get(), ossh)
+    st = orc.OracleState(om, ssh, u, h)
+    mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dtv))
+    for _ in range(nsteps):
+        mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)
+        nl.step_rk4(st, dtv)
+    assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.layerThickness[-1].get(), st.h[1])
+    assert np.array_equal(Tend.tendNormalVelocity.get(), st.tendU)
+    mk.run_steps(Prog, mk.RungeKutta4, dtv, 5)                          # graph replay
+    for _ in range(5):
+        nl.step_rk4(st, dtv)
+    assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.ssh[-1].get(), st.ssh[1])
+    mk.set_nonlinear(Prog, True, visc_del2=0.0)                         # mixing off again: the plain nonlinear form
+    plain = orc.OracleNonlinear(om)
+    st2 = orc.OracleState(om, st.ssh[1], st.u[1], st.h[1])
+    mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)
+    plain.step_rk4(st2, dtv)
+    assert np.array_equal(Prog.normalVelocity[-1].get(), st2.u[1])
+    Prog._state.close(); Setup.mesh.close()
+
+
 def test_nonlinear_needs_the_extra_mesh_arrays(backend):
     import dataclasses
     mesh = dataclasses.replace(get_mesh("ico16"), kiteAreasOnVertex=None)
