@@ -21,10 +21,10 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_workers(nproc, *args, timeout=300):
+def run_workers(nproc, *args, timeout=300, worker="dist_worker.py"):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), *map(str, args)]
+           os.path.join(ROOT, "tests", worker), *map(str, args)]
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -87,6 +87,12 @@ def test_partition_and_local_mesh_properties():
 @pytest.mark.parametrize("K,variant", [(60, 0), (1, 0), (60, 3)])
 def test_distributed_rk4_hip_two_ranks_one_gpu(K, variant):
     run_workers(2, "gpu", K, variant)
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_on_the_library_comm_stream():
+    """What one GPU can show of the RCCL transport: see tests/rccl_worker.py."""
+    run_workers(1, worker="rccl_worker.py")
 
 
 @pytest.mark.gpu
