@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--ordering", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--tend-iters", type=int, default=20)
-    ap.add_argument("--transport", default="nccl", choices=["nccl", "nccl-default-stream", "gloo"],
+    ap.add_argument("--transport", default="nccl", choices=["nccl", "nccl-a2a", "nccl-p2p", "nccl-default-stream", "gloo"],
                     help="halo transport for N > 1: nccl = RCCL over xGMI (default); gloo = host-staged (rehearsal on one GPU)")
     args = ap.parse_args()
 
@@ -201,29 +201,19 @@ def main():
                                     patch_cells=args.patch_cells, transport=args.transport, group=gloo_group,
                                     state_bytes=sbytes)
         log(f"[bench] rank {rank}: partition + local plan + upload: {time.time() - t0:.1f}s  {model.info()}")
+        if args.transport == "nccl-p2p":
+            model.transport = "nccl"
         if args.transport == "nccl":
-            # The overlapped form issues RCCL P2P on the library's comm stream (torch.cuda.ExternalStream).  If this torch /
-            # RCCL build rejects that, fall back to the same P2P on the default stream, then to host-staged gloo, rather
-            # than lose the run; the ranks agree on the outcome over the gloo group so nobody is left waiting.
-            for cand in ("nccl", "nccl-default-stream", "gloo"):
-                model.transport = cand
-                ok = 1.0
-                try:
-                    model.step_rk4()
-                    backend.synchronize(); torch.cuda.synchronize()
-                except Exception as exc:             # noqa: BLE001
-                    log(f"[bench] rank {rank}: halo transport {cand} failed: {exc!r}")
-                    ok = 0.0
-                flag = torch.tensor([ok], dtype=torch.float64)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=gloo_group)
-                if float(flag[0]) == 1.0:
-                    break
-            else:
-                raise RuntimeError("no halo transport works on this node")
-            if cand != "nccl":
-                log(f"[bench] rank {rank}: using halo transport {cand}")
-                model.exchange_state()               # a failed attempt may have left halos behind: refresh them
-            args.transport = cand
+            # Choose the halo transport on this node.  Each candidate must (1) run a step without raising and (2) deliver
+            # exactly the bytes the host-staged gloo exchange delivers for the same packed state; the ranks agree on the
+            # outcome over the gloo group so nobody is left waiting.  Among the overlapped RCCL forms (one
+            # all_to_all_single per stage / batched P2P, both on the library's comm stream) the faster one is kept;
+            # P2P on the default stream with full synchronisation and gloo are the fallbacks.
+            cand, times = mp.choose_transport(model, ("nccl-a2a", "nccl"), ("nccl-default-stream", "gloo"), gloo_group,
+                                              lambda msg: log(f"[bench] rank {rank}: {msg}"))
+            model.transport = cand
+            model.exchange_state()                   # failed attempts may have left halos behind: refresh them
+            args.transport = {"nccl": "nccl-p2p"}.get(cand, cand)
         step = model.step_rk4
         sync = backend.synchronize
         info = model.info()

@@ -153,6 +153,18 @@ def message_slices(lm: LocalMesh, K: int, send: bool):
     return out
 
 
+def alltoall_splits(lm: LocalMesh, K: int):
+    """(input_split_sizes, output_split_sizes) of the one all_to_all_single that moves every halo message of a stage:
+    neighbours are kept in ascending rank order, so the packed buffers ARE the rank-ordered concatenation."""
+    assert list(lm.neighbors) == sorted(lm.neighbors)
+    ins, outs = [0] * lm.world, [0] * lm.world
+    for q, a, b in message_slices(lm, K, True):
+        ins[q] = b - a
+    for q, a, b in message_slices(lm, K, False):
+        outs[q] = b - a
+    return ins, outs
+
+
 def pack_numpy(lm: LocalMesh, K: int, ssh, u, h):
     """The library's send-buffer layout, in numpy (used by the CPU tests)."""
     parts = []
@@ -182,9 +194,10 @@ def unpack_numpy(lm: LocalMesh, K: int, buf, ssh, u, h):
 class DistributedModel:
     """Partitioned shallow-water model: RK4 steps with halo exchange between stages.
 
-    transport = "nccl": torch.distributed P2P on device buffers (RCCL over xGMI), issued on the library's comm
-    stream so that the interior patches of the stage overlap the exchange;  "gloo": staged through the host
-    (tests: two ranks may share one GPU)."""
+    transport = "nccl-a2a": one all_to_all_single per stage on device buffers (RCCL over xGMI: a grouped send/recv per
+    neighbour underneath, one host call), issued on the library's comm stream so that the interior patches of the stage
+    overlap the exchange;  "nccl": the same messages as batched P2P ops;  "nccl-default-stream": P2P with full
+    synchronisation (no overlap);  "gloo": staged through the host (tests: two ranks may share one GPU)."""
 
     def __init__(self, mesh, ssh, u, h, rest, dt, backend, rank, world, ordering=0, patch_cells=0,
                  transport="nccl", part=None, group=None, state_bytes=8):
@@ -237,6 +250,7 @@ class DistributedModel:
         self.send_slices = message_slices(lm, K, True)
         self.recv_slices = message_slices(lm, K, False)
         self._p2p = None                      # P2POp list of the nccl transport, built once
+        self._splits = alltoall_splits(lm, K)
         cs, ms = C.c_void_p(), C.c_void_p()
         L.check(L.lib().moka_ctx_streams(backend._h, C.byref(cs), C.byref(ms)))
         self.comm_stream = torch.cuda.ExternalStream(ms.value, device=dev)
@@ -247,7 +261,11 @@ class DistributedModel:
         torch, dist = self.torch, self.dist
         if not self.lm.neighbors:
             return
-        if self.transport == "nccl":
+        if self.transport == "nccl-a2a":
+            ins, outs = self._splits
+            with torch.cuda.stream(self.comm_stream):     # stream-ordered after the pack kernel; the host does not wait
+                dist.all_to_all_single(self.recvbuf[:sum(outs)], self.sendbuf[:sum(ins)], outs, ins)
+        elif self.transport == "nccl":
             if self._p2p is None:             # one message per neighbour and direction; the op list is reused
                 self._p2p = [dist.P2POp(dist.irecv, self.recvbuf[a:b], q) for q, a, b in self.recv_slices if b > a] + \
                             [dist.P2POp(dist.isend, self.sendbuf[a:b], q) for q, a, b in self.send_slices if b > a]
@@ -264,6 +282,8 @@ class DistributedModel:
             torch.cuda.synchronize()
         elif self.transport == "local":
             raise RuntimeError("transport 'local' is driven by LocalCluster.step_rk4")
+        elif self.transport != "gloo":
+            raise ValueError(f"unknown halo transport {self.transport!r}")
         else:                                    # gloo: through the host
             self.backend.synchronize()
             send_cpu, recv_cpu = self.sendbuf.cpu(), torch.empty_like(self.recvbuf, device="cpu")
@@ -273,6 +293,27 @@ class DistributedModel:
                 w.wait()
             self.recvbuf.copy_(recv_cpu)
             torch.cuda.synchronize()
+
+    def verify_transport(self, trusted="gloo") -> bool:
+        """Pack the current state, move it with this model's transport and again with `trusted`: True when both deliver
+        the same bytes on this rank (callers combine the ranks' answers)."""
+        lib = L.lib()
+        mine = self.transport
+        L.check(lib.moka_halo_pack(self._halo, 0, self.sendbuf.data_ptr()), self.backend._h)
+        self.recvbuf.zero_()
+        self.torch.cuda.synchronize()
+        self._transport()
+        self.backend.synchronize(); self.torch.cuda.synchronize()
+        got = self.recvbuf.clone()
+        self.recvbuf.zero_()
+        self.torch.cuda.synchronize()
+        try:
+            self.transport = trusted
+            self._transport()
+        finally:
+            self.transport = mine
+        self.backend.synchronize(); self.torch.cuda.synchronize()
+        return bool(self.torch.equal(got, self.recvbuf))
 
     def exchange_state(self):
         """Halo exchange of the current time level (e.g. after an upload)."""
@@ -305,6 +346,67 @@ class DistributedModel:
                   "neighbors": len(self.lm.neighbors), "halo_bytes_per_stage": self.halo_bytes_per_stage,
                   "patches_boundary": self.p_boundary, "patches_owned": self.p_owned})
         return d
+
+
+def choose_transport(model: DistributedModel, overlapped, fallbacks, control_group, log=lambda msg: None, trial_steps=5):
+    """Pick the halo transport of `model` on this node; every rank calls this and all return the same name.
+
+    A candidate qualifies when, on every rank, it moves the packed state to exactly the bytes the host-staged gloo
+    exchange delivers AND a full RK4 step with it runs without raising; the ranks combine their answers over
+    `control_group` (gloo) so that nobody is left waiting.  Of the qualifying `overlapped` candidates the fastest over
+    `trial_steps` steps is kept (max over ranks); otherwise the first qualifying one of `fallbacks`.
+    Returns (name, {candidate: ms per step})."""
+    import time
+    torch, dist = model.torch, model.dist
+
+    def agree(x, op):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=op, group=control_group)
+        return float(t[0])
+
+    def sync_all():
+        model.backend.synchronize(); torch.cuda.synchronize()
+        dist.barrier(group=control_group)
+
+    def works(cand):
+        model.transport = cand
+        ok = 1.0
+        try:
+            if not model.verify_transport("gloo"):
+                log(f"halo transport {cand} delivered different bytes than gloo")
+                ok = 0.0
+            model.transport = cand
+            model.step_rk4()
+            model.backend.synchronize(); torch.cuda.synchronize()
+        except Exception as exc:                 # noqa: BLE001
+            log(f"halo transport {cand} failed: {exc!r}")
+            ok = 0.0
+        return agree(ok, dist.ReduceOp.MIN) == 1.0
+
+    def trial_ms(cand):
+        model.transport = cand
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(trial_steps):
+            model.step_rk4()
+        sync_all()
+        return agree((time.perf_counter() - t0) / trial_steps * 1e3, dist.ReduceOp.MAX)
+
+    times = {}
+    good = [c for c in overlapped if works(c)]
+    if good:
+        times = {c: trial_ms(c) for c in good}
+        cand = min(good, key=lambda c: times[c])
+        log(f"overlapped halo transports, ms/step over {trial_steps} steps: {times} -> {cand}")
+    else:
+        for cand in fallbacks:
+            if works(cand):
+                break
+        else:
+            raise RuntimeError("no halo transport works on this node")
+        log(f"using halo transport {cand}")
+    model.transport = cand
+    return cand, times
 
 
 class LocalCluster:

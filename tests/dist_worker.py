@@ -33,6 +33,17 @@ def exchange_numpy(lm, K, fields, dist):
     par.unpack_numpy(lm, K, recvbuf.numpy(), ssh, u, h)
 
 
+def exchange_numpy_a2a(lm, K, fields, dist):
+    """The same exchange as one all_to_all_single with the split sizes of the "nccl-a2a" transport."""
+    ssh, u, h = fields
+    ins, outs = par.alltoall_splits(lm, K)
+    sendbuf = torch.from_numpy(par.pack_numpy(lm, K, ssh, u, h))
+    recvbuf = torch.zeros(sum(outs), dtype=torch.float64)
+    assert sendbuf.numel() == sum(ins)
+    dist.all_to_all_single(recvbuf, sendbuf, outs, ins)
+    par.unpack_numpy(lm, K, recvbuf.numpy(), ssh, u, h)
+
+
 def main():
     mode = sys.argv[1]
     dist.init_process_group("gloo")
@@ -78,7 +89,7 @@ def main():
                 if s < 3:
                     pu, ph = cu + a[s] * tu, ch + a[s] * th
                     pssh = oml.update_ssh(ph)
-                    exchange_numpy(lm, K, (pssh, pu, ph), dist)
+                    (exchange_numpy if s % 2 else exchange_numpy_a2a)(lm, K, (pssh, pu, ph), dist)   # both forms
                 nu, nh = nu + b[s] * tu, nh + b[s] * th
             cssh = oml.update_ssh(nh)
             exchange_numpy(lm, K, (cssh, nu, nh), dist)
@@ -91,6 +102,19 @@ def main():
         backend.set_kernel_variant(variant)
         model = par.DistributedModel(mesh, ssh, u, h, rest, dt, backend, rank, world, transport="gloo", part=part)
         assert model.p_boundary <= model.p_owned <= model.mesh.info()["nPatches"]
+        # the transport selection bench.py runs before timing (on a model of its own: the trials advance the state):
+        # broken candidates are skipped by agreement of the ranks
+        probe = par.DistributedModel(mesh, ssh, u, h, rest, dt, backend, rank, world, transport="gloo", part=part)
+        probe.exchange_state()
+        msgs = []
+        assert par.choose_transport(probe, ("bogus", "gloo"), ("gloo",), None, msgs.append, trial_steps=1)[0] == "gloo"
+        assert par.choose_transport(probe, ("bogus",), ("bogus2", "gloo"), None, msgs.append)[0] == "gloo"
+        assert sum("failed" in m for m in msgs) == 3, msgs
+        try:
+            par.choose_transport(probe, (), ("bogus",), None)
+            raise AssertionError("no transport should have qualified")
+        except RuntimeError:
+            pass
         for _ in range(nsteps):
             model.step_rk4()
         got = (model.Prog.ssh[-1].get(), model.Prog.normalVelocity[-1].get(), model.Prog.layerThickness[-1].get())
