@@ -174,6 +174,27 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         return ldsU + (cached ? loc : 0u);
     };
 
+    // Stores are deferred by one iteration: an entity's results are written during the NEXT iteration, right after that
+    // iteration's loads have arrived.  Issued at the end of their own iteration they force a vmcnt(0) at the loop top
+    // (their data registers are reused at once), i.e. every iteration waited for its stores to be acknowledged before
+    // the next gathers could start; now the acknowledgement overlaps the arithmetic and the next record reads.
+    double2 pA = make_double2(0.0, 0.0), pB = pA;
+    double pS = 0.0;
+    uint32_t pOff = 0;
+    int pC = 0;
+    bool pend = false;
+    auto flush_cell = [&]() {
+        if (act) {
+            if constexpr (MODE == 0) gstore2(a.tendH, pOff, pA);
+            if constexpr (MODE == 1 || MODE == 2) {
+                gstore2(a.ph_out, pOff, pA);
+                gstore2(a.nh_out, pOff, pB);
+            }
+            if constexpr (MODE == 3) gstore2(a.nh_out, pOff, pB);
+        }
+        if constexpr (MODE != 0)
+            if (l == 0) a.ssh_out[pC] = pS;
+    };
     // ---------------- cells ----------------
     for (int ci = grp; ci < nOwnC; ci += NG) {
         const int c = c0 + ci;
@@ -194,7 +215,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 const uint32_t off = r[i];
                 ad[i] = urow_addr(off, cached[i]);
                 goff[i] = off + voff;
-                asm volatile("" : "+v"(goff[i]));      // stays in a VGPR (see the edge loop)
+                asm("" : "+v"(goff[i]));               // stays in a VGPR (see the edge loop)
             }
             lds_burst<ME>(raw, ad);
 #pragma unroll
@@ -205,6 +226,8 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (MODE == 2) cur = gload2(a.ch, own);
             if constexpr (MODE >= 2) nin = gload2(a.nh_in, own);
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this iteration's loads (needed next anyway) ...
+        if (pend) flush_cell();                                        // ... so that the stores queue up behind them, not ahead
         double2 t = make_double2(0.0, 0.0);
         // regular entity (every slot valid, every level active) in BOTH half-waves: no per-slot masks (wave-uniform branch)
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME) - 1u && all)) == 0;
@@ -229,17 +252,17 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         }
         double2 hs = make_double2(0.0, 0.0);
         if (act) {
-            if constexpr (MODE == 0) gstore2(a.tendH, own, t);
+            if constexpr (MODE == 0) pA = t;
             if constexpr (MODE == 1 || MODE == 2) {
                 const double2 hcur = MODE == 2 ? cur : hc;
                 const double2 nb = MODE == 2 ? nin : hcur;
                 hs = make_double2(hcur.x + a.a * t.x, hcur.y + a.a * t.y);                    // time_integration.jl:125
-                gstore2(a.ph_out, own, hs);
-                gstore2(a.nh_out, own, make_double2(nb.x + a.b * t.x, nb.y + a.b * t.y));     // :135
+                pA = hs;
+                pB = make_double2(nb.x + a.b * t.x, nb.y + a.b * t.y);                        // :135
             }
             if constexpr (MODE == 3) {
                 hs = make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y);
-                gstore2(a.nh_out, own, hs);
+                pB = hs;
             }
         }
         if constexpr (MODE != 0) {
@@ -248,9 +271,24 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 const double ox = __shfl_xor(hs.x, sft, 32), oy = __shfl_xor(hs.y, sft, 32);
                 hs = make_double2(hs.x + ox, hs.y + oy);
             }
-            if (l == 0) a.ssh_out[c] = (hs.x + hs.y) - L.rsum[ci];                            // :209 (+N3)
+            pS = (hs.x + hs.y) - L.rsum[ci];                                                  // :209 (+N3)
         }
+        pOff = own;
+        pC = c;
+        pend = true;
     }
+    if (pend) flush_cell();
+    pend = false;
+    auto flush_edge = [&]() {
+        if (act) {
+            if constexpr (MODE == 0) gstore2(a.tendU, pOff, pA);
+            if constexpr (MODE == 1 || MODE == 2) {
+                gstore2(a.pu_out, pOff, pA);
+                gstore2(a.nu_out, pOff, pB);
+            }
+            if constexpr (MODE == 3) gstore2(a.nu_out, pOff, pB);
+        }
+    };
 
     // ---------------- edges ----------------
     for (int ei = grp; ei < nOwnE; ei += NG) {
@@ -275,7 +313,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 const uint32_t off = r[i];
                 ad[i] = urow_addr(off, cached[i]);
                 goff[i] = off + voff;
-                asm volatile("" : "+v"(goff[i]));      // keep it in a VGPR: otherwise each masked load re-reads r[i] from LDS first
+                asm("" : "+v"(goff[i]));               // keep it in a VGPR: otherwise each masked load re-reads r[i] from LDS first
             }
             lds_burst<ME2>(raw, ad);
 #pragma unroll
@@ -286,6 +324,8 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (MODE == 2) cur = gload2(a.cu, own);
             if constexpr (MODE >= 2) nin = gload2(a.nu_in, own);
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this iteration's loads (needed next anyway) ...
+        if (pend) flush_edge();                                        // ... so that the stores queue up behind them, not ahead
         const double ds = __shfl(sB, 1, 32) - __shfl(sA, 0, 32);       // ssh[c2] - ssh[c1]
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME2) - 1u && mlt >= K)) == 0;   // wave-uniform
         if (act) {
@@ -310,19 +350,22 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                     if (on && ay) t.y += py;
                 }
             }
-            if constexpr (MODE == 0) gstore2(a.tendU, own, t);
+            if constexpr (MODE == 0) pA = t;
             if constexpr (MODE == 1) {
                 const double2 up = ubuf2[(size_t)ei * K2 + l];          // own row is in the cache
-                gstore2(a.pu_out, own, make_double2(up.x + a.a * t.x, up.y + a.a * t.y));   // time_integration.jl:124
-                gstore2(a.nu_out, own, make_double2(up.x + a.b * t.x, up.y + a.b * t.y));   // :134
+                pA = make_double2(up.x + a.a * t.x, up.y + a.a * t.y);  // time_integration.jl:124
+                pB = make_double2(up.x + a.b * t.x, up.y + a.b * t.y);  // :134
             }
             if constexpr (MODE == 2) {
-                gstore2(a.pu_out, own, make_double2(cur.x + a.a * t.x, cur.y + a.a * t.y));
-                gstore2(a.nu_out, own, make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y));
+                pA = make_double2(cur.x + a.a * t.x, cur.y + a.a * t.y);
+                pB = make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y);
             }
-            if constexpr (MODE == 3) gstore2(a.nu_out, own, make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y));
+            if constexpr (MODE == 3) pB = make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y);
         }
+        pOff = own;
+        pend = true;
     }
+    if (pend) flush_edge();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,7 +484,9 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
                 const uint32_t off = r[i];
                 ad[i] = urow_addr(off, cached[i]);
                 goff[i] = off + voff;
-                asm volatile("" : "+v"(goff[i]));      // stays in a VGPR (see k_stage_rec2c)
+                asm volatile("" : "+v"(goff[i]));      // stays in a VGPR (see k_stage_rec2c); volatile on purpose: batching the
+                                                       // record reads and deferring the stores as k_stage_rec2c does costs
+                                                       // registers this kernel does not have (spills: 26.8 -> 30.6 ms, config 5)
             }
             lds_burst<ME>(raw, ad);
 #pragma unroll
