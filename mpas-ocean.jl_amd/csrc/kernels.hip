@@ -300,9 +300,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         const int mlt = (int)r[ME2 + 3];
         const double g = L.g[ei];
         const uint32_t own = (uint32_t)e * rowB + voff;
-        double sA = 0.0, sB = 0.0;
-        if (l == 0) sA = a.ssh[r[ME2]];
-        if (l == 1) sB = a.ssh[r[ME2 + 1]];
+        double sv = 0.0;
         double2 uv[ME2], cur = make_double2(0.0, 0.0), nin = cur;
         if (act) {
             bool cached[ME2];
@@ -324,9 +322,10 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (MODE == 2) cur = gload2(a.cu, own);
             if constexpr (MODE >= 2) nin = gload2(a.nu_in, own);
         }
+        if (l < 2) sv = a.ssh[r[ME2 + l]];                             // ssh of cellsOnEdge[l]: after the gathers in the queue
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this iteration's loads (needed next anyway) ...
         if (pend) flush_edge();                                        // ... so that the stores queue up behind them, not ahead
-        const double ds = __shfl(sB, 1, 32) - __shfl(sA, 0, 32);       // ssh[c2] - ssh[c1]
+        const double ds = __shfl(sv, 1, 32) - __shfl(sv, 0, 32);       // ssh[c2] - ssh[c1]
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME2) - 1u && mlt >= K)) == 0;   // wave-uniform
         if (act) {
             const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
