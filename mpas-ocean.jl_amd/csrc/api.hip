@@ -762,7 +762,29 @@ int moka_step_fe(moka_state *st, double dt, int flags)
     // advanceTimeLevels! + diagnostic_compute! + both tendencies + updates (time_integration.jl:163-189)
     // in one launch: new values are written into the previous level's buffers, then the levels swap.
     FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE | FE_TENDU | FE_TENDH | FE_UPDATE, flags, dt);
-    HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
+    // All levels on a whole mesh with the default kernel choice: the step runs in the tuned stage kernel (modes 4 / 5 of
+    // k_stage_rec2c: everything but relativeVorticity) plus the vertex pass of the generic kernel.  Anything else --
+    // MOKA_FE_LEVEL1_ONLY, odd or large K, explicit kernel variants, partitioned meshes -- takes the generic one-launch kernel.
+    bool fast = false;
+    const moka_mesh *mm = st->mesh;
+    if (!(flags & MOKA_FE_LEVEL1_ONLY) && (st->ctx->variant == 0 || st->ctx->variant == 11) && mm->lpc == 64 && mm->colOk &&
+        mm->plan.nPatchesLaunch == mm->plan.nPatches) {
+        StageArgs g{};
+        g.pu = a.u; g.ph = a.h; g.ssh = a.ssh;
+        g.pu_out = a.u_new; g.ph_out = a.h_new; g.ssh_out = a.ssh_new;
+        g.tendU = a.tendU; g.tendH = a.tendH; g.a = dt;
+        g.hEdgeOld = (flags & MOKA_FE_STALE_HEDGE) ? a.hEdgeOld : nullptr;
+        g.hEdgeNew = a.hEdgeNew; g.F = a.F; g.div = a.div; g.areaCell = mm->dev.areaCell;
+        const hipError_t e = launch_stage_rec2c(mm->dev, g, st->ctx->stream);
+        if (e == hipSuccess) {
+            fast = true;
+            a.ops = FE_CURL;
+            HIPCHK(st->ctx, launch_fe(mm->dev, a, mm->lpc, st->ctx->stream));
+        } else if (e != hipErrorNotSupported) {
+            HIPCHK(st->ctx, e);
+        }
+    }
+    if (!fast) HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
     std::swap(st->lev[0], st->lev[1]);
     std::swap(st->hEdge[0], st->hEdge[1]);
     st->sshConsistent = !(flags & MOKA_FE_LEVEL1_ONLY) || st->mesh->plan.K == 1;

@@ -178,7 +178,11 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     // iteration's loads have arrived.  Issued at the end of their own iteration they force a vmcnt(0) at the loop top
     // (their data registers are reused at once), i.e. every iteration waited for its stores to be acknowledged before
     // the next gathers could start; now the acknowledgement overlaps the arithmetic and the next record reads.
-    double2 pA = make_double2(0.0, 0.0), pB = pA;
+    // MODE 4 / 5: one Forward-Euler step (time_integration.jl:150-193) with the diagnostics of diagnostic_compute!
+    // (DiagnosticVars.jl:108-117) except relativeVorticity; 4 = thickness flux from the previous step's
+    // layerThicknessEdge (MOKA_FE_STALE_HEDGE, the reference's behaviour), 5 = from this step's.
+    constexpr bool FE = MODE >= 4, STALE = MODE == 4;
+    double2 pA = make_double2(0.0, 0.0), pB = pA, pD = pA, pE = pA;
     double pS = 0.0;
     uint32_t pOff = 0;
     int pC = 0;
@@ -191,6 +195,11 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 gstore2(a.nh_out, pOff, pB);
             }
             if constexpr (MODE == 3) gstore2(a.nh_out, pOff, pB);
+            if constexpr (FE) {
+                gstore2(a.ph_out, pOff, pA);
+                gstore2(a.tendH, pOff, pB);
+                gstore2(a.div, pOff, pD);
+            }
         }
         if constexpr (MODE != 0)
             if (l == 0) a.ssh_out[pC] = pS;
@@ -211,8 +220,8 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             hc = gload2(a.ph, own);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
-                hv[i] = gload2(a.ph, r[ME + i] + voff);
                 const uint32_t off = r[i];
+                hv[i] = STALE ? gload2(a.hEdgeOld, off + voff) : gload2(a.ph, r[ME + i] + voff);
                 ad[i] = urow_addr(off, cached[i]);
                 goff[i] = off + voff;
                 asm("" : "+v"(goff[i]));               // stays in a VGPR (see the edge loop)
@@ -224,19 +233,29 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 if (!cached[i]) uv[i] = glb_row2(puG + goff[i]);
             }
             if constexpr (MODE == 2) cur = gload2(a.ch, own);
-            if constexpr (MODE >= 2) nin = gload2(a.nh_in, own);
+            if constexpr (MODE == 2 || MODE == 3) nin = gload2(a.nh_in, own);
         }
+        double area = 0.0;
+        if constexpr (FE) area = a.areaCell[c];
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this iteration's loads (needed next anyway) ...
         if (pend) flush_cell();                                        // ... so that the stores queue up behind them, not ahead
         double2 t = make_double2(0.0, 0.0);
         // regular entity (every slot valid, every level active) in BOTH half-waves: no per-slot masks (wave-uniform branch)
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME) - 1u && all)) == 0;
+        double2 dv = make_double2(0.0, 0.0);                            // velocityDivCell (FE): Operators.jl:18,39
+        // thickness at the edge: interpolated (Operators.jl:217) or, MODE 4, what the previous step stored
+        auto hE = [&](int i) { return STALE ? hv[i] : make_double2(0.5 * (hc.x + hv[i].x), 0.5 * (hc.y + hv[i].y)); };
         if (plain) {
             if (act) {
 #pragma unroll
                 for (int i = 0; i < ME; ++i) {
-                    t.x += uv[i].x * (0.5 * (hc.x + hv[i].x)) * rs[i] * invA;
-                    t.y += uv[i].y * (0.5 * (hc.y + hv[i].y)) * rs[i] * invA;
+                    const double2 he = hE(i);
+                    t.x += uv[i].x * he.x * rs[i] * invA;
+                    t.y += uv[i].y * he.y * rs[i] * invA;
+                    if constexpr (FE) {
+                        dv.x -= uv[i].x * rs[i];
+                        dv.y -= uv[i].y * rs[i];
+                    }
                 }
             }
         } else if (act) {
@@ -244,10 +263,17 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             for (int i = 0; i < ME; ++i) {
                 const int ml = all ? K : cptr(m.mltc)[(size_t)c * ME + i];
                 const bool on = (mask >> i) & 1u;
-                const double dx = uv[i].x * (0.5 * (hc.x + hv[i].x)) * rs[i] * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
-                const double dy = uv[i].y * (0.5 * (hc.y + hv[i].y)) * rs[i] * invA;   // horizontal_advection.jl:63
+                const double2 he = hE(i);
+                const double dx = uv[i].x * he.x * rs[i] * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
+                const double dy = uv[i].y * he.y * rs[i] * invA;   // horizontal_advection.jl:63
                 if (on && k0 < ml) t.x += dx;
                 if (on && k0 + 1 < ml) t.y += dy;
+                if constexpr (FE) {
+                    if (on) {
+                        dv.x -= uv[i].x * rs[i];
+                        dv.y -= uv[i].y * rs[i];
+                    }
+                }
             }
         }
         double2 hs = make_double2(0.0, 0.0);
@@ -263,6 +289,12 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (MODE == 3) {
                 hs = make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y);
                 pB = hs;
+            }
+            if constexpr (FE) {
+                hs = make_double2(hc.x + a.a * t.x, hc.y + a.a * t.y);                        // time_integration.jl:199
+                pA = hs;
+                pB = t;
+                pD = make_double2(dv.x / area, dv.y / area);                                  // Operators.jl:41
             }
         }
         if constexpr (MODE != 0) {
@@ -287,6 +319,12 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 gstore2(a.nu_out, pOff, pB);
             }
             if constexpr (MODE == 3) gstore2(a.nu_out, pOff, pB);
+            if constexpr (FE) {
+                gstore2(a.pu_out, pOff, pA);
+                gstore2(a.tendU, pOff, pB);
+                gstore2(a.F, pOff, pD);
+                gstore2(a.hEdgeNew, pOff, pE);
+            }
         }
     };
 
@@ -301,7 +339,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         const double g = L.g[ei];
         const uint32_t own = (uint32_t)e * rowB + voff;
         double sv = 0.0;
-        double2 uv[ME2], cur = make_double2(0.0, 0.0), nin = cur;
+        double2 uv[ME2], cur = make_double2(0.0, 0.0), nin = cur, hx = cur, hy = cur, hEo = cur;
         if (act) {
             bool cached[ME2];
             uint32_t ad[ME2], goff[ME2];
@@ -320,7 +358,12 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 if (!cached[i]) uv[i] = glb_row2(puG + goff[i]);
             }
             if constexpr (MODE == 2) cur = gload2(a.cu, own);
-            if constexpr (MODE >= 2) nin = gload2(a.nu_in, own);
+            if constexpr (MODE == 2 || MODE == 3) nin = gload2(a.nu_in, own);
+            if constexpr (FE) {
+                hx = gload2(a.ph, r[ME2] * rowB + voff);               // layerThickness of cellsOnEdge[1], [2]
+                hy = gload2(a.ph, r[ME2 + 1] * rowB + voff);
+                if constexpr (STALE) hEo = gload2(a.hEdgeOld, own);
+            }
         }
         if (l < 2) sv = a.ssh[r[ME2 + l]];                             // ssh of cellsOnEdge[l]: after the gathers in the queue
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this iteration's loads (needed next anyway) ...
@@ -360,6 +403,14 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 pB = make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y);
             }
             if constexpr (MODE == 3) pB = make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y);
+            if constexpr (FE) {
+                const double2 up = ubuf2[(size_t)ei * K2 + l];          // own row is in the cache
+                pE = make_double2(0.5 * (hx.x + hy.x), 0.5 * (hx.y + hy.y));              // layerThicknessEdge, Operators.jl:217
+                const double2 hF = STALE ? hEo : pE;
+                pD = make_double2(up.x * hF.x, up.y * hF.y);                              // thicknessFlux, DiagnosticVars.jl:165
+                pA = make_double2(up.x + a.a * t.x, up.y + a.a * t.y);                    // time_integration.jl:199
+                pB = t;
+            }
         }
         pOff = own;
         pend = true;
@@ -959,6 +1010,8 @@ static bool launch_rec2c(const ColMesh &m, const StageArgs &a, int mode, dim3 g,
         case 1: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 1>), g, b, lds, s, m, a, mE, mC); return true;
         case 2: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 2>), g, b, lds, s, m, a, mE, mC); return true;
         case 3: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 3>), g, b, lds, s, m, a, mE, mC); return true;
+        case 4: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 4>), g, b, lds, s, m, a, mE, mC); return true;
+        case 5: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 5>), g, b, lds, s, m, a, mE, mC); return true;
     }
     return false;
 }

@@ -18,6 +18,11 @@ struct StageArgs {
     double *tendU, *tendH;        // tendencies
     double a, b;
     int dbg;                      // diagnostics only (MOKA_DBG): 1 no stores, 2 gathers read the own row, 4 constant records
+    // Forward-Euler step in the default stage kernel (k_stage_rec2c modes 4 / 5; every other kernel ignores these):
+    // pu/ph/ssh = current level, pu_out/ph_out/ssh_out = new level, a = dt, tendU/tendH, and the diagnostics below
+    const double *hEdgeOld;       // previous step's layerThicknessEdge (mode 4: MOKA_FE_STALE_HEDGE) or NULL (mode 5)
+    double *hEdgeNew, *F, *div;   // layerThicknessEdge, thicknessFlux, velocityDivCell
+    const double *areaCell;
 };
 
 // the slice of MeshDev the column kernel reads (kept small: kernel arguments live in SGPRs)
