@@ -253,6 +253,9 @@ int  moka_rk4_dist_end(moka_halo *h);
  * without the row cache; 7 = record-staged 8-byte lanes; 1/4 = column kernel pipelined/plain; 5/6 = 16-byte-lane column;
  * 2 = LDS patch-tiled; 9 = tiled, two-burst prefetch; 10 = persistent double-buffered tile; 3 = generic index kernel. */
 int moka_set_kernel_variant(moka_ctx *ctx, int variant);
+/* which kernel the last moka_step_fe of this state used: 1 = the tuned stage kernel (+ vertex pass), 0 = the generic
+ * one-launch kernel, -1 = no Forward-Euler step yet.  For tests and measurement; results are identical either way. */
+int moka_last_fe_path(const moka_state *st);
 
 /* ---- optional nonlinear terms (extension; NOT in the reference, parity unpinned) ---------------------------------
  * north_star names potential-vorticity Coriolis over edgesOnEdge, the KE + ssh gradient over cellsOnEdge and vertex

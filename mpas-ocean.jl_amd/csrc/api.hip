@@ -69,6 +69,7 @@ struct moka_state {
     // optional nonlinear terms (moka_set_nonlinear): scratch of the three preparation passes
     bool nonlinear = false;
     double *nlQv = nullptr, *nlQe = nullptr, *nlKe = nullptr;
+    int feFast = -1;                            // moka_last_fe_path
     double *nlZv = nullptr, *nlDiv = nullptr;   // Del2 mixing (moka_set_viscosity_del2)
     double viscDel2 = 0.0;
     std::vector<void *> allocs;
@@ -785,6 +786,7 @@ int moka_step_fe(moka_state *st, double dt, int flags)
         }
     }
     if (!fast) HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
+    st->feFast = fast ? 1 : 0;
     std::swap(st->lev[0], st->lev[1]);
     std::swap(st->hEdge[0], st->hEdge[1]);
     st->sshConsistent = !(flags & MOKA_FE_LEVEL1_ONLY) || st->mesh->plan.K == 1;
@@ -1102,6 +1104,8 @@ int moka_rk4_dist_end(moka_halo *h)
     rk4_end(h->st);
     return MOKA_OK;
 }
+
+int moka_last_fe_path(const moka_state *st) { return st ? st->feFast : -1; }
 
 int moka_set_nonlinear(moka_state *st, int on)
 {

@@ -76,7 +76,7 @@ EXPORTS = [
     "moka_sum_sq", "moka_set_kernel_variant",
     "moka_ctx_streams", "moka_halo_create", "moka_halo_destroy", "moka_halo_buffer_elems", "moka_halo_pack",
     "moka_halo_unpack", "moka_rk4_dist_begin", "moka_rk4_dist_stage", "moka_rk4_dist_end",
-    "moka_set_nonlinear", "moka_set_viscosity_del2", "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
+    "moka_set_nonlinear", "moka_last_fe_path", "moka_set_viscosity_del2", "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
     "moka_adjoint_download",
 ]
 
@@ -159,6 +159,7 @@ def lib():
     L.moka_rk4_dist_stage.argtypes = [vp, C.c_int, C.c_int]
     L.moka_rk4_dist_end.argtypes = [vp]
     L.moka_set_nonlinear.argtypes = [vp, C.c_int]
+    L.moka_last_fe_path.argtypes = [vp]
     L.moka_set_viscosity_del2.argtypes = [vp, C.c_double]
     L.moka_tape_create.argtypes = [vp, C.c_int64, C.POINTER(vp)]
     L.moka_tape_destroy.argtypes = [vp]

@@ -218,6 +218,73 @@ def test_forward_euler_multilayer_bitwise(backend, K, flags, multilayer):
     Prog._state.close(); Setup.mesh.close()
 
 
+@pytest.mark.parametrize("meshname,K,flags,P", [("ico16", 60, 3, 0), ("ico16", 60, 0, 0), ("ico16", 60, 1, 0), ("ico16", 60, 2, 0),
+                                                ("ico12f", 60, 3, 0), ("planar", 60, 3, 0), ("ico16", 34, 3, 0), ("ico16", 64, 0, 12),
+                                                ("ico32", 60, 3, 24), ("ico12f", 40, 0, 7)])
+def test_forward_euler_tuned_path_bitwise(backend, meshname, K, flags, P):
+    """Even 34 <= K <= 64, all levels stepped: moka_step_fe runs in the tuned stage kernel (modes 4 / 5) plus the vertex
+    pass.  Every field of the three structs against the oracle after several steps, stale and fresh flux thickness,
+    accumulating and plain vorticity, pentagons / flipped edges (masked slots), then graph replay of a longer run."""
+    mesh = get_mesh(meshname)
+    ssh, u, h, rest = random_state(mesh, K, 40 + K + flags)
+    dtv = 2.0 if meshname == "planar" else 20.0
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True, patch_cells=P)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    for step in range(4):
+        mk.ocn_timestep(np.array([dtv]), Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=flags)
+        st.step_fe(dtv, flags)
+        assert L.lib().moka_last_fe_path(Prog._state._h) == 1          # the tuned kernel, not the generic one
+        if step in (0, 3):
+            got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+            for k in exp:
+                assert np.array_equal(got[k], exp[k]), (k, step)
+    mk.run_steps(Prog, mk.ForwardEuler, dtv, 7, flags)
+    for _ in range(7):
+        st.step_fe(dtv, flags)
+    got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), (k, "replay")
+    # an RK4 step in between: its lazily produced diagnostics are what the next stale-thickness FE step reads
+    mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dtv))
+    mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)
+    st.step_rk4(dtv)
+    mk.ocn_timestep(np.array([dtv]), Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=flags)
+    st.step_fe(dtv, flags)
+    assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.layerThickness[-1].get(), st.h[1])
+    assert np.array_equal(Prog.ssh[-1].get(), st.ssh[1])
+    Prog._state.close(); Setup.mesh.close()
+
+
+def test_forward_euler_tuned_path_level_masks(backend):
+    """maxLevelEdgeTop < K on random edges: the masked branches of modes 4 / 5 (divergence ignores the mask, the
+    thickness tendency and the velocity tendency honour it)."""
+    mesh = get_mesh("ico16")
+    K = 60
+    ssh, u, h, rest = random_state(mesh, K, 9)
+    mlt = np.random.default_rng(4).integers(0, K + 1, mesh.nEdges).astype(np.int32)
+    mlt[np.random.default_rng(5).random(mesh.nEdges) < 0.5] = K
+    hm = mk.HorzMesh(mesh)
+    vm = mk.VerticalMesh(hm, nVertLevels=K, restingThickness=rest, multilayer=True)
+    vm.maxLevelEdge.Top[:] = mlt
+    M = mk.Mesh(hm, vm, backend=backend)
+    Prog = mk.PrognosticVars(ssh, u, h, 2, M)
+    Diag, Tend = mk.DiagnosticVars(None, M, Prog._state), mk.TendencyVars(None, M, Prog._state)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=mlt)
+    for flags in (3, 0):
+        st = orc.OracleState(om, Prog.ssh[-1].get(), Prog.normalVelocity[-1].get(), Prog.layerThickness[-1].get())
+        st.hEdge[:] = Diag.layerThicknessEdge.get(); st.vort[:] = Diag.relativeVorticity.get()
+        for _ in range(3):
+            L.check(L.lib().moka_step_fe(Prog._state._h, 20.0, flags), backend._h)
+            assert L.lib().moka_last_fe_path(Prog._state._h) == 1
+            st.step_fe(20.0, flags)
+        got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+        for k in exp:
+            if k not in ("ssh0", "u0", "h0"):
+                assert np.array_equal(got[k], exp[k]), (k, flags)
+    Prog._state.close(); M.close()
+
+
 def test_reference_call_sequence_piecewise(backend):
     """The separately exported reference entry points, called in the order of time_integration.jl:163-177,
     give the same Diag/Tend arrays as the oracle's restatement of that order."""
