@@ -779,8 +779,13 @@ int moka_step_fe(moka_state *st, double dt, int flags)
         const hipError_t e = launch_stage_rec2c(mm->dev, g, st->ctx->stream);
         if (e == hipSuccess) {
             fast = true;
-            a.ops = FE_CURL;
-            HIPCHK(st->ctx, launch_fe(mm->dev, a, mm->lpc, st->ctx->stream));
+            const hipError_t ec = launch_curl2(mm->dev, a.u, a.vort, flags & MOKA_FE_ACCUM_VORT, st->ctx->stream);
+            if (ec == hipErrorNotSupported) {
+                a.ops = FE_CURL;
+                HIPCHK(st->ctx, launch_fe(mm->dev, a, mm->lpc, st->ctx->stream));
+            } else {
+                HIPCHK(st->ctx, ec);
+            }
         } else if (e != hipErrorNotSupported) {
             HIPCHK(st->ctx, e);
         }

@@ -824,6 +824,33 @@ __global__ __launch_bounds__(BLOCK) void k_fe(const MeshDev m, const FeArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// relativeVorticity alone (CurlOnVertex, Operators.jl:137-146) for even K <= 64: half a wave per vertex, a lane owns two
+// levels (16-byte loads), summation in edgesOnVertex order as k_fe's vertex pass.  The companion of the tuned
+// Forward-Euler step (k_stage_rec2c modes 4 / 5).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_curl2(const MeshDev m, const double *u, double *vort, int accum)
+{
+    const int pl_ = patch_of_block(m.nPatches);
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
+    const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+    if (2 * l >= m.K) return;
+    const uint32_t rowB = (uint32_t)m.K * 8u, voff = (uint32_t)l * 16u;
+    const int v0 = m.patchVertStart[p], v1 = m.patchVertStart[p + 1], VD = m.VD;
+    for (int v = v0 + grp; v < v1; v += BLOCK / 32) {
+        const uint32_t own = (uint32_t)v * rowB + voff;
+        double2 c = accum ? gload2(vort, own) : make_double2(0.0, 0.0);
+        for (int j = 0; j < VD; ++j) {
+            const double w = m.cv[(size_t)v * VD + j];
+            const double2 uv = gload2(u, (uint32_t)m.eov[(size_t)v * VD + j] * rowB + voff);
+            c.x += w * uv.x;
+            c.y += w * uv.y;
+        }
+        gstore2(vort, own, c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stand-alone operators on arbitrary (K,n) arrays in the new numbering (Operators.jl).
 // ------------------------------------------------------------------------------------------------
 template <int LPC>
@@ -1083,6 +1110,14 @@ hipError_t launch_stage_rec2c_f32(const MeshDev &md, const StageArgs &a, hipStre
     else if (md.ME == 8 && md.ME2 == 14) ok = launch_rec2c_f32<8, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
     else if (md.ME <= 6 && md.ME2 <= 14) ok = launch_rec2c_f32<6, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
     return ok ? hipGetLastError() : hipErrorNotSupported;
+}
+
+// valid for even K <= 64 on meshes whose rows stay below 4 GiB (the caller checks: the tuned Forward-Euler path)
+hipError_t launch_curl2(const MeshDev &m, const double *u, double *vort, bool accum, hipStream_t s)
+{
+    if (m.K > 64 || (m.K & 1) || (size_t)std::max(m.nE, m.nV) * m.K * 8 >= ((size_t)1 << 32)) return hipErrorNotSupported;
+    hipLaunchKernelGGL(k_curl2, dim3(patch_grid(m)), dim3(BLOCK), 0, s, m, u, vort, accum ? 1 : 0);
+    return hipGetLastError();
 }
 
 hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s)

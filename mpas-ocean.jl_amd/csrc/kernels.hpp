@@ -81,6 +81,7 @@ hipError_t launch_stage_col(const MeshDev &m, const StageArgs &a, bool pipelined
 hipError_t launch_stage_lds(const MeshDev &m, const StageArgs &a, size_t ldsBytes, hipStream_t s);
 hipError_t prepare_stage_lds(size_t ldsBytes);
 hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s);
+hipError_t launch_curl2(const MeshDev &m, const double *u, double *vort, bool accum, hipStream_t s);
 hipError_t launch_operator(const MeshDev &m, const OpArgs &a, int lpc, hipStream_t s);
 hipError_t launch_update_ssh(const MeshDev &m, const double *h, double *ssh, int nlev, int lpc, hipStream_t s);
 hipError_t launch_permute_rows(double *dst, const double *src, const int32_t *n2o, int64_t n, int K, int to_device,
