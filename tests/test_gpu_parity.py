@@ -285,6 +285,32 @@ def test_forward_euler_tuned_path_level_masks(backend):
     Prog._state.close(); M.close()
 
 
+@pytest.mark.parametrize("nx,ny,K", [(4, 4, 60), (4, 6, 1), (6, 4, 34), (2, 4, 60), (4, 2, 8)])
+def test_tiny_periodic_meshes_bitwise(backend, nx, ny, K):
+    """Smallest doubly periodic hexagon meshes: a cell meets the same neighbour across both boundaries, an edge's
+    edgesOnEdge list repeats entries, and the whole mesh is one or two patches -- RK4, Forward Euler and the
+    tendencies still equal the oracle bit for bit."""
+    mesh = mg.planar_hex_mesh(nx, ny, 1000.0, f0=1e-4)
+    ssh, u, h, rest = random_state(mesh, K, 100 + nx * ny + K)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
+    tu, th, _ = om.tendencies_clean(u, h)
+    assert np.array_equal(Tend.tendNormalVelocity.get(), tu) and np.array_equal(Tend.tendLayerThickness.get(), th)
+    mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=2.0))
+    for _ in range(3):
+        mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)
+        st.step_rk4(2.0)
+    for _ in range(3):
+        mk.ocn_timestep(np.array([2.0]), Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=3)
+        st.step_fe(2.0, 3)
+    got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    Prog._state.close(); Setup.mesh.close()
+
+
 def test_reference_call_sequence_piecewise(backend):
     """The separately exported reference entry points, called in the order of time_integration.jl:163-177,
     give the same Diag/Tend arrays as the oracle's restatement of that order."""
