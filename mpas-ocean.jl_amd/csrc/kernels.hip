@@ -434,6 +434,10 @@ struct d4 {
 };
 __device__ __forceinline__ d4 widen4(float4 v) { return d4{(double)v.x, (double)v.y, (double)v.z, (double)v.w}; }
 __device__ __forceinline__ float4 narrow4(d4 v) { return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w); }
+__device__ __forceinline__ float4 gload4f(const double *base, uint32_t off)
+{
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off);
+}
 __device__ __forceinline__ d4 gload4(const double *base, uint32_t off)
 {
     return widen4(*reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off));
@@ -520,23 +524,25 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         const uint32_t mask = r[2 * ME], all = r[2 * ME + 1];
         const double invA = L.invA[ci];
         const uint32_t own = (uint32_t)c * rowB + voff;
-        d4 hc = zero, uv[ME], hv[ME], cur = zero, nin = zero;
+        // the cell loop keeps its 14 gathered rows packed as fp32 until the arithmetic needs them: widened at load they held
+        // twice the registers through the whole latency window (mode 2 spilled)
+        const float4 zf = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 hcf = zf, uf[ME], hf[ME], curf = zf, ninf = zf;
         if (act) {
             bool cached[ME];
             uint32_t ad[ME];
             v4u_t raw[ME];
-            float4 uf[ME];
             uint32_t goff[ME];
-            hc = gload4(a.ph, own);
+            hcf = gload4f(a.ph, own);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
-                hv[i] = gload4(a.ph, r[ME + i] + voff);
+                hf[i] = gload4f(a.ph, r[ME + i] + voff);
                 const uint32_t off = r[i];
                 ad[i] = urow_addr(off, cached[i]);
                 goff[i] = off + voff;
-                asm volatile("" : "+v"(goff[i]));      // stays in a VGPR (see k_stage_rec2c); volatile on purpose: batching the
-                                                       // record reads and deferring the stores as k_stage_rec2c does costs
-                                                       // registers this kernel does not have (spills: 26.8 -> 30.6 ms, config 5)
+                asm("" : "+v"(goff[i]));               // stays in a VGPR (see k_stage_rec2c).  The deferred stores of that kernel
+                                                       // are NOT taken over: they cost registers this one does not have
+                                                       // (spills at three waves per SIMD: 26.8 -> 30.6 ms on config 5)
             }
             lds_burst<ME>(raw, ad);
 #pragma unroll
@@ -544,21 +550,21 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
                 uf[i] = __builtin_bit_cast(float4, raw[i]);
                 if (!cached[i]) uf[i] = glb_row4f(puG + goff[i]);
             }
-            if constexpr (MODE == 2) cur = gload4(a.ch, own);
-            if constexpr (MODE >= 2) nin = gload4(a.nh_in, own);
-#pragma unroll
-            for (int i = 0; i < ME; ++i) uv[i] = widen4(uf[i]);
+            if constexpr (MODE == 2) curf = gload4f(a.ch, own);
+            if constexpr (MODE >= 2) ninf = gload4f(a.nh_in, own);
         }
+        const d4 hc = widen4(hcf);
         d4 t = zero;
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME) - 1u && all)) == 0;   // see k_stage_rec2c
         if (plain) {
             if (act) {
 #pragma unroll
                 for (int i = 0; i < ME; ++i) {
-                    t.x += uv[i].x * (0.5 * (hc.x + hv[i].x)) * rs[i] * invA;
-                    t.y += uv[i].y * (0.5 * (hc.y + hv[i].y)) * rs[i] * invA;
-                    t.z += uv[i].z * (0.5 * (hc.z + hv[i].z)) * rs[i] * invA;
-                    t.w += uv[i].w * (0.5 * (hc.w + hv[i].w)) * rs[i] * invA;
+                    const d4 uvi = widen4(uf[i]), hvi = widen4(hf[i]);
+                    t.x += uvi.x * (0.5 * (hc.x + hvi.x)) * rs[i] * invA;
+                    t.y += uvi.y * (0.5 * (hc.y + hvi.y)) * rs[i] * invA;
+                    t.z += uvi.z * (0.5 * (hc.z + hvi.z)) * rs[i] * invA;
+                    t.w += uvi.w * (0.5 * (hc.w + hvi.w)) * rs[i] * invA;
                 }
             }
         } else if (act) {
@@ -566,10 +572,11 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
             for (int i = 0; i < ME; ++i) {
                 const int ml = all ? K : cptr(m.mltc)[(size_t)c * ME + i];
                 const bool on = (mask >> i) & 1u;
-                const double dx = uv[i].x * (0.5 * (hc.x + hv[i].x)) * rs[i] * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
-                const double dy = uv[i].y * (0.5 * (hc.y + hv[i].y)) * rs[i] * invA;   // horizontal_advection.jl:63
-                const double dz = uv[i].z * (0.5 * (hc.z + hv[i].z)) * rs[i] * invA;
-                const double dw = uv[i].w * (0.5 * (hc.w + hv[i].w)) * rs[i] * invA;
+                const d4 uvi = widen4(uf[i]), hvi = widen4(hf[i]);
+                const double dx = uvi.x * (0.5 * (hc.x + hvi.x)) * rs[i] * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
+                const double dy = uvi.y * (0.5 * (hc.y + hvi.y)) * rs[i] * invA;   // horizontal_advection.jl:63
+                const double dz = uvi.z * (0.5 * (hc.z + hvi.z)) * rs[i] * invA;
+                const double dw = uvi.w * (0.5 * (hc.w + hvi.w)) * rs[i] * invA;
                 if (on && k0 < ml) t.x += dx;
                 if (on && k0 + 1 < ml) t.y += dy;
                 if (on && k0 + 2 < ml) t.z += dz;
@@ -584,14 +591,14 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
                 gstore2(a.tendH, ownD + 16u, make_double2(t.z, t.w));
             }
             if constexpr (MODE == 1 || MODE == 2) {
-                const d4 hcur = MODE == 2 ? cur : hc;
-                const d4 nb = MODE == 2 ? nin : hcur;
+                const d4 hcur = MODE == 2 ? widen4(curf) : hc;
+                const d4 nb = MODE == 2 ? widen4(ninf) : hcur;
                 hs = round4(axpy4(hcur, a.a, t));                                             // time_integration.jl:125
                 gstore4(a.ph_out, own, hs);
                 gstore4(a.nh_out, own, axpy4(nb, a.b, t));                                    // :135
             }
             if constexpr (MODE == 3) {
-                hs = round4(axpy4(nin, a.b, t));
+                hs = round4(axpy4(widen4(ninf), a.b, t));
                 gstore4(a.nh_out, own, hs);
             }
         }
@@ -629,7 +636,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
                 const uint32_t off = r[i];
                 ad[i] = urow_addr(off, cached[i]);
                 goff[i] = off + voff;
-                asm volatile("" : "+v"(goff[i]));
+                asm("" : "+v"(goff[i]));         
             }
             lds_burst<ME2>(raw, ad);
 #pragma unroll
