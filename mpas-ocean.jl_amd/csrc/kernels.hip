@@ -622,8 +622,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         const int mlt = (int)r[ME2 + 3];
         const double g = L.g[ei];
         const uint32_t own = (uint32_t)e * rowB + voff;
-        double ds0 = 0.0;
-        if (l == 0) ds0 = (double)sshf[r[ME2 + 1]] - (double)sshf[r[ME2]];     // ssh[c2] - ssh[c1], in the group's first lane
+        float sA = 0.f, sB = 0.f;
         d4 uv[ME2], cur = zero, nin = zero;
         if (act) {
             bool cached[ME2];
@@ -646,10 +645,14 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
             }
             if constexpr (MODE == 2) cur = gload4(a.cu, own);
             if constexpr (MODE >= 2) nin = gload4(a.nu_in, own);
+            if (l == 0) {                                              // behind the gathers in the queue: nothing waits for these two alone
+                sA = sshf[r[ME2]];
+                sB = sshf[r[ME2 + 1]];
+            }
 #pragma unroll
             for (int i = 0; i < ME2; ++i) uv[i] = widen4(uf[i]);
         }
-        const double ds = __shfl(ds0, gbase, 64);
+        const double ds = __shfl((double)sB - (double)sA, gbase, 64);  // ssh[c2] - ssh[c1], from the group's first lane
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME2) - 1u && mlt >= K)) == 0;   // wave-uniform
         if (act) {
             const bool ax = k0 < mlt, ay = k0 + 1 < mlt, az = k0 + 2 < mlt, aw = k0 + 3 < mlt;
