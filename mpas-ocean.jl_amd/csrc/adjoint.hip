@@ -100,6 +100,115 @@ __global__ __launch_bounds__(BLOCK) void k_adj_cell(const AdjMesh m, const AdjAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same two kernels for even K <= 64 with 16-byte lanes: half a wave per entity, a lane owns levels 2l and 2l+1 (the
+// layout of the forward stage kernel), every sum in the same order -- bit-identical to k_adj_edge / k_adj_cell.  The
+// column sum csum follows oracle_ksum: butterfly over the lanes for each of the two levels, then their sum.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 ld2(const double *p, size_t row, int K, int l)
+{
+    return reinterpret_cast<const double2 *>(p + row * K)[l];
+}
+__device__ __forceinline__ void st2(double *p, size_t row, int K, int l, double2 v)
+{
+    reinterpret_cast<double2 *>(p + row * K)[l] = v;
+}
+
+template <bool TT>
+__global__ __launch_bounds__(BLOCK) void k_adj_edge2(const AdjMesh m, const AdjArgs a)
+{
+    constexpr int NG = BLOCK / 32;
+    const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int K = m.K, k0 = 2 * l;
+    const bool act = k0 < K;
+    for (int e = blockIdx.x * NG + grp; e < m.nE; e += gridDim.x * NG) {
+        const int c1 = m.ehdr[(size_t)e * 4], c2 = m.ehdr[(size_t)e * 4 + 1], mlt = m.ehdr[(size_t)e * 4 + 3];
+        const double sd1 = m.sd[(size_t)e * 2], sd2 = m.sd[(size_t)e * 2 + 1];
+        const double fe = m.fEdge[e];
+        double s1 = 0.0, s2 = 0.0;
+        if constexpr (!TT) { s1 = a.lamS1[c1]; s2 = a.lamS1[c2]; }
+        double2 tu = make_double2(0.0, 0.0);
+        if (act) {
+            const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
+            const double2 l1 = ld2(a.lamH1, c1, K, l), l2 = ld2(a.lamH1, c2, K, l);
+            double2 Fbar;
+            if constexpr (TT) {
+                Fbar = make_double2(sd1 * l1.x + sd2 * l2.x, sd1 * l1.y + sd2 * l2.y);
+            } else {
+                const double2 tH1 = make_double2(a.dt * (l1.x + s1), a.dt * (l1.y + s1));
+                const double2 tH2 = make_double2(a.dt * (l2.x + s2), a.dt * (l2.y + s2));
+                Fbar = make_double2(sd1 * tH1.x + sd2 * tH2.x, sd1 * tH1.y + sd2 * tH2.y);
+            }
+            if (!ax) Fbar.x = 0.0;
+            if (!ay) Fbar.y = 0.0;
+            double2 cor = make_double2(0.0, 0.0);
+            for (int j = 0; j < m.W; ++j) {
+                const int s = m.teoe[(size_t)e * m.W + j];
+                if (s < 0) continue;
+                const int ms = m.ehdr[(size_t)s * 4 + 3];
+                const double w = m.tw[(size_t)e * m.W + j] * fe;
+                const double2 ls = ld2(a.lamU1, s, K, l);
+                if (k0 < ms) cor.x += TT ? w * ls.x : w * (a.dt * ls.x);
+                if (k0 + 1 < ms) cor.y += TT ? w * ls.y : w * (a.dt * ls.y);
+            }
+            const double2 lu = ld2(a.lamU1, e, K, l);
+            if constexpr (TT) {
+                const double2 h1 = ld2(a.h, c1, K, l), h2 = ld2(a.h, c2, K, l);
+                const double2 hI = make_double2(0.5 * (h1.x + h2.x), 0.5 * (h1.y + h2.y));           // Operators.jl:217
+                st2(a.lamU0, e, K, l, make_double2(hI.x * Fbar.x + cor.x, hI.y * Fbar.y + cor.y));
+            } else {
+                const double2 hE = ld2(a.hEuse, e, K, l);
+                st2(a.lamU0, e, K, l, make_double2((lu.x + hE.x * Fbar.x) + cor.x, (lu.y + hE.y * Fbar.y) + cor.y));
+            }
+            const double2 uu = ld2(a.u, e, K, l);
+            st2(a.Enew, e, K, l, make_double2(uu.x * Fbar.x, uu.y * Fbar.y));
+            if (ax) tu.x = TT ? lu.x : a.dt * lu.x;
+            if (ay) tu.y = TT ? lu.y : a.dt * lu.y;
+        }
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) {                       // oracle_ksum order
+            const double ox = __shfl_xor(tu.x, sft, 32), oy = __shfl_xor(tu.y, sft, 32);
+            tu = make_double2(tu.x + ox, tu.y + oy);
+        }
+        if (l == 0) a.csum[e] = tu.x + tu.y;
+    }
+}
+
+template <bool TT>
+__global__ __launch_bounds__(BLOCK) void k_adj_cell2(const AdjMesh m, const AdjArgs a)
+{
+    constexpr int NG = BLOCK / 32;
+    const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int K = m.K, ME = m.ME;
+    const bool act = 2 * l < K;
+    const double *Eread = (TT || !a.stale) ? a.Enew : a.lamE1;
+    for (int c = blockIdx.x * NG + grp; c < m.nC; c += gridDim.x * NG) {
+        const int32_t *re = m.eoc + (size_t)c * ME;
+        double ls = 0.0;
+        double2 acc = make_double2(0.0, 0.0);
+        for (int i = 0; i < ME; ++i) {
+            const int e = re[i];
+            if (e < 0) continue;
+            ls += (-(double)m.csgn[(size_t)c * ME + i]) * m.gInvDc[e] * a.csum[e];
+            if (act) {
+                const double2 v = ld2(Eread, e, K, l);
+                acc.x += v.x;
+                acc.y += v.y;
+            }
+        }
+        if constexpr (TT) {
+            if (act) st2(a.lamH0, c, K, l, make_double2(0.5 * acc.x + ls, 0.5 * acc.y + ls));
+        } else {
+            const double s1 = a.lamS1[c];
+            if (l == 0) a.lamS0[c] = ls;
+            if (act) {
+                const double2 lh = ld2(a.lamH1, c, K, l);
+                st2(a.lamH0, c, K, l, make_double2((lh.x + s1) + 0.5 * acc.x, (lh.y + s1) + 0.5 * acc.y));
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_scale_copy(double *dst, const double *src, double f, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = f * src[i];
@@ -146,8 +255,15 @@ static hipError_t launch_adj_cell_lpc(const AdjMesh &m, const AdjArgs &a, hipStr
     return hipGetLastError();
 }
 
+static int grid2(int n) { return std::min(std::max((n + 7) / 8, 1), 65536); }
+
 hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s)
 {
+    if (lpc == 64 && m.K <= 64 && !(m.K & 1)) {   // even 34 <= K <= 64: 16-byte lanes
+        if (a.tt) hipLaunchKernelGGL((k_adj_edge2<true>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
+        else hipLaunchKernelGGL((k_adj_edge2<false>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
+        return hipGetLastError();
+    }
 #define CALL(L) launch_adj_edge_lpc<L>(m, a, s)
     DISPATCH_LPC(lpc, CALL)
 #undef CALL
@@ -155,6 +271,11 @@ hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStrea
 
 hipError_t launch_adj_cell(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s)
 {
+    if (lpc == 64 && m.K <= 64 && !(m.K & 1)) {
+        if (a.tt) hipLaunchKernelGGL((k_adj_cell2<true>), dim3(grid2(m.nC)), dim3(BLOCK), 0, s, m, a);
+        else hipLaunchKernelGGL((k_adj_cell2<false>), dim3(grid2(m.nC)), dim3(BLOCK), 0, s, m, a);
+        return hipGetLastError();
+    }
 #define CALL(L) launch_adj_cell_lpc<L>(m, a, s)
     DISPATCH_LPC(lpc, CALL)
 #undef CALL

@@ -597,7 +597,8 @@ def test_driver_from_yaml_and_mpas_files(tmp_path):
 # (tests/test_oracle_adjoint.py, the reference's test/enzyme/test_Enzyme_end2end.jl check)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("meshname,K,flags,nsteps", [("igw200", 1, 7, 12), ("igw200", 1, 0, 12), ("ico16", 1, 7, 6), ("ico16", 3, 3, 5),
-                                                       ("ico16", 60, 0, 3), ("ico12f", 5, 1, 4), ("ico16", 70, 3, 2)])
+                                                       ("ico16", 60, 0, 3), ("ico12f", 5, 1, 4), ("ico16", 70, 3, 2),
+                                                       ("ico16", 60, 3, 3), ("ico12f", 40, 3, 3), ("ico16", 34, 1, 3)])
 def test_fe_adjoint_bitwise(backend, meshname, K, flags, nsteps):
     mesh = get_mesh(meshname)
     if meshname == "igw200":
@@ -679,7 +680,8 @@ def test_adjoint_refuses_what_it_does_not_cover(backend):
     P2._state.close(); S2.mesh.close()
 
 
-@pytest.mark.parametrize("meshname,K,nsteps", [("igw200", 1, 6), ("ico16", 3, 4), ("ico16", 60, 2), ("ico12f", 5, 3), ("ico16", 70, 2)])
+@pytest.mark.parametrize("meshname,K,nsteps", [("igw200", 1, 6), ("ico16", 3, 4), ("ico16", 60, 2), ("ico12f", 5, 3), ("ico16", 70, 2),
+                                                 ("ico12f", 34, 2), ("ico16", 64, 2)])
 def test_rk4_adjoint_bitwise(backend, meshname, K, nsteps):
     mesh = get_mesh(meshname)
     if meshname == "igw200":
