@@ -721,7 +721,7 @@ def test_rk4_adjoint_bitwise(backend, meshname, K, nsteps):
 # kernels reproduce the oracle's restatement of the scheme bit for bit and keep Williamson test case 2 steady
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("meshname,K,nsteps", [("ico16", 1, 4), ("ico16", 3, 3), ("ico16", 60, 2), ("planar", 4, 3), ("ico12f", 5, 2),
-                                               ("ico16", 70, 2)])
+                                               ("ico16", 70, 2), ("ico12f", 40, 2), ("planar", 64, 2), ("ico16", 34, 2)])
 def test_nonlinear_tendency_and_rk4_bitwise(backend, meshname, K, nsteps):
     mesh = get_mesh(meshname)
     ssh, u, h, rest = random_state(mesh, K, 51 + K)
@@ -763,7 +763,8 @@ def test_nonlinear_tendency_and_rk4_bitwise(backend, meshname, K, nsteps):
     Prog._state.close(); Setup.mesh.close()
 
 
-@pytest.mark.parametrize("meshname,K,nsteps", [("ico16", 1, 3), ("ico16", 60, 2), ("planar", 4, 3), ("ico12f", 5, 2), ("ico16", 70, 2)])
+@pytest.mark.parametrize("meshname,K,nsteps", [("ico16", 1, 3), ("ico16", 60, 2), ("planar", 4, 3), ("ico12f", 5, 2), ("ico16", 70, 2),
+                                               ("ico12f", 40, 2), ("planar", 34, 2)])
 def test_del2_mixing_bitwise(backend, meshname, K, nsteps):
     """Del2 momentum mixing (the reference's uncalled sketch, horizontal_momentum_mixing.jl:53-80) on top of the nonlinear
     terms: tendencies, RK4 steps and graph replay against the oracle's restatement, bit for bit."""
