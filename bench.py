@@ -307,7 +307,7 @@ def main():
             fms = backend.timer_stop() / args.tend_iters
             out["forward_euler_compat"] = {"ms_per_step": fms, "value": mesh.nCells * K / (fms * 1e-3),
                                            "unit": "cell-updates/s", "note": "moka_step_fe, reference_compat flags, all levels"}
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:       # the CPU leg belongs to the N = 1 line only
         t0 = time.time()
         mixed = sbytes == 4
         if mesh.nCells * K > 1.5e8:        # bounded sample: the same workload family on a quarter of the cells
