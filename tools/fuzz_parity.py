@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""GPU box helper: randomized parity sweep of the tuned kernels against the oracle (bit for bit).
+Random meshes (icosahedral with edge flips, planar periodic), even K in 34..64 (Float64) or K % 4 == 0 (fp32 storage),
+patch sizes, level masks, Forward-Euler flags; RK4 + FE + tendencies.   python tools/fuzz_parity.py [seconds=150] [seed=0]"""
+import datetime as dt
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "mpas-ocean.jl_amd"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np                         # noqa: E402
+import moka_hip as mk                      # noqa: E402
+import oracle as orc                       # noqa: E402
+from moka_hip import lib as L              # noqa: E402
+from moka_hip import meshgen as mg         # noqa: E402
+
+budget, seed = (float(sys.argv[1]) if len(sys.argv) > 1 else 150.0), (int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+rng = np.random.default_rng(seed)
+b = mk.MokaHIP(0)
+t0, n = time.time(), 0
+stats = {"f32": 0, "fe_tuned": 0, "fe_generic": 0, "masked": 0, "cells_max": 0}
+while time.time() - t0 < budget:
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        mesh = mg.icosahedral_mesh(int(rng.integers(3, 14)), flips=int(rng.integers(0, 10)), seed=int(rng.integers(0, 1000)))
+        dtv = 20.0
+    elif kind == 1:
+        mesh = mg.icosahedral_mesh(int(rng.integers(3, 18)))
+        dtv = 20.0
+    else:
+        mesh = mg.planar_hex_mesh(2 * int(rng.integers(1, 9)), 2 * int(rng.integers(1, 9)), 1000.0, f0=1e-4)
+        dtv = 2.0
+    f32 = bool(rng.integers(0, 4) == 0)
+    K = int(4 * rng.integers(1, 33)) if f32 else int(2 * rng.integers(17, 33))
+    P = int(rng.choice([0, 0, 5, 8, 12, 16, 20, 24]))
+    r = np.random.default_rng(int(rng.integers(0, 1 << 30)))
+    rest = np.full((mesh.nCells, K), 1000.0 / K) + r.uniform(0, 0.1, (mesh.nCells, K))
+    h = rest + r.uniform(-1, 1, (mesh.nCells, K))
+    u = r.uniform(-1, 1, (mesh.nEdges, K))
+    ssh = h.sum(1) - rest.sum(1)
+    mlt = np.full(mesh.nEdges, K, dtype=np.int32)
+    if rng.integers(0, 2):
+        sel = r.random(mesh.nEdges) < 0.3
+        mlt[sel] = r.integers(0, K + 1, int(sel.sum()))
+    hm = mk.HorzMesh(mesh)
+    vm = mk.VerticalMesh(hm, nVertLevels=K, restingThickness=rest, multilayer=True)
+    vm.maxLevelEdge.Top[:] = mlt
+    try:
+        M = mk.Mesh(hm, vm, backend=b, patch_cells=P, state_bytes=4 if f32 else 8)
+        Prog = mk.PrognosticVars(ssh, u, h, 2, M)
+    except mk.MokaError as exc:            # e.g. fp32 shapes the library refuses
+        continue
+    tag = f"case {n}: kind {kind} cells {mesh.nCells} K {K} P {P} f32 {f32} masks {int((mlt < K).sum())}"
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=mlt)
+    st = orc.OracleState(om, ssh, u, h, mixed=f32)
+    Diag, Tend = (None, None) if f32 else (mk.DiagnosticVars(None, M, Prog._state), mk.TendencyVars(None, M, Prog._state))
+    for _ in range(2):
+        L.check(L.lib().moka_step_rk4(Prog._state._h, dtv), b._h)
+        st.step_rk4(dtv)
+    assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]), tag + " rk4 u"
+    assert np.array_equal(Prog.layerThickness[-1].get(), st.h[1]), tag + " rk4 h"
+    assert np.array_equal(Prog.ssh[-1].get(), st.ssh[1]), tag + " rk4 ssh"
+    if not f32:
+        flags = int(rng.choice([0, 1, 2, 3]))
+        for _ in range(2):
+            L.check(L.lib().moka_step_fe(Prog._state._h, dtv, flags), b._h)
+            st.step_fe(dtv, flags)
+        for name, got, exp in (("u", Prog.normalVelocity[-1].get(), st.u[1]), ("h", Prog.layerThickness[-1].get(), st.h[1]),
+                               ("ssh", Prog.ssh[-1].get(), st.ssh[1]), ("hEdge", Diag.layerThicknessEdge.get(), st.hEdge),
+                               ("F", Diag.thicknessFlux.get(), st.F), ("div", Diag.velocityDivCell.get(), st.div),
+                               ("vort", Diag.relativeVorticity.get(), st.vort), ("tendU", Tend.tendNormalVelocity.get(), st.tendU),
+                               ("tendH", Tend.tendLayerThickness.get(), st.tendH)):
+            assert np.array_equal(got, exp), f"{tag} fe flags {flags} path {L.lib().moka_last_fe_path(Prog._state._h)} {name}"
+        stats["fe_tuned" if L.lib().moka_last_fe_path(Prog._state._h) == 1 else "fe_generic"] += 1
+    stats["f32"] += int(f32); stats["masked"] += int((mlt < K).any()); stats["cells_max"] = max(stats["cells_max"], mesh.nCells)
+    Prog._state.close(); M.close()
+    n += 1
+    if n % 10 == 0:
+        print(f"{n} cases, {time.time() - t0:.0f}s", flush=True)
+print(f"fuzz_parity: {n} random cases bit-identical to the oracle (seed {seed}); {stats}")
