@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""GPU box helper: randomized sweep of the distributed RK4 step (all ranks of a partition in one process, stream-ordered
+device copies as halo transport: parallel.LocalCluster) against the single-domain oracle, bit for bit.
+   python tools/fuzz_cluster.py [seconds=120] [seed=0]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "mpas-ocean.jl_amd"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np                         # noqa: E402
+import oracle as orc                       # noqa: E402
+from moka_hip import meshgen as mg         # noqa: E402
+from moka_hip import parallel as par       # noqa: E402
+
+budget, seed = (float(sys.argv[1]) if len(sys.argv) > 1 else 120.0), (int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+rng = np.random.default_rng(seed)
+t0, n, skipped = time.time(), 0, 0
+meshes = {}
+while time.time() - t0 < budget:
+    m = int(rng.integers(8, 28))
+    mesh = meshes.setdefault(m, mg.icosahedral_mesh(m))
+    world = int(rng.integers(2, 9))
+    f32 = bool(rng.integers(0, 3) == 0)
+    K = int(4 * rng.integers(9, 21)) if f32 else int(rng.choice([1, 3, 8, 34, 40, 60, 64, 70]))
+    P = int(rng.choice([0, 0, 8, 12, 16]))
+    r = np.random.default_rng(int(rng.integers(0, 1 << 30)))
+    rest = np.full((mesh.nCells, K), 1000.0 / K) + r.uniform(0, 0.1, (mesh.nCells, K))
+    h = rest + r.uniform(-1, 1, (mesh.nCells, K))
+    u = r.uniform(-1, 1, (mesh.nEdges, K))
+    ssh = h.sum(1) - rest.sum(1)
+    tag = f"case {n}: m {m} world {world} K {K} P {P} f32 {f32}"
+    try:
+        cl = par.LocalCluster(mesh, ssh, u, h, rest, 20.0, world, patch_cells=P, state_bytes=4 if f32 else 8)
+    except Exception as exc:               # noqa: BLE001  shapes the library refuses (e.g. fp32 with a huge straddling patch)
+        skipped += 1
+        continue
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    ref = orc.OracleState(om, ssh, u, h, mixed=f32)
+    cl.exchange_state()
+    for _ in range(3):
+        cl.step_rk4()
+        ref.step_rk4(20.0)
+    gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
+    assert np.array_equal(gu, ref.u[1]), tag + " u"
+    assert np.array_equal(gh, ref.h[1]), tag + " h"
+    assert np.array_equal(gs, ref.ssh[1]), tag + " ssh"
+    cl.close()
+    n += 1
+    if n % 10 == 0:
+        print(f"{n} cases, {time.time() - t0:.0f}s", flush=True)
+print(f"fuzz_cluster: {n} random partitions bit-identical to the single-domain oracle (seed {seed}, {skipped} refused)")
