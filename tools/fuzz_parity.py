@@ -20,7 +20,7 @@ budget, seed = (float(sys.argv[1]) if len(sys.argv) > 1 else 150.0), (int(sys.ar
 rng = np.random.default_rng(seed)
 b = mk.MokaHIP(0)
 t0, n = time.time(), 0
-stats = {"f32": 0, "fe_tuned": 0, "fe_generic": 0, "masked": 0, "cells_max": 0}
+stats = {"f32": 0, "fe_tuned": 0, "fe_generic": 0, "masked": 0, "cells_max": 0, "adjoint": 0, "nonlinear": 0}
 while time.time() - t0 < budget:
     kind = rng.integers(0, 3)
     if kind == 0:
@@ -74,6 +74,33 @@ while time.time() - t0 < budget:
                                ("tendH", Tend.tendLayerThickness.get(), st.tendH)):
             assert np.array_equal(got, exp), f"{tag} fe flags {flags} path {L.lib().moka_last_fe_path(Prog._state._h)} {name}"
         stats["fe_tuned" if L.lib().moka_last_fe_path(Prog._state._h) == 1 else "fe_generic"] += 1
+        if n % 4 == 1 and not (mlt < K).any():                      # reverse mode of two more Forward-Euler steps
+            Prog2 = mk.PrognosticVars(st.ssh[1], st.u[1], st.h[1], 2, M)
+            tape = mk.AdjointTape(Prog2, 2)
+            st2 = orc.OracleState(om, st.ssh[1], st.u[1], st.h[1])
+            adj = orc.OracleAdjoint(st2)
+            fl = int(rng.choice([0, 1, 2, 3]))
+            for _ in range(2):
+                tape.step(np.array([dtv]), fl)
+                adj.step_fe(dtv, fl)
+            g = tape.gradient()
+            gS, gU, gH, gE = adj.gradient_sum_sq_ssh()
+            assert np.array_equal(g["ssh"], gS) and np.array_equal(g["normalVelocity"], gU) and \
+                np.array_equal(g["layerThickness"], gH), tag + f" adjoint flags {fl}"
+            tape.close(); Prog2._state.close()
+            stats["adjoint"] += 1
+        if n % 4 == 3 and not (mlt < K).any() and mesh.kiteAreasOnVertex is not None:   # nonlinear terms + Del2, one RK4 step
+            visc = float(rng.choice([0.0, 0.01 * float(mesh.dcEdge.min()) ** 2 / dtv]))
+            Prog3 = mk.PrognosticVars(st.ssh[1], st.u[1], st.h[1], 2, M)
+            mk.set_nonlinear(Prog3, True, visc_del2=visc)
+            nl = orc.OracleNonlinear(om, visc_del2=visc)
+            st3 = orc.OracleState(om, st.ssh[1], st.u[1], st.h[1])
+            L.check(L.lib().moka_step_rk4(Prog3._state._h, dtv), b._h)
+            nl.step_rk4(st3, dtv)
+            assert np.array_equal(Prog3.normalVelocity[-1].get(), st3.u[1]) and np.array_equal(Prog3.layerThickness[-1].get(), st3.h[1]), \
+                tag + f" nonlinear visc {visc}"
+            Prog3._state.close()
+            stats["nonlinear"] += 1
     stats["f32"] += int(f32); stats["masked"] += int((mlt < K).any()); stats["cells_max"] = max(stats["cells_max"], mesh.nCells)
     Prog._state.close(); M.close()
     n += 1
