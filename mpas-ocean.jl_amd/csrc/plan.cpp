@@ -263,17 +263,67 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
         }
         std::stable_sort(flex.begin(), flex.end(), [&](int x, int y) { return lo[x] < lo[y]; });
         for (int e : flex) {
+            // start from a coin flip per edge (a hash: deterministic): unlike "the patch with fewer edges so far", which
+            // drifts -- whole regions end one edge up, others one down, and levelling that takes mesh-wide paths -- it
+            // leaves only local fluctuations, which the sweeps and the short breadth-first searches below remove
             const int pa = lo[e] / P, pb = hi[e] / P;
-            if (cnt[pa] <= cnt[pb]) { ownerCell[e] = lo[e]; ++cnt[pa]; }
+            if (((uint32_t)e * 2654435761u >> 15) & 1u) { ownerCell[e] = lo[e]; ++cnt[pa]; }
             else { ownerCell[e] = hi[e]; ++cnt[pb]; }
         }
-        for (int sweep = 0; sweep < 8; ++sweep) {
+        for (int sweep = 0; sweep < 16; ++sweep) {
             int moved = 0;
             for (int e : flex) {
                 const int cur = ownerCell[e], oth = cur == lo[e] ? hi[e] : lo[e];
                 if (cnt[cur / P] > cnt[oth / P] + 1) { ownerCell[e] = oth; --cnt[cur / P]; ++cnt[oth / P]; ++moved; }
             }
             if (!moved) break;
+        }
+        // Then level the remaining +-1 differences: a half-wave group handles one edge per iteration, so a patch costs
+        // ceil(edges / groups) iterations and a patch one edge above the mean pays a whole iteration for it.  Every patch
+        // above the mean looks (breadth first, over edges it could hand over) for the nearest patch below the mean and
+        // passes one edge along that path.
+        {
+            int64_t total = 0;
+            for (int q = 0; q < nP; ++q) total += cnt[q];
+            const int T = (int)((total + nP - 1) / nP);
+            std::vector<int32_t> pstart(nP + 1, 0), plist;
+            for (int e : flex) { ++pstart[lo[e] / P + 1]; ++pstart[hi[e] / P + 1]; }
+            for (int q = 0; q < nP; ++q) pstart[q + 1] += pstart[q];
+            plist.resize(pstart[nP]);
+            {
+                std::vector<int32_t> fill(pstart.begin(), pstart.end() - 1);
+                for (int e : flex) { plist[fill[lo[e] / P]++] = e; plist[fill[hi[e] / P]++] = e; }
+            }
+            std::vector<int32_t> stamp(nP, -1), via(nP, -1), queue;
+            int32_t tick = 0;
+            for (int s = 0; s < nP; ++s) {
+                for (int guard = 0; cnt[s] > T && guard < 8; ++guard) {
+                    queue.assign(1, s);
+                    ++tick;
+                    stamp[s] = tick; via[s] = -1;
+                    int found = -1;
+                    for (size_t h = 0; h < queue.size() && found < 0 && queue.size() < 2048; ++h) {
+                        const int x = queue[h];
+                        for (int k = pstart[x]; k < pstart[x + 1] && found < 0; ++k) {
+                            const int e = plist[k];
+                            if (ownerCell[e] / P != x) continue;                 // x can only hand over what it owns
+                            const int y = (ownerCell[e] == lo[e] ? hi[e] : lo[e]) / P;
+                            if (stamp[y] == tick) continue;
+                            stamp[y] = tick; via[y] = e;
+                            if (cnt[y] < T) found = y;
+                            else queue.push_back(y);
+                        }
+                    }
+                    if (found < 0) break;
+                    for (int y = found; y != s;) {                               // pass one edge along every hop of the path
+                        const int e = via[y];
+                        const int x = ownerCell[e] / P;
+                        ownerCell[e] = ownerCell[e] == lo[e] ? hi[e] : lo[e];
+                        --cnt[x]; ++cnt[y];
+                        y = x;
+                    }
+                }
+            }
         }
     }
     auto edgeOwner = renumber(nE, [&](int e) { return ownerCell[e]; }, p.edgeN2O, p.edgeO2N);
