@@ -181,3 +181,20 @@ def test_state_bytes_scales_the_gather_records():
     assert L.Plan(m, 60, max_level_edge_top=60).info["patch_cells"] == 16
     with pytest.raises(L.MokaError):
         L.Plan(m, K, state_bytes=2)
+
+
+@pytest.mark.parametrize("P,groups", [(16, 8), (24, 12), (12, 8)])
+def test_edge_ownership_is_levelled_to_the_mean(P, groups):
+    """A half-wave group handles one own edge per iteration, so a patch costs ceil(edges / groups) iterations: the plan levels
+    edge ownership until (nearly) every full patch owns exactly 3 * P edges on a hexagon mesh -- a patch one edge above
+    pays a whole extra iteration (12 % of the patches did before the levelling)."""
+    mesh = mg.icosahedral_mesh(40)
+    p = L.Plan(mesh, 60, patch_cells=P)
+    cs, es, _ = p.patch_ranges()
+    nc, ne = np.diff(cs), np.diff(es)
+    full = nc == P
+    assert ne.sum() == mesh.nEdges
+    assert (ne[full] == 3 * P).mean() > 0.95, np.bincount(ne[full])[-6:]
+    assert ne.max() <= 3 * P + 1
+    assert np.ceil(ne[full] / groups).mean() < np.ceil(3 * P / groups) + 0.02
+    p.close()
