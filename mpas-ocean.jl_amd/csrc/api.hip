@@ -1195,7 +1195,12 @@ static int tape_upload(moka_tape *t, const std::vector<T> &v, const T **out)
     void *d = nullptr;
     int rc = tape_alloc(t, &d, v.size() * sizeof(T));
     if (rc) return rc;
-    if (!v.empty()) HIPCHK(t->st->ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    // on the context's stream, behind tape_alloc's memset: a plain hipMemcpy runs on the null stream, which the (non-blocking)
+    // context stream does not order against -- once in ~1500 tapes the zero fill landed after the copy and wiped the lists
+    if (!v.empty()) {
+        HIPCHK(t->st->ctx, hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, t->st->ctx->stream));
+        HIPCHK(t->st->ctx, hipStreamSynchronize(t->st->ctx->stream));        // v is a temporary of the caller
+    }
     *out = static_cast<const T *>(d);
     return MOKA_OK;
 }

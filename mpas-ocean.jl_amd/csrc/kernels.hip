@@ -141,21 +141,28 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     const int nOwnC = c1 - c0, nOwnE = e1 - e0;
     const uint32_t e0B = (uint32_t)e0 * rowB, nOwnB = (uint32_t)nOwnE * rowB;
 
-    for (int i = tid; i < nOwnE * m.EI; i += NT) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
-    for (int i = tid; i < nOwnE * ME2; i += NT) {
-        L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
-        L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
-    }
-    for (int i = tid; i < nOwnE; i += NT) L.g[i] = m.gInvDc[e0 + i];
-    for (int i = tid; i < nOwnC * m.CI; i += NT) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
-    for (int i = tid; i < nOwnC * ME; i += NT) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
-    for (int i = tid; i < nOwnC; i += NT) {
-        L.invA[i] = m.invArea[c0 + i];
-        L.rsum[i] = m.rsum[c0 + i];
-    }
-    {   // own u rows: one contiguous, fully coalesced copy
+    {   // own u rows: one contiguous, fully coalesced copy; the loads of all six chunks go out before the first LDS write
         const double2 *src = reinterpret_cast<const double2 *>(a.pu) + (size_t)e0 * K2;
-        for (int i = tid; i < nOwnE * K2; i += NT) ubuf2[i] = src[i];
+        const int nU = nOwnE * K2;
+        constexpr int UU = 6;
+        double2 vU[UU];
+#pragma unroll
+        for (int j = 0; j < UU; ++j) vU[j] = (tid + j * NT < nU) ? src[tid + j * NT] : make_double2(0.0, 0.0);
+        for (int i = tid; i < nOwnE * m.EI; i += NT) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
+        for (int i = tid; i < nOwnE * ME2; i += NT) {
+            L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
+            L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
+        }
+        for (int i = tid; i < nOwnE; i += NT) L.g[i] = m.gInvDc[e0 + i];
+        for (int i = tid; i < nOwnC * m.CI; i += NT) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
+        for (int i = tid; i < nOwnC * ME; i += NT) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
+        for (int i = tid; i < nOwnC; i += NT) {
+            L.invA[i] = m.invArea[c0 + i];
+            L.rsum[i] = m.rsum[c0 + i];
+        }
+#pragma unroll
+        for (int j = 0; j < UU; ++j) if (tid + j * NT < nU) ubuf2[tid + j * NT] = vU[j];
+        for (int i = tid + UU * NT; i < nU; i += NT) ubuf2[i] = src[i];
     }
     __syncthreads();
 

@@ -247,6 +247,7 @@ class DistributedModel:
         real = torch.float32 if state_bytes == 4 else torch.float64      # halo messages carry state reals
         self.sendbuf = torch.zeros(max(ns.value, 1), dtype=real, device=dev)
         self.recvbuf = torch.zeros(max(nr.value, 1), dtype=real, device=dev)
+        torch.cuda.synchronize(dev)           # the zero fills ran on torch's stream; the library's streams do not order against it
         self.send_slices = message_slices(lm, K, True)
         self.recv_slices = message_slices(lm, K, False)
         self._p2p = None                      # P2POp list of the nccl transport, built once
