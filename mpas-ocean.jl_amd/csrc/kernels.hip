@@ -141,28 +141,59 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     const int nOwnC = c1 - c0, nOwnE = e1 - e0;
     const uint32_t e0B = (uint32_t)e0 * rowB, nOwnB = (uint32_t)nOwnE * rowB;
 
-    {   // own u rows: one contiguous, fully coalesced copy; the loads of all six chunks go out before the first LDS write
+    {   // Staging: every global load of the patch's records and own u rows is issued before the first LDS write, so the workgroup
+        // pays one memory latency here instead of one per array.  The unrolled part covers the default patch (P = 16: 48-51
+        // own edges at K <= 64); larger patches finish in the plain loops at the end.
         const double2 *src = reinterpret_cast<const double2 *>(a.pu) + (size_t)e0 * K2;
-        const int nU = nOwnE * K2;
-        constexpr int UU = 6;
+        const int nU = nOwnE * K2, nER = nOwnE * m.EI, nW = nOwnE * ME2, nCR = nOwnC * m.CI, nS = nOwnC * ME;
+        constexpr int UU = 6, UE = 3, UW = 2;
         double2 vU[UU];
+        uint32_t vE[UE], vC;
+        double vW[UW], vF[UW], vG, vS, vA, vR;
 #pragma unroll
         for (int j = 0; j < UU; ++j) vU[j] = (tid + j * NT < nU) ? src[tid + j * NT] : make_double2(0.0, 0.0);
-        for (int i = tid; i < nOwnE * m.EI; i += NT) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
-        for (int i = tid; i < nOwnE * ME2; i += NT) {
+#pragma unroll
+        for (int j = 0; j < UE; ++j) vE[j] = (tid + j * NT < nER) ? m.eRec[(size_t)e0 * m.EI + tid + j * NT] : 0u;
+#pragma unroll
+        for (int j = 0; j < UW; ++j) {
+            vW[j] = (tid + j * NT < nW) ? m.woe[(size_t)e0 * ME2 + tid + j * NT] : 0.0;
+            vF[j] = (tid + j * NT < nW) ? m.feoe[(size_t)e0 * ME2 + tid + j * NT] : 0.0;
+        }
+        vG = tid < nOwnE ? m.gInvDc[e0 + tid] : 0.0;
+        vC = tid < nCR ? m.cRec[(size_t)c0 * m.CI + tid] : 0u;
+        vS = tid < nS ? m.sdv[(size_t)c0 * ME + tid] : 0.0;
+        vA = tid < nOwnC ? m.invArea[c0 + tid] : 0.0;
+        vR = tid < nOwnC ? m.rsum[c0 + tid] : 0.0;
+#pragma unroll
+        for (int j = 0; j < UU; ++j) if (tid + j * NT < nU) ubuf2[tid + j * NT] = vU[j];
+#pragma unroll
+        for (int j = 0; j < UE; ++j) if (tid + j * NT < nER) L.eRec[tid + j * NT] = vE[j];
+#pragma unroll
+        for (int j = 0; j < UW; ++j)
+            if (tid + j * NT < nW) {
+                L.woe[tid + j * NT] = vW[j];
+                L.feoe[tid + j * NT] = vF[j];
+            }
+        if (tid < nOwnE) L.g[tid] = vG;
+        if (tid < nCR) L.cRec[tid] = vC;
+        if (tid < nS) L.sdv[tid] = vS;
+        if (tid < nOwnC) {
+            L.invA[tid] = vA;
+            L.rsum[tid] = vR;
+        }
+        for (int i = tid + UU * NT; i < nU; i += NT) ubuf2[i] = src[i];
+        for (int i = tid + UE * NT; i < nER; i += NT) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
+        for (int i = tid + UW * NT; i < nW; i += NT) {
             L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
             L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
         }
-        for (int i = tid; i < nOwnE; i += NT) L.g[i] = m.gInvDc[e0 + i];
-        for (int i = tid; i < nOwnC * m.CI; i += NT) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
-        for (int i = tid; i < nOwnC * ME; i += NT) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
-        for (int i = tid; i < nOwnC; i += NT) {
+        for (int i = tid + NT; i < nOwnE; i += NT) L.g[i] = m.gInvDc[e0 + i];
+        for (int i = tid + NT; i < nCR; i += NT) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
+        for (int i = tid + NT; i < nS; i += NT) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
+        for (int i = tid + NT; i < nOwnC; i += NT) {
             L.invA[i] = m.invArea[c0 + i];
             L.rsum[i] = m.rsum[c0 + i];
         }
-#pragma unroll
-        for (int j = 0; j < UU; ++j) if (tid + j * NT < nU) ubuf2[tid + j * NT] = vU[j];
-        for (int i = tid + UU * NT; i < nU; i += NT) ubuf2[i] = src[i];
     }
     __syncthreads();
 
