@@ -525,21 +525,60 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
     const uint32_t e0B = (uint32_t)e0 * rowB, nOwnB = (uint32_t)nOwnE * rowB;
     const float *sshf = reinterpret_cast<const float *>(a.ssh);
 
-    for (int i = tid; i < nOwnE * m.EI; i += BLOCK) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
-    for (int i = tid; i < nOwnE * ME2; i += BLOCK) {
-        L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
-        L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
-    }
-    for (int i = tid; i < nOwnE; i += BLOCK) L.g[i] = m.gInvDc[e0 + i];
-    for (int i = tid; i < nOwnC * m.CI; i += BLOCK) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
-    for (int i = tid; i < nOwnC * ME; i += BLOCK) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
-    for (int i = tid; i < nOwnC; i += BLOCK) {
-        L.invA[i] = m.invArea[c0 + i];
-        L.rsum[i] = m.rsum[c0 + i];
-    }
-    {   // own u rows: one contiguous, fully coalesced copy
+    {   // staging in one phase (see k_stage_rec2c): every global load before the first LDS write; the unrolled part covers the
+        // default patch (P = 24: 72-75 own edges at K = 80), the plain loops at the end whatever is larger
         const float4 *src = reinterpret_cast<const float4 *>(a.pu) + (size_t)e0 * K4;
-        for (int i = tid; i < nOwnE * K4; i += BLOCK) ubuf4[i] = src[i];
+        const int nU = nOwnE * K4, nER = nOwnE * m.EI, nW = nOwnE * ME2, nCR = nOwnC * m.CI, nS = nOwnC * ME;
+        constexpr int UU = 6, UE = 4, UW = 3, UC = 2;
+        float4 vU[UU];
+        uint32_t vE[UE], vC[UC];
+        double vW[UW], vF[UW], vG, vS, vA, vR;
+#pragma unroll
+        for (int j = 0; j < UU; ++j) vU[j] = (tid + j * BLOCK < nU) ? src[tid + j * BLOCK] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < UE; ++j) vE[j] = (tid + j * BLOCK < nER) ? m.eRec[(size_t)e0 * m.EI + tid + j * BLOCK] : 0u;
+#pragma unroll
+        for (int j = 0; j < UW; ++j) {
+            vW[j] = (tid + j * BLOCK < nW) ? m.woe[(size_t)e0 * ME2 + tid + j * BLOCK] : 0.0;
+            vF[j] = (tid + j * BLOCK < nW) ? m.feoe[(size_t)e0 * ME2 + tid + j * BLOCK] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < UC; ++j) vC[j] = (tid + j * BLOCK < nCR) ? m.cRec[(size_t)c0 * m.CI + tid + j * BLOCK] : 0u;
+        vG = tid < nOwnE ? m.gInvDc[e0 + tid] : 0.0;
+        vS = tid < nS ? m.sdv[(size_t)c0 * ME + tid] : 0.0;
+        vA = tid < nOwnC ? m.invArea[c0 + tid] : 0.0;
+        vR = tid < nOwnC ? m.rsum[c0 + tid] : 0.0;
+#pragma unroll
+        for (int j = 0; j < UU; ++j) if (tid + j * BLOCK < nU) ubuf4[tid + j * BLOCK] = vU[j];
+#pragma unroll
+        for (int j = 0; j < UE; ++j) if (tid + j * BLOCK < nER) L.eRec[tid + j * BLOCK] = vE[j];
+#pragma unroll
+        for (int j = 0; j < UW; ++j)
+            if (tid + j * BLOCK < nW) {
+                L.woe[tid + j * BLOCK] = vW[j];
+                L.feoe[tid + j * BLOCK] = vF[j];
+            }
+#pragma unroll
+        for (int j = 0; j < UC; ++j) if (tid + j * BLOCK < nCR) L.cRec[tid + j * BLOCK] = vC[j];
+        if (tid < nOwnE) L.g[tid] = vG;
+        if (tid < nS) L.sdv[tid] = vS;
+        if (tid < nOwnC) {
+            L.invA[tid] = vA;
+            L.rsum[tid] = vR;
+        }
+        for (int i = tid + UU * BLOCK; i < nU; i += BLOCK) ubuf4[i] = src[i];
+        for (int i = tid + UE * BLOCK; i < nER; i += BLOCK) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
+        for (int i = tid + UW * BLOCK; i < nW; i += BLOCK) {
+            L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
+            L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
+        }
+        for (int i = tid + UC * BLOCK; i < nCR; i += BLOCK) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
+        for (int i = tid + BLOCK; i < nOwnE; i += BLOCK) L.g[i] = m.gInvDc[e0 + i];
+        for (int i = tid + BLOCK; i < nS; i += BLOCK) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
+        for (int i = tid + BLOCK; i < nOwnC; i += BLOCK) {
+            L.invA[i] = m.invArea[c0 + i];
+            L.rsum[i] = m.rsum[c0 + i];
+        }
     }
     __syncthreads();
 
