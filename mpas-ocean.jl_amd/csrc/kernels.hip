@@ -222,11 +222,11 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     constexpr bool FE = MODE >= 4, STALE = MODE == 4;
     double2 pA = make_double2(0.0, 0.0), pB = pA, pD = pA, pE = pA;
     double pS = 0.0;
-    // No "anything pending?" flag (the compiler peels a copy of the whole loop body for it): the pending slot starts out as
-    // the group's FIRST entity with zeros, so the first flush writes zeros where the second writes that entity's results
-    // (same lanes, same addresses, program order); the entity's own loads of in-place arrays come before either.
-    uint32_t pOff = (uint32_t)(c0 + grp) * rowB + voff;
-    int pC = c0 + grp;
+    // `pend` is false only in a group's first iteration; the loops carry `#pragma nounroll` so that the compiler does not peel
+    // a copy of the whole loop body for it (a third more code, more registers)
+    uint32_t pOff = 0;
+    int pC = 0;
+    bool pend = false;
     auto flush_cell = [&]() {
         if (act) {
             if constexpr (MODE == 0) gstore2(a.tendH, pOff, pA);
@@ -245,6 +245,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if (l == 0) a.ssh_out[pC] = pS;
     };
     // ---------------- cells ----------------
+#pragma nounroll
     for (int ci = grp; ci < nOwnC; ci += NG) {
         const int c = c0 + ci;
         const uint32_t *r = L.cRec + (size_t)ci * m.CI;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         double area = 0.0;
         if constexpr (FE) area = a.areaCell[c];
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this iteration's loads (needed next anyway) ...
-        flush_cell();                                                  // ... so that the stores queue up behind them, not ahead
+        if (pend) flush_cell();                                        // ... so that the stores queue up behind them, not ahead
         double2 t = make_double2(0.0, 0.0);
         // regular entity (every slot valid, every level active) in BOTH half-waves: no per-slot masks (wave-uniform branch)
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME) - 1u && all)) == 0;
@@ -347,10 +348,10 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         }
         pOff = own;
         pC = c;
+        pend = true;
     }
-    if (grp < nOwnC) flush_cell();
-    pA = pB = pD = pE = make_double2(0.0, 0.0);
-    pOff = (uint32_t)(e0 + grp) * rowB + voff;
+    if (pend) flush_cell();
+    pend = false;
     auto flush_edge = [&]() {
         if (act) {
             if constexpr (MODE == 0) gstore2(a.tendU, pOff, pA);
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     };
 
     // ---------------- edges ----------------
+#pragma nounroll
     for (int ei = grp; ei < nOwnE; ei += NG) {
         const int e = e0 + ei;
         const uint32_t *r = L.eRec + (size_t)ei * m.EI;
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         }
         if (l < 2) sv = a.ssh[r[ME2 + l]];                             // ssh of cellsOnEdge[l]: after the gathers in the queue
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this iteration's loads (needed next anyway) ...
-        flush_edge();                                                  // ... so that the stores queue up behind them, not ahead
+        if (pend) flush_edge();                                        // ... so that the stores queue up behind them, not ahead
         const double ds = __shfl(sv, 1, 32) - __shfl(sv, 0, 32);       // ssh[c2] - ssh[c1]
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME2) - 1u && mlt >= K)) == 0;   // wave-uniform
         if (act) {
@@ -453,8 +455,9 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             }
         }
         pOff = own;
+        pend = true;
     }
-    if (grp < nOwnE) flush_edge();
+    if (pend) flush_edge();
 }
 
 // ------------------------------------------------------------------------------------------------
