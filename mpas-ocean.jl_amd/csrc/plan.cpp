@@ -283,9 +283,18 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
         // above the mean looks (breadth first, over edges it could hand over) for the nearest patch below the mean and
         // passes one edge along that path.
         {
-            int64_t total = 0;
-            for (int q = 0; q < nP; ++q) total += cnt[q];
-            const int T = (int)((total + nP - 1) / nP);
+            // the mean is taken per cell class (partitioned meshes: boundary patches own every edge they share with interior
+            // ones, halo patches are never launched -- one mean over all of them would miss the interior's)
+            std::vector<int32_t> pcls(nP), Tc(64, 0);
+            {
+                std::vector<int64_t> tot(64, 0), num(64, 0);
+                for (int q = 0; q < nP; ++q) {
+                    pcls[q] = cls(std::min(q * P, nC - 1));
+                    if (std::min((q + 1) * P, nC) - q * P == P) { tot[pcls[q]] += cnt[q]; ++num[pcls[q]]; }   // full patches only
+                }
+                for (int c = 0; c < 64; ++c) Tc[c] = num[c] ? (int)((tot[c] + num[c] - 1) / num[c]) : 0;
+            }
+            auto T_of = [&](int q) { return Tc[pcls[q]]; };
             std::vector<int32_t> pstart(nP + 1, 0), plist;
             for (int e : flex) { ++pstart[lo[e] / P + 1]; ++pstart[hi[e] / P + 1]; }
             for (int q = 0; q < nP; ++q) pstart[q + 1] += pstart[q];
@@ -297,7 +306,7 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
             std::vector<int32_t> stamp(nP, -1), via(nP, -1), queue;
             int32_t tick = 0;
             for (int s = 0; s < nP; ++s) {
-                for (int guard = 0; cnt[s] > T && guard < 8; ++guard) {
+                for (int guard = 0; cnt[s] > T_of(s) && guard < 8; ++guard) {
                     queue.assign(1, s);
                     ++tick;
                     stamp[s] = tick; via[s] = -1;
@@ -310,7 +319,7 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
                             const int y = (ownerCell[e] == lo[e] ? hi[e] : lo[e]) / P;
                             if (stamp[y] == tick) continue;
                             stamp[y] = tick; via[y] = e;
-                            if (cnt[y] < T) found = y;
+                            if (cnt[y] < T_of(y)) found = y;
                             else queue.push_back(y);
                         }
                     }
