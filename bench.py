@@ -43,13 +43,21 @@ WORKLOADS = {
 
 
 def algorithmic_bytes(nC, nE, K, S=8, I=4):
-    """the one formula for algorithmic bytes."""
+    """the one formula for algorithmic bytes (the contract formula: 5 streams per RK stage 1-3,
+    3 for stage 4 = 18 per step)."""
     nnzEE = 10 * nE - 60
     nnzEC = 2 * nE
-    b_mesh = nE * (2 * I + 3 * 8 + 2 * I) + nnzEE * (I + 8) + nC * (I + 8 + 8) + nnzEC * 2 * I
+    b_mesh = nE * (2 * I + 3 * 8 + 2 * I) + nnzEE * (I + 8) + nnzEC * 2 * I + nC * (I + 8 + 8)
     b_tend = 2 * S * K * (nE + nC) + b_mesh
     b_step = 18 * S * K * (nE + nC) + 4 * b_mesh
     return b_mesh, b_tend, b_step
+
+
+# State streams (one stream = S*K*(nE+nC) bytes) the stage-s launch has to move AT LEAST, aliasing taken into account:
+# stage 1: Provis == Curr == the current level and New starts from it -> read 1, write Provis' and New = 3 (the contract
+# formula counts 5); stages 2, 3: read Provis, Curr, New, write Provis', New' = 5; stage 4: read Provis, New, write New = 3.
+STAGE_MIN_STREAMS = (3, 5, 5, 3)
+STAGE_CONTRACT_STREAMS = (5, 5, 5, 3)
 
 
 def log(*a):
@@ -97,7 +105,7 @@ def cpu_baseline(mesh, K, ssh, u, h, rest, dts, budget_s=25.0, mixed=False):
     t = (time.time() - t0) / n if n else t_probe
     out = {"value": mesh.nCells * K / t, "unit": "cell-updates/s", "cores": cores, "kind": "port",
            "sample": f"{max(n, 1)} RK4 step(s) on {mesh.nCells} cells x {K} layers, "
-                     f"oracle/moka_oracle.c with OpenMP on {cores} host threads",
+                     f"oracle/moka_oracle.c with OpenMP on {cores} host threads (the box's CPU share for one GPU)",
            "ms_per_step": t * 1e3}
     if not mixed:
         # the reference's live path: reference_compat Forward-Euler steps (time_integration.jl:150-193), same threads
@@ -115,24 +123,24 @@ def cpu_baseline(mesh, K, ssh, u, h, rest, dts, budget_s=25.0, mixed=False):
     return out
 
 
-def cpu_baseline_1t(K, budget_s=12.0, mixed=False):
-    """Single-thread figure (what `julia mpas_ocean.jl` gives with JULIA_NUM_THREADS=1), small sphere."""
+def cpu_baseline_1t(mesh, K, ssh, u, h, rest, dts, budget_s=12.0, mixed=False):
+    """Single-thread figure (what `julia mpas_ocean.jl` gives with JULIA_NUM_THREADS=1) on the SAME mesh as the GPU line:
+    one warm-up step is the size probe; then as many steps as fit the budget (at least one)."""
     import oracle as orc
-    from moka_hip import meshgen as mg
-    mesh = mg.icosahedral_mesh(32)
-    ssh, u, h, rest, dts = mg.sphere_synthetic_state(mesh, K)
     orc.set_threads(1)
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     st = orc.OracleState(om, ssh, u, h, mixed=mixed)
-    st.step_rk4(dts)
     t0 = time.time()
-    n = 0
-    while time.time() - t0 < budget_s and n < 20:
+    st.step_rk4(dts)
+    t_probe = time.time() - t0
+    n = max(1, min(5, int(budget_s / max(t_probe, 1e-3))))
+    t0 = time.time()
+    for _ in range(n):
         st.step_rk4(dts)
-        n += 1
     t = (time.time() - t0) / n
     return {"value": mesh.nCells * K / t, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{n} RK4 steps on a {mesh.nCells}-cell x {K}-layer sphere, 1 thread"}
+            "sample": f"{n} RK4 step(s) on {mesh.nCells} cells x {K} layers (the GPU line's mesh), 1 thread",
+            "ms_per_step": t * 1e3}
 
 
 def main():
@@ -250,24 +258,58 @@ def main():
     value = mesh.nCells * K / (elapsed / args.steps)
 
     b_mesh, b_tend, b_step = algorithmic_bytes(mesh.nCells, mesh.nEdges, K, S=sbytes)
-    # dominant kernel = the fused RK-stage kernel k_stage: 4 launches per step, average launch time from HIP
-    # events on the library's compute stream over the timed region; algorithmic bytes per launch = B_step / 4.
+    stream_bytes = sbytes * K * (mesh.nEdges + mesh.nCells)
+    # dominant kernel = the fused RK-stage kernel (k_stage_rec2c): 4 launches per step.  Average launch duration from HIP
+    # events on the library's compute stream over the timed region (the four launches of a step run back to back on that
+    # stream, nothing else does); algorithmic bytes per launch = B_step / 4 (contract formula).
     launches = 4 * args.steps
     avg_launch_ms = ev_ms / launches
     per_rank_bytes = b_step / 4 / world
     achieved = per_rank_bytes / (avg_launch_ms * 1e-3) / 1e9
-    traffic = None
+    # the same with the bytes the four launches really have to move (stage 1 aliases Provis = Curr = New): 16 streams
+    min_step_bytes = (sum(STAGE_MIN_STREAMS) * stream_bytes + 4 * b_mesh) / world
+    achieved_min = min_step_bytes / 4 / (avg_launch_ms * 1e-3) / 1e9
+    # HBM traffic per launch from PMC counters: measured by tools/profile.sh in separate rocprofv3 passes (a process cannot
+    # read them about itself), so it is quoted only when that profile was taken with THIS configuration, with its source
+    traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile):
+    if os.path.exists(tfile) and world == 1:
         try:
-            traffic = json.load(open(tfile)).get(args.workload, {}).get("stage_bytes_per_launch")
+            rec = json.load(open(tfile)).get(args.workload, {})
+            same = all(rec.get("config", {}).get(k) == v for k, v in
+                       (("patch_cells", info.get("patch_cells")), ("ordering", info.get("ordering")),
+                        ("kernel_variant", args.variant)))
+            if same and rec.get("stage_bytes_per_launch"):
+                traffic = rec["stage_bytes_per_launch"]
+                traffic_source = {"file": "profiles/pmc_traffic.json", "profiled_at_commit": rec.get("commit"),
+                                  "note": "FETCH_SIZE x2 (gfx950 rule) + WRITE_SIZE, separate --pmc passes; not measured in this run"}
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_stage (fused TRiSK tendency + RK4 stage update)",
+    roofline = {"bound": "hbm", "kernel": "k_stage_rec2c (fused TRiSK tendency + RK4 stage update), mean of the 4 launches of a step",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS, "traffic": traffic,
+                "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": per_rank_bytes, "avg_launch_ms": avg_launch_ms,
-                "launches_timed": launches}
+                "launches_timed": launches, "formula": "contract: 18 state streams per step (5, 5, 5, 3) + 4 B_mesh",
+                "frac_kernel_minimum_bytes": achieved_min / HBM_PEAK_GBS,
+                "kernel_minimum_note": "16 state streams per step (3, 5, 5, 3): stage 1 aliases Provis = Curr = New"}
+    if world == 1:
+        # per-stage launch durations: a second pass of the same steps with one HIP event between the launches
+        nrec = max(5, min(args.steps, 20))
+        backend.stage_timing(True)
+        for _ in range(nrec):
+            step()
+        ms4, nst = backend.stage_timing_read()
+        backend.stage_timing(False)
+        per_stage = []
+        for sidx, ms in enumerate(ms4):
+            bc = STAGE_CONTRACT_STREAMS[sidx] * stream_bytes + b_mesh
+            bm = STAGE_MIN_STREAMS[sidx] * stream_bytes + b_mesh
+            per_stage.append({"stage": sidx + 1, "kernel_mode": (1, 2, 2, 3)[sidx], "ms": ms,
+                              "bytes_contract": bc, "frac_contract": bc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "bytes_minimum": bm, "frac_minimum": bm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        roofline["per_stage"] = per_stage
+        roofline["per_stage_steps"] = nst
+        roofline["per_stage_sum_ms"] = sum(ms4)
 
     out = {"metric": "cell-updates/sec per RK4 step", "value": value, "unit": "cell-updates/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -315,9 +357,10 @@ def main():
             cm = get_mesh(m // 2, stretch)
             cssh, cu, ch, crest, cdts = mg.sphere_synthetic_state(cm, K)
             out["cpu_baseline"] = cpu_baseline(cm, K, cssh, cu, ch, crest, cdts, mixed=mixed)
+            out["cpu_baseline_1t"] = cpu_baseline_1t(cm, K, cssh, cu, ch, crest, cdts, mixed=mixed)
         else:
             out["cpu_baseline"] = cpu_baseline(mesh, K, ssh, u, h, rest, dts, mixed=mixed)
-        out["cpu_baseline_1t"] = cpu_baseline_1t(K, mixed=mixed)
+            out["cpu_baseline_1t"] = cpu_baseline_1t(mesh, K, ssh, u, h, rest, dts, mixed=mixed)
         out["cpu_baseline"]["host"] = _cpu_model()
         log(f"[bench] cpu baseline legs: {time.time() - t0:.1f}s")
     if rank == 0:

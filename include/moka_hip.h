@@ -248,11 +248,19 @@ int  moka_rk4_dist_begin(moka_halo *h, double dt);
 int  moka_rk4_dist_stage(moka_halo *h, int stage, int part);
 int  moka_rk4_dist_end(moka_halo *h);
 
-/* kernel variant selection for measurement (all variants give identical results): 0 = auto [default: 11 when it fits,
- * else 8, 7, 4, 3]; 11 = record-staged, 16-byte lanes, two entities per wave, own u rows cached in LDS; 8 = the same
- * without the row cache; 7 = record-staged 8-byte lanes; 1/4 = column kernel pipelined/plain; 5/6 = 16-byte-lane column;
- * 2 = LDS patch-tiled; 9 = tiled, two-burst prefetch; 10 = persistent double-buffered tile; 3 = generic index kernel. */
+/* kernel variant selection for measurement (all variants give identical results): 0 = auto [default: 11 when the mesh
+ * allows it (even 34 <= nVertLevels <= 64), else 4 (nVertLevels >= 33), else 3]; 11 = record-staged, 16-byte lanes, two
+ * entities per wave, own u rows cached in LDS; 4 = plain column kernel; 3 = generic index kernel.
+ * The design points measured in round 1 (1 pipelined column, 5/6 16-byte-lane column, 7/8 record-staged without the row
+ * cache, 2 LDS patch-tiled, 9 tiled two-burst prefetch, 10 persistent double-buffered tile) are experiments: they are only
+ * in a library built with `make VARIANTS=1`; moka_set_kernel_variant returns MOKA_ERR_UNSUPPORTED for them otherwise. */
+int moka_kernel_variant_available(int variant);
 int moka_set_kernel_variant(moka_ctx *ctx, int variant);
+/* Per-stage durations of moka_step_rk4 from HIP events on the compute stream (measurement: bench.py's per-mode roofline
+ * lines).  moka_stage_timing(ctx, 1) forgets earlier samples and records 5 events per step from now on; (ctx, 0) stops.
+ * moka_stage_timing_read: ms[s-1] = mean duration of the stage-s launch over the *steps recorded steps. */
+int moka_stage_timing(moka_ctx *ctx, int enable);
+int moka_stage_timing_read(moka_ctx *ctx, double ms[4], int64_t *steps);
 /* which kernel the last moka_step_fe of this state used: 1 = the tuned stage kernel (+ vertex pass), 0 = the generic
  * one-launch kernel, -1 = no Forward-Euler step yet.  For tests and measurement; results are identical either way. */
 int moka_last_fe_path(const moka_state *st);

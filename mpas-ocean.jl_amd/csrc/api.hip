@@ -25,6 +25,10 @@ struct moka_ctx {
     int variant = 0;
     int nCUs = 256;
     std::string err;
+    // per-stage HIP-event timing of moka_step_rk4 (moka_stage_timing): 5 events per recorded step, read back on request
+    bool stageTiming = false;
+    std::vector<hipEvent_t> evPool;          // events owned by the context (reused between measurements)
+    size_t evUsed = 0;
 };
 
 struct moka_mesh {
@@ -100,6 +104,18 @@ int lanes_per_column(int K)
     return l;
 }
 
+// Rule of this file: no null-stream hipMemcpy / hipMemset after context creation.  The context's streams are non-blocking,
+// i.e. NOT ordered against the null stream, so a null-stream copy can overtake (or be overtaken by) a hipMemsetAsync queued
+// on the context stream (the tape-list race of round 1).  Every host->device copy goes through h2d(): on the context's
+// stream, then synchronised (the source is usually a temporary).  tools/check_streams.sh greps for offenders.
+int h2d(moka_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return MOKA_OK;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MOKA_OK;
+}
+
 template <class T>
 int upload_vec(moka_mesh *m, const std::vector<T> &v, const T **out)
 {
@@ -107,7 +123,7 @@ int upload_vec(moka_mesh *m, const std::vector<T> &v, const T **out)
     const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
     HIPCHK(m->ctx, hipMalloc(&d, bytes));
     m->allocs.push_back(d);
-    if (!v.empty()) HIPCHK(m->ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (int rc = h2d(m->ctx, d, v.data(), v.size() * sizeof(T))) return rc;
     *out = static_cast<const T *>(d);
     return MOKA_OK;
 }
@@ -138,15 +154,23 @@ int alloc_field(moka_state *st, double **out, size_t elems, size_t elemBytes = s
 
 int ensure_rk_bufs(moka_state *st)
 {
-    if (st->rk[0].u) return MOKA_OK;
+    if (st->rk[1].ssh) return MOKA_OK;       // the last of the six: set only when all of them exist
     const Plan &p = st->mesh->plan;
-    for (auto &r : st->rk) {
-        int rc;
-        const size_t sb = st->f32 ? 4 : 8;
-        if ((rc = alloc_field(st, &r.u, (size_t)p.K * p.nE, sb))) return rc;
-        if ((rc = alloc_field(st, &r.h, (size_t)p.K * p.nC, sb))) return rc;
-        if ((rc = alloc_field(st, &r.ssh, (size_t)p.nC, sb))) return rc;
+    LevelBufs tmp[2];
+    const size_t mark = st->allocs.size();
+    const size_t sb = st->f32 ? 4 : 8;
+    int rc = MOKA_OK;
+    for (auto &r : tmp) {
+        if (rc == MOKA_OK) rc = alloc_field(st, &r.u, (size_t)p.K * p.nE, sb);
+        if (rc == MOKA_OK) rc = alloc_field(st, &r.h, (size_t)p.K * p.nC, sb);
+        if (rc == MOKA_OK) rc = alloc_field(st, &r.ssh, (size_t)p.nC, sb);
     }
+    if (rc != MOKA_OK) {                     // free what a partial failure left behind: a later call starts over
+        (void)hipStreamSynchronize(st->ctx->stream);
+        while (st->allocs.size() > mark) { (void)hipFree(st->allocs.back()); st->allocs.pop_back(); }
+        return rc;
+    }
+    st->rk[0] = tmp[0]; st->rk[1] = tmp[1];
     return MOKA_OK;
 }
 
@@ -231,9 +255,7 @@ FeArgs fe_args(moka_state *st, int ops, int flags, double dt)
 // their own kernels.
 hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int pCount = -1, hipStream_t on = nullptr, int tail = -1)
 {
-    StageArgs g = g_in;
-    static const int dbg = [] { const char *e = std::getenv("MOKA_DBG"); return e ? std::atoi(e) : 0; }();
-    g.dbg = dbg;   // diagnostics only; 0 in normal operation
+    const StageArgs &g = g_in;
     const moka_mesh *m = st->mesh;
     MeshDev dev = m->dev;                 // the launch covers patches [pBegin, pBegin + pCount) (+ the patch `tail`)
     dev.tailPatch = -1;
@@ -294,8 +316,10 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
         return launch_stage_rec2c_f32(dev, g, s);
     }
     const int v = st->ctx->variant;
-    // 0 = auto (rec2c, then rec2, rec, col, generic as the mesh allows); 11 rec2c, 8 rec2, 7 rec, 1 colp, 4 col, 5/6 colx,
-    // 2 LDS-tiled, 9 tile, 10 ptile, 3 generic
+    // 0 = auto: rec2c (even 34 <= K <= 64, patches whose records + own rows fit the LDS), else the plain column kernel (K >= 33),
+    // else the generic index kernel.  11 rec2c, 4 column, 3 generic.  Built with VARIANTS=1 only (csrc/experiments):
+    // 8 rec2, 7 rec, 1 pipelined column, 5/6 16-byte-lane column, 2 LDS-tiled, 9 tile, 10 ptile.
+#ifdef MOKA_VARIANTS
     if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(dev, g, m->ldsBytes, s);
     if (v == 10 && m->ptileOk) {           // persistent double-buffered tiled kernel (needs patch_cells <= ~14)
         hipError_t e = launch_stage_ptile(dev, g, st->ctx->nCUs, s);
@@ -305,15 +329,17 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
         hipError_t e = launch_stage_tile(dev, g, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if ((v == 0 || v == 11) && m->lpc == 64 && m->colOk) {   // default: rec2 + own-edge u rows cached in LDS
+#endif
+    if ((v == 0 || v == 11) && m->lpc == 64 && m->colOk) {   // default: 16-byte lanes + own-edge u rows cached in LDS
         hipError_t e = launch_stage_rec2c(dev, g, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if ((v == 0 || v == 8) && m->lpc == 64 && m->colOk) {
+#ifdef MOKA_VARIANTS
+    if (v == 8 && m->lpc == 64 && m->colOk) {
         hipError_t e = launch_stage_rec2(dev, g, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if ((v == 0 || v == 7) && m->lpc == 64 && m->colOk) {
+    if (v == 7 && m->lpc == 64 && m->colOk) {
         hipError_t e = launch_stage_rec(dev, g, s);
         if (e != hipErrorNotSupported) return e;
     }
@@ -321,7 +347,12 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int 
         hipError_t e = launch_stage_colx(dev, g, v == 6, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if (v != 3 && m->lpc == 64 && m->colOk) return launch_stage_col(dev, g, v == 1, s);
+    if (v == 1 && m->lpc == 64 && m->colOk) {
+        hipError_t e = launch_stage_colp(dev, g, s);
+        if (e != hipErrorNotSupported) return e;
+    }
+#endif
+    if (v != 3 && m->lpc == 64 && m->colOk) return launch_stage_col(dev, g, s);
     return launch_stage(dev, g, m->lpc, s);
 }
 
@@ -392,7 +423,7 @@ int moka_ctx_create(int device, moka_ctx **out)
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->evInterior, hipEventDisableTiming);
     if (e3 == hipSuccess) e3 = hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-        delete c;
+        moka_ctx_destroy(c);                  // destroys whatever was created
         return fail(nullptr, MOKA_ERR_HIP, "failed to create stream/events");
     }
     *out = c;
@@ -408,6 +439,7 @@ void moka_ctx_destroy(moka_ctx *ctx)
     for (hipEvent_t e : {ctx->evBoundary, ctx->evInterior, ctx->evHalo}) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -444,10 +476,21 @@ int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
     return MOKA_OK;
 }
 
+int moka_kernel_variant_available(int variant)
+{
+#ifdef MOKA_VARIANTS
+    return variant >= 0 && variant <= 11;
+#else
+    return variant == 0 || variant == 3 || variant == 4 || variant == 11;
+#endif
+}
+
 int moka_set_kernel_variant(moka_ctx *ctx, int variant)
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
     if (variant < 0 || variant > 11) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..11");
+    if (!moka_kernel_variant_available(variant))
+        return fail(ctx, MOKA_ERR_UNSUPPORTED, "this kernel variant is an experiment: build the library with `make VARIANTS=1`");
     ctx->variant = variant;
     return MOKA_OK;
 }
@@ -498,6 +541,7 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     m->colOk = p.colOk;
 
     d.maxRows = p.maxRows; d.maxOwnE = p.maxOwnE; d.maxOwnC = p.maxOwnC;
+#ifdef MOKA_VARIANTS
     if (p.colOk && stage_tile_usable(d, p.ldsOk) && prepare_stage_tile(d) == hipSuccess) m->tileOk = true;
     if (p.colOk && stage_ptile_usable(d, p.ldsOk) && prepare_stage_ptile(d) == hipSuccess) m->ptileOk = true;
     if (p.ldsOk && p.K % 2 == 0 && p.K >= 8) {
@@ -510,6 +554,7 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
             m->ldsBytes = (size_t)need;
         }
     }
+#endif
     *out = m;
     return MOKA_OK;
 }
@@ -856,8 +901,53 @@ int moka_step_rk4(moka_state *st, double dt)
     const double *ssh0 = nullptr;
     int rc = rk4_begin(st, &ssh0);
     if (rc) return rc;
-    for (int s = 1; s <= 4; ++s) HIPCHK(st->ctx, run_stage(st, rk4_stage_args(st, s, dt, ssh0)));
+    moka_ctx *c = st->ctx;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(c->stream, &cap);
+    const bool timed = c->stageTiming && cap == hipStreamCaptureStatusNone;
+    auto stamp = [&]() -> hipError_t {
+        if (c->evUsed == c->evPool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipError_t er = hipEventCreate(&e); er != hipSuccess) return er;
+            c->evPool.push_back(e);
+        }
+        return hipEventRecord(c->evPool[c->evUsed++], c->stream);
+    };
+    for (int s = 1; s <= 4; ++s) {
+        if (timed) HIPCHK(c, stamp());
+        HIPCHK(c, run_stage(st, rk4_stage_args(st, s, dt, ssh0)));
+    }
+    if (timed) HIPCHK(c, stamp());
     rk4_end(st);
+    return MOKA_OK;
+}
+
+// Per-stage kernel durations of moka_step_rk4 from HIP events on the compute stream (bench.py's per-mode roofline lines).
+// enable != 0: forget earlier samples and start recording 5 events per step; enable == 0: stop.
+int moka_stage_timing(moka_ctx *ctx, int enable)
+{
+    if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stageTiming = enable != 0;
+    if (enable) ctx->evUsed = 0;
+    return MOKA_OK;
+}
+
+// ms[s-1] = mean duration of the stage-s launch over the recorded steps; *steps = how many steps were recorded
+int moka_stage_timing_read(moka_ctx *ctx, double ms[4], int64_t *steps)
+{
+    if (!ctx || !ms || !steps) return fail(ctx, MOKA_ERR_ARG, "NULL argument");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t n = ctx->evUsed / 5;
+    for (int s = 0; s < 4; ++s) ms[s] = 0.0;
+    for (size_t i = 0; i < n; ++i)
+        for (int s = 0; s < 4; ++s) {
+            float t = 0.f;
+            HIPCHK(ctx, hipEventElapsedTime(&t, ctx->evPool[5 * i + s], ctx->evPool[5 * i + s + 1]));
+            ms[s] += t;
+        }
+    for (int s = 0; s < 4; ++s) ms[s] = n ? ms[s] / (double)n : 0.0;
+    *steps = (int64_t)n;
     return MOKA_OK;
 }
 
@@ -894,11 +984,13 @@ int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flag
             }
             // the capture recorded the launches but executed nothing: the host-side level swaps of the two steps cancel
             if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                while (nsteps - done >= 2) {
-                    HIPCHK(st->ctx, hipGraphLaunch(exec, s));
-                    done += 2;
-                }
+                hipError_t el = hipSuccess;
+                while (nsteps - done >= 2 && (el = hipGraphLaunch(exec, s)) == hipSuccess) done += 2;
                 (void)hipGraphExecDestroy(exec);
+                if (el != hipSuccess) {
+                    (void)hipGraphDestroy(graph);
+                    return fail(st->ctx, MOKA_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(el));
+                }
             }
             (void)hipGraphDestroy(graph);
             st->diagDirty = st->tendDirty = (integrator == MOKA_RUNGE_KUTTA_4);
@@ -972,7 +1064,7 @@ static int build_halo_map(moka_state *st, int nNbr, const int32_t *cells, const 
     void *d = nullptr;
     HIPCHK(st->ctx, hipMalloc(&d, map.size() * sizeof(uint32_t)));
     st->allocs.push_back(d);
-    HIPCHK(st->ctx, hipMemcpy(d, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (int rc = h2d(st->ctx, d, map.data(), map.size() * sizeof(uint32_t))) return rc;
     *outDev = static_cast<uint32_t *>(d);
     return MOKA_OK;
 }
@@ -1197,10 +1289,7 @@ static int tape_upload(moka_tape *t, const std::vector<T> &v, const T **out)
     if (rc) return rc;
     // on the context's stream, behind tape_alloc's memset: a plain hipMemcpy runs on the null stream, which the (non-blocking)
     // context stream does not order against -- once in ~1500 tapes the zero fill landed after the copy and wiped the lists
-    if (!v.empty()) {
-        HIPCHK(t->st->ctx, hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, t->st->ctx->stream));
-        HIPCHK(t->st->ctx, hipStreamSynchronize(t->st->ctx->stream));        // v is a temporary of the caller
-    }
+    if ((rc = h2d(t->st->ctx, d, v.data(), v.size() * sizeof(T)))) return rc;     // v is a temporary of the caller
     *out = static_cast<const T *>(d);
     return MOKA_OK;
 }

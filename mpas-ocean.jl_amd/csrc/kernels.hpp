@@ -17,7 +17,6 @@ struct StageArgs {
     double *ssh_out;              // ssh of ph_out (or of nh_out when ph_out == NULL)
     double *tendU, *tendH;        // tendencies
     double a, b;
-    int dbg;                      // diagnostics only (MOKA_DBG): 1 no stores, 2 gathers read the own row, 4 constant records
     // Forward-Euler step in the default stage kernel (k_stage_rec2c modes 4 / 5; every other kernel ignores these):
     // pu/ph/ssh = current level, pu_out/ph_out/ssh_out = new level, a = dt, tendU/tendH, and the diagnostics below
     const double *hEdgeOld;       // previous step's layerThicknessEdge (mode 4: MOKA_FE_STALE_HEDGE) or NULL (mode 5)
@@ -58,15 +57,10 @@ struct OpArgs {
     double *out;
 };
 
-hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream_t s);
-bool stage_ptile_usable(const MeshDev &md, bool ldsOk);
-hipError_t prepare_stage_ptile(const MeshDev &md);
-hipError_t launch_stage_ptile(const MeshDev &m, const StageArgs &a, int nCUs, hipStream_t s);
-bool stage_tile_usable(const MeshDev &md, bool ldsOk);
-hipError_t prepare_stage_tile(const MeshDev &md);
-hipError_t launch_stage_tile(const MeshDev &m, const StageArgs &a, hipStream_t s);
+// the product's stage kernels: default (kernels.hip) and the two fallbacks (stage_fallback.hip)
+hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream_t s);          // generic index kernel
+hipError_t launch_stage_col(const MeshDev &m, const StageArgs &a, hipStream_t s);               // plain column kernel
 hipError_t launch_stage_rec2c(const MeshDev &m, const StageArgs &a, hipStream_t s);
-hipError_t launch_stage_rec2(const MeshDev &m, const StageArgs &a, hipStream_t s);
 // fp32-state form (state pointers of StageArgs are float arrays); stage_f32_supported: can this mesh carry one
 bool stage_f32_supported(const MeshDev &m);
 hipError_t launch_stage_rec2c_f32(const MeshDev &m, const StageArgs &a, hipStream_t s);
@@ -75,11 +69,21 @@ hipError_t launch_permute_rows_f32(void *dst, const void *src, const int32_t *n2
                                    hipStream_t s);
 hipError_t launch_halo_map_f32(float *buf, float *h, float *ssh, float *u, const uint32_t *map, int64_t n, int unpack,
                                hipStream_t s);
+#ifdef MOKA_VARIANTS
+// experiments (csrc/experiments/stage_variants.hip, `make VARIANTS=1`): the measured design points of round 1
+bool stage_ptile_usable(const MeshDev &md, bool ldsOk);
+hipError_t prepare_stage_ptile(const MeshDev &md);
+hipError_t launch_stage_ptile(const MeshDev &m, const StageArgs &a, int nCUs, hipStream_t s);
+bool stage_tile_usable(const MeshDev &md, bool ldsOk);
+hipError_t prepare_stage_tile(const MeshDev &md);
+hipError_t launch_stage_tile(const MeshDev &m, const StageArgs &a, hipStream_t s);
+hipError_t launch_stage_rec2(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_rec(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_colx(const MeshDev &m, const StageArgs &a, bool pipelined, hipStream_t s);
-hipError_t launch_stage_col(const MeshDev &m, const StageArgs &a, bool pipelined, hipStream_t s);
+hipError_t launch_stage_colp(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_lds(const MeshDev &m, const StageArgs &a, size_t ldsBytes, hipStream_t s);
 hipError_t prepare_stage_lds(size_t ldsBytes);
+#endif
 hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s);
 hipError_t launch_curl2(const MeshDev &m, const double *u, double *vort, bool accum, hipStream_t s);
 hipError_t launch_operator(const MeshDev &m, const OpArgs &a, int lpc, hipStream_t s);

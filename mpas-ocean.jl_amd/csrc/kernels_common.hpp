@@ -110,18 +110,6 @@ __device__ __forceinline__ RecLds rec_carve(unsigned char *smem, const ColMesh &
     return L;
 }
 
-// experiment (MOKA_DBG 16 / 32): 16 = identity map (consecutive patches on different XCDs); 32 = tiles of 64
-// consecutive patches per XCD, tiles dealt round-robin, so the 8 XCDs sweep memory together
-__device__ __forceinline__ int patch_of_block_dbg(int nPatches, int dbg)
-{
-    if (dbg & 16) return (int)blockIdx.x;
-    if (dbg & 32) {
-        const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
-        return ((j >> 6) * 8 + x) * 64 + (j & 63);
-    }
-    return patch_of_block(nPatches);
-}
-
 // ---- host-side helpers of the launchers ----
 // ------------------------------------------------------------------------------------------------
 // launchers

@@ -62,6 +62,16 @@ class MokaHIP:
         L.check(L.lib().moka_timer_stop(self._h, C.byref(ms)), self._h)
         return float(ms.value)
 
+    def stage_timing(self, enable: bool):
+        """Record HIP events around every stage launch of the RK4 steps that follow (moka_stage_timing)."""
+        L.check(L.lib().moka_stage_timing(self._h, 1 if enable else 0), self._h)
+
+    def stage_timing_read(self):
+        """(mean ms of the stage-1..4 launches, number of steps recorded)."""
+        ms, n = (C.c_double * 4)(), C.c_int64()
+        L.check(L.lib().moka_stage_timing_read(self._h, ms, C.byref(n)), self._h)
+        return [float(x) for x in ms], int(n.value)
+
     def set_kernel_variant(self, v: int):
         L.check(L.lib().moka_set_kernel_variant(self._h, int(v)), self._h)
 

@@ -73,7 +73,7 @@ EXPORTS = [
     "moka_state_create", "moka_state_destroy", "moka_state_upload", "moka_state_download",
     "moka_advance_time_levels", "moka_diagnostic_compute", "moka_compute_normal_velocity_tendency",
     "moka_compute_layer_thickness_tendency", "moka_tendencies", "moka_step_fe", "moka_step_rk4", "moka_run",
-    "moka_sum_sq", "moka_set_kernel_variant",
+    "moka_sum_sq", "moka_set_kernel_variant", "moka_kernel_variant_available", "moka_stage_timing", "moka_stage_timing_read",
     "moka_ctx_streams", "moka_halo_create", "moka_halo_destroy", "moka_halo_buffer_elems", "moka_halo_pack",
     "moka_halo_unpack", "moka_rk4_dist_begin", "moka_rk4_dist_stage", "moka_rk4_dist_end",
     "moka_set_nonlinear", "moka_last_fe_path", "moka_set_viscosity_del2", "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
@@ -146,6 +146,9 @@ def lib():
     L.moka_run.argtypes = [vp, C.c_int, C.c_double, C.c_int64, C.c_int]
     L.moka_sum_sq.argtypes = [vp, C.c_int, C.c_int, _f64p]
     L.moka_set_kernel_variant.argtypes = [vp, C.c_int]
+    L.moka_kernel_variant_available.argtypes = [C.c_int]
+    L.moka_stage_timing.argtypes = [vp, C.c_int]
+    L.moka_stage_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.moka_ctx_streams.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     i64p = C.POINTER(C.c_int64)
     L.moka_halo_create.argtypes = [vp, C.c_int32, _i32p, i64p, _i32p, i64p, _i32p, i64p, _i32p, i64p,

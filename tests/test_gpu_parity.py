@@ -29,6 +29,9 @@ def backend():
 
 
 _MESH_CACHE = {}
+# kernel variants this build of the library carries: the product has 11 (default) / 4 (column) / 3 (generic); the round-1
+# experiments (csrc/experiments, `make VARIANTS=1`) add 1, 2, 5-10
+VARIANTS = [v for v in (11, 10, 9, 8, 7, 1, 2, 3, 4, 5, 6) if L.lib().moka_kernel_variant_available(v)]
 
 
 def get_mesh(name):
@@ -129,7 +132,7 @@ def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     tu, th, ossh = om.tendencies_clean(u, h)
     info = Setup.mesh.info()
-    for variant in (11, 10, 9, 8, 7, 1, 2, 3, 4, 5, 6):   # 1 pipelined column, 2 LDS patch-tiled, 3 generic index, 4 plain column, 5/6 16-byte-lane column (plain/pipelined)
+    for variant in VARIANTS:   # 11 default, 4 plain column, 3 generic index (+ the experiments when built)
         backend.set_kernel_variant(variant)
         Tend.tendNormalVelocity.set(np.full_like(tu, np.nan)); Tend.tendLayerThickness.set(np.full_like(th, np.nan))
         Prog.ssh[-1].set(ssh)
@@ -339,8 +342,11 @@ def test_reference_call_sequence_piecewise(backend):
 # RK4 stage loop
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("meshname,K,nsteps,variant", [("igw200", 1, 10, 0), ("ico16", 1, 5, 0), ("ico16", 60, 3, 1),
-                                                         ("ico16", 60, 3, 2), ("ico16", 80, 2, 2), ("ico32", 60, 2, 0), ("ico32", 60, 3, 9), ("ico32", 60, 3, 10), ("ico12f", 60, 3, 0), ("ico12f", 3, 3, 0), ("ico32", 60, 3, 11)])
+                                                         ("ico16", 60, 3, 2), ("ico16", 80, 2, 2), ("ico32", 60, 2, 0), ("ico32", 60, 3, 9), ("ico32", 60, 3, 10), ("ico12f", 60, 3, 0), ("ico12f", 3, 3, 0), ("ico32", 60, 3, 11),
+                                                         ("ico16", 60, 3, 4), ("ico16", 80, 2, 4), ("ico16", 60, 3, 3), ("ico16", 33, 2, 0), ("ico16", 100, 2, 0)])
 def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
+    if not L.lib().moka_kernel_variant_available(variant):
+        pytest.skip("experimental kernel variant: build the library with `make VARIANTS=1`")
     backend.set_kernel_variant(variant)
     mesh = get_mesh(meshname)
     if meshname == "igw200":

@@ -16,11 +16,51 @@ def short(name):
     return n[:70]
 
 
+# ---- the bench line of the traced run (the same process the kernel trace comes from) ----
+import json
+import re
+
+bench = None
+bj = os.path.join(out, "bench_trace.json")
+if os.path.exists(bj):
+    for line in open(bj):
+        if line.startswith("{"):
+            bench = json.loads(line)
+    if bench:
+        print("== bench.py line of the traced run ==")
+        print(json.dumps({k: bench[k] for k in ("value", "ms_per_step", "steps", "warmup", "config", "roofline", "tendency_kernel")
+                          if k in bench}))
+if os.path.exists(os.path.join(out, "command.txt")):
+    print(open(os.path.join(out, "command.txt")).read())
+
 # ---- kernel trace: durations ----
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
     dur = defaultdict(list)
+    seq = []
     for r in csv.DictReader(open(f)):
         dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        seq.append((int(r["Start_Timestamp"]), short(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    # reproducibility check against the bench line: the LAST steps*4 RK-stage launches (modes 1,2,2,3) before the tendency
+    # launches are the timed region + the per-stage pass; take the timed region = launches [warmup*4, (warmup+steps)*4)
+    if bench:
+        seq.sort()
+        stage = [(n, d) for _, n, d in seq if re.match(r"k_stage_rec2c(_f32)?<\d+, \d+, [123]", n)]
+        w, k = bench["warmup"], bench["steps"]
+        timed = stage[4 * w:4 * (w + k)]
+        if len(timed) == 4 * k:
+            per_mode = defaultdict(list)
+            for n, d in timed:
+                per_mode[n].append(d)
+            tot = sum(d for _, d in timed) / k / 1e6
+            print("== timed region of the traced run: stage kernels per RK4 step ==")
+            for n, v in per_mode.items():
+                print(f"{n:70s} launches/step={len(v) / k:.0f} avg_us={sum(v) / len(v) / 1e3:10.1f}")
+            ok = tot <= bench["ms_per_step"] * 1.001
+            print(f"sum of the stage kernels per step = {tot:.3f} ms; bench ms_per_step of the same run = {bench['ms_per_step']:.3f} ms "
+                  f"-> {'CONSISTENT' if ok else 'INCONSISTENT (kernel time exceeds wall time)'}")
+            b_contract = bench["roofline"]["algorithmic_bytes_per_launch"] * 4
+            print(f"roofline frac recomputed from this trace (contract bytes / kernel time / 8 TB/s) = {b_contract / (tot * 1e-3) / 8e12:.4f}; "
+                  f"bench.py printed {bench['roofline']['frac']:.4f}")
     print("== kernel trace (ns) ==")
     print(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>10s}")
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
