@@ -143,7 +143,59 @@ def cpu_baseline_1t(mesh, K, ssh, u, h, rest, dts, budget_s=12.0, mixed=False):
             "ms_per_step": t * 1e3}
 
 
+def rccl_probe_child():
+    """Child process of probe_rccl: bring RCCL up between the ranks and move a few bytes the two ways the halo transports
+    do (all_to_all_single with uneven splits, batched isend / irecv).  Exit code 0 = it works on this node."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(torch.cuda.device_count(), 1)
+    if ndev < world:
+        print(f"[rccl-probe] {world} ranks on {ndev} device(s): RCCL needs one device per rank", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local % ndev)
+    dev = torch.device("cuda", local % ndev)
+    dist.init_process_group("nccl", device_id=dev, timeout=dt.timedelta(seconds=60))
+    ins = [(rank + q) % 3 + 1 if q != rank else 0 for q in range(world)]
+    outs = [(q + rank) % 3 + 1 if q != rank else 0 for q in range(world)]
+    send = torch.full((sum(ins),), float(rank), device=dev, dtype=torch.float64)
+    recv = torch.zeros(sum(outs), device=dev, dtype=torch.float64)
+    dist.all_to_all_single(recv, send, outs, ins)
+    exp = torch.cat([torch.full((outs[q],), float(q), dtype=torch.float64) for q in range(world)])
+    ok = torch.equal(recv.cpu(), exp)
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
+    a, b = torch.full((5,), float(rank), device=dev), torch.zeros(5, device=dev)
+    for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, prv), dist.P2POp(dist.isend, a, nxt)]):
+        w.wait()
+    torch.cuda.synchronize()
+    ok = ok and bool((b.cpu() == float(prv)).all())
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 4)
+
+
+def probe_rccl(timeout_s=120):
+    """Does RCCL work between the ranks of this launch?  Answered by a CHILD process per rank (its own rendezvous port),
+    started before this process has touched the GPU: a wedged RCCL collective does not raise, it hangs until a watchdog
+    kills the process -- so the risk is taken by a process whose only job is to take it.  True = every step ran."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 23)
+    env["MASTER_ADDR"] = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-probe"], env=env, timeout=timeout_s,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            log(f"[bench] RCCL probe failed (exit {r.returncode}): {r.stdout.strip().splitlines()[-1:] }")
+        return r.returncode == 0
+    except subprocess.TimeoutExpired:
+        log(f"[bench] RCCL probe did not finish within {timeout_s} s (killed)")
+        return False
+
+
 def main():
+    if "--rccl-probe" in sys.argv:
+        rccl_probe_child()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -154,8 +206,10 @@ def main():
     ap.add_argument("--ordering", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--tend-iters", type=int, default=20)
-    ap.add_argument("--transport", default="nccl", choices=["nccl", "nccl-a2a", "nccl-p2p", "nccl-default-stream", "gloo"],
-                    help="halo transport for N > 1: nccl = RCCL over xGMI (default); gloo = host-staged (rehearsal on one GPU)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "ipc", "nccl", "nccl-a2a", "nccl-p2p", "nccl-default-stream", "gloo"],
+                    help="halo transport for N > 1: auto = the fastest of those that qualify on this node -- ipc (direct stores "
+                         "into the neighbours' IPC-mapped fields over xGMI) and the RCCL forms (nccl-a2a, nccl-p2p); nccl = the RCCL "
+                         "forms only; gloo = host-staged (rehearsal on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,28 +224,39 @@ def main():
     import moka_hip as mk
     from moka_hip import meshgen as mg
 
-    ndev = max(torch.cuda.device_count(), 1)
-    device_index = local_rank % ndev            # rehearsals may put several ranks on one GPU (gloo transport only)
+    ndev = max(torch.cuda.device_count(), 1)            # counting devices does not initialise the GPU
+    device_index = local_rank % ndev            # rehearsals may put several ranks on one GPU (ipc and gloo transports)
     gloo_group = None
+    rccl_ok = False
     if world > 1:
         import torch.distributed as dist
+        want_rccl = args.transport in ("auto", "nccl", "nccl-a2a", "nccl-p2p", "nccl-default-stream")
+        if want_rccl and ndev >= world:
+            rccl_ok = probe_rccl()               # in a child process, before this one touches the GPU
         torch.cuda.set_device(device_index)
-        if args.transport.startswith("nccl"):
-            # a wedged exchange should surface within minutes, not after the default 10-minute watchdog
+        if rccl_ok:
             try:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", device_index),
                                         timeout=dt.timedelta(seconds=300))
                 gloo_group = dist.new_group(backend="gloo")     # control messages + last-resort halo transport
-            except Exception as exc:                 # noqa: BLE001  e.g. several ranks on one GPU in a rehearsal
-                log(f"[bench] rank {rank}: RCCL process group unavailable ({str(exc).splitlines()[0]}); host-staged gloo instead")
+            except Exception as exc:                 # noqa: BLE001
+                log(f"[bench] rank {rank}: RCCL process group unavailable ({str(exc).splitlines()[0]})")
+                rccl_ok = False
                 try:
                     dist.destroy_process_group()
                 except Exception:                    # noqa: BLE001
                     pass
-                dist.init_process_group("gloo")
-                args.transport = "gloo"
-        else:
+        if not rccl_ok:
             dist.init_process_group("gloo")
+            if args.transport not in ("auto", "ipc", "gloo"):
+                log(f"[bench] rank {rank}: RCCL is not usable here; --transport {args.transport} falls back to auto (ipc, gloo)")
+                args.transport = "auto"
+        # every rank must have reached the same verdict about RCCL
+        t = torch.tensor([1.0 if rccl_ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=gloo_group)
+        if rccl_ok and float(t[0]) != 1.0:
+            log(f"[bench] rank {rank}: another rank has no RCCL: this launch cannot continue consistently")
+            sys.exit(5)
     m, K, sbytes, stretch = (tuple(WORKLOADS[args.workload]) + (8, 1.0))[:4]
     mesh = get_mesh(m, stretch)
     ssh, u, h, rest, dts = mg.sphere_synthetic_state(mesh, K)
@@ -202,26 +267,33 @@ def main():
     if args.variant:
         backend.set_kernel_variant(args.variant)
 
+    transport_trials = {}
     if world > 1:
         from moka_hip import parallel as mp
         t0 = time.time()
         model = mp.DistributedModel(mesh, ssh, u, h, rest, dts, backend, rank, world, ordering=args.ordering,
-                                    patch_cells=args.patch_cells, transport=args.transport, group=gloo_group,
+                                    patch_cells=args.patch_cells, transport="gloo", group=gloo_group,
                                     state_bytes=sbytes)
         log(f"[bench] rank {rank}: partition + local plan + upload: {time.time() - t0:.1f}s  {model.info()}")
-        if args.transport == "nccl-p2p":
-            model.transport = "nccl"
-        if args.transport == "nccl":
-            # Choose the halo transport on this node.  Each candidate must (1) run a step without raising and (2) deliver
-            # exactly the bytes the host-staged gloo exchange delivers for the same packed state; the ranks agree on the
-            # outcome over the gloo group so nobody is left waiting.  Among the overlapped RCCL forms (one
-            # all_to_all_single per stage / batched P2P, both on the library's comm stream) the faster one is kept;
-            # P2P on the default stream with full synchronisation and gloo are the fallbacks.
-            cand, times = mp.choose_transport(model, ("nccl-a2a", "nccl"), ("nccl-default-stream", "gloo"), gloo_group,
-                                              lambda msg: log(f"[bench] rank {rank}: {msg}"))
-            model.transport = cand
-            model.exchange_state()                   # failed attempts may have left halos behind: refresh them
-            args.transport = {"nccl": "nccl-p2p"}.get(cand, cand)
+        # Choose the halo transport on this node.  Every candidate must, on every rank, (1) set up, (2) deliver exactly the
+        # bytes the host-staged gloo exchange delivers for the same state, (3) run a step; the ranks agree after each phase
+        # over the gloo group so nobody is left waiting in a collective.  The fastest qualifying candidate is kept.
+        rccl_forms = ("nccl-a2a", "nccl") if rccl_ok else ()
+        cands = {"auto": ("ipc",) + rccl_forms, "nccl": rccl_forms, "ipc": ("ipc",), "nccl-a2a": rccl_forms[:1],
+                 "nccl-p2p": rccl_forms[1:], "nccl-default-stream": (), "gloo": ()}[args.transport]
+        fallbacks = (("nccl-default-stream",) if rccl_ok else ()) + ("gloo",)
+        model.transport = "gloo"
+        model.exchange_state()
+        cand, times = mp.choose_transport(model, cands, fallbacks, gloo_group, lambda msg: log(f"[bench] rank {rank}: {msg}"))
+        model.transport = cand
+        # the trials advanced the state: start the timed run from the initial state again
+        lm = model.lm
+        for f, a in ((model.Prog.ssh, ssh[lm.cells_g]), (model.Prog.normalVelocity, u[lm.edges_g]),
+                     (model.Prog.layerThickness, h[lm.cells_g])):
+            f[0].set(a); f[-1].set(a)
+        model.exchange_state()
+        args.transport = {"nccl": "nccl-p2p"}.get(cand, cand)
+        transport_trials = times
         step = model.step_rk4
         sync = backend.synchronize
         info = model.info()
@@ -237,7 +309,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=gloo_group)
 
     for _ in range(args.warmup):
         step()
@@ -251,8 +323,8 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed, ev_ms], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tt = torch.tensor([elapsed, ev_ms], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=gloo_group)
         elapsed, ev_ms = float(tt[0]), float(tt[1])
     ms_per_step = elapsed / args.steps * 1e3
     value = mesh.nCells * K / (elapsed / args.steps)
@@ -322,7 +394,9 @@ def main():
                       "kernel_variant": args.variant,
                       "parallelism": "single GPU" if world == 1 else
                       f"mesh partitioned over {world} GPUs (RCB), 1-deep halo exchanged per RK stage over {args.transport}, "
-                      f"overlapped with the interior patches; halo {info.get('halo_bytes_per_stage', 0) / 1e6:.1f} MB/stage/rank"},
+                      f"overlapped with the interior patches; halo {info.get('halo_bytes_per_stage', 0) / 1e6:.1f} MB/stage/rank",
+                      **({"halo_transport": args.transport, "halo_transport_trials_ms_per_step": transport_trials,
+                          "rccl_usable": rccl_ok} if world > 1 else {})},
            "roofline": roofline}
 
     if world == 1:
@@ -366,7 +440,8 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=gloo_group)
+        model.close()
         dist.destroy_process_group()
 
 

@@ -159,6 +159,9 @@ int  moka_plan_info(const moka_plan *plan, moka_mesh_info *info);
 int  moka_plan_permutation(const moka_plan *plan, int kind, int32_t *new_to_old);
 /* first cell / edge / vertex of every patch, nPatches+1 entries each */
 int  moka_plan_patch_ranges(const moka_plan *plan, int32_t *cellStart, int32_t *edgeStart, int32_t *vertexStart);
+/* patch / cell / edge range of every cell class (see moka_mesh_class_ranges) */
+int  moka_plan_class_ranges(const moka_plan *plan, int32_t capacity, int32_t *nClasses, int32_t *patchStart,
+                            int32_t *cellStart, int32_t *edgeStart);
 
 /* Read-only view of one of the plan's per-entity record arrays (device layout, new numbering):
  * lets host tests check the reordered mesh without a GPU.  `data` stays valid until plan destroy. */
@@ -219,34 +222,85 @@ int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flag
 /* sumArray                                   src/forward/run_loop.jl:39-51 : sum_j a[j]^2 */
 int moka_sum_sq(moka_state *st, int field, int time_level, double *out);
 
-/* ---- multi-GPU (one process per GPU) --------------------------------------
+/* ---- multi-GPU (one process per GPU; the reference has no distributed code) -----------------
  * The mesh handed to moka_mesh_create is the rank's LOCAL mesh: owned cells + a one-cell-deep halo, with
- * cellClass = 0 (owned, needed by another rank) / 1 (owned interior) / 2 (halo).  The library packs the rows
- * other ranks need into one device buffer and unpacks received rows; moving the buffers between ranks is the
- * host layer's job (torch.distributed on RCCL over xGMI in bench.py; gloo in the tests; MPI.jl from Julia).
- *   buffer layout, per neighbour i (one message each way per neighbour and stage):
- *     [K doubles of layerThickness for cells[off[i]..off[i+1])] [ssh of the same cells] [K doubles of normalVelocity
- *      for edges[off[i]..off[i+1])]
+ * cellClass = 0 (owned, needed by another rank) / 1 (owned interior) / 2 + i (halo cells owned by the rank's i-th
+ * neighbour; plain 2 for all of them also works, but then only the buffered transport is available).  The plan orders
+ * cells class-major and never lets a patch straddle a class: moka_mesh_class_ranges reports the patch / cell / edge range
+ * of every class, moka_mesh_permutation the library's numbering (new -> caller's), which is the order in which a rank
+ * has to list the halo cells / edges it receives for the direct transport.
+ *
+ * Two transports, per neighbour and stage the rows [layerThickness | ssh | normalVelocity] of the listed cells / edges:
+ *   buffered: moka_halo_pack -> one contiguous device buffer -> the host layer moves it (torch.distributed on RCCL over
+ *     xGMI in bench.py; gloo in the tests; MPI.jl from Julia) -> moka_halo_unpack.  Buffer layout, per neighbour i:
+ *     [K reals of layerThickness for cells[off[i]..off[i+1])] [ssh of the same cells] [K reals of normalVelocity for
+ *      edges[off[i]..off[i+1])]   (reals = double, or float for an fp32-storage state; sizes in elements)
+ *   direct: after moka_halo_export / moka_halo_connect with every neighbour, moka_halo_push_begin stores the rows straight
+ *     into the neighbours' fields (peer-mapped memory over xGMI: hipIpcOpenMemHandle between processes, plain pointers
+ *     inside one process), moka_halo_push_signal / _wait complete the exchange through flag words in host (shared)
+ *     memory.  No send buffer, no unpack, no collective library, no kernel that spins on the device.
  * Entity ids are in the caller's (local mesh) numbering; the *Off arrays have nNeighbors+1 entries. */
 typedef struct moka_halo moka_halo;
 int  moka_ctx_streams(moka_ctx *ctx, void **compute_stream, void **comm_stream);   /* hipStream_t handles */
+int  moka_mesh_permutation(const moka_mesh *mesh, int kind, int32_t *new_to_old);
+/* class k covers patches [patchStart[k], patchStart[k+1]), cells [cellStart[k], ...), edges [edgeStart[k], ...) of the
+ * library's numbering; the arrays take min(nClasses + 1, capacity) entries (any of them may be NULL) */
+int  moka_mesh_class_ranges(const moka_mesh *mesh, int32_t capacity, int32_t *nClasses, int32_t *patchStart,
+                            int32_t *cellStart, int32_t *edgeStart);
+/* nPatchesBoundary / nPatchesOwned: patchStart[1] / patchStart[2] of moka_mesh_class_ranges */
 int  moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCells, const int64_t *sendCellOff,
                       const int32_t *sendEdges, const int64_t *sendEdgeOff, const int32_t *recvCells,
                       const int64_t *recvCellOff, const int32_t *recvEdges, const int64_t *recvEdgeOff,
                       int32_t nPatchesBoundary, int32_t nPatchesOwned, moka_halo **out);
 void moka_halo_destroy(moka_halo *h);
 int  moka_halo_buffer_elems(const moka_halo *h, int64_t *sendElems, int64_t *recvElems);
-/* what: 0 = current time level, 1..4 = output of RK4 stage `what`.  pack runs on the comm stream after the work
- * already queued on the compute stream; unpack makes later compute-stream work wait for it. */
-/* Buffers hold state reals: double, or float for an fp32-storage state (moka_mesh_desc.stateBytes = 4); sizes from
- * moka_halo_buffer_elems are in elements either way. */
+/* what: 0 = current time level, 1..4 = output of RK4 stage `what` (4 = also the new level of a distributed
+ * Forward-Euler step).  pack runs on the comm stream after the work already queued on the compute stream; unpack makes
+ * later compute-stream work wait for it. */
 int  moka_halo_pack(moka_halo *h, int what, void *sendbuf_device);
 int  moka_halo_unpack(moka_halo *h, int what, const void *recvbuf_device);
-/* distributed form of moka_step_rk4: begin; for stage 1..4 { stage(s,0) boundary patches; pack(s); stage(s,1)
- * interior patches (overlaps the transport); transport; unpack(s) }; end */
+
+/* direct transport.  What a rank tells neighbour `nbr` so that the neighbour can push to it (moka_halo_export), to be
+ * carried to that neighbour by the host layer (any byte transport: it is plain data) and given to moka_halo_connect
+ * there.  shared = 1: the two ranks are different processes (IPC handles + a POSIX shared-memory flag block);
+ * shared = 0: same process (raw pointers; several devices are mapped with hipDeviceEnablePeerAccess). */
+typedef struct {
+    unsigned char ipc[12][64];   /* hipIpcMemHandle_t of the four buffer sets x (normalVelocity, layerThickness, ssh) */
+    uint64_t ptr[12];            /* the same allocations as raw device pointers */
+    uint64_t flagPtr;            /* the rank's flag block as a raw host pointer */
+    char     shmName[64];        /* ... and as a POSIX shared-memory object (shared = 1) */
+    int32_t  dstCell, dstEdge;   /* first cell / edge (library numbering) of the ranges the neighbour's rows go to */
+    int32_t  nCells, nEdges;     /* their lengths: must equal what the neighbour lists as its send cells / edges */
+    int32_t  slot;               /* the neighbour's slot in the flag block */
+    int32_t  nNeighbors, pid, device, stateBytes, nVertLevels;
+} moka_halo_peer_info;
+int  moka_halo_direct_available(const moka_halo *h);   /* 1: the receive lists are contiguous ranges (see above) */
+int  moka_halo_export(moka_halo *h, int32_t nbr, int32_t shared, moka_halo_peer_info *out);
+int  moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer, int32_t shared);
+int  moka_halo_push_begin(moka_halo *h, int what);        /* queue the push behind the work on the compute stream */
+int  moka_halo_push_signal(moka_halo *h);                 /* host: wait for the own push, then signal the neighbours */
+int  moka_halo_push_wait(moka_halo *h, double timeout_s); /* host: wait for every neighbour's signal (MOKA_ERR_COMM on timeout) */
+
+/* distributed form of moka_step_rk4, piecewise: begin; for stage 1..4 { stage(s,0) boundary patches; pack(s) or
+ * push_begin(s); stage(s,1) interior patches (overlaps the exchange); transport + unpack(s), or push_signal + push_wait };
+ * end.  moka_rk4_dist_stage_launch(s) = stage(s,0) + push_begin(s) + stage(s,1). */
 int  moka_rk4_dist_begin(moka_halo *h, double dt);
 int  moka_rk4_dist_stage(moka_halo *h, int stage, int part);
+int  moka_rk4_dist_stage_launch(moka_halo *h, int stage);
 int  moka_rk4_dist_end(moka_halo *h);
+/* ... and as ONE call per step.  Direct when every neighbour is connected; otherwise `transport` moves the packed send
+ * buffer of a stage to the neighbours and fills the receive buffer (stream-ordered on the comm stream, or synchronously;
+ * returns 0 on success).  timeout_s bounds every wait of the direct form. */
+typedef int (*moka_transport_fn)(void *user, int what, void *sendbuf_device, void *recvbuf_device);
+int  moka_rk4_dist_step(moka_halo *h, double dt, moka_transport_fn transport, void *user, void *sendbuf_device,
+                        void *recvbuf_device, double timeout_s);
+/* distributed form of moka_step_fe (ocn_timestep(..., ForwardEuler), time_integration.jl:150-193) with the same flags:
+ * part 0 boundary patches, 1 interior patches, 2 relativeVorticity; the new level is exchanged as `what` = 4 between
+ * part 0 and the end; moka_fe_dist_end swaps the time levels.  moka_fe_dist_step does all of it in one call. */
+int  moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part);
+int  moka_fe_dist_end(moka_halo *h);
+int  moka_fe_dist_step(moka_halo *h, double dt, int flags, moka_transport_fn transport, void *user, void *sendbuf_device,
+                       void *recvbuf_device, double timeout_s);
 
 /* kernel variant selection for measurement (all variants give identical results): 0 = auto [default: 11 when the mesh
  * allows it (even 34 <= nVertLevels <= 64), else 4 (nVertLevels >= 33), else 3]; 11 = record-staged, 16-byte lanes, two

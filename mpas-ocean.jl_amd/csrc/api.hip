@@ -11,77 +11,11 @@
 #include <utility>
 #include <vector>
 
-#include "kernels.hpp"
-#include "moka_internal.hpp"
+#include "state.hpp"
 
 namespace moka { void fill_mesh_info(const Plan &p, moka_mesh_info *info); }
 
-struct moka_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t comm = nullptr;                       // halo pack / transport / unpack
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t evBoundary = nullptr, evInterior = nullptr, evHalo = nullptr;
-    int variant = 0;
-    int nCUs = 256;
-    std::string err;
-    // per-stage HIP-event timing of moka_step_rk4 (moka_stage_timing): 5 events per recorded step, read back on request
-    bool stageTiming = false;
-    std::vector<hipEvent_t> evPool;          // events owned by the context (reused between measurements)
-    size_t evUsed = 0;
-};
-
-struct moka_mesh {
-    moka_ctx *ctx = nullptr;
-    moka::Plan plan;          // host copy (permutations, sizes)
-    moka::MeshDev dev{};
-    std::vector<void *> allocs;
-    int lpc = 1;
-    size_t ldsBytes = 0;      // > 0: the LDS-tiled stage kernel is usable for this mesh
-    bool colOk = false;       // byte-offset records exist (every field < 4 GiB)
-    bool tileOk = false;      // the tiled stage kernel (u rows + records in LDS) fits this mesh
-    bool ptileOk = false;     // the persistent double-buffered tiled kernel fits this mesh
-    double *opBuf[3] = {nullptr, nullptr, nullptr};   // operator / transfer scratch, lazily sized
-    size_t opBufElems = 0;
-    // (maxOwnE, maxOwnC) of a launched patch sub-range: a partition's halo-only patches own up to 6 edges per cell
-    // and are never launched, so the LDS carve of a boundary / interior launch is sized by the patches it covers
-    std::map<std::pair<int, int>, std::pair<int, int>> rangeMax;
-};
-
-struct LevelBufs {
-    double *ssh = nullptr, *u = nullptr, *h = nullptr;
-};
-
-struct moka_state {
-    moka_ctx *ctx = nullptr;
-    moka_mesh *mesh = nullptr;
-    LevelBufs lev[2];                 // [0] previous, [1] current   (reference Vector index 1 / end)
-    double *hEdge[2] = {nullptr, nullptr};   // [0] is Diag.layerThicknessEdge, [1] the write target of the next step
-    double *F = nullptr, *div = nullptr, *vort = nullptr, *tendU = nullptr, *tendH = nullptr;
-    LevelBufs rk[2];                  // RK4 provisional states (lazily allocated)
-    double *scalar = nullptr;         // 1 double (sum_sq result)
-    bool sshConsistent = false;       // lev[1].ssh == ksum(lev[1].h) - restingThicknessSum
-    // moka_step_rk4 ends with diagnostic_compute! of the new state and leaves the stage-4 tendencies in
-    // Tend (time_integration.jl:114-147).  Neither is needed by the next RK4 step, so they are produced
-    // lazily -- on the first read (download, Forward-Euler step, reference-sequenced calls) -- with
-    // results identical to computing them at the end of the step.
-    bool diagDirty = false;
-    bool tendDirty = false;           // stage-4 provisional state still sits in rk[0]
-    // fp32 storage of the prognostic fields (mesh stateBytes == 4): lev[] / rk[] then point at float arrays
-    // (the pointer type stays double* so that one StageArgs block serves both), Diag arrays do not exist.
-    bool f32 = false;
-    // optional nonlinear terms (moka_set_nonlinear): scratch of the three preparation passes
-    bool nonlinear = false;
-    double *nlQv = nullptr, *nlQe = nullptr, *nlKe = nullptr;
-    int feFast = -1;                            // moka_last_fe_path
-    double *nlZv = nullptr, *nlDiv = nullptr;   // Del2 mixing (moka_set_viscosity_del2)
-    double viscDel2 = 0.0;
-    std::vector<void *> allocs;
-};
-
-namespace {
-
-using namespace moka;
+namespace mk {
 
 int fail(moka_ctx *ctx, int code, const std::string &msg)
 {
@@ -89,13 +23,6 @@ int fail(moka_ctx *ctx, int code, const std::string &msg)
     if (ctx) ctx->err = msg;
     return code;
 }
-
-#define HIPCHK(ctx, call)                                                                      \
-    do {                                                                                       \
-        hipError_t _e = (call);                                                                \
-        if (_e != hipSuccess)                                                                  \
-            return fail(ctx, MOKA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
-    } while (0)
 
 int lanes_per_column(int K)
 {
@@ -142,7 +69,7 @@ int ensure_op_bufs(moka_mesh *m)
     return MOKA_OK;
 }
 
-int alloc_field(moka_state *st, double **out, size_t elems, size_t elemBytes = sizeof(double))
+int alloc_field(moka_state *st, double **out, size_t elems, size_t elemBytes)
 {
     void *d = nullptr;
     HIPCHK(st->ctx, hipMalloc(&d, std::max<size_t>(elems * elemBytes, 16)));
@@ -171,6 +98,7 @@ int ensure_rk_bufs(moka_state *st)
         return rc;
     }
     st->rk[0] = tmp[0]; st->rk[1] = tmp[1];
+    st->phys[2] = tmp[0]; st->phys[3] = tmp[1];
     return MOKA_OK;
 }
 
@@ -253,7 +181,7 @@ FeArgs fe_args(moka_state *st, int ops, int flags, double dt)
 // One fused tendency / RK-stage launch over patches [pBegin, pBegin + pCount) (default: all) on the compute stream (or `on`).
 // variant 0 (auto): k_stage_rec2c, then rec2 / rec / col / generic as the mesh allows; fp32-storage and nonlinear states have
 // their own kernels.
-hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin = 0, int pCount = -1, hipStream_t on = nullptr, int tail = -1)
+hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCount, hipStream_t on, int tail)
 {
     const StageArgs &g = g_in;
     const moka_mesh *m = st->mesh;
@@ -380,7 +308,9 @@ int flush_lazy(moka_state *st, bool diag, bool tend)
 bool is_diag_field(int f) { return f >= MOKA_F_LAYER_THICKNESS_EDGE && f <= MOKA_F_RELATIVE_VORTICITY; }
 bool is_tend_field(int f) { return f == MOKA_F_TEND_NORMAL_VELOCITY || f == MOKA_F_TEND_LAYER_THICKNESS; }
 
-}  // namespace
+}  // namespace mk
+
+using namespace mk;
 
 extern "C" {
 
@@ -570,6 +500,31 @@ void moka_mesh_destroy(moka_mesh *mesh)
     delete mesh;
 }
 
+int moka_mesh_permutation(const moka_mesh *mesh, int kind, int32_t *new_to_old)
+{
+    if (!mesh || !new_to_old) return fail(nullptr, MOKA_ERR_ARG, "NULL argument");
+    const Plan &p = mesh->plan;
+    const std::vector<int32_t> *v = kind == MOKA_CELL ? &p.cellN2O : kind == MOKA_EDGE ? &p.edgeN2O : kind == MOKA_VERTEX ? &p.vertN2O : nullptr;
+    if (!v) return fail(mesh->ctx, MOKA_ERR_ARG, "kind must be MOKA_CELL, MOKA_EDGE or MOKA_VERTEX");
+    std::copy(v->begin(), v->end(), new_to_old);
+    return MOKA_OK;
+}
+
+int moka_mesh_class_ranges(const moka_mesh *mesh, int32_t capacity, int32_t *nClasses, int32_t *patchStart, int32_t *cellStart,
+                           int32_t *edgeStart)
+{
+    if (!mesh || !nClasses) return fail(nullptr, MOKA_ERR_ARG, "NULL argument");
+    const Plan &p = mesh->plan;
+    const int n = (int)p.classPatchStart.size() - 1;
+    *nClasses = n;
+    for (int k = 0; k <= n && k < capacity; ++k) {
+        if (patchStart) patchStart[k] = p.classPatchStart[k];
+        if (cellStart) cellStart[k] = p.classCellStart[k];
+        if (edgeStart) edgeStart[k] = p.classEdgeStart[k];
+    }
+    return MOKA_OK;
+}
+
 int moka_mesh_info_get(const moka_mesh *mesh, moka_mesh_info *info)
 {
     if (!mesh || !info) return fail(nullptr, MOKA_ERR_ARG, "NULL argument");
@@ -671,6 +626,7 @@ int moka_state_create(moka_ctx *ctx, moka_mesh *mesh, moka_state **out)
     A(&st->tendU, nEK); A(&st->tendH, nCK);
     A(&st->scalar, 2);
     if (rc != MOKA_OK) { moka_state_destroy(st); return rc; }
+    st->phys[0] = st->lev[0]; st->phys[1] = st->lev[1];
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *out = st;
     return MOKA_OK;
@@ -845,7 +801,9 @@ int moka_step_fe(moka_state *st, double dt, int flags)
 
 // Argument block of RK4 stage s (1..4).  A = Curr (current level), B = New accumulator (the previous
 // level's buffers, becomes the current level at the end), R1/R2 = provisional states.
-static StageArgs rk4_stage_args(moka_state *st, int s, double dt, const double *ssh0)
+}  // extern "C"
+namespace mk {
+StageArgs rk4_stage_args(moka_state *st, int s, double dt, const double *ssh0)
 {
     const double a[3] = {dt / 2., dt / 2., dt};                         // time_integration.jl:77
     const double b[4] = {dt / 6., dt / 3., dt / 3., dt / 6.};           // :78
@@ -869,12 +827,12 @@ static StageArgs rk4_stage_args(moka_state *st, int s, double dt, const double *
 }
 
 // buffers a stage writes that other ranks gather from next: stage 1,3 -> R1; 2 -> R2; 4 -> B; 0 -> current level
-static LevelBufs &rk4_stage_output(moka_state *st, int s)
+LevelBufs &rk4_stage_output(moka_state *st, int s)
 {
     return s == 0 ? st->lev[1] : s == 4 ? st->lev[0] : s == 2 ? st->rk[1] : st->rk[0];
 }
 
-static int rk4_begin(moka_state *st, const double **ssh0)
+int rk4_begin(moka_state *st, const double **ssh0)
 {
     int rc = ensure_rk_bufs(st);
     if (rc) return rc;
@@ -886,13 +844,15 @@ static int rk4_begin(moka_state *st, const double **ssh0)
     return MOKA_OK;
 }
 
-static void rk4_end(moka_state *st)
+void rk4_end(moka_state *st)
 {
     std::swap(st->lev[0], st->lev[1]);
     st->sshConsistent = true;
     st->diagDirty = true;
     st->tendDirty = true;
 }
+}  // namespace mk
+extern "C" {
 
 int moka_step_rk4(moka_state *st, double dt)
 {
@@ -1016,189 +976,6 @@ int moka_sum_sq(moka_state *st, int field, int time_level, double *out)
     HIPCHK(st->ctx, launch_sum_sq_serial(st->mesh->opBuf[2], r.n * r.K, st->scalar, s));
     HIPCHK(st->ctx, hipMemcpyAsync(out, st->scalar, sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(st->ctx, hipStreamSynchronize(s));
-    return MOKA_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// multi-GPU: halo lists + distributed RK4 stages.  Transport between ranks is the
-// host layer's business (torch.distributed on RCCL over xGMI, or gloo in tests): the library packs the rows
-// other ranks need into one contiguous device buffer, and unpacks the rows it receives.
-//   send buffer = [sendCells x K doubles of h][sendCells x 1 double of ssh][sendEdges x K doubles of u]
-// ---------------------------------------------------------------------------------------------
-struct moka_halo {
-    moka_state *st = nullptr;
-    uint32_t *sendMap = nullptr, *recvMap = nullptr;     // element maps, device
-    int64_t nSend = 0, nRecv = 0;                        // doubles
-    int32_t pBoundary = 0, pOwned = 0;
-    double dt = 0.0;
-    const double *ssh0 = nullptr;
-};
-
-// Element map of one direction.  Per neighbour i the buffer segment is
-//   [h rows of cells[co[i]..co[i+1]) | ssh of the same cells | u rows of edges[eo[i]..eo[i+1])]   (one message)
-static int build_halo_map(moka_state *st, int nNbr, const int32_t *cells, const int64_t *co, const int32_t *edges,
-                          const int64_t *eo, uint32_t **outDev, int64_t *outN)
-{
-    const Plan &p = st->mesh->plan;
-    const int K = p.K;
-    if ((int64_t)p.K * std::max(p.nE, p.nC) >= (1ll << 30))
-        return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "halo element map: a local field has more than 2^30 elements");
-    std::vector<uint32_t> map;
-    map.reserve((size_t)(co[nNbr] * (K + 1) + eo[nNbr] * K));
-    for (int i = 0; i < nNbr; ++i) {
-        for (int64_t j = co[i]; j < co[i + 1]; ++j) {
-            if (cells[j] < 0 || cells[j] >= p.nC) return fail(st->ctx, MOKA_ERR_ARG, "halo cell id out of range");
-            const uint32_t base = (uint32_t)p.cellO2N[cells[j]] * (uint32_t)K;
-            for (int k = 0; k < K; ++k) map.push_back((0u << 30) | (base + k));
-        }
-        for (int64_t j = co[i]; j < co[i + 1]; ++j) map.push_back((1u << 30) | (uint32_t)p.cellO2N[cells[j]]);
-        for (int64_t j = eo[i]; j < eo[i + 1]; ++j) {
-            if (edges[j] < 0 || edges[j] >= p.nE) return fail(st->ctx, MOKA_ERR_ARG, "halo edge id out of range");
-            const uint32_t base = (uint32_t)p.edgeO2N[edges[j]] * (uint32_t)K;
-            for (int k = 0; k < K; ++k) map.push_back((2u << 30) | (base + k));
-        }
-    }
-    *outN = (int64_t)map.size();
-    *outDev = nullptr;
-    if (map.empty()) return MOKA_OK;
-    void *d = nullptr;
-    HIPCHK(st->ctx, hipMalloc(&d, map.size() * sizeof(uint32_t)));
-    st->allocs.push_back(d);
-    if (int rc = h2d(st->ctx, d, map.data(), map.size() * sizeof(uint32_t))) return rc;
-    *outDev = static_cast<uint32_t *>(d);
-    return MOKA_OK;
-}
-
-int moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCells, const int64_t *sendCellOff,
-                     const int32_t *sendEdges, const int64_t *sendEdgeOff, const int32_t *recvCells,
-                     const int64_t *recvCellOff, const int32_t *recvEdges, const int64_t *recvEdgeOff,
-                     int32_t nPatchesBoundary, int32_t nPatchesOwned, moka_halo **out)
-{
-    if (!st || !out || nNeighbors < 0 || !sendCellOff || !sendEdgeOff || !recvCellOff || !recvEdgeOff)
-        return fail(st ? st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
-    *out = nullptr;
-    const Plan &p = st->mesh->plan;
-    if (nPatchesBoundary < 0 || nPatchesOwned < nPatchesBoundary || nPatchesOwned > p.nPatches)
-        return fail(st->ctx, MOKA_ERR_ARG, "patch ranges must satisfy 0 <= boundary <= owned <= nPatches");
-    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
-    moka_halo *h = new (std::nothrow) moka_halo();
-    if (!h) return fail(st->ctx, MOKA_ERR_ALLOC, "out of host memory");
-    h->st = st;
-    h->pBoundary = nPatchesBoundary; h->pOwned = nPatchesOwned;
-    int rc;
-    try {
-        if ((rc = build_halo_map(st, nNeighbors, sendCells, sendCellOff, sendEdges, sendEdgeOff, &h->sendMap, &h->nSend)) ||
-            (rc = build_halo_map(st, nNeighbors, recvCells, recvCellOff, recvEdges, recvEdgeOff, &h->recvMap, &h->nRecv))) {
-            delete h;
-            return rc;
-        }
-    } catch (const std::bad_alloc &) {
-        delete h;
-        return fail(st->ctx, MOKA_ERR_ALLOC, "out of host memory building the halo maps");
-    }
-    *out = h;
-    return MOKA_OK;
-}
-
-void moka_halo_destroy(moka_halo *h) { delete h; }
-
-int moka_halo_buffer_elems(const moka_halo *h, int64_t *sendElems, int64_t *recvElems)
-{
-    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
-    if (sendElems) *sendElems = h->nSend;
-    if (recvElems) *recvElems = h->nRecv;
-    return MOKA_OK;
-}
-
-// what: 0 = the current time level, 1..4 = the output of RK4 stage `what` (valid between dist_begin and dist_end)
-int moka_halo_pack(moka_halo *h, int what, void *sendbuf)
-{
-    if (!h || (!sendbuf && h->nSend)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
-    if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
-    moka_state *st = h->st;
-    moka_ctx *c = st->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
-    const LevelBufs &o = rk4_stage_output(st, what);
-    // the rows to send are produced by the boundary patches (or by whatever last ran on the compute stream)
-    HIPCHK(c, hipEventRecord(c->evBoundary, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->comm, c->evBoundary, 0));
-    if (st->f32)
-        HIPCHK(c, launch_halo_map_f32(static_cast<float *>(sendbuf), (float *)o.h, (float *)o.ssh, (float *)o.u, h->sendMap,
-                                      h->nSend, 0, c->comm));
-    else
-        HIPCHK(c, launch_halo_map(static_cast<double *>(sendbuf), o.h, o.ssh, o.u, h->sendMap, h->nSend, 0, c->comm));
-    return MOKA_OK;
-}
-
-int moka_halo_unpack(moka_halo *h, int what, const void *recvbuf)
-{
-    if (!h || (!recvbuf && h->nRecv)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
-    if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
-    moka_state *st = h->st;
-    moka_ctx *c = st->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
-    const LevelBufs &o = rk4_stage_output(st, what);
-    // Inside an RK4 step (what >= 1) every row this overwrites was last written on this stream (moka_rk4_dist_stage part 0
-    // carries the straddling patch), so the exchange and the unpack overlap the interior launch completely.  For the
-    // current time level (what == 0) anything may have run on the compute stream before: wait for it.
-    if (what == 0) {
-        HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
-    }
-    if (st->f32)
-        HIPCHK(c, launch_halo_map_f32(static_cast<float *>(const_cast<void *>(recvbuf)), (float *)o.h, (float *)o.ssh,
-                                      (float *)o.u, h->recvMap, h->nRecv, 1, c->comm));
-    else
-        HIPCHK(c, launch_halo_map(static_cast<double *>(const_cast<void *>(recvbuf)), o.h, o.ssh, o.u, h->recvMap, h->nRecv, 1,
-                                  c->comm));
-    HIPCHK(c, hipEventRecord(c->evHalo, c->comm));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evHalo, 0));     // whatever comes next on the compute stream sees the halo
-    return MOKA_OK;
-}
-
-int moka_rk4_dist_begin(moka_halo *h, double dt)
-{
-    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
-    moka_state *st = h->st;
-    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
-    // like moka_step_rk4: lazily pending diagnostics / stage-4 tendencies of the previous step are superseded, not computed
-    h->dt = dt;
-    return rk4_begin(st, &h->ssh0);
-}
-
-// part 0: patches [0, boundary) -- their rows are what other ranks need; part 1: [boundary, owned).
-// Halo patches [owned, nPatches) are never computed: their rows arrive through moka_halo_unpack.
-int moka_rk4_dist_stage(moka_halo *h, int stage, int part)
-{
-    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
-    if (stage < 1 || stage > 4 || part < 0 || part > 1) return fail(h->st->ctx, MOKA_ERR_ARG, "stage must be 1..4, part 0 or 1");
-    moka_state *st = h->st;
-    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
-    if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms are not available on partitioned meshes");
-    const StageArgs g = rk4_stage_args(st, stage, h->dt, h->ssh0);
-    // The last owned patch may straddle into the halo cells (patches are P consecutive cells): it writes rows that
-    // moka_halo_unpack overwrites, so it travels with the boundary group on the comm stream -- the interior launch then
-    // touches no received row and the unpack of a stage does not have to wait for it.
-    const int pTail = h->pOwned - 1 >= h->pBoundary ? h->pOwned - 1 : h->pOwned;      // == pOwned: no separate tail patch
-    const int p0 = part == 0 ? 0 : h->pBoundary, cnt = part == 0 ? h->pBoundary : pTail - h->pBoundary;
-    moka_ctx *c = st->ctx;
-    if (part == 0) {
-        // Boundary group first, interior right behind it on the same (compute) stream: in-order, no cross-queue wait in the
-        // compute chain.  Launched concurrently the two kernels share the CUs and the ~130 boundary workgroups finish no
-        // earlier than the thousands of interior ones (measured 290 us instead of 35 us), which would push pack and
-        // transport behind the interior compute they are meant to hide under.  moka_halo_pack then makes the comm stream
-        // wait for the boundary group only (it records its event before the interior launch is queued).
-        HIPCHK(c, run_stage(st, g, p0, cnt, nullptr, pTail < h->pOwned ? pTail : -1));
-    } else {
-        HIPCHK(c, run_stage(st, g, p0, cnt));
-    }
-    return MOKA_OK;
-}
-
-int moka_rk4_dist_end(moka_halo *h)
-{
-    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
-    rk4_end(h->st);
     return MOKA_OK;
 }
 

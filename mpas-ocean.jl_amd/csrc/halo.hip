@@ -1,0 +1,754 @@
+// halo.hip -- multi-GPU layer of libmoka_hip (the reference has no distributed code at all).
+//
+// One process per GPU; the mesh of a state is the rank's LOCAL mesh (owned cells + a one-cell-deep halo).  Cell classes
+// (moka_mesh_desc.cellClass): 0 = owned and needed by another rank, 1 = owned interior, 2 + i = halo cells owned by the
+// rank's i-th neighbour.  The plan numbers cells class-major and never lets a patch straddle a class, so
+//   * patches [0, pBoundary) produce everything other ranks need, [pBoundary, pOwned) is the interior, halo patches are
+//     never computed,
+//   * what neighbour i sends lands in ONE contiguous range of cells and ONE of edges (edges are numbered by owner cell).
+//
+// Two transports for the rows [h | ssh | u] of the cells / edges a neighbour needs, once per RK stage:
+//   buffered : moka_halo_pack -> one contiguous send buffer -> the host layer moves it (torch.distributed on RCCL over
+//              xGMI, gloo in tests, MPI.jl from Julia) -> moka_halo_unpack.
+//   direct   : the sender's push kernel stores the rows straight into the receiver's fields over xGMI (peer-mapped
+//              memory: hipIpcOpenMemHandle between processes, plain pointers inside one process) -- no send buffer, no
+//              unpack, no collective library.  Completion is signalled through flag words in host shared memory: the
+//              sender's host thread waits for its push kernel (one event) and then stores the exchange's sequence number
+//              into each neighbour's flag slot; the receiver's host thread polls its slots before it launches the next
+//              stage's boundary patches.  All of that happens while the interior patches of the stage run on the compute
+//              stream, so the host never sits on the critical path unless the exchange is later than the interior launch.
+//              No kernel ever spins on the device (a spinning kernel can starve whatever shares its hardware queue).
+// Why the direct form needs no back-pressure: halo rows are read only by boundary launches; the rows a neighbour
+// overwrites at stage s+1 (its output set) were last read by my boundary launch of an earlier stage, which precedes my
+// push of that stage, whose flag the neighbour has waited for before it computed what it now pushes.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "state.hpp"
+
+using namespace mk;
+
+namespace {
+
+struct PushDst {              // where the rows for one neighbour go, for one physical buffer set of the peer
+    unsigned char *u, *h, *ssh;
+};
+
+struct PeerLink {
+    bool connected = false, ipc = false;
+    void *mapped[12] = {};                // peer field bases as this process sees them: [set][u, h, ssh]
+    volatile uint64_t *flags = nullptr;   // the peer's flag block (host memory)
+    size_t flagsBytes = 0;
+    int32_t dstCell = 0, dstEdge = 0, slot = 0;
+};
+
+}  // namespace
+
+struct moka_halo {
+    moka_state *st = nullptr;
+    int32_t nNbr = 0;
+    // buffered transport
+    uint32_t *sendMap = nullptr, *recvMap = nullptr;     // element maps, device
+    int64_t nSend = 0, nRecv = 0;                        // elements
+    int32_t pBoundary = 0, pOwned = 0;
+    double dt = 0.0;
+    const double *ssh0 = nullptr;
+    int feFlags = 0;
+    // direct transport
+    bool directOk = false;
+    std::string directWhy;
+    std::vector<int32_t> recvCellStart, recvCellCount, recvEdgeStart, recvEdgeCount;   // per neighbour, library numbering
+    std::vector<int32_t> sendCellCount, sendEdgeCount;
+    uint32_t *pushRows = nullptr;         // device: {source row (library numbering), row within the message part, nbr | kind << 16}
+    int64_t nPushRows = 0;
+    std::vector<PeerLink> peers;
+    PushDst *peerTab = nullptr;           // device: [4 sets][nNbr]
+    bool tabDirty = true;
+    volatile uint64_t *flags = nullptr;   // my flag block: slot i = last exchange neighbour i has completed towards me
+    size_t flagsBytes = 0;
+    std::string shmName;                  // non-empty: the block is a POSIX shared-memory object (multi-process)
+    uint64_t seq = 0;                     // exchanges started so far
+    hipEvent_t evPush = nullptr;
+    std::vector<void *> allocs;           // device allocations of this object
+};
+
+namespace {
+
+int hfail(moka_halo *h, int code, const std::string &msg) { return fail(h ? h->st->ctx : nullptr, code, msg); }
+
+// Element map of one direction (buffered transport).  Per neighbour i the buffer segment is
+//   [h rows of cells[co[i]..co[i+1]) | ssh of the same cells | u rows of edges[eo[i]..eo[i+1])]   (one message)
+int build_halo_map(moka_halo *hh, int nNbr, const int32_t *cells, const int64_t *co, const int32_t *edges,
+                   const int64_t *eo, uint32_t **outDev, int64_t *outN)
+{
+    moka_state *st = hh->st;
+    const Plan &p = st->mesh->plan;
+    const int K = p.K;
+    if ((int64_t)p.K * std::max(p.nE, p.nC) >= (1ll << 30))
+        return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "halo element map: a local field has more than 2^30 elements");
+    std::vector<uint32_t> map;
+    map.reserve((size_t)(co[nNbr] * (K + 1) + eo[nNbr] * K));
+    for (int i = 0; i < nNbr; ++i) {
+        for (int64_t j = co[i]; j < co[i + 1]; ++j) {
+            if (cells[j] < 0 || cells[j] >= p.nC) return fail(st->ctx, MOKA_ERR_ARG, "halo cell id out of range");
+            const uint32_t base = (uint32_t)p.cellO2N[cells[j]] * (uint32_t)K;
+            for (int k = 0; k < K; ++k) map.push_back((0u << 30) | (base + k));
+        }
+        for (int64_t j = co[i]; j < co[i + 1]; ++j) map.push_back((1u << 30) | (uint32_t)p.cellO2N[cells[j]]);
+        for (int64_t j = eo[i]; j < eo[i + 1]; ++j) {
+            if (edges[j] < 0 || edges[j] >= p.nE) return fail(st->ctx, MOKA_ERR_ARG, "halo edge id out of range");
+            const uint32_t base = (uint32_t)p.edgeO2N[edges[j]] * (uint32_t)K;
+            for (int k = 0; k < K; ++k) map.push_back((2u << 30) | (base + k));
+        }
+    }
+    *outN = (int64_t)map.size();
+    *outDev = nullptr;
+    if (map.empty()) return MOKA_OK;
+    void *d = nullptr;
+    HIPCHK(st->ctx, hipMalloc(&d, map.size() * sizeof(uint32_t)));
+    hh->allocs.push_back(d);
+    if (int rc = h2d(st->ctx, d, map.data(), map.size() * sizeof(uint32_t))) return rc;
+    *outDev = static_cast<uint32_t *>(d);
+    return MOKA_OK;
+}
+
+// index (0..3) of the physical buffer set a LevelBufs currently names: 0/1 the two time levels as allocated, 2/3 the RK
+// provisional states.  Ranks that have applied the same sequence of steps agree on it.
+int phys_index(const moka_state *st, const LevelBufs &b)
+{
+    for (int i = 0; i < 4; ++i)
+        if (st->phys[i].u && st->phys[i].u == b.u) return i;
+    return -1;
+}
+
+// One half-wave (32 lanes) per row: 16 bytes per lane when the row size allows it, else one element per lane.
+__global__ __launch_bounds__(256) void k_halo_push(const uint32_t *rows, int64_t nRows, const PushDst *tab, const unsigned char *u,
+                                                   const unsigned char *h, const unsigned char *ssh, uint32_t rowB, uint32_t elemB)
+{
+    const int l = threadIdx.x & 31;
+    const int64_t g0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5, ng = ((int64_t)gridDim.x * 256) >> 5;
+    for (int64_t r = g0; r < nRows; r += ng) {
+        const uint32_t src = rows[3 * r], dst = rows[3 * r + 1], meta = rows[3 * r + 2];
+        const uint32_t nbr = meta & 0xFFFFu, kind = meta >> 16;          // 0 = h row, 1 = ssh element, 2 = u row
+        const PushDst d = tab[nbr];
+        if (kind == 1) {
+            if (l == 0) {
+                if (elemB == 8) reinterpret_cast<double *>(d.ssh)[dst] = reinterpret_cast<const double *>(ssh)[src];
+                else reinterpret_cast<float *>(d.ssh)[dst] = reinterpret_cast<const float *>(ssh)[src];
+            }
+            continue;
+        }
+        const unsigned char *s = (kind == 0 ? h : u) + (size_t)src * rowB;
+        unsigned char *t = (kind == 0 ? d.h : d.u) + (size_t)dst * rowB;
+        if ((rowB & 15u) == 0) {
+            for (uint32_t off = (uint32_t)l * 16u; off < rowB; off += 512u)
+                *reinterpret_cast<uint4 *>(t + off) = *reinterpret_cast<const uint4 *>(s + off);
+        } else if (elemB == 8) {
+            for (uint32_t off = (uint32_t)l * 8u; off < rowB; off += 256u)
+                *reinterpret_cast<double *>(t + off) = *reinterpret_cast<const double *>(s + off);
+        } else {
+            for (uint32_t off = (uint32_t)l * 4u; off < rowB; off += 128u)
+                *reinterpret_cast<float *>(t + off) = *reinterpret_cast<const float *>(s + off);
+        }
+    }
+    __threadfence_system();          // the rows are in the peer's memory before the kernel (hence its event) completes
+}
+
+int upload_peer_tab(moka_halo *h)
+{
+    if (!h->tabDirty) return MOKA_OK;
+    const moka_state *st = h->st;
+    const Plan &p = st->mesh->plan;
+    const size_t sb = st->f32 ? 4 : 8, rowB = (size_t)p.K * sb;
+    std::vector<PushDst> tab((size_t)4 * std::max(h->nNbr, 1));
+    for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < h->nNbr; ++i) {
+            const PeerLink &pl = h->peers[i];
+            PushDst d{};
+            d.u = static_cast<unsigned char *>(pl.mapped[3 * t + 0]) + (size_t)pl.dstEdge * rowB;
+            d.h = static_cast<unsigned char *>(pl.mapped[3 * t + 1]) + (size_t)pl.dstCell * rowB;
+            d.ssh = static_cast<unsigned char *>(pl.mapped[3 * t + 2]) + (size_t)pl.dstCell * sb;
+            tab[(size_t)t * h->nNbr + i] = d;
+        }
+    if (!h->peerTab) {
+        void *d = nullptr;
+        HIPCHK(st->ctx, hipMalloc(&d, tab.size() * sizeof(PushDst)));
+        h->allocs.push_back(d);
+        h->peerTab = static_cast<PushDst *>(d);
+    }
+    if (int rc = h2d(st->ctx, h->peerTab, tab.data(), tab.size() * sizeof(PushDst))) return rc;
+    h->tabDirty = false;
+    return MOKA_OK;
+}
+
+bool all_connected(const moka_halo *h)
+{
+    for (const PeerLink &pl : h->peers)
+        if (!pl.connected) return false;
+    return h->directOk;
+}
+
+int ensure_flags(moka_halo *h, bool shared)
+{
+    if (h->flags) return MOKA_OK;
+    const size_t bytes = sizeof(uint64_t) * (size_t)std::max(h->nNbr, 1);
+    if (shared) {
+        char name[64];
+        snprintf(name, sizeof name, "/moka_halo_%d_%llx", (int)getpid(), (unsigned long long)(uintptr_t)h);
+        const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return hfail(h, MOKA_ERR_COMM, std::string("shm_open(") + name + ") failed");
+        if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); return hfail(h, MOKA_ERR_COMM, "ftruncate on the flag block failed"); }
+        void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (q == MAP_FAILED) { shm_unlink(name); return hfail(h, MOKA_ERR_COMM, "mmap of the flag block failed"); }
+        h->flags = static_cast<volatile uint64_t *>(q);
+        h->shmName = name;
+    } else {
+        h->flags = static_cast<volatile uint64_t *>(calloc(1, bytes));
+        if (!h->flags) return hfail(h, MOKA_ERR_ALLOC, "out of host memory");
+    }
+    h->flagsBytes = bytes;
+    for (int i = 0; i < h->nNbr; ++i) h->flags[i] = 0;
+    return MOKA_OK;
+}
+
+// the part of one stage that goes on the device queues: boundary patches, then (direct) the push on the comm stream or
+// (buffered) nothing yet -- the caller packs --, then the interior patches
+int dist_stage_part(moka_halo *h, int stage, int part)
+{
+    moka_state *st = h->st;
+    const StageArgs g = rk4_stage_args(st, stage, h->dt, h->ssh0);
+    const int p0 = part == 0 ? 0 : h->pBoundary, cnt = part == 0 ? h->pBoundary : h->pOwned - h->pBoundary;
+    HIPCHK(st->ctx, run_stage(st, g, p0, cnt));
+    return MOKA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCells, const int64_t *sendCellOff,
+                     const int32_t *sendEdges, const int64_t *sendEdgeOff, const int32_t *recvCells,
+                     const int64_t *recvCellOff, const int32_t *recvEdges, const int64_t *recvEdgeOff,
+                     int32_t nPatchesBoundary, int32_t nPatchesOwned, moka_halo **out)
+{
+    if (!st || !out || nNeighbors < 0 || !sendCellOff || !sendEdgeOff || !recvCellOff || !recvEdgeOff)
+        return fail(st ? st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    const Plan &p = st->mesh->plan;
+    if (nNeighbors > 60) return fail(st->ctx, MOKA_ERR_ARG, "at most 60 neighbours");
+    if (nPatchesBoundary < 0 || nPatchesOwned < nPatchesBoundary || nPatchesOwned > p.nPatches)
+        return fail(st->ctx, MOKA_ERR_ARG, "patch ranges must satisfy 0 <= boundary <= owned <= nPatches");
+    // the two ranges must be whole cell classes of the plan (patches never straddle a class)
+    {
+        const auto &cp = p.classPatchStart;
+        const bool okB = std::find(cp.begin(), cp.end(), nPatchesBoundary) != cp.end();
+        const bool okO = std::find(cp.begin(), cp.end(), nPatchesOwned) != cp.end();
+        if (!okB || !okO)
+            return fail(st->ctx, MOKA_ERR_ARG, "boundary / owned patch counts must be class boundaries of the mesh (moka_mesh_class_ranges)");
+    }
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (int rc = ensure_rk_bufs(st)) return rc;     // the four physical buffer sets exist from here on
+    moka_halo *h = new (std::nothrow) moka_halo();
+    if (!h) return fail(st->ctx, MOKA_ERR_ALLOC, "out of host memory");
+    h->st = st;
+    h->nNbr = nNeighbors;
+    h->pBoundary = nPatchesBoundary; h->pOwned = nPatchesOwned;
+    int rc = MOKA_OK;
+    try {
+        if ((rc = build_halo_map(h, nNeighbors, sendCells, sendCellOff, sendEdges, sendEdgeOff, &h->sendMap, &h->nSend)) ||
+            (rc = build_halo_map(h, nNeighbors, recvCells, recvCellOff, recvEdges, recvEdgeOff, &h->recvMap, &h->nRecv))) {
+            moka_halo_destroy(h);
+            return rc;
+        }
+        // direct transport: every neighbour's receive lists must be contiguous ranges of the library's numbering
+        h->peers.resize(nNeighbors);
+        h->recvCellStart.assign(nNeighbors, 0); h->recvCellCount.assign(nNeighbors, 0);
+        h->recvEdgeStart.assign(nNeighbors, 0); h->recvEdgeCount.assign(nNeighbors, 0);
+        h->sendCellCount.resize(nNeighbors); h->sendEdgeCount.resize(nNeighbors);
+        for (int i = 0; i < nNeighbors; ++i) {
+            h->sendCellCount[i] = (int32_t)(sendCellOff[i + 1] - sendCellOff[i]);
+            h->sendEdgeCount[i] = (int32_t)(sendEdgeOff[i + 1] - sendEdgeOff[i]);
+        }
+        h->directOk = true;
+        for (int i = 0; i < nNeighbors && h->directOk; ++i) {
+            const int64_t nc = recvCellOff[i + 1] - recvCellOff[i], ne = recvEdgeOff[i + 1] - recvEdgeOff[i];
+            h->recvCellCount[i] = (int32_t)nc; h->recvEdgeCount[i] = (int32_t)ne;
+            if (nc) h->recvCellStart[i] = p.cellO2N[recvCells[recvCellOff[i]]];
+            if (ne) h->recvEdgeStart[i] = p.edgeO2N[recvEdges[recvEdgeOff[i]]];
+            for (int64_t j = 0; j < nc && h->directOk; ++j)
+                if (p.cellO2N[recvCells[recvCellOff[i] + j]] != h->recvCellStart[i] + j) h->directOk = false;
+            for (int64_t j = 0; j < ne && h->directOk; ++j)
+                if (p.edgeO2N[recvEdges[recvEdgeOff[i] + j]] != h->recvEdgeStart[i] + j) h->directOk = false;
+            if (!h->directOk)
+                h->directWhy = "the receive lists of neighbour " + std::to_string(i) + " are not a contiguous range in the library's order "
+                               "(give halo cells the class 2 + neighbour index and list them in moka_mesh_permutation order)";
+        }
+        if (h->directOk) {
+            std::vector<uint32_t> rows;
+            rows.reserve((size_t)(2 * sendCellOff[nNeighbors] + sendEdgeOff[nNeighbors]) * 3);
+            for (int i = 0; i < nNeighbors; ++i) {
+                for (int64_t j = sendCellOff[i]; j < sendCellOff[i + 1]; ++j) {
+                    const uint32_t src = (uint32_t)p.cellO2N[sendCells[j]], dst = (uint32_t)(j - sendCellOff[i]);
+                    rows.insert(rows.end(), {src, dst, (uint32_t)i | (0u << 16)});
+                    rows.insert(rows.end(), {src, dst, (uint32_t)i | (1u << 16)});
+                }
+                for (int64_t j = sendEdgeOff[i]; j < sendEdgeOff[i + 1]; ++j)
+                    rows.insert(rows.end(), {(uint32_t)p.edgeO2N[sendEdges[j]], (uint32_t)(j - sendEdgeOff[i]), (uint32_t)i | (2u << 16)});
+            }
+            h->nPushRows = (int64_t)rows.size() / 3;
+            if (!rows.empty()) {
+                void *d = nullptr;
+                hipError_t e = hipMalloc(&d, rows.size() * sizeof(uint32_t));
+                if (e != hipSuccess) { moka_halo_destroy(h); return fail(st->ctx, MOKA_ERR_ALLOC, "hipMalloc of the push row list failed"); }
+                h->allocs.push_back(d);
+                if ((rc = h2d(st->ctx, d, rows.data(), rows.size() * sizeof(uint32_t)))) { moka_halo_destroy(h); return rc; }
+                h->pushRows = static_cast<uint32_t *>(d);
+            }
+        }
+    } catch (const std::bad_alloc &) {
+        moka_halo_destroy(h);
+        return fail(st->ctx, MOKA_ERR_ALLOC, "out of host memory building the halo maps");
+    }
+    if (hipEventCreateWithFlags(&h->evPush, hipEventDisableTiming) != hipSuccess) {
+        moka_halo_destroy(h);
+        return fail(st->ctx, MOKA_ERR_HIP, "hipEventCreate failed");
+    }
+    *out = h;
+    return MOKA_OK;
+}
+
+void moka_halo_destroy(moka_halo *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->st->ctx->device);
+    (void)hipStreamSynchronize(h->st->ctx->stream);
+    (void)hipStreamSynchronize(h->st->ctx->comm);
+    for (PeerLink &pl : h->peers) {
+        if (pl.connected && pl.ipc) {
+            for (void *q : pl.mapped) if (q) (void)hipIpcCloseMemHandle(q);
+            if (pl.flags) munmap((void *)pl.flags, pl.flagsBytes);
+        }
+    }
+    if (h->flags) {
+        if (!h->shmName.empty()) { munmap((void *)h->flags, h->flagsBytes); shm_unlink(h->shmName.c_str()); }
+        else free((void *)h->flags);
+    }
+    if (h->evPush) (void)hipEventDestroy(h->evPush);
+    for (void *q : h->allocs) (void)hipFree(q);
+    delete h;
+}
+
+int moka_halo_buffer_elems(const moka_halo *h, int64_t *sendElems, int64_t *recvElems)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    if (sendElems) *sendElems = h->nSend;
+    if (recvElems) *recvElems = h->nRecv;
+    return MOKA_OK;
+}
+
+// what: 0 = the current time level, 1..4 = the output of RK4 stage `what` (valid between dist_begin and dist_end);
+// 4 is also the new time level of a distributed Forward-Euler step before its levels swap
+int moka_halo_pack(moka_halo *h, int what, void *sendbuf)
+{
+    if (!h || (!sendbuf && h->nSend)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
+    moka_state *st = h->st;
+    moka_ctx *c = st->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    const LevelBufs &o = rk4_stage_output(st, what);
+    // the rows to send are produced by the boundary patches (or by whatever last ran on the compute stream)
+    HIPCHK(c, hipEventRecord(c->evBoundary, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm, c->evBoundary, 0));
+    if (st->f32)
+        HIPCHK(c, launch_halo_map_f32(static_cast<float *>(sendbuf), (float *)o.h, (float *)o.ssh, (float *)o.u, h->sendMap,
+                                      h->nSend, 0, c->comm));
+    else
+        HIPCHK(c, launch_halo_map(static_cast<double *>(sendbuf), o.h, o.ssh, o.u, h->sendMap, h->nSend, 0, c->comm));
+    return MOKA_OK;
+}
+
+int moka_halo_unpack(moka_halo *h, int what, const void *recvbuf)
+{
+    if (!h || (!recvbuf && h->nRecv)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
+    moka_state *st = h->st;
+    moka_ctx *c = st->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    const LevelBufs &o = rk4_stage_output(st, what);
+    // Inside a step (what >= 1) no launch of the stage writes a received row (patches never straddle into the halo
+    // classes), so the exchange and the unpack overlap the interior launch completely.  For the current time level
+    // (what == 0) anything may have run on the compute stream before: wait for it.
+    if (what == 0) {
+        HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
+    }
+    if (st->f32)
+        HIPCHK(c, launch_halo_map_f32(static_cast<float *>(const_cast<void *>(recvbuf)), (float *)o.h, (float *)o.ssh,
+                                      (float *)o.u, h->recvMap, h->nRecv, 1, c->comm));
+    else
+        HIPCHK(c, launch_halo_map(static_cast<double *>(const_cast<void *>(recvbuf)), o.h, o.ssh, o.u, h->recvMap, h->nRecv, 1,
+                                  c->comm));
+    HIPCHK(c, hipEventRecord(c->evHalo, c->comm));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evHalo, 0));     // whatever comes next on the compute stream sees the halo
+    return MOKA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// direct transport
+// ---------------------------------------------------------------------------------------------
+int moka_halo_direct_available(const moka_halo *h)
+{
+    return h && h->directOk ? 1 : 0;
+}
+
+int moka_halo_export(moka_halo *h, int32_t nbr, int32_t shared, moka_halo_peer_info *out)
+{
+    if (!h || !out) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (nbr < 0 || nbr >= h->nNbr) return hfail(h, MOKA_ERR_ARG, "neighbour index out of range");
+    if (!h->directOk) return hfail(h, MOKA_ERR_UNSUPPORTED, "direct halo transport unavailable: " + h->directWhy);
+    moka_state *st = h->st;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (int rc = ensure_flags(h, shared != 0)) return rc;
+    if (shared && h->shmName.empty()) return hfail(h, MOKA_ERR_ARG, "the flag block of this halo was created process-local");
+    std::memset(out, 0, sizeof *out);
+    for (int t = 0; t < 4; ++t) {
+        void *ptrs[3] = {st->phys[t].u, st->phys[t].h, st->phys[t].ssh};
+        for (int f = 0; f < 3; ++f) {
+            out->ptr[3 * t + f] = (uint64_t)(uintptr_t)ptrs[f];
+            if (shared) {
+                hipIpcMemHandle_t hd;
+                HIPCHK(st->ctx, hipIpcGetMemHandle(&hd, ptrs[f]));
+                static_assert(sizeof hd <= sizeof out->ipc[0], "IPC handle larger than its slot");
+                std::memcpy(out->ipc[3 * t + f], &hd, sizeof hd);
+            }
+        }
+    }
+    out->flagPtr = (uint64_t)(uintptr_t)h->flags;
+    std::strncpy(out->shmName, h->shmName.c_str(), sizeof out->shmName - 1);
+    out->dstCell = h->recvCellStart[nbr]; out->dstEdge = h->recvEdgeStart[nbr];
+    out->nCells = h->recvCellCount[nbr]; out->nEdges = h->recvEdgeCount[nbr];
+    out->slot = nbr;
+    out->nNeighbors = h->nNbr;
+    out->pid = (int32_t)getpid();
+    out->device = st->ctx->device;
+    out->stateBytes = st->f32 ? 4 : 8;
+    out->nVertLevels = st->mesh->plan.K;
+    return MOKA_OK;
+}
+
+int moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer, int32_t shared)
+{
+    if (!h || !peer) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (nbr < 0 || nbr >= h->nNbr) return hfail(h, MOKA_ERR_ARG, "neighbour index out of range");
+    if (!h->directOk) return hfail(h, MOKA_ERR_UNSUPPORTED, "direct halo transport unavailable: " + h->directWhy);
+    moka_state *st = h->st;
+    const Plan &p = st->mesh->plan;
+    if (peer->stateBytes != (st->f32 ? 4 : 8) || peer->nVertLevels != p.K)
+        return hfail(h, MOKA_ERR_ARG, "peer state has another storage type or nVertLevels");
+    // what I send to this neighbour must be exactly what it expects to receive from me
+    if (peer->nCells != h->sendCellCount[nbr] || peer->nEdges != h->sendEdgeCount[nbr])
+        return hfail(h, MOKA_ERR_ARG, "neighbour " + std::to_string(nbr) + " expects " + std::to_string(peer->nCells) + " cells / " +
+                                          std::to_string(peer->nEdges) + " edges, this rank lists " + std::to_string(h->sendCellCount[nbr]) +
+                                          " / " + std::to_string(h->sendEdgeCount[nbr]));
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    PeerLink pl;
+    pl.ipc = shared != 0;
+    pl.dstCell = peer->dstCell; pl.dstEdge = peer->dstEdge; pl.slot = peer->slot;
+    if (shared) {
+        if (peer->pid == (int32_t)getpid()) return hfail(h, MOKA_ERR_ARG, "shared = 1 is for peers in ANOTHER process (use shared = 0 inside one process)");
+        for (int i = 0; i < 12; ++i) {
+            hipIpcMemHandle_t hd;
+            std::memcpy(&hd, peer->ipc[i], sizeof hd);
+            void *q = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&q, hd, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                for (void *m : pl.mapped) if (m) (void)hipIpcCloseMemHandle(m);
+                return hfail(h, MOKA_ERR_COMM, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+            }
+            pl.mapped[i] = q;
+        }
+        const int fd = shm_open(peer->shmName, O_RDWR, 0600);
+        if (fd < 0) return hfail(h, MOKA_ERR_COMM, std::string("shm_open(") + peer->shmName + ") of the peer's flag block failed");
+        pl.flagsBytes = sizeof(uint64_t) * (size_t)std::max(peer->nNeighbors, 1);
+        void *q = mmap(nullptr, pl.flagsBytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (q == MAP_FAILED) return hfail(h, MOKA_ERR_COMM, "mmap of the peer's flag block failed");
+        pl.flags = static_cast<volatile uint64_t *>(q);
+    } else {
+        for (int i = 0; i < 12; ++i) pl.mapped[i] = (void *)(uintptr_t)peer->ptr[i];
+        pl.flags = (volatile uint64_t *)(uintptr_t)peer->flagPtr;
+        if (peer->device != st->ctx->device) {        // one process driving several devices: map the peer's memory
+            const hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                return hfail(h, MOKA_ERR_COMM, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+    }
+    if (!pl.flags) return hfail(h, MOKA_ERR_ARG, "peer info carries no flag block");
+    pl.connected = true;
+    h->peers[nbr] = pl;
+    h->tabDirty = true;
+    return MOKA_OK;
+}
+
+// queue the push of `what` on the comm stream behind whatever the compute stream holds now (the boundary patches)
+int moka_halo_push_begin(moka_halo *h, int what)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    if (what < 0 || what > 4) return hfail(h, MOKA_ERR_ARG, "what must be 0..4");
+    if (!all_connected(h)) return hfail(h, MOKA_ERR_ARG, "direct halo transport: not every neighbour is connected");
+    moka_state *st = h->st;
+    moka_ctx *c = st->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = upload_peer_tab(h)) return rc;
+    const LevelBufs &o = rk4_stage_output(st, what);
+    const int t = phys_index(st, o);
+    if (t < 0) return hfail(h, MOKA_ERR_ARG, "internal: unknown buffer set");
+    HIPCHK(c, hipEventRecord(c->evBoundary, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm, c->evBoundary, 0));
+    if (h->nPushRows > 0) {
+        const Plan &p = st->mesh->plan;
+        const uint32_t sb = st->f32 ? 4u : 8u, rowB = (uint32_t)p.K * sb;
+        int64_t blocks = (h->nPushRows + 7) / 8;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_halo_push, dim3((unsigned)blocks), dim3(256), 0, c->comm, h->pushRows, h->nPushRows,
+                           h->peerTab + (size_t)t * h->nNbr, (const unsigned char *)o.u, (const unsigned char *)o.h,
+                           (const unsigned char *)o.ssh, rowB, sb);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(h->evPush, c->comm));
+    ++h->seq;
+    return MOKA_OK;
+}
+
+// wait (host) for this rank's push kernel, then tell every neighbour that exchange `seq` has arrived
+int moka_halo_push_signal(moka_halo *h)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    moka_ctx *c = h->st->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(h->evPush));
+    for (const PeerLink &pl : h->peers)
+        __atomic_store_n(const_cast<uint64_t *>(pl.flags) + pl.slot, h->seq, __ATOMIC_RELEASE);
+    return MOKA_OK;
+}
+
+// wait (host) until every neighbour has signalled exchange `seq`; MOKA_ERR_COMM after timeout_s seconds
+int moka_halo_push_wait(moka_halo *h, double timeout_s)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < h->nNbr; ++i) {
+        unsigned spins = 0;
+        while (__atomic_load_n(const_cast<uint64_t *>(h->flags) + i, __ATOMIC_ACQUIRE) < h->seq) {
+            if ((++spins & 1023u) == 0) {
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (el > timeout_s)
+                    return hfail(h, MOKA_ERR_COMM, "halo exchange " + std::to_string(h->seq) + ": neighbour " + std::to_string(i) +
+                                                       " has not signalled after " + std::to_string(timeout_s) + " s");
+                if (el > 0.002) std::this_thread::yield();
+            }
+        }
+    }
+    return MOKA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// distributed RK4 step
+// ---------------------------------------------------------------------------------------------
+int moka_rk4_dist_begin(moka_halo *h, double dt)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    moka_state *st = h->st;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    // like moka_step_rk4: lazily pending diagnostics / stage-4 tendencies of the previous step are superseded, not computed
+    h->dt = dt;
+    return rk4_begin(st, &h->ssh0);
+}
+
+// part 0: patches [0, boundary) -- their rows are what other ranks need; part 1: [boundary, owned).
+// Halo patches [owned, nPatches) are never computed: their rows arrive through the exchange.
+int moka_rk4_dist_stage(moka_halo *h, int stage, int part)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    if (stage < 1 || stage > 4 || part < 0 || part > 1) return hfail(h, MOKA_ERR_ARG, "stage must be 1..4, part 0 or 1");
+    moka_state *st = h->st;
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (st->nonlinear) return hfail(h, MOKA_ERR_UNSUPPORTED, "nonlinear terms are not available on partitioned meshes");
+    // Boundary group first, interior right behind it on the same (compute) stream: in-order, no cross-queue wait in the
+    // compute chain.  Launched concurrently the two kernels share the CUs and the ~130 boundary workgroups finish no
+    // earlier than the thousands of interior ones (measured 290 us instead of 35 us), which would push the exchange
+    // behind the interior compute it is meant to hide under.  The comm stream waits for the boundary group only (its
+    // event is recorded before the interior launch is queued).
+    return dist_stage_part(h, stage, part);
+}
+
+// direct transport, the device-queue half of a stage: boundary patches, push (comm stream), interior patches
+int moka_rk4_dist_stage_launch(moka_halo *h, int stage)
+{
+    int rc;
+    if ((rc = moka_rk4_dist_stage(h, stage, 0))) return rc;
+    if ((rc = moka_halo_push_begin(h, stage))) return rc;
+    return moka_rk4_dist_stage(h, stage, 1);
+}
+
+int moka_rk4_dist_end(moka_halo *h)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    rk4_end(h->st);
+    return MOKA_OK;
+}
+
+// One whole distributed RK4 step in one call.  With every neighbour connected (moka_halo_connect) the exchange is the
+// direct one; otherwise `transport(user, stage, sendbuf, recvbuf)` has to move the packed send buffer of the stage to
+// the neighbours and fill the receive buffer (stream-ordered on the comm stream, or synchronously), and sendbuf / recvbuf
+// are the device buffers it works on.
+int moka_rk4_dist_step(moka_halo *h, double dt, moka_transport_fn transport, void *user, void *sendbuf, void *recvbuf,
+                       double timeout_s)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    int rc;
+    const bool direct = all_connected(h) && h->nNbr > 0;
+    if (!direct && h->nNbr > 0 && !transport) return hfail(h, MOKA_ERR_ARG, "no transport callback and not every neighbour is connected");
+    if ((rc = moka_rk4_dist_begin(h, dt))) return rc;
+    for (int s = 1; s <= 4; ++s) {
+        if ((rc = moka_rk4_dist_stage(h, s, 0))) return rc;
+        if (direct) {
+            if ((rc = moka_halo_push_begin(h, s))) return rc;
+            if ((rc = moka_rk4_dist_stage(h, s, 1))) return rc;
+            if ((rc = moka_halo_push_signal(h))) return rc;
+            if ((rc = moka_halo_push_wait(h, timeout_s))) return rc;
+        } else if (h->nNbr > 0) {
+            if ((rc = moka_halo_pack(h, s, sendbuf))) return rc;
+            if ((rc = moka_rk4_dist_stage(h, s, 1))) return rc;
+            if (int trc = transport(user, s, sendbuf, recvbuf))
+                return hfail(h, MOKA_ERR_COMM, "the halo transport callback failed at stage " + std::to_string(s) + " (code " + std::to_string(trc) + ")");
+            if ((rc = moka_halo_unpack(h, s, recvbuf))) return rc;
+        } else {
+            if ((rc = moka_rk4_dist_stage(h, s, 1))) return rc;
+        }
+    }
+    return moka_rk4_dist_end(h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// distributed Forward-Euler step: the reference's live integrator (time_integration.jl:150-193) on a partitioned mesh.
+// Everything a computed entity reads is local: an edge with an owned cell is computed here (its layerThicknessEdge
+// too, from the exchanged layerThickness of the halo cell -- so the stale-thickness flux of reference_compat needs no
+// exchange of its own), an edge without one arrives by exchange together with the new level's layerThickness / ssh.
+//   launch: boundary patches -> (push or pack of the NEW level, `what` = 4) -> interior patches -> relativeVorticity
+//   then the exchange completes (push_signal / push_wait, or transport + unpack), then moka_fe_dist_end swaps the levels.
+// ---------------------------------------------------------------------------------------------
+static int fe_stage_args(moka_state *st, double dt, int flags, StageArgs *g, FeArgs *a)
+{
+    *a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE | FE_TENDU | FE_TENDH | FE_UPDATE, flags, dt);
+    StageArgs s{};
+    s.pu = a->u; s.ph = a->h; s.ssh = a->ssh;
+    s.pu_out = a->u_new; s.ph_out = a->h_new; s.ssh_out = a->ssh_new;
+    s.tendU = a->tendU; s.tendH = a->tendH; s.a = dt;
+    s.hEdgeOld = (flags & MOKA_FE_STALE_HEDGE) ? a->hEdgeOld : nullptr;
+    s.hEdgeNew = a->hEdgeNew; s.F = a->F; s.div = a->div; s.areaCell = st->mesh->dev.areaCell;
+    *g = s;
+    return MOKA_OK;
+}
+
+int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    if (part < 0 || part > 2) return hfail(h, MOKA_ERR_ARG, "part must be 0 (boundary), 1 (interior) or 2 (vertices)");
+    moka_state *st = h->st;
+    moka_ctx *c = st->ctx;
+    if (st->nonlinear || st->f32) return hfail(h, MOKA_ERR_UNSUPPORTED, "distributed Forward Euler: Float64 states with the reference's linear terms");
+    if (flags & MOKA_FE_LEVEL1_ONLY && st->mesh->plan.K > 1)
+        return hfail(h, MOKA_ERR_UNSUPPORTED, "distributed Forward Euler steps all levels (MOKA_FE_LEVEL1_ONLY is for nVertLevels = 1)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (part == 0)
+        if (int rc = flush_lazy(st, true, true)) return rc;
+    StageArgs g;
+    FeArgs a;
+    fe_stage_args(st, dt, flags, &g, &a);
+    h->feFlags = flags;
+    const moka_mesh *mm = st->mesh;
+    if (part == 2) {
+        // relativeVorticity of the OLD state (DiagnosticVars.jl:108-117 runs before the update): every local vertex
+        const hipError_t ec = launch_curl2(mm->dev, a.u, a.vort, flags & MOKA_FE_ACCUM_VORT, c->stream);
+        if (ec == hipErrorNotSupported) {
+            a.ops = FE_CURL;
+            HIPCHK(c, launch_fe(mm->dev, a, mm->lpc, c->stream));
+        } else {
+            HIPCHK(c, ec);
+        }
+        return MOKA_OK;
+    }
+    const int p0 = part == 0 ? 0 : h->pBoundary, cnt = part == 0 ? h->pBoundary : h->pOwned - h->pBoundary;
+    if (cnt <= 0) return MOKA_OK;
+    MeshDev dev = mm->dev;
+    dev.patchBegin = p0; dev.nPatches = cnt; dev.tailPatch = -1;
+    {
+        const moka::Plan &p = mm->plan;
+        int mE = 1, mC = 1;
+        for (int q = p0; q < p0 + cnt; ++q) {
+            mE = std::max(mE, p.patchEdgeStart[q + 1] - p.patchEdgeStart[q]);
+            mC = std::max(mC, p.patchCellStart[q + 1] - p.patchCellStart[q]);
+        }
+        dev.maxOwnE = mE; dev.maxOwnC = mC;
+    }
+    hipError_t e = hipErrorNotSupported;
+    if ((c->variant == 0 || c->variant == 11) && mm->lpc == 64 && mm->colOk) e = launch_stage_rec2c(dev, g, c->stream);
+    if (e == hipErrorNotSupported) {
+        a.ops &= ~FE_CURL;                 // the generic one-launch kernel over the same patch range, vertices in part 2
+        e = launch_fe(dev, a, mm->lpc, c->stream);
+    }
+    HIPCHK(c, e);
+    return MOKA_OK;
+}
+
+int moka_fe_dist_end(moka_halo *h)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    moka_state *st = h->st;
+    std::swap(st->lev[0], st->lev[1]);
+    std::swap(st->hEdge[0], st->hEdge[1]);
+    st->sshConsistent = true;
+    st->feFast = 1;
+    return MOKA_OK;
+}
+
+int moka_fe_dist_step(moka_halo *h, double dt, int flags, moka_transport_fn transport, void *user, void *sendbuf, void *recvbuf,
+                      double timeout_s)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    int rc;
+    const bool direct = all_connected(h) && h->nNbr > 0;
+    if (!direct && h->nNbr > 0 && !transport) return hfail(h, MOKA_ERR_ARG, "no transport callback and not every neighbour is connected");
+    if ((rc = moka_fe_dist_launch(h, dt, flags, 0))) return rc;
+    if (direct) {
+        if ((rc = moka_halo_push_begin(h, 4))) return rc;
+    } else if (h->nNbr > 0) {
+        if ((rc = moka_halo_pack(h, 4, sendbuf))) return rc;
+    }
+    if ((rc = moka_fe_dist_launch(h, dt, flags, 1))) return rc;
+    if ((rc = moka_fe_dist_launch(h, dt, flags, 2))) return rc;
+    if (direct) {
+        if ((rc = moka_halo_push_signal(h))) return rc;
+        if ((rc = moka_halo_push_wait(h, timeout_s))) return rc;
+    } else if (h->nNbr > 0) {
+        if (int trc = transport(user, 4, sendbuf, recvbuf))
+            return hfail(h, MOKA_ERR_COMM, "the halo transport callback failed (code " + std::to_string(trc) + ")");
+        if ((rc = moka_halo_unpack(h, 4, recvbuf))) return rc;
+    }
+    return moka_fe_dist_end(h);
+}
+
+}  // extern "C"

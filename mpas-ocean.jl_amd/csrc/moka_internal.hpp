@@ -28,6 +28,9 @@ struct Plan {
 
     std::vector<int32_t> cellN2O, cellO2N, edgeN2O, edgeO2N, vertN2O, vertO2N;
     std::vector<int32_t> patchCellStart, patchEdgeStart, patchVertStart;   // nPatches + 1
+    // cell classes (moka_mesh_desc.cellClass; one class without it): class k covers patches [classPatchStart[k], [k+1]),
+    // cells [classCellStart[k], [k+1]) and -- edges being numbered by their owner cell -- edges [classEdgeStart[k], [k+1])
+    std::vector<int32_t> classPatchStart, classCellStart, classEdgeStart;   // nClasses + 1
 
     // cells
     std::vector<int32_t> eoc;      // nC*ME  edge of slot i                (edgesOnCell)

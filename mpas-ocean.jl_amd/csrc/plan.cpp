@@ -230,6 +230,38 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     p.cellO2N.assign(nC, -1);
     for (int i = 0; i < nC; ++i) p.cellO2N[p.cellN2O[i]] = i;
 
+    // ---- patches: runs of P consecutive cells that never straddle a cell class (the last patch of a class may be short).
+    // On a partitioned mesh the classes are: 0 owned cells another rank needs, 1 owned interior, 2 + i halo cells owned by
+    // the rank's i-th neighbour -- so a launch over the patches of a class range touches rows of that range only, halo
+    // patches are never computed, and what a neighbour sends lands in one contiguous range of cells and edges.
+    std::vector<int32_t> patchOf(nC);
+    p.classCellStart.assign(1, 0);
+    p.classPatchStart.assign(1, 0);
+    p.patchCellStart.assign(1, 0);
+    {
+        auto cls0 = [&](int cn) { return d->cellClass ? d->cellClass[p.cellN2O[cn]] : 0; };
+        int begin = 0;
+        while (begin < nC) {
+            const int k = cls0(begin);
+            int end = begin;
+            while (end < nC && cls0(end) == k) ++end;
+            REQUIRE((int)p.classCellStart.size() - 1 <= k, "internal: cell ordering is not class-major");
+            while ((int)p.classCellStart.size() - 1 < k) {          // empty classes below k
+                p.classCellStart.push_back(begin);
+                p.classPatchStart.push_back((int)p.patchCellStart.size() - 1);
+            }
+            for (int c = begin; c < end; c += p.P) {
+                const int q = (int)p.patchCellStart.size() - 1;
+                for (int x = c; x < std::min(c + p.P, end); ++x) patchOf[x] = q;
+                p.patchCellStart.push_back(std::min(c + p.P, end));
+            }
+            p.classCellStart.push_back(end);
+            p.classPatchStart.push_back((int)p.patchCellStart.size() - 1);
+            begin = end;
+        }
+    }
+    p.nPatches = (int)p.patchCellStart.size() - 1;
+
     // ---- edges / vertices numbered by their owner cell (new numbering): counting sort by owner ----
     auto renumber = [&](int n, auto owner_of, std::vector<int32_t> &n2o, std::vector<int32_t> &o2n) {
         std::vector<int32_t> owner(n), cnt(nC + 1, 0);
@@ -246,16 +278,17 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     // "lowest-numbered cell owns the edge" gives early patches up to 1.7x the average (61 vs 36 edges at P = 12).
     std::vector<int32_t> ownerCell(nE);
     {
-        const int P = p.P, nP = (nC + P - 1) / P;
+        const int P = p.P, nP = p.nPatches;
         std::vector<int32_t> cnt(nP, 0), flex;
+        auto PO = [&](int cn) { return patchOf[cn]; };
         auto cls = [&](int cn) { return d->cellClass ? d->cellClass[p.cellN2O[cn]] : 0; };
         std::vector<int32_t> lo(nE), hi(nE);
         for (int e = 0; e < nE; ++e) {
             const int a = p.cellO2N[d->cellsOnEdge[2 * (int64_t)e] - 1], b = p.cellO2N[d->cellsOnEdge[2 * (int64_t)e + 1] - 1];
             lo[e] = std::min(a, b); hi[e] = std::max(a, b);
-            if (lo[e] / P == hi[e] / P || cls(lo[e]) != cls(hi[e])) {   // class order == numbering order: lower class = lo
+            if (PO(lo[e]) == PO(hi[e]) || cls(lo[e]) != cls(hi[e])) {   // class order == numbering order: lower class = lo
                 ownerCell[e] = lo[e];
-                ++cnt[lo[e] / P];
+                ++cnt[PO(lo[e])];
             } else {
                 ownerCell[e] = -1;
                 flex.push_back(e);
@@ -266,7 +299,7 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
             // start from a coin flip per edge (a hash: deterministic): unlike "the patch with fewer edges so far", which
             // drifts -- whole regions end one edge up, others one down, and levelling that takes mesh-wide paths -- it
             // leaves only local fluctuations, which the sweeps and the short breadth-first searches below remove
-            const int pa = lo[e] / P, pb = hi[e] / P;
+            const int pa = PO(lo[e]), pb = PO(hi[e]);
             if (((uint32_t)e * 2654435761u >> 15) & 1u) { ownerCell[e] = lo[e]; ++cnt[pa]; }
             else { ownerCell[e] = hi[e]; ++cnt[pb]; }
         }
@@ -274,7 +307,7 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
             int moved = 0;
             for (int e : flex) {
                 const int cur = ownerCell[e], oth = cur == lo[e] ? hi[e] : lo[e];
-                if (cnt[cur / P] > cnt[oth / P] + 1) { ownerCell[e] = oth; --cnt[cur / P]; ++cnt[oth / P]; ++moved; }
+                if (cnt[PO(cur)] > cnt[PO(oth)] + 1) { ownerCell[e] = oth; --cnt[PO(cur)]; ++cnt[PO(oth)]; ++moved; }
             }
             if (!moved) break;
         }
@@ -289,19 +322,19 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
             {
                 std::vector<int64_t> tot(64, 0), num(64, 0);
                 for (int q = 0; q < nP; ++q) {
-                    pcls[q] = cls(std::min(q * P, nC - 1));
-                    if (std::min((q + 1) * P, nC) - q * P == P) { tot[pcls[q]] += cnt[q]; ++num[pcls[q]]; }   // full patches only
+                    pcls[q] = cls(p.patchCellStart[q]);
+                    if (p.patchCellStart[q + 1] - p.patchCellStart[q] == P) { tot[pcls[q]] += cnt[q]; ++num[pcls[q]]; }   // full patches only
                 }
                 for (int c = 0; c < 64; ++c) Tc[c] = num[c] ? (int)((tot[c] + num[c] - 1) / num[c]) : 0;
             }
             auto T_of = [&](int q) { return Tc[pcls[q]]; };
             std::vector<int32_t> pstart(nP + 1, 0), plist;
-            for (int e : flex) { ++pstart[lo[e] / P + 1]; ++pstart[hi[e] / P + 1]; }
+            for (int e : flex) { ++pstart[PO(lo[e]) + 1]; ++pstart[PO(hi[e]) + 1]; }
             for (int q = 0; q < nP; ++q) pstart[q + 1] += pstart[q];
             plist.resize(pstart[nP]);
             {
                 std::vector<int32_t> fill(pstart.begin(), pstart.end() - 1);
-                for (int e : flex) { plist[fill[lo[e] / P]++] = e; plist[fill[hi[e] / P]++] = e; }
+                for (int e : flex) { plist[fill[PO(lo[e])]++] = e; plist[fill[PO(hi[e])]++] = e; }
             }
             std::vector<int32_t> stamp(nP, -1), via(nP, -1), queue;
             int32_t tick = 0;
@@ -315,8 +348,8 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
                         const int x = queue[h];
                         for (int k = pstart[x]; k < pstart[x + 1] && found < 0; ++k) {
                             const int e = plist[k];
-                            if (ownerCell[e] / P != x) continue;                 // x can only hand over what it owns
-                            const int y = (ownerCell[e] == lo[e] ? hi[e] : lo[e]) / P;
+                            if (PO(ownerCell[e]) != x) continue;                 // x can only hand over what it owns
+                            const int y = PO(ownerCell[e] == lo[e] ? hi[e] : lo[e]);
                             if (stamp[y] == tick) continue;
                             stamp[y] = tick; via[y] = e;
                             if (cnt[y] < T_of(y)) found = y;
@@ -326,7 +359,7 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
                     if (found < 0) break;
                     for (int y = found; y != s;) {                               // pass one edge along every hop of the path
                         const int e = via[y];
-                        const int x = ownerCell[e] / P;
+                        const int x = PO(ownerCell[e]);
                         ownerCell[e] = ownerCell[e] == lo[e] ? hi[e] : lo[e];
                         --cnt[x]; ++cnt[y];
                         y = x;
@@ -351,19 +384,16 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
         return best == nC ? 0 : best;
     }, p.vertN2O, p.vertO2N);
 
-    // ---- patches: P consecutive cells + the edges / vertices they own ----
-    p.nPatches = (nC + p.P - 1) / p.P;
-    p.patchCellStart.resize(p.nPatches + 1);
-    p.patchEdgeStart.assign(p.nPatches + 1, 0);
-    p.patchVertStart.assign(p.nPatches + 1, 0);
-    for (int q = 0; q <= p.nPatches; ++q) p.patchCellStart[q] = std::min(q * p.P, nC);
+    // ---- the edges / vertices the patches own ----
     {
         std::vector<int32_t> ce(p.nPatches + 1, 0), cv(p.nPatches + 1, 0);
-        for (int e = 0; e < nE; ++e) ++ce[edgeOwner[e] / p.P + 1];
-        for (int v = 0; v < nV; ++v) ++cv[vertOwner[v] / p.P + 1];
+        for (int e = 0; e < nE; ++e) ++ce[patchOf[edgeOwner[e]] + 1];
+        for (int v = 0; v < nV; ++v) ++cv[patchOf[vertOwner[v]] + 1];
         for (int q = 0; q < p.nPatches; ++q) { ce[q + 1] += ce[q]; cv[q + 1] += cv[q]; }
         p.patchEdgeStart = ce;
         p.patchVertStart = cv;
+        p.classEdgeStart.resize(p.classPatchStart.size());
+        for (size_t k = 0; k < p.classPatchStart.size(); ++k) p.classEdgeStart[k] = ce[p.classPatchStart[k]];
     }
 
     // ---- records ----
@@ -665,6 +695,21 @@ int moka_plan_patch_ranges(const moka_plan *plan, int32_t *cellStart, int32_t *e
     if (cellStart) std::copy(p.patchCellStart.begin(), p.patchCellStart.end(), cellStart);
     if (edgeStart) std::copy(p.patchEdgeStart.begin(), p.patchEdgeStart.end(), edgeStart);
     if (vertexStart) std::copy(p.patchVertStart.begin(), p.patchVertStart.end(), vertexStart);
+    return MOKA_OK;
+}
+
+int moka_plan_class_ranges(const moka_plan *plan, int32_t capacity, int32_t *nClasses, int32_t *patchStart, int32_t *cellStart,
+                           int32_t *edgeStart)
+{
+    if (!plan || !nClasses) { moka::set_error("NULL argument"); return MOKA_ERR_ARG; }
+    const moka::Plan &p = plan->p;
+    const int n = (int)p.classPatchStart.size() - 1;
+    *nClasses = n;
+    for (int k = 0; k <= n && k < capacity; ++k) {
+        if (patchStart) patchStart[k] = p.classPatchStart[k];
+        if (cellStart) cellStart[k] = p.classCellStart[k];
+        if (edgeStart) edgeStart[k] = p.classEdgeStart[k];
+    }
     return MOKA_OK;
 }
 

@@ -1,0 +1,104 @@
+// state.hpp -- the objects behind the opaque handles of include/moka_hip.h and the helpers api.hip shares with halo.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "kernels.hpp"
+#include "moka_internal.hpp"
+
+struct moka_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t comm = nullptr;                       // halo pack / transport / unpack
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evBoundary = nullptr, evInterior = nullptr, evHalo = nullptr;
+    int variant = 0;
+    int nCUs = 256;
+    std::string err;
+    // per-stage HIP-event timing of moka_step_rk4 (moka_stage_timing): 5 events per recorded step, read back on request
+    bool stageTiming = false;
+    std::vector<hipEvent_t> evPool;          // events owned by the context (reused between measurements)
+    size_t evUsed = 0;
+};
+
+struct moka_mesh {
+    moka_ctx *ctx = nullptr;
+    moka::Plan plan;          // host copy (permutations, sizes)
+    moka::MeshDev dev{};
+    std::vector<void *> allocs;
+    int lpc = 1;
+    size_t ldsBytes = 0;      // > 0: the LDS-tiled stage kernel is usable for this mesh
+    bool colOk = false;       // byte-offset records exist (every field < 4 GiB)
+    bool tileOk = false;      // the tiled stage kernel (u rows + records in LDS) fits this mesh
+    bool ptileOk = false;     // the persistent double-buffered tiled kernel fits this mesh
+    double *opBuf[3] = {nullptr, nullptr, nullptr};   // operator / transfer scratch, lazily sized
+    size_t opBufElems = 0;
+    // (maxOwnE, maxOwnC) of a launched patch sub-range: a partition's halo-only patches own up to 6 edges per cell
+    // and are never launched, so the LDS carve of a boundary / interior launch is sized by the patches it covers
+    std::map<std::pair<int, int>, std::pair<int, int>> rangeMax;
+};
+
+struct LevelBufs {
+    double *ssh = nullptr, *u = nullptr, *h = nullptr;
+};
+
+struct moka_state {
+    moka_ctx *ctx = nullptr;
+    moka_mesh *mesh = nullptr;
+    LevelBufs lev[2];                 // [0] previous, [1] current   (reference Vector index 1 / end)
+    double *hEdge[2] = {nullptr, nullptr};   // [0] is Diag.layerThicknessEdge, [1] the write target of the next step
+    double *F = nullptr, *div = nullptr, *vort = nullptr, *tendU = nullptr, *tendH = nullptr;
+    LevelBufs rk[2];                  // RK4 provisional states (lazily allocated)
+    LevelBufs phys[4];                // the same four buffer sets by allocation: [0],[1] the time levels as created (lev[] swaps),
+                                      // [2],[3] = rk[]: what a neighbour rank addresses when it pushes halo rows (halo.hip)
+    double *scalar = nullptr;         // 1 double (sum_sq result)
+    bool sshConsistent = false;       // lev[1].ssh == ksum(lev[1].h) - restingThicknessSum
+    // moka_step_rk4 ends with diagnostic_compute! of the new state and leaves the stage-4 tendencies in
+    // Tend (time_integration.jl:114-147).  Neither is needed by the next RK4 step, so they are produced
+    // lazily -- on the first read (download, Forward-Euler step, reference-sequenced calls) -- with
+    // results identical to computing them at the end of the step.
+    bool diagDirty = false;
+    bool tendDirty = false;           // stage-4 provisional state still sits in rk[0]
+    // fp32 storage of the prognostic fields (mesh stateBytes == 4): lev[] / rk[] then point at float arrays
+    // (the pointer type stays double* so that one StageArgs block serves both), Diag arrays do not exist.
+    bool f32 = false;
+    // optional nonlinear terms (moka_set_nonlinear): scratch of the three preparation passes
+    bool nonlinear = false;
+    double *nlQv = nullptr, *nlQe = nullptr, *nlKe = nullptr;
+    int feFast = -1;                            // moka_last_fe_path
+    double *nlZv = nullptr, *nlDiv = nullptr;   // Del2 mixing (moka_set_viscosity_del2)
+    double viscDel2 = 0.0;
+    std::vector<void *> allocs;
+};
+
+namespace mk {
+
+using namespace moka;
+
+int fail(moka_ctx *ctx, int code, const std::string &msg);
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return mk::fail(ctx, MOKA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// every host->device copy of the library: on the context's stream, then synchronised (see api.hip)
+int h2d(moka_ctx *ctx, void *dst, const void *src, size_t bytes);
+int alloc_field(moka_state *st, double **out, size_t elems, size_t elemBytes = sizeof(double));
+int ensure_rk_bufs(moka_state *st);
+int flush_lazy(moka_state *st, bool diag, bool tend);
+// one fused tendency / RK-stage launch over patches [pBegin, pBegin + pCount) (default: all) on the compute stream (or `on`)
+hipError_t run_stage(moka_state *st, const StageArgs &g, int pBegin = 0, int pCount = -1, hipStream_t on = nullptr, int tail = -1);
+StageArgs rk4_stage_args(moka_state *st, int s, double dt, const double *ssh0);
+LevelBufs &rk4_stage_output(moka_state *st, int s);
+int rk4_begin(moka_state *st, const double **ssh0);
+void rk4_end(moka_state *st);
+FeArgs fe_args(moka_state *st, int ops, int flags, double dt);
+
+}  // namespace mk

@@ -76,6 +76,9 @@ EXPORTS = [
     "moka_sum_sq", "moka_set_kernel_variant", "moka_kernel_variant_available", "moka_stage_timing", "moka_stage_timing_read",
     "moka_ctx_streams", "moka_halo_create", "moka_halo_destroy", "moka_halo_buffer_elems", "moka_halo_pack",
     "moka_halo_unpack", "moka_rk4_dist_begin", "moka_rk4_dist_stage", "moka_rk4_dist_end",
+    "moka_plan_class_ranges", "moka_mesh_class_ranges", "moka_mesh_permutation", "moka_halo_direct_available",
+    "moka_halo_export", "moka_halo_connect", "moka_halo_push_begin", "moka_halo_push_signal", "moka_halo_push_wait",
+    "moka_rk4_dist_stage_launch", "moka_rk4_dist_step", "moka_fe_dist_launch", "moka_fe_dist_end", "moka_fe_dist_step",
     "moka_set_nonlinear", "moka_last_fe_path", "moka_set_viscosity_del2", "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
     "moka_adjoint_download",
 ]
@@ -161,6 +164,20 @@ def lib():
     L.moka_rk4_dist_begin.argtypes = [vp, C.c_double]
     L.moka_rk4_dist_stage.argtypes = [vp, C.c_int, C.c_int]
     L.moka_rk4_dist_end.argtypes = [vp]
+    L.moka_plan_class_ranges.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), _i32p, _i32p, _i32p]
+    L.moka_mesh_class_ranges.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), _i32p, _i32p, _i32p]
+    L.moka_mesh_permutation.argtypes = [vp, C.c_int, _i32p]
+    L.moka_halo_direct_available.argtypes = [vp]
+    L.moka_halo_export.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(HaloPeerInfo)]
+    L.moka_halo_connect.argtypes = [vp, C.c_int32, C.POINTER(HaloPeerInfo), C.c_int32]
+    L.moka_halo_push_begin.argtypes = [vp, C.c_int]
+    L.moka_halo_push_signal.argtypes = [vp]
+    L.moka_halo_push_wait.argtypes = [vp, C.c_double]
+    L.moka_rk4_dist_stage_launch.argtypes = [vp, C.c_int]
+    L.moka_rk4_dist_step.argtypes = [vp, C.c_double, TRANSPORT_FN, vp, vp, vp, C.c_double]
+    L.moka_fe_dist_launch.argtypes = [vp, C.c_double, C.c_int, C.c_int]
+    L.moka_fe_dist_end.argtypes = [vp]
+    L.moka_fe_dist_step.argtypes = [vp, C.c_double, C.c_int, TRANSPORT_FN, vp, vp, vp, C.c_double]
     L.moka_set_nonlinear.argtypes = [vp, C.c_int]
     L.moka_last_fe_path.argtypes = [vp]
     L.moka_set_viscosity_del2.argtypes = [vp, C.c_double]
@@ -242,6 +259,28 @@ PLAN_ARRAYS = {  # name -> (id, dtype)
 }
 
 
+class HaloPeerInfo(C.Structure):
+    """moka_halo_peer_info: what a rank tells a neighbour so that the neighbour can push halo rows to it (plain data)."""
+    _fields_ = [("ipc", (C.c_ubyte * 64) * 12), ("ptr", C.c_uint64 * 12), ("flagPtr", C.c_uint64),
+                ("shmName", C.c_char * 64), ("dstCell", C.c_int32), ("dstEdge", C.c_int32), ("nCells", C.c_int32),
+                ("nEdges", C.c_int32), ("slot", C.c_int32), ("nNeighbors", C.c_int32), ("pid", C.c_int32),
+                ("device", C.c_int32), ("stateBytes", C.c_int32), ("nVertLevels", C.c_int32)]
+
+
+# int transport(void *user, int what, void *sendbuf_device, void *recvbuf_device)
+TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
+
+
+def class_ranges(handle, of_mesh: bool):
+    """(patchStart, cellStart, edgeStart) of the cell classes of a plan / device mesh, nClasses + 1 entries each."""
+    fn = lib().moka_mesh_class_ranges if of_mesh else lib().moka_plan_class_ranges
+    n = C.c_int32()
+    check(fn(handle, 0, C.byref(n), None, None, None))
+    a, b, c = (np.empty(n.value + 1, dtype=np.int32) for _ in range(3))
+    check(fn(handle, n.value + 1, C.byref(n), i32(a), i32(b), i32(c)))
+    return a, b, c
+
+
 class Plan:
     """Host-only reordered mesh (moka_plan_*): usable without a GPU."""
 
@@ -260,6 +299,9 @@ class Plan:
         out = np.empty(n, dtype=np.int32)
         check(lib().moka_plan_permutation(self._h, kind, i32(out)))
         return out
+
+    def class_ranges(self):
+        return class_ranges(self._h, False)
 
     def patch_ranges(self):
         n = self.info["nPatches"] + 1

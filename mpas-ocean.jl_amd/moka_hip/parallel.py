@@ -47,7 +47,12 @@ class LocalMesh:
 
 
 def _halo_sets(mesh, part, r):
-    """(ring cells of rank r, local edge mask, edges rank r must receive)."""
+    """(ring cells of rank r, local cell mask, local edge mask, edges rank r must receive, the rank that sends each edge).
+
+    An edge without an r-owned cell cannot be computed on r and arrives by exchange.  Its sender is the LOWEST rank
+    among the owners of those of its cells that are local on r: every such owner computes the edge (it owns one of
+    its cells), and the rule matches the numbering of r's local plan, where a halo-halo edge belongs to the cell of
+    the lower class (= the lower neighbour), so that what one neighbour sends is one contiguous range of edges."""
     coe = mesh.cellsOnEdge.astype(np.int64) - 1
     own = part == r
     o1, o2 = own[coe[:, 0]], own[coe[:, 1]]
@@ -55,35 +60,40 @@ def _halo_sets(mesh, part, r):
     ring[coe[o1 & ~o2, 1]] = True
     ring[coe[o2 & ~o1, 0]] = True
     local_c = own | ring
-    local_e = local_c[coe[:, 0]] | local_c[coe[:, 1]]
+    l1, l2 = local_c[coe[:, 0]], local_c[coe[:, 1]]
+    local_e = l1 | l2
     recv_e = local_e & ~o1 & ~o2                      # no owned cell incident: cannot be computed here
-    return ring, local_c, local_e, recv_e
+    big = np.iinfo(np.int32).max
+    p1 = np.where(l1, part[coe[:, 0]], big)
+    p2 = np.where(l2, part[coe[:, 1]], big)
+    sender = np.minimum(p1, p2)
+    return ring, local_c, local_e, recv_e, sender
 
 
 def build_local(mesh, part: np.ndarray, rank: int, world: int) -> LocalMesh:
     coe = mesh.cellsOnEdge.astype(np.int64) - 1
     own = part == rank
-    ring, local_c, local_e, recv_e = _halo_sets(mesh, part, rank)
-    edge_owner = part[coe[:, 0]]                       # an edge is owned by the rank of cellsOnEdge[1]
+    ring, local_c, local_e, recv_e, sender = _halo_sets(mesh, part, rank)
 
     # ---- exchange lists (global ids, sorted: both sides derive the same order) ----
     recv_cells = {q: np.nonzero(ring & (part == q))[0] for q in range(world) if q != rank}
-    recv_edges = {q: np.nonzero(recv_e & (edge_owner == q))[0] for q in range(world) if q != rank}
+    recv_edges = {q: np.nonzero(recv_e & (sender == q))[0] for q in range(world) if q != rank}
     send_cells, send_edges = {}, {}
     for q in range(world):
         if q == rank:
             continue
-        ring_q, _, _, recv_e_q = _halo_sets(mesh, part, q)
+        ring_q, _, _, recv_e_q, sender_q = _halo_sets(mesh, part, q)
         send_cells[q] = np.nonzero(ring_q & own)[0]
-        send_edges[q] = np.nonzero(recv_e_q & (edge_owner == rank))[0]
+        send_edges[q] = np.nonzero(recv_e_q & (sender_q == rank))[0]
     nbrs = [q for q in range(world) if q != rank and
             (recv_cells[q].size or recv_edges[q].size or send_cells[q].size or send_edges[q].size)]
 
-    # ---- cell classes: 0 owned & needed elsewhere, 1 owned interior, 2 halo ----
+    # ---- cell classes: 0 owned & needed elsewhere, 1 owned interior, 2 + i halo cells owned by neighbour i ----
     boundary = np.zeros(mesh.nCells, dtype=bool)
     for q in nbrs:
         boundary[send_cells[q]] = True
-        boundary[coe[send_edges[q], 0]] = True
+        ce = coe[send_edges[q]]                       # a sent edge is computed by the boundary launch: its owned cell(s)
+        boundary[ce[own[ce]]] = True
     assert not np.any(boundary & ~own)
 
     cells_g = np.concatenate([np.nonzero(own)[0], np.nonzero(ring)[0]])
@@ -127,10 +137,16 @@ def build_local(mesh, part: np.ndarray, rank: int, world: int) -> LocalMesh:
     lm = LocalMesh()
     lm.rank, lm.world, lm.mesh = rank, world, m
     lm.cells_g, lm.edges_g, lm.verts_g = cells_g, edges_g, verts_g
+    lm.g2l_c, lm.g2l_e = g2l_c, g2l_e
     lm.n_owned_cells = int(own.sum())
     lm.owned_cell_mask = own[cells_g]
-    lm.owned_edge_mask = (edge_owner[edges_g] == rank) & (own[coe[edges_g, 0]])
-    lm.cell_class = np.where(boundary[cells_g], 0, np.where(own[cells_g], 1, 2)).astype(np.int32)
+    # an edge is reported by the rank of cellsOnEdge[1] (every edge with an owned cell is computed locally)
+    lm.owned_edge_mask = own[coe[edges_g, 0]]
+    # a vertex is reported by the owner of its first edge's first cell: all three of its edges are local there
+    lm.owned_vert_mask = own[coe[eov[verts_g, 0], 0]]
+    nbr_index = {q: i for i, q in enumerate(nbrs)}
+    halo_class = np.array([2 + nbr_index[q] if q in nbr_index else 2 for q in part[cells_g]], dtype=np.int32)
+    lm.cell_class = np.where(boundary[cells_g], 0, np.where(own[cells_g], 1, halo_class)).astype(np.int32)
     lm.neighbors = nbrs
     # local ids, concatenated in neighbour order, + per-neighbour offsets
     cat = lambda d, g2l: (np.concatenate([g2l[d[q]] for q in nbrs]).astype(np.int32) if nbrs else np.zeros(0, np.int32),
@@ -192,23 +208,31 @@ def unpack_numpy(lm: LocalMesh, K: int, buf, ssh, u, h):
 # device model
 # ---------------------------------------------------------------------------------------------
 class DistributedModel:
-    """Partitioned shallow-water model: RK4 steps with halo exchange between stages.
+    """Partitioned shallow-water model: RK4 (and reference Forward-Euler) steps with one halo exchange per stage.
 
-    transport = "nccl-a2a": one all_to_all_single per stage on device buffers (RCCL over xGMI: a grouped send/recv per
-    neighbour underneath, one host call), issued on the library's comm stream so that the interior patches of the stage
-    overlap the exchange;  "nccl": the same messages as batched P2P ops;  "nccl-default-stream": P2P with full
-    synchronisation (no overlap);  "gloo": staged through the host (tests: two ranks may share one GPU)."""
+    Halo transports:
+      "ipc"       direct: every rank pushes its rows straight into the neighbours' fields (IPC-mapped device memory over
+                  xGMI between processes), completion through flag words in shared host memory; one library call per
+                  step (moka_rk4_dist_step), no send buffer, no unpack, no collective library;
+      "nccl-a2a"  buffered: one all_to_all_single per stage on device buffers (RCCL: a grouped send/recv per neighbour
+                  underneath), issued on the library's comm stream so that the interior patches overlap it;
+      "nccl"      the same messages as batched P2P ops;  "nccl-default-stream": P2P with full synchronisation;
+      "gloo"      buffered, staged through the host (tests: ranks may share one GPU);
+      "local"     driven by LocalCluster (all ranks in one process)."""
 
     def __init__(self, mesh, ssh, u, h, rest, dt, backend, rank, world, ordering=0, patch_cells=0,
-                 transport="nccl", part=None, group=None, state_bytes=8):
+                 transport="nccl", part=None, group=None, state_bytes=8, exchange_lists=None, timeout_s=30.0):
+        """exchange_lists(wants: {rank: obj}) -> {rank: obj}: all-to-all of small Python objects between the ranks
+        (default: torch.distributed.all_gather_object on `group`); LocalCluster passes None and calls finish() itself."""
         import torch
         import torch.distributed as dist
         from . import api
         self.torch, self.dist = torch, dist
         self.rank, self.world, self.dt, self.backend, self.transport = rank, world, float(dt), backend, transport
-        self.group = group                 # process group of the gloo transport (None = default group)
+        self.group = group                 # process group of the gloo transport / control messages (None = default group)
+        self.timeout_s = float(timeout_s)
         K = np.asarray(u).reshape(mesh.nEdges, -1).shape[1]
-        self.K = K
+        self.K, self.state_bytes = K, int(state_bytes)
         self.part = partition_cells(mesh, world) if part is None else np.asarray(part, dtype=np.int32)
         lm = self.lm = build_local(mesh, self.part, rank, world)
         rest = np.asarray(rest).reshape(mesh.nCells, -1)
@@ -216,6 +240,7 @@ class DistributedModel:
         v_mesh = api.VerticalMesh(h_mesh, nVertLevels=K, restingThickness=rest[lm.cells_g], multilayer=True)
         self.mesh = api.Mesh.__new__(api.Mesh)
         self.mesh.HorzMesh, self.mesh.VertMesh, self.mesh.backend = h_mesh, v_mesh, backend
+        self.mesh.state_bytes = int(state_bytes)
         self.mesh._h = C.c_void_p()
         desc, keep = L.make_desc(lm.mesh, K, v_mesh.restingThicknessSum, v_mesh.maxLevelEdge.Top, ordering,
                                  patch_cells, cell_class=lm.cell_class, state_bytes=state_bytes)
@@ -226,12 +251,46 @@ class DistributedModel:
                                        np.asarray(h).reshape(mesh.nCells, K)[lm.cells_g], 2, self.mesh)
         self.Diag = api.DiagnosticVars(None, self.mesh, self.Prog._state)
         self.Tend = api.TendencyVars(None, self.mesh, self.Prog._state)
-        P = self.mesh.info()["patch_cells"]
-        nB = int((lm.cell_class == 0).sum())
-        nO = int((lm.cell_class <= 1).sum())
-        self.p_boundary, self.p_owned = -(-nB // P), -(-nO // P)
+        # launch ranges and receive order come from the plan: class 0 = boundary patches, 1 = interior, 2 + i = what
+        # neighbour i sends, contiguous and in the library's order
+        pS, cS, eS = L.class_ranges(self.mesh._h, True)
+        self.p_boundary, self.p_owned = int(pS[1]), int(pS[2])
+        cperm = np.empty(lm.mesh.nCells, dtype=np.int32)
+        eperm = np.empty(lm.mesh.nEdges, dtype=np.int32)
+        L.check(L.lib().moka_mesh_permutation(self.mesh._h, L.CELL, L.i32(cperm)), backend._h)
+        L.check(L.lib().moka_mesh_permutation(self.mesh._h, L.EDGE, L.i32(eperm)), backend._h)
+        rc, re_ = [], []
+        for i in range(len(lm.neighbors)):
+            c = cperm[cS[2 + i]:cS[3 + i]]
+            e = eperm[eS[2 + i]:eS[3 + i]]
+            assert np.array_equal(np.sort(c), np.sort(lm.recv_cells[lm.recv_cell_off[i]:lm.recv_cell_off[i + 1]]))
+            assert np.array_equal(np.sort(e), np.sort(lm.recv_edges[lm.recv_edge_off[i]:lm.recv_edge_off[i + 1]]))
+            rc.append(c); re_.append(e)
+        if lm.neighbors:
+            lm.recv_cells, lm.recv_edges = np.concatenate(rc).astype(np.int32), np.concatenate(re_).astype(np.int32)
+        # the senders have to list their rows in the same order: tell them (global ids)
+        self._wants = {q: (lm.cells_g[rc[i]], lm.edges_g[re_[i]]) for i, q in enumerate(lm.neighbors)}
         self._halo = C.c_void_p()
-        i32 = lambda a: L.i32(np.ascontiguousarray(a, dtype=np.int32))
+        self._ready = False
+        if exchange_lists is not None or transport != "local":
+            self.finish((exchange_lists or self._gather_lists)(self._wants))
+
+    def _gather_lists(self, wants):
+        everyone = [None] * self.world
+        self.dist.all_gather_object(everyone, wants, group=self.group)
+        return {q: everyone[q][self.rank] for q in self.lm.neighbors}
+
+    def finish(self, asked):
+        """asked[q] = (global cell ids, global edge ids) neighbour q wants from this rank, in the order it wants them."""
+        torch, lm, backend, K = self.torch, self.lm, self.backend, self.K
+        sc, se = [], []
+        for i, q in enumerate(lm.neighbors):
+            c, e = lm.g2l_c[np.asarray(asked[q][0], dtype=np.int64)], lm.g2l_e[np.asarray(asked[q][1], dtype=np.int64)]
+            assert np.array_equal(np.sort(c), np.sort(lm.send_cells[lm.send_cell_off[i]:lm.send_cell_off[i + 1]]))
+            assert np.array_equal(np.sort(e), np.sort(lm.send_edges[lm.send_edge_off[i]:lm.send_edge_off[i + 1]]))
+            sc.append(c); se.append(e)
+        if lm.neighbors:
+            lm.send_cells, lm.send_edges = np.concatenate(sc).astype(np.int32), np.concatenate(se).astype(np.int32)
         self._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (lm.send_cells, lm.send_edges, lm.recv_cells, lm.recv_edges)]
         offs = [np.ascontiguousarray(a, dtype=np.int64)
                 for a in (lm.send_cell_off, lm.send_edge_off, lm.recv_cell_off, lm.recv_edge_off)]
@@ -244,7 +303,7 @@ class DistributedModel:
         ns, nr = C.c_int64(), C.c_int64()
         L.check(L.lib().moka_halo_buffer_elems(self._halo, C.byref(ns), C.byref(nr)))
         dev = torch.device("cuda", backend.device)
-        real = torch.float32 if state_bytes == 4 else torch.float64      # halo messages carry state reals
+        real = torch.float32 if self.state_bytes == 4 else torch.float64      # halo messages carry state reals
         self.sendbuf = torch.zeros(max(ns.value, 1), dtype=real, device=dev)
         self.recvbuf = torch.zeros(max(nr.value, 1), dtype=real, device=dev)
         torch.cuda.synchronize(dev)           # the zero fills ran on torch's stream; the library's streams do not order against it
@@ -255,7 +314,45 @@ class DistributedModel:
         cs, ms = C.c_void_p(), C.c_void_p()
         L.check(L.lib().moka_ctx_streams(backend._h, C.byref(cs), C.byref(ms)))
         self.comm_stream = torch.cuda.ExternalStream(ms.value, device=dev)
-        self.halo_bytes_per_stage = int(state_bytes) * (ns.value + nr.value)
+        self.halo_bytes_per_stage = int(self.state_bytes) * (ns.value + nr.value)
+        self.direct_available = bool(L.lib().moka_halo_direct_available(self._halo))
+        self.connected = False
+        self._cb_error = None
+
+        def _cb(user, what, sendbuf, recvbuf):   # the buffered transport as a C callback of moka_rk4_dist_step
+            try:
+                self._transport()
+                return 0
+            except Exception as exc:             # noqa: BLE001  (an exception must not cross the C frame)
+                self._cb_error = exc
+                return 1
+        self._cb = L.TRANSPORT_FN(_cb)
+        self._ready = True
+
+    # ---- direct transport: tell the neighbours where to push ----
+    def export_peer_info(self, shared: bool):
+        """{neighbour rank: bytes} -- what each neighbour needs to push its rows into this rank's fields."""
+        out = {}
+        for i, q in enumerate(self.lm.neighbors):
+            info = L.HaloPeerInfo()
+            L.check(L.lib().moka_halo_export(self._halo, i, 1 if shared else 0, C.byref(info)), self.backend._h)
+            out[q] = bytes(info)
+        return out
+
+    def connect_peers(self, infos, shared: bool):
+        """infos[q] = what neighbour q exported FOR this rank."""
+        for i, q in enumerate(self.lm.neighbors):
+            info = L.HaloPeerInfo.from_buffer_copy(infos[q])
+            L.check(L.lib().moka_halo_connect(self._halo, i, C.byref(info), 1 if shared else 0), self.backend._h)
+        self.connected = True
+
+    def connect_ipc(self):
+        """Multi-process set-up of the direct transport: IPC handles and flag-block names travel over `group`."""
+        mine = self.export_peer_info(True)
+        everyone = [None] * self.world
+        self.dist.all_gather_object(everyone, mine, group=self.group)
+        self.connect_peers({q: everyone[q][self.rank] for q in self.lm.neighbors}, True)
+        self.dist.barrier(group=self.group)
 
     # ---- transport of the packed buffers ----
     def _transport(self):
@@ -281,8 +378,8 @@ class DistributedModel:
                     [dist.P2POp(dist.isend, self.sendbuf[a:b], q) for q, a, b in self.send_slices if b > a]):
                 w.wait()
             torch.cuda.synchronize()
-        elif self.transport == "local":
-            raise RuntimeError("transport 'local' is driven by LocalCluster.step_rk4")
+        elif self.transport in ("local", "ipc"):
+            raise RuntimeError(f"transport {self.transport!r} has no buffered form")
         elif self.transport != "gloo":
             raise ValueError(f"unknown halo transport {self.transport!r}")
         else:                                    # gloo: through the host
@@ -295,11 +392,45 @@ class DistributedModel:
             self.recvbuf.copy_(recv_cpu)
             torch.cuda.synchronize()
 
+    def received_bytes(self):
+        """The halo rows of the current time level as this rank holds them now, in message order: what a transport has
+        to have delivered."""
+        self.backend.synchronize()
+        hh, ssh, uu = self.Prog.layerThickness[-1].get(), self.Prog.ssh[-1].get(), self.Prog.normalVelocity[-1].get()
+        parts = []
+        lm = self.lm
+        for i in range(len(lm.neighbors)):
+            c = lm.recv_cells[lm.recv_cell_off[i]:lm.recv_cell_off[i + 1]]
+            e = lm.recv_edges[lm.recv_edge_off[i]:lm.recv_edge_off[i + 1]]
+            parts += [hh[c].ravel(), ssh[c], uu[e].ravel()]
+        return np.concatenate(parts) if parts else np.zeros(0)
+
     def verify_transport(self, trusted="gloo") -> bool:
-        """Pack the current state, move it with this model's transport and again with `trusted`: True when both deliver
+        """Move the current state's halo with this model's transport and again with `trusted`: True when both deliver
         the same bytes on this rank (callers combine the ranks' answers)."""
         lib = L.lib()
         mine = self.transport
+        if mine == "ipc":
+            lm = self.lm
+            # wipe the halo rows, exchange directly, read them back
+            hh, ssh, uu = self.Prog.layerThickness[-1].get(), self.Prog.ssh[-1].get(), self.Prog.normalVelocity[-1].get()
+            rc, re_ = lm.recv_cells, lm.recv_edges
+            hh[rc], ssh[rc], uu[re_] = -7.0, -7.0, -7.0
+            self.Prog.layerThickness[-1].set(hh); self.Prog.ssh[-1].set(ssh); self.Prog.normalVelocity[-1].set(uu)
+            self.dist.barrier(group=self.group)
+            self.exchange_state()
+            self.backend.synchronize()
+            got = self.received_bytes()
+            hh[rc], ssh[rc], uu[re_] = -9.0, -9.0, -9.0
+            self.Prog.layerThickness[-1].set(hh); self.Prog.ssh[-1].set(ssh); self.Prog.normalVelocity[-1].set(uu)
+            self.dist.barrier(group=self.group)
+            try:
+                self.transport = trusted
+                self.exchange_state()
+            finally:
+                self.transport = mine
+            self.backend.synchronize()
+            return bool(np.array_equal(got, self.received_bytes()))
         L.check(lib.moka_halo_pack(self._halo, 0, self.sendbuf.data_ptr()), self.backend._h)
         self.recvbuf.zero_()
         self.torch.cuda.synchronize()
@@ -316,14 +447,44 @@ class DistributedModel:
         self.backend.synchronize(); self.torch.cuda.synchronize()
         return bool(self.torch.equal(got, self.recvbuf))
 
+    def _direct(self):
+        return self.transport == "ipc" and self.connected
+
     def exchange_state(self):
-        """Halo exchange of the current time level (e.g. after an upload)."""
+        """Halo exchange of the current time level (e.g. after an upload).  Collective: every rank calls it."""
         lib, h = L.lib(), self._halo
+        if self._direct():
+            self.backend.synchronize()
+            self.dist.barrier(group=self.group)          # nobody is still reading the rows about to be overwritten
+            L.check(lib.moka_halo_push_begin(h, 0), self.backend._h)
+            L.check(lib.moka_halo_push_signal(h), self.backend._h)
+            L.check(lib.moka_halo_push_wait(h, self.timeout_s), self.backend._h)
+            return
         L.check(lib.moka_halo_pack(h, 0, self.sendbuf.data_ptr()), self.backend._h)
         self._transport()
         L.check(lib.moka_halo_unpack(h, 0, self.recvbuf.data_ptr()), self.backend._h)
 
+    def _check_cb(self, rc):
+        if self._cb_error is not None:
+            exc, self._cb_error = self._cb_error, None
+            raise exc
+        L.check(rc, self.backend._h)
+
     def step_rk4(self):
+        """One distributed RK4 step = ONE library call (the stage loop, the launches and -- for the direct transport --
+        the flag waits are in C; the buffered transports come back into Python once per stage through a callback)."""
+        cb = L.TRANSPORT_FN() if self._direct() or not self.lm.neighbors else self._cb
+        self._check_cb(L.lib().moka_rk4_dist_step(self._halo, self.dt, cb, None, self.sendbuf.data_ptr(),
+                                                  self.recvbuf.data_ptr(), self.timeout_s))
+
+    def step_fe(self, flags=L.FE_REFERENCE_COMPAT & ~L.FE_LEVEL1_ONLY):
+        """One distributed Forward-Euler step (the reference's live integrator) with the given compat flags."""
+        cb = L.TRANSPORT_FN() if self._direct() or not self.lm.neighbors else self._cb
+        self._check_cb(L.lib().moka_fe_dist_step(self._halo, self.dt, int(flags), cb, None, self.sendbuf.data_ptr(),
+                                                 self.recvbuf.data_ptr(), self.timeout_s))
+
+    def step_rk4_piecewise(self):
+        """The same step through the piecewise entry points (17 library calls): kept for tests and host-overhead timing."""
         lib, h, ctx = L.lib(), self._halo, self.backend._h
         L.check(lib.moka_rk4_dist_begin(h, self.dt), ctx)
         for s in (1, 2, 3, 4):
@@ -341,22 +502,42 @@ class DistributedModel:
         cm, em = lm.owned_cell_mask, lm.owned_edge_mask
         return (lm.cells_g[cm], ssh[cm], hh[cm]), (lm.edges_g[em], uu[em])
 
+    def owned_diagnostics(self):
+        """Owned parts of Diag / Tend: {name: (global ids, values)} (cells, edges and vertices this rank reports)."""
+        lm = self.lm
+        cm, em, vm = lm.owned_cell_mask, lm.owned_edge_mask, lm.owned_vert_mask
+        D, T = self.Diag, self.Tend
+        return {"hEdge": (lm.edges_g[em], D.layerThicknessEdge.get()[em]), "F": (lm.edges_g[em], D.thicknessFlux.get()[em]),
+                "div": (lm.cells_g[cm], D.velocityDivCell.get()[cm]), "vort": (lm.verts_g[vm], D.relativeVorticity.get()[vm]),
+                "tendU": (lm.edges_g[em], T.tendNormalVelocity.get()[em]), "tendH": (lm.cells_g[cm], T.tendLayerThickness.get()[cm])}
+
     def info(self):
         d = self.mesh.info()
         d.update({"rank_cells_owned": self.lm.n_owned_cells, "rank_cells_local": self.lm.mesh.nCells,
                   "neighbors": len(self.lm.neighbors), "halo_bytes_per_stage": self.halo_bytes_per_stage,
-                  "patches_boundary": self.p_boundary, "patches_owned": self.p_owned})
+                  "patches_boundary": self.p_boundary, "patches_owned": self.p_owned,
+                  "direct_transport_available": self.direct_available})
         return d
 
+    def close(self):
+        """Release the device objects in dependency order (halo, state, mesh); the backend stays with the caller."""
+        if getattr(self, "_halo", None):
+            L.lib().moka_halo_destroy(self._halo)
+            self._halo = C.c_void_p()
+        self.Prog._state.close()
+        self.mesh.close()
 
-def choose_transport(model: DistributedModel, overlapped, fallbacks, control_group, log=lambda msg: None, trial_steps=5):
+
+def choose_transport(model: DistributedModel, candidates, fallbacks, control_group, log=lambda msg: None, trial_steps=5):
     """Pick the halo transport of `model` on this node; every rank calls this and all return the same name.
 
-    A candidate qualifies when, on every rank, it moves the packed state to exactly the bytes the host-staged gloo
-    exchange delivers AND a full RK4 step with it runs without raising; the ranks combine their answers over
-    `control_group` (gloo) so that nobody is left waiting.  Of the qualifying `overlapped` candidates the fastest over
-    `trial_steps` steps is kept (max over ranks); otherwise the first qualifying one of `fallbacks`.
-    Returns (name, {candidate: ms per step})."""
+    A candidate qualifies in three phases, each closed by an agreement of all ranks over `control_group` (gloo), so that
+    nobody runs ahead into a collective the others will never post: (1) it can be set up on every rank, (2) on every
+    rank it moves the current state's halo to exactly the bytes the host-staged gloo exchange delivers, (3) a full RK4
+    step with it runs on every rank.  Any failure makes ALL ranks drop the candidate.  Of the qualifying `candidates`
+    the fastest over `trial_steps` steps is kept (max over ranks); otherwise the first qualifying one of `fallbacks`.
+    Candidates whose failure mode is a hang rather than an exception (an RCCL collective that never completes) must be
+    screened BEFORE this function, in a child process (bench.py: probe_rccl).  Returns (name, {candidate: ms/step})."""
     import time
     torch, dist = model.torch, model.dist
 
@@ -369,20 +550,34 @@ def choose_transport(model: DistributedModel, overlapped, fallbacks, control_gro
         model.backend.synchronize(); torch.cuda.synchronize()
         dist.barrier(group=control_group)
 
-    def works(cand):
-        model.transport = cand
+    def phase(cand, what, fn):
         ok = 1.0
         try:
-            if not model.verify_transport("gloo"):
-                log(f"halo transport {cand} delivered different bytes than gloo")
+            if fn() is False:
                 ok = 0.0
+                log(f"halo transport {cand}: {what} failed")
+        except Exception as exc:                 # noqa: BLE001
+            log(f"halo transport {cand}: {what} raised {exc!r}")
+            ok = 0.0
+        return agree(ok, dist.ReduceOp.MIN) == 1.0
+
+    def works(cand):
+        model.transport = cand
+
+        def setup():
+            if cand == "ipc":
+                if not model.direct_available:
+                    return False
+                if not model.connected:
+                    model.connect_ipc()
+            return True
+
+        def step():
             model.transport = cand
             model.step_rk4()
             model.backend.synchronize(); torch.cuda.synchronize()
-        except Exception as exc:                 # noqa: BLE001
-            log(f"halo transport {cand} failed: {exc!r}")
-            ok = 0.0
-        return agree(ok, dist.ReduceOp.MIN) == 1.0
+        return (phase(cand, "set-up", setup) and phase(cand, "byte comparison with gloo", lambda: model.verify_transport("gloo"))
+                and phase(cand, "one RK4 step", step))
 
     def trial_ms(cand):
         model.transport = cand
@@ -394,11 +589,11 @@ def choose_transport(model: DistributedModel, overlapped, fallbacks, control_gro
         return agree((time.perf_counter() - t0) / trial_steps * 1e3, dist.ReduceOp.MAX)
 
     times = {}
-    good = [c for c in overlapped if works(c)]
+    good = [c for c in candidates if works(c)]
     if good:
         times = {c: trial_ms(c) for c in good}
         cand = min(good, key=lambda c: times[c])
-        log(f"overlapped halo transports, ms/step over {trial_steps} steps: {times} -> {cand}")
+        log(f"qualified halo transports, ms/step over {trial_steps} steps: {times} -> {cand}")
     else:
         for cand in fallbacks:
             if works(cand):
@@ -411,21 +606,33 @@ def choose_transport(model: DistributedModel, overlapped, fallbacks, control_gro
 
 
 class LocalCluster:
-    """All ranks of a partition inside ONE process on ONE GPU: every rank is a DistributedModel with its own context
-    (two HIP streams each), and the halo messages are device-to-device copies issued on the receiver's comm stream
-    behind an event of the sender's comm stream -- stream-ordered end to end, never synchronised with the host, which
-    is the ordering an RCCL send/recv pair gives.  A test harness for the stream / event choreography of the
-    distributed RK4 step (RCCL itself refuses several ranks on one device)."""
+    """All ranks of a partition inside ONE process on ONE GPU (or on a list of devices): every rank is a
+    DistributedModel with its own context (two HIP streams each).
 
-    def __init__(self, mesh, ssh, u, h, rest, dt, world, device=0, ordering=0, patch_cells=0, state_bytes=8):
+    direct=True (default when the plan allows it): the ranks are connected with the library's direct transport exactly
+    as processes would be -- push kernels store into the neighbours' fields, flag words (plain host memory here) complete
+    the exchange; only the launch / signal / wait phases of a stage are interleaved over the ranks because one host
+    thread drives all of them.  direct=False: the buffered transport with device-to-device copies between the ranks'
+    send and receive buffers, ordered by stream events only."""
+
+    def __init__(self, mesh, ssh, u, h, rest, dt, world, device=0, ordering=0, patch_cells=0, state_bytes=8, direct=True,
+                 devices=None):
         import torch
         from . import api
         self.torch, self.world = torch, world
-        self.backends = [api.MokaHIP(device) for _ in range(world)]
+        devs = list(devices) if devices is not None else [device] * world
+        self.backends = [api.MokaHIP(devs[r]) for r in range(world)]
         part = partition_cells(mesh, world)
         self.models = [DistributedModel(mesh, ssh, u, h, rest, dt, self.backends[r], r, world, ordering=ordering,
                                         patch_cells=patch_cells, transport="local", part=part, state_bytes=state_bytes)
                        for r in range(world)]
+        for r, m in enumerate(self.models):        # every rank learns the order its neighbours want their rows in
+            m.finish({q: self.models[q]._wants[r] for q in m.lm.neighbors})
+        self.direct = bool(direct) and all(m.direct_available for m in self.models)
+        if self.direct:
+            exported = [m.export_peer_info(False) for m in self.models]
+            for r, m in enumerate(self.models):
+                m.connect_peers({q: exported[q][r] for q in m.lm.neighbors}, False)
         self.events = [torch.cuda.Event() for _ in range(world)]
         # (receiver, a, b) <- (sender, c, d): slices of the packed buffers, matched by construction (message_slices)
         self.moves = []
@@ -462,16 +669,34 @@ class LocalCluster:
         for m in self.models:
             L.check(lib.moka_halo_unpack(m._halo, what, m.recvbuf.data_ptr()), m.backend._h)
 
+    def _finish_direct(self):
+        lib = L.lib()
+        for m in self.models:
+            L.check(lib.moka_halo_push_signal(m._halo), m.backend._h)
+        for m in self.models:
+            L.check(lib.moka_halo_push_wait(m._halo, m.timeout_s), m.backend._h)
+
     def exchange_state(self):
-        self._exchange(0)
+        if not self.direct:
+            return self._exchange(0)
+        for m in self.models:
+            m.backend.synchronize()
+        for m in self.models:
+            L.check(L.lib().moka_halo_push_begin(m._halo, 0), m.backend._h)
+        self._finish_direct()
 
     def step_rk4(self):
         lib = L.lib()
         for m in self.models:
             L.check(lib.moka_rk4_dist_begin(m._halo, m.dt), m.backend._h)
         for s in (1, 2, 3, 4):
+            if self.direct:
+                for m in self.models:
+                    L.check(lib.moka_rk4_dist_stage_launch(m._halo, s), m.backend._h)   # boundary, push, interior
+                self._finish_direct()
+                continue
             for m in self.models:
-                L.check(lib.moka_rk4_dist_stage(m._halo, s, 0), m.backend._h)     # boundary patches (comm stream)
+                L.check(lib.moka_rk4_dist_stage(m._halo, s, 0), m.backend._h)     # boundary patches
             for m in self.models:
                 L.check(lib.moka_halo_pack(m._halo, s, m.sendbuf.data_ptr()), m.backend._h)
             for m in self.models:
@@ -479,6 +704,27 @@ class LocalCluster:
             self._exchange(s, pack=False)
         for m in self.models:
             L.check(lib.moka_rk4_dist_end(m._halo), m.backend._h)
+
+    def step_fe(self, flags=L.FE_REFERENCE_COMPAT & ~L.FE_LEVEL1_ONLY):
+        """The reference's Forward-Euler step on the partition: boundary patches, exchange of the new level (what = 4),
+        interior patches and relativeVorticity meanwhile."""
+        lib = L.lib()
+        for m in self.models:
+            L.check(lib.moka_fe_dist_launch(m._halo, m.dt, int(flags), 0), m.backend._h)
+        for m in self.models:
+            if self.direct:
+                L.check(lib.moka_halo_push_begin(m._halo, 4), m.backend._h)
+            else:
+                L.check(lib.moka_halo_pack(m._halo, 4, m.sendbuf.data_ptr()), m.backend._h)
+        for m in self.models:
+            L.check(lib.moka_fe_dist_launch(m._halo, m.dt, int(flags), 1), m.backend._h)
+            L.check(lib.moka_fe_dist_launch(m._halo, m.dt, int(flags), 2), m.backend._h)
+        if self.direct:
+            self._finish_direct()
+        else:
+            self._exchange(4, pack=False)
+        for m in self.models:
+            L.check(lib.moka_fe_dist_end(m._halo), m.backend._h)
 
     def gather_owned(self, nCells, nEdges, K):
         """(ssh, u, h) of the whole mesh assembled from the ranks' owned entities (synchronises)."""
@@ -488,6 +734,20 @@ class LocalCluster:
             ssh[cg], h[cg], u[eg] = s, hh, uu
         return ssh, u, h
 
+    def gather_diagnostics(self, mesh, K):
+        """Diag / Tend of the whole mesh assembled from the ranks' owned entities."""
+        n = {"hEdge": mesh.nEdges, "F": mesh.nEdges, "div": mesh.nCells, "vort": mesh.nVertices, "tendU": mesh.nEdges,
+             "tendH": mesh.nCells}
+        out = {k: np.full((v, K), np.nan) for k, v in n.items()}
+        for m in self.models:
+            for k, (ids, vals) in m.owned_diagnostics().items():
+                out[k][ids] = vals
+        return out
+
     def close(self):
         for b in self.backends:
             b.synchronize()
+        for m in self.models:
+            m.close()
+        for b in self.backends:
+            b.close()

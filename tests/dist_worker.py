@@ -1,8 +1,11 @@
 """Worker for the multi-rank tests (launched under torch.distributed.run).
 
 mode cpu : validates the partition, the local meshes and the exchange lists with the CPU ORACLE as each rank's
-           compute (gloo, no GPU): the distributed RK4 must reproduce the single-domain oracle bit for bit.
-mode gpu : the same check for the HIP path (DistributedModel); ranks share GPU 0 and exchange through gloo.
+           compute (gloo, no GPU): the distributed RK4 -- and the reference's Forward-Euler step with its stale
+           layerThicknessEdge, which needs no exchange of its own -- must reproduce the single-domain oracle bit for bit.
+mode gpu : the same check for the HIP path (DistributedModel); ranks share GPU 0.  argv: K variant transport, transport =
+           gloo (buffered, host-staged) or ipc (direct: IPC-mapped fields, flag words in shared memory -- the ranks are
+           separate processes exactly as under bench.py, only the GPU is shared).
 """
 import os
 import sys
@@ -63,7 +66,7 @@ def main():
 
     part = par.partition_cells(mesh, world)
     lm = par.build_local(mesh, part, rank, world)
-    assert set(lm.neighbors) == set(range(world)) - {rank}
+    assert world > 3 or set(lm.neighbors) == set(range(world)) - {rank}
     cm, em = lm.owned_cell_mask, lm.owned_edge_mask
     # every cell is owned exactly once, every edge exactly once
     owned_c = torch.zeros(mesh.nCells, dtype=torch.int32); owned_c[lm.cells_g[cm]] = 1
@@ -95,29 +98,73 @@ def main():
             exchange_numpy(lm, K, (cssh, nu, nh), dist)
             cu, ch = nu, nh
         got = (cssh, cu, ch)
+        # the reference's Forward-Euler step on the partition (time_integration.jl:150-193), quirks included: only the
+        # new level is exchanged; the carried layerThicknessEdge of every edge with an owned cell is local
+        for flags in (3, 0):
+            gref = orc.OracleState(om, ssh, u, h)
+            loc = orc.OracleState(oml, ssh[lm.cells_g], u[lm.edges_g], h[lm.cells_g])
+            vm = lm.owned_vert_mask
+            for _ in range(4):
+                gref.step_fe(dt, flags)
+                loc.step_fe(dt, flags)
+                exchange_numpy(lm, K, (loc.ssh[1], loc.u[1], loc.h[1]), dist)
+                for name, mask, ids in (("u", em, lm.edges_g), ("h", cm, lm.cells_g), ("ssh", cm, lm.cells_g)):
+                    assert np.array_equal(getattr(loc, name)[1][mask], getattr(gref, name)[1][ids[mask]]), (flags, name)
+                for name, mask, ids in (("hEdge", em, lm.edges_g), ("F", em, lm.edges_g), ("tendU", em, lm.edges_g),
+                                        ("div", cm, lm.cells_g), ("tendH", cm, lm.cells_g), ("vort", vm, lm.verts_g)):
+                    assert np.array_equal(getattr(loc, name)[mask], getattr(gref, name)[ids[mask]]), (flags, name)
     else:
         import moka_hip as mk
         backend = mk.MokaHIP(0)
         variant = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+        transport = sys.argv[4] if len(sys.argv) > 4 else "gloo"
         backend.set_kernel_variant(variant)
-        model = par.DistributedModel(mesh, ssh, u, h, rest, dt, backend, rank, world, transport="gloo", part=part)
+        model = par.DistributedModel(mesh, ssh, u, h, rest, dt, backend, rank, world, transport=transport, part=part)
         assert model.p_boundary <= model.p_owned <= model.mesh.info()["nPatches"]
+        assert model.direct_available
         # the transport selection bench.py runs before timing (on a model of its own: the trials advance the state):
-        # broken candidates are skipped by agreement of the ranks
+        # broken candidates are dropped by agreement of the ranks, phase by phase
         probe = par.DistributedModel(mesh, ssh, u, h, rest, dt, backend, rank, world, transport="gloo", part=part)
         probe.exchange_state()
         msgs = []
         assert par.choose_transport(probe, ("bogus", "gloo"), ("gloo",), None, msgs.append, trial_steps=1)[0] == "gloo"
         assert par.choose_transport(probe, ("bogus",), ("bogus2", "gloo"), None, msgs.append)[0] == "gloo"
-        assert sum("failed" in m for m in msgs) == 3, msgs
+        assert sum("bogus" in m for m in msgs) == 3, msgs
         try:
             par.choose_transport(probe, (), ("bogus",), None)
             raise AssertionError("no transport should have qualified")
         except RuntimeError:
             pass
+        if transport == "ipc":
+            # the direct transport qualifies (set-up, byte comparison with gloo, a step) and is kept over gloo when faster
+            name, times = par.choose_transport(probe, ("ipc", "gloo"), ("gloo",), None, msgs.append, trial_steps=2)
+            assert "ipc" in times and "gloo" in times, (name, times, msgs)
+            model.connect_ipc()
+            model.exchange_state()
+            assert model.verify_transport("gloo")
+            model.Prog.ssh[-1].set(ssh[lm.cells_g]); model.Prog.layerThickness[-1].set(h[lm.cells_g])
+            model.Prog.normalVelocity[-1].set(u[lm.edges_g])
+            for f in (model.Prog.ssh, model.Prog.layerThickness, model.Prog.normalVelocity):
+                f[0].set(f[-1].get())
+            model.exchange_state()
+        probe.close()
         for _ in range(nsteps):
             model.step_rk4()
         got = (model.Prog.ssh[-1].get(), model.Prog.normalVelocity[-1].get(), model.Prog.layerThickness[-1].get())
+        if K % 2 == 0 or K == 1:
+            # the reference's Forward-Euler step on the partition, continuing from the RK4 state
+            flags = 7 if K == 1 else 3
+            for _ in range(3):
+                model.step_fe(flags)
+                ref.step_fe(dt, flags)
+            diag = model.owned_diagnostics()
+            for name, exp in (("hEdge", ref.hEdge), ("F", ref.F), ("div", ref.div), ("vort", ref.vort), ("tendU", ref.tendU),
+                              ("tendH", ref.tendH)):
+                ids, vals = diag[name]
+                assert np.array_equal(vals, exp[ids]), name
+            got = (model.Prog.ssh[-1].get(), model.Prog.normalVelocity[-1].get(), model.Prog.layerThickness[-1].get())
+        dist.barrier()               # nobody pushes into fields that are about to be freed
+        model.close()
     assert np.array_equal(got[0][cm], ref.ssh[1][lm.cells_g[cm]]), "ssh"
     assert np.array_equal(got[2][cm], ref.h[1][lm.cells_g[cm]]), "layerThickness"
     assert np.array_equal(got[1][em], ref.u[1][lm.edges_g[em]]), "normalVelocity"

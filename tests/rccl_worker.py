@@ -39,7 +39,12 @@ def main():
 
     backend = mk.MokaHIP(0)
     # a 2-way partition, rank 0's half: its send buffer is packed by the library on the comm stream
-    dm = par.DistributedModel(mesh, ssh, u, h, rest, dt, backend, 0, 2, transport="nccl")
+    # (there is no rank 1 to say in which order it wants its rows: take the default order of the exchange lists)
+    part = par.partition_cells(mesh, 2)
+    lm0 = par.build_local(mesh, part, 0, 2)
+    asked = {1: (lm0.cells_g[lm0.send_cells], lm0.edges_g[lm0.send_edges])}
+    dm = par.DistributedModel(mesh, ssh, u, h, rest, dt, backend, 0, 2, transport="nccl", part=part,
+                              exchange_lists=lambda wants: asked)
     lib, ctx = mk.lib.lib(), backend._h
     mk.lib.check(lib.moka_halo_pack(dm._halo, 0, dm.sendbuf.data_ptr()), ctx)
     expect = par.pack_numpy(dm.lm, K, ssh[dm.lm.cells_g], u[dm.lm.edges_g], h[dm.lm.cells_g])

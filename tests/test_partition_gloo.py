@@ -47,32 +47,46 @@ def test_partition_and_local_mesh_properties():
         for r in range(world):
             lm = par.build_local(mesh, part, r, world)
             assert lm.n_owned_cells == counts[r]
-            assert np.all(lm.cell_class[lm.owned_cell_mask] <= 1) and np.all(lm.cell_class[~lm.owned_cell_mask] == 2)
+            assert np.all(lm.cell_class[lm.owned_cell_mask] <= 1) and np.all(lm.cell_class[~lm.owned_cell_mask] >= 2)
+            assert lm.cell_class.max() == 1 + len(lm.neighbors)                 # halo cells: class 2 + neighbour index
             # every halo cell is received, every local edge without an owned cell is received
             assert set(lm.recv_cells.tolist()) == set(np.nonzero(~lm.owned_cell_mask)[0].tolist())
-            # the local mesh is accepted by the host plan, classes order the patches
+            coe = lm.mesh.cellsOnEdge - 1
+            has_owned = lm.owned_cell_mask[coe[:, 0]] | lm.owned_cell_mask[coe[:, 1]]
+            assert set(lm.recv_edges.tolist()) == set(np.nonzero(~has_owned)[0].tolist())
+            # the local mesh is accepted by the host plan, classes order the patches and no patch straddles a class
             plan = L.Plan(lm.mesh, 3, max_level_edge_top=3, ordering=L.ORDER_RCB, patch_cells=8, cell_class=lm.cell_class)
             cperm = plan.permutation(L.CELL)
             cls = lm.cell_class[cperm]
             assert np.all(np.diff(cls) >= 0)                                     # class-major ordering
             cs, es, _ = plan.patch_ranges()      # the record-staging kernels size their LDS from these maxima
             assert plan.info["maxPatchEdges"] == np.diff(es).max() and plan.info["maxPatchCells"] == np.diff(cs).max()
-            # launch ranges: patches [0, pB) are computed before the halo is packed, [pB, pO) while it travels, the rest never.
+            pS, cS, eS = plan.class_ranges()
+            assert len(pS) == 3 + len(lm.neighbors) and pS[0] == 0 and pS[-1] == plan.info["nPatches"]
+            for k in range(len(pS) - 1):
+                assert cS[k] == cs[pS[k]] and eS[k] == es[pS[k]]
+                assert np.all(cls[cS[k]:cS[k + 1]] == k)
+            assert np.diff(cs).max() <= 8
+            # launch ranges: patches [0, pB) are computed before the halo leaves, [pB, pO) while it travels, the rest never.
             # Whatever the balancing of edge ownership does, every sent edge must be produced by the boundary launch and
             # every edge with an owned cell by a launched patch.
-            P = plan.info["patch_cells"]
-            nB, nO = int((lm.cell_class == 0).sum()), int((lm.cell_class <= 1).sum())
-            pB, pO = -(-nB // P), -(-nO // P)
+            pB, pO = int(pS[1]), int(pS[2])
             eperm = plan.permutation(L.EDGE)
             patch_of_edge = np.empty(lm.mesh.nEdges, dtype=np.int64)
             patch_of_edge[eperm] = np.searchsorted(es, np.arange(lm.mesh.nEdges), side="right") - 1
             assert np.all(patch_of_edge[lm.send_edges] < pB)
-            coe = lm.mesh.cellsOnEdge - 1
-            has_owned = lm.owned_cell_mask[coe[:, 0]] | lm.owned_cell_mask[coe[:, 1]]
-            assert np.all(patch_of_edge[has_owned] < pO)
+            assert np.all(patch_of_edge[has_owned] < pO) and np.all(patch_of_edge[~has_owned] >= pO)
             cpos = np.empty(lm.mesh.nCells, dtype=np.int64)
             cpos[cperm] = np.arange(lm.mesh.nCells)
-            assert np.all(cpos[lm.send_cells] // P < pB)
+            assert np.all(cpos[lm.send_cells] < cS[1])
+            # what neighbour i sends is ONE contiguous range of cells and ONE of edges in the plan's numbering
+            epos = np.empty(lm.mesh.nEdges, dtype=np.int64)
+            epos[eperm] = np.arange(lm.mesh.nEdges)
+            for i in range(len(lm.neighbors)):
+                rc = lm.recv_cells[lm.recv_cell_off[i]:lm.recv_cell_off[i + 1]]
+                re_ = lm.recv_edges[lm.recv_edge_off[i]:lm.recv_edge_off[i + 1]]
+                assert sorted(cpos[rc].tolist()) == list(range(cS[2 + i], cS[3 + i]))
+                assert sorted(epos[re_].tolist()) == list(range(eS[2 + i], eS[3 + i]))
             for i, q in enumerate(lm.neighbors):
                 sent[(r, q)] = (lm.cells_g[lm.send_cells[lm.send_cell_off[i]:lm.send_cell_off[i + 1]]],
                                 lm.edges_g[lm.send_edges[lm.send_edge_off[i]:lm.send_edge_off[i + 1]]])
@@ -90,19 +104,33 @@ def test_distributed_rk4_hip_two_ranks_one_gpu(K, variant):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,K", [(2, 60), (3, 60), (4, 1)])
+def test_direct_ipc_transport_between_processes_on_one_gpu(world, K):
+    """The direct halo transport as bench.py uses it on a multi-GPU node -- one process per rank, fields mapped with
+    hipIpcOpenMemHandle, push kernels storing into the neighbours' memory, flag words in POSIX shared memory -- with the
+    ranks sharing GPU 0: RK4 and Forward-Euler steps bit-identical to the single-domain oracle, the transport selection
+    (set-up / byte comparison with gloo / step, agreed phase by phase) qualifies it."""
+    run_workers(world, "gpu", K, 0, "ipc")
+
+
+@pytest.mark.gpu
 def test_rccl_collectives_on_the_library_comm_stream():
     """What one GPU can show of the RCCL transport: see tests/rccl_worker.py."""
     run_workers(1, worker="rccl_worker.py")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,K,P,nsteps,sbytes", [(2, 60, 0, 4, 8), (4, 60, 0, 4, 8), (8, 60, 0, 3, 8), (3, 1, 0, 5, 8), (4, 60, 8, 3, 8),
-                                                     (5, 80, 0, 2, 8), (4, 80, 0, 3, 4), (3, 60, 0, 2, 4)])
-def test_stream_ordered_exchange_in_one_process(world, K, P, nsteps, sbytes):
-    """All ranks in one process on one GPU, halo messages as stream-ordered device copies with no host synchronisation
-    anywhere in the step -- the ordering RCCL gives.  Exercises the two-stream / event choreography of the distributed
-    RK4 step (boundary patches + pack on the comm stream, interior on the compute stream, unpack overlapping it): any
-    missing dependency shows up as a mismatch against the single-domain oracle."""
+@pytest.mark.parametrize("world,K,P,nsteps,sbytes,direct", [(2, 60, 0, 4, 8, True), (4, 60, 0, 4, 8, True), (8, 60, 0, 3, 8, True),
+                                                            (3, 1, 0, 5, 8, True), (4, 60, 8, 3, 8, True), (5, 80, 0, 2, 8, True),
+                                                            (4, 80, 0, 3, 4, True), (3, 60, 0, 2, 4, True),
+                                                            (2, 60, 0, 4, 8, False), (8, 60, 0, 3, 8, False), (3, 1, 0, 5, 8, False),
+                                                            (4, 80, 0, 3, 4, False)])
+def test_stream_ordered_exchange_in_one_process(world, K, P, nsteps, sbytes, direct):
+    """All ranks in one process on one GPU.  direct: the library's direct transport (push kernels store into the neighbours'
+    fields, flag words complete the exchange) exactly as between processes; otherwise the buffered transport with
+    stream-ordered device copies and no host synchronisation anywhere in the step -- the ordering RCCL gives.  Exercises
+    the two-stream / event choreography of the distributed RK4 step (boundary patches, exchange on the comm stream,
+    interior on the compute stream): any missing dependency shows up as a mismatch against the single-domain oracle."""
     import oracle as orc
     mesh = mg.icosahedral_mesh(24)
     rng = np.random.default_rng(17 + world)
@@ -113,7 +141,8 @@ def test_stream_ordered_exchange_in_one_process(world, K, P, nsteps, sbytes):
     dt = 20.0
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     ref = orc.OracleState(om, ssh, u, h, mixed=sbytes == 4)          # fp32-storage states exchange fp32 halos
-    cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, world, patch_cells=P, state_bytes=sbytes)
+    cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, world, patch_cells=P, state_bytes=sbytes, direct=direct)
+    assert cl.direct == direct
     cl.exchange_state()
     for rep in range(3):                      # several rounds: timing-dependent races get more than one chance to show
         for _ in range(nsteps):
@@ -123,4 +152,41 @@ def test_stream_ordered_exchange_in_one_process(world, K, P, nsteps, sbytes):
         assert np.array_equal(gu, ref.u[1]), (world, rep)
         assert np.array_equal(gh, ref.h[1]), (world, rep)
         assert np.array_equal(gs, ref.ssh[1]), (world, rep)
+    cl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,K,flags,direct", [(2, 60, 3, True), (4, 60, 0, True), (3, 60, 1, False), (8, 60, 3, True), (3, 1, 7, True),
+                                                  (4, 1, 0, False), (5, 34, 2, True), (4, 7, 3, True)])
+def test_forward_euler_on_a_partitioned_mesh(world, K, flags, direct):
+    """The reference's live integrator (ocn_timestep(..., ForwardEuler), time_integration.jl:150-193) with its quirks
+    (stale layerThicknessEdge in the flux, accumulating relativeVorticity, level-1-only kernels when K = 1) on 2-8 ranks:
+    every field of Prog, Diag and Tend equals the single-domain oracle bit for bit.  Only the new time level is
+    exchanged: the carried layerThicknessEdge of every edge with an owned cell is computed where it is used."""
+    import oracle as orc
+    mesh = mg.icosahedral_mesh(20)
+    rng = np.random.default_rng(29 + world)
+    rest = np.full((mesh.nCells, K), 1000.0 / K) + rng.uniform(0, 0.1, (mesh.nCells, K))
+    h = rest + rng.uniform(-1, 1, (mesh.nCells, K))
+    u = rng.uniform(-1, 1, (mesh.nEdges, K))
+    ssh = h.sum(1) - rest.sum(1)
+    dt = 15.0
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    ref = orc.OracleState(om, ssh, u, h)
+    cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, world, direct=direct)
+    cl.exchange_state()
+    for step in range(5):
+        cl.step_fe(flags)
+        ref.step_fe(dt, flags)
+        gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
+        assert np.array_equal(gu, ref.u[1]) and np.array_equal(gh, ref.h[1]) and np.array_equal(gs, ref.ssh[1]), step
+    d = cl.gather_diagnostics(mesh, K)
+    for name, exp in (("hEdge", ref.hEdge), ("F", ref.F), ("div", ref.div), ("vort", ref.vort), ("tendU", ref.tendU),
+                      ("tendH", ref.tendH)):
+        assert np.array_equal(d[name], exp), name
+    # an RK4 step after Forward-Euler steps (and back) keeps the ranks' buffer sets aligned
+    cl.step_rk4(); ref.step_rk4(dt)
+    cl.step_fe(flags); ref.step_fe(dt, flags)
+    gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
+    assert np.array_equal(gu, ref.u[1]) and np.array_equal(gh, ref.h[1]) and np.array_equal(gs, ref.ssh[1])
     cl.close()
