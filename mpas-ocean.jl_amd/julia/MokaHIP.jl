@@ -1,17 +1,31 @@
 # MokaHIP.jl -- Julia shim that puts libmoka_hip.so behind MOKA.jl's own interface.
 #
-# NOT EXECUTED IN THIS PIPELINE (no Julia toolchain on either box).  It documents, method by method,
-# the binding a MOKA.jl maintainer adds so that src/driver/mpas_ocean.jl runs unchanged except for
-# its backend line (`backend = MokaHIP.Backend()` instead of `CUDABackend()`, mpas_ocean.jl:28).
-# The Python mirror mpas-ocean.jl_amd/moka_hip/api.py makes the same calls in the same order and is
-# what the tests exercise.
+# STATUS: written against the reference sources, NEVER EXECUTED (no Julia toolchain on either box of this pipeline).
+# mpas-ocean.jl_amd/moka_hip/shim.py is a line-by-line Python transliteration of the logic below (lazy arrays, binding at
+# the first device call, version-stamped host copies) and tests/test_gpu_parity.py::test_driver_in_the_reference_constructor_order
+# replays src/driver/mpas_ocean.jl:20-53 through it on the GPU; INTEGRATION.md lists, per driver line, the method that
+# catches it.  The only line of the driver that changes is `backend = CUDABackend()` (mpas_ocean.jl:28) ->
+# `backend = MokaHIP.Backend()`.
 #
-# Design: arrays stay plain host `Array`s on the Julia side (so OutPut.jl, the tests' norms, etc. keep
-# working); the device copy lives in a moka_state owned by the library.  `MArray` is a thin
-# AbstractArray whose getindex/copyto! download lazily and whose setindex!/copyto! upload.
+# How the reference's own constructors end up on the library without being touched:
+#   * every array the reference puts "on the backend" -- Adapt.adapt(backend, a) (HorzMesh.jl:354-398,
+#     PrognosticVars.jl:101-104, TendencyVars.jl:66), KA.zeros(backend, T, dims...) (DiagnosticVars.jl:90-93,
+#     TendencyVars.jl:62, mpas_ocean.jl:36), KA.ones (VertMesh.jl:32-33) -- becomes an `MArray`: a host Array plus an
+#     optional binding to a field of a device state.  Unbound, it behaves like the Array it wraps (the mesh arrays and
+#     the 1-element `timestep` stay that way for ever).
+#   * the inner constructors' checks (Architectures.jl:19-46: same type name, same backend, same eltype) hold for MArrays;
+#     `deepcopy` per time level (PrognosticVars.jl:50-54) copies the host data of a still unbound array.
+#   * the first call that needs the device (ocn_timestep, diagnostic_compute!, compute...Tendency!) BINDS: the device
+#     mesh is created from the MArrays of `Setup.mesh` (moka_mesh_create), one moka_state is created, the host data of
+#     Prog's arrays is uploaded, and every array of Prog / Diag / Tend gets (state, field id, time level).  From then on
+#     the device holds the truth; reading a bound array downloads it ONCE per device change (version stamp), scalar
+#     writes are collected on the host and uploaded before the next device call.
+#   * Adapt.adapt_structure(KA.CPU(), x) of write_netcdf (OutPut.jl:122-124) reaches Adapt.adapt_storage(::KA.CPU, ::MArray)
+#     = a plain Array with the current device contents.
 module MokaHIP
 
 import Adapt
+import Dates
 import KernelAbstractions as KA
 using MOKA
 using MOKA: Mesh, HorzMesh, VerticalMesh, PrognosticVars, DiagnosticVars, TendencyVars, ModelSetup,
@@ -20,15 +34,33 @@ using MOKA: Mesh, HorzMesh, VerticalMesh, PrognosticVars, DiagnosticVars, Tenden
 const lib = joinpath(@__DIR__, "..", "libmoka_hip.so")
 
 # ---- backend tag -------------------------------------------------------------------------------
-mutable struct Backend <: KA.Backend
+# A GPU backend for KernelAbstractions' purposes (`typeof(backend) <: KA.GPU`, mpas_ocean.jl:49).  The context is
+# reference-counted on the Julia side: finalizers run in no particular order, and moka_state_destroy / moka_mesh_destroy /
+# moka_tape_destroy dereference the context, so it is destroyed only when the tag AND everything created on it are gone.
+mutable struct Backend <: KA.GPU
     ctx::Ptr{Cvoid}
+    refs::Int                      # live meshes / states / tapes
+    dead::Bool                     # the tag itself has been finalized
     function Backend(device::Integer = 0)
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:moka_ctx_create, lib), Cint, (Cint, Ref{Ptr{Cvoid}}), device, ref), C_NULL)
-        b = new(ref[])
-        finalizer(x -> ccall((:moka_ctx_destroy, lib), Cvoid, (Ptr{Cvoid},), x.ctx), b)
+        b = new(ref[], 0, false)
+        finalizer(b) do x
+            x.dead = true
+            x.refs == 0 && destroy_ctx!(x)
+        end
         b
     end
+end
+function destroy_ctx!(b::Backend)
+    b.ctx == C_NULL && return
+    ccall((:moka_ctx_destroy, lib), Cvoid, (Ptr{Cvoid},), b.ctx)
+    b.ctx = C_NULL
+end
+retain!(b::Backend) = (b.refs += 1; b)
+function release!(b::Backend)
+    b.refs -= 1
+    b.dead && b.refs == 0 && destroy_ctx!(b)
 end
 
 function check(rc::Cint, ctx)
@@ -39,7 +71,75 @@ end
 
 KA.synchronize(b::Backend) = check(ccall((:moka_sync, lib), Cint, (Ptr{Cvoid},), b.ctx), b.ctx)
 
-# ---- mesh: Adapt.adapt_structure(backend, ::Mesh)  (MPASMesh.jl:26) ------------------------------
+# ---- arrays "on the backend" ----------------------------------------------------------------------
+# field ids of include/moka_hip.h (moka_field)
+const F_SSH, F_U, F_H, F_HEDGE, F_FLUX, F_DIV, F_VORT, F_TENDU, F_TENDH = Int32.(0:8)
+
+mutable struct State                   # one moka_state behind Prog / Diag / Tend of a model
+    handle::Ptr{Cvoid}
+    mesh                               # DeviceMesh (keeps it alive)
+    backend::Backend
+    version::Int                       # bumped by every call that changes device fields
+    bound::Vector{WeakRef}             # the MArrays bound to this state (to flush pending host writes)
+end
+
+mutable struct MArray{T,N} <: AbstractArray{T,N}
+    host::Array{T,N}
+    backend::Backend
+    state::Union{Nothing,State}        # nothing = unbound: `host` is the data
+    field::Int32
+    level::Int32
+    host_version::Int                  # state.version the host copy corresponds to (-1 = never downloaded)
+    host_dirty::Bool                   # host copy carries writes the device has not seen
+end
+MArray(a::Array{T,N}, b::Backend) where {T,N} = MArray{T,N}(a, b, nothing, Int32(-1), Int32(0), -1, false)
+
+Base.size(a::MArray) = size(a.host)
+Base.IndexStyle(::Type{<:MArray}) = IndexLinear()
+KA.get_backend(a::MArray) = a.backend                                   # Architectures.jl:33; mpas_ocean.jl:48
+Base.similar(a::MArray, ::Type{T}, dims::Dims) where {T} = MArray(Array{T}(undef, dims), a.backend)
+# deepcopy of a still unbound array copies the host data (PrognosticVars.jl:50-54); a bound one is read back first
+function Base.deepcopy_internal(a::MArray{T,N}, d::IdDict) where {T,N}
+    haskey(d, a) && return d[a]
+    c = MArray(copy(Array(a)), a.backend)
+    d[a] = c
+    c
+end
+
+"bring the host copy of a bound array up to date (one download per device change, not one per element)"
+function sync_host!(a::MArray{Float64})
+    s = a.state
+    (s === nothing || a.host_dirty || a.host_version == s.version) && return a
+    check(ccall((:moka_state_download, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}), s.handle, a.field, a.level, a.host), s.backend.ctx)
+    a.host_version = s.version
+    a
+end
+sync_host!(a::MArray) = a                                               # Int32 mesh arrays are never bound
+Base.Array(a::MArray) = copy(sync_host!(a).host)
+Base.getindex(a::MArray, i::Int) = sync_host!(a).host[i]                # @allowscalar-style access: correct and cheap
+function Base.setindex!(a::MArray, v, i::Int)                           # e.g. `@allowscalar timestep[1] = dt` (mpas_ocean.jl:37)
+    sync_host!(a).host[i] = v
+    a.state === nothing || (a.host_dirty = true)
+    a
+end
+function Base.copyto!(a::MArray{T,N}, src::Array{T,N}) where {T,N}
+    copyto!(a.host, src)
+    a.state === nothing || (a.host_dirty = true)
+    a
+end
+Base.copyto!(dst::Array{T,N}, a::MArray{T,N}) where {T,N} = copyto!(dst, sync_host!(a).host)   # mycopyto!(sumCPU, sumGPU)
+
+# Adapt / KernelAbstractions entry points the reference's constructors use
+Adapt.adapt_storage(b::Backend, a::Array) = MArray(copy(a), b)          # on_architecture (Architectures.jl:12)
+Adapt.adapt_storage(::Backend, a::MArray) = a
+Adapt.adapt_storage(::KA.CPU, a::MArray) = Array(a)                     # write_netcdf (OutPut.jl:122-124)
+KA.allocate(b::Backend, ::Type{T}, dims::Tuple) where {T} = MArray(Array{T}(undef, dims), b)
+KA.zeros(b::Backend, ::Type{T}, dims::Tuple) where {T} = MArray(zeros(T, dims), b)   # DiagnosticVars.jl:90-93, mpas_ocean.jl:36
+KA.ones(b::Backend, ::Type{T}, dims::Tuple) where {T} = MArray(ones(T, dims), b)     # VertMesh.jl:32-33
+KA.zeros(b::Backend, ::Type{T}, dims::Integer...) where {T} = KA.zeros(b, T, Tuple(dims))
+KA.ones(b::Backend, ::Type{T}, dims::Integer...) where {T} = KA.ones(b, T, Tuple(dims))
+
+# ---- mesh: built from the MArrays of the reference's Mesh at binding time ---------------------------
 # mirrors `struct moka_mesh_desc` of include/moka_hip.h field by field (isbits, C layout)
 struct MeshDesc
     nCells::Int32; nEdges::Int32; nVertices::Int32
@@ -52,151 +152,229 @@ struct MeshDesc
     edgesOnVertex::Ptr{Int32}; cellsOnVertex::Ptr{Int32}; edgeSignOnVertex::Ptr{Int32}; areaTriangle::Ptr{Float64}
     maxLevelEdgeTop::Ptr{Int32}; restingThicknessSum::Ptr{Float64}
     ordering::Int32; patch_cells::Int32
-    cellClass::Ptr{Int32}          # C_NULL on one GPU; 0/1/2 per local cell in the multi-GPU layer
+    cellClass::Ptr{Int32}          # C_NULL on one GPU; 0 / 1 / 2 + neighbour index per local cell in the multi-GPU layer
     stateBytes::Int32              # 0/8 = Float64 state (the reference); 4 = fp32 storage, fp64 arithmetic (RK4 only)
     kiteAreasOnVertex::Ptr{Float64}; fVertex::Ptr{Float64}   # C_NULL unless the optional nonlinear terms are wanted
 end
 
-struct DeviceMesh{HM,VM}           # what Adapt returns: the host Mesh plus the library handle
-    host::Mesh{HM,VM}
+mutable struct DeviceMesh
     handle::Ptr{Cvoid}
     backend::Backend
 end
+const MESHES = IdDict{Any,DeviceMesh}()          # reference Mesh object -> its device mesh (weak in spirit: cleared by close!)
 
-function Adapt.adapt_structure(b::Backend, m::Mesh)
+hostof(a::MArray) = a.host
+hostof(a::Array) = a
+
+"moka_mesh_create from the arrays the reference's Mesh holds (Adapt.adapt_structure(backend, ::Mesh), MPASMesh.jl:26)"
+function device_mesh(m::Mesh, b::Backend)
+    haskey(MESHES, m) && return MESHES[m]
     C, D, E, V = m.HorzMesh.PrimaryCells, m.HorzMesh.DualCells, m.HorzMesh.Edges, m.VertMesh
-    rsum = vec(Array(V.restingThicknessSum))                      # (1,nC) or (nC): indexed linearly (SURVEY N5)
-    GC.@preserve C D E V rsum begin
-        d = MeshDesc(C.nCells, E.nEdges, D.nVertices, C.maxEdges, size(E.edgesOnEdge, 1), D.vertexDegree,
-                     V.nVertLevels, size(D.edgeSignOnVertex, 1),
-                     pointer(C.xᶜ), pointer(C.yᶜ), pointer(C.zᶜ),
-                     pointer(C.nEdgesOnCell), pointer(C.edgesOnCell), pointer(C.edgeSignOnCell), pointer(C.areaCell),
-                     pointer(E.cellsOnEdge), pointer(E.verticesOnEdge), pointer(E.nEdgesOnEdge), pointer(E.edgesOnEdge),
-                     pointer(E.weightsOnEdge), pointer(E.dvEdge), pointer(E.dcEdge), pointer(E.fᵉ),
-                     pointer(D.edgesOnVertex), pointer(D.cellsOnVertex), pointer(D.edgeSignOnVertex), pointer(D.areaTriangle),
-                     pointer(V.maxLevelEdge.Top), pointer(rsum), 0, 0, C_NULL, 0, C_NULL, C_NULL)
+    rsum = vec(copy(hostof(V.restingThicknessSum)))               # (1,nC) or (nC): indexed linearly (SURVEY N5)
+    arrs = map(hostof, (C.xᶜ, C.yᶜ, C.zᶜ, C.nEdgesOnCell, C.edgesOnCell, C.edgeSignOnCell, C.areaCell,
+                        E.cellsOnEdge, E.verticesOnEdge, E.nEdgesOnEdge, E.edgesOnEdge, E.weightsOnEdge, E.dvEdge, E.dcEdge, E.fᵉ,
+                        D.edgesOnVertex, D.cellsOnVertex, D.edgeSignOnVertex, D.areaTriangle, V.maxLevelEdge.Top))
+    GC.@preserve arrs rsum begin
+        d = MeshDesc(C.nCells, E.nEdges, D.nVertices, C.maxEdges, size(arrs[11], 1), D.vertexDegree,
+                     V.nVertLevels, size(arrs[18], 1),
+                     pointer(arrs[1]), pointer(arrs[2]), pointer(arrs[3]),
+                     pointer(arrs[4]), pointer(arrs[5]), pointer(arrs[6]), pointer(arrs[7]),
+                     pointer(arrs[8]), pointer(arrs[9]), pointer(arrs[10]), pointer(arrs[11]),
+                     pointer(arrs[12]), pointer(arrs[13]), pointer(arrs[14]), pointer(arrs[15]),
+                     pointer(arrs[16]), pointer(arrs[17]), pointer(arrs[18]), pointer(arrs[19]),
+                     pointer(arrs[20]), pointer(rsum), 0, 0, C_NULL, 0, C_NULL, C_NULL)
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:moka_mesh_create, lib), Cint, (Ptr{Cvoid}, Ref{MeshDesc}, Ref{Ptr{Cvoid}}), b.ctx, d, ref), b.ctx)
-        return DeviceMesh(m, ref[], b)
+        dm = DeviceMesh(ref[], retain!(b))
+        finalizer(dm) do x
+            ccall((:moka_mesh_destroy, lib), Cvoid, (Ptr{Cvoid},), x.handle)
+            release!(x.backend)
+        end
+        MESHES[m] = dm
+        return dm
     end
 end
 
-# ---- operators (Operators.jl:46,102,151,179): host arrays in/out, synchronous -------------------
-function MOKA.GradientOnEdge!(grad::Matrix{Float64}, h::Matrix{Float64}, m::DeviceMesh; backend = m.backend, workgroupsize = 64)
-    check(ccall((:moka_gradient_on_edge, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), m.handle, h, grad), m.backend.ctx)
+# ---- operators (Operators.jl:46,102,151,179): arrays on the backend in/out, synchronous -----------------
+# called by test/ocn/test_Operators.jl:47,67,85 with arrays adapted to the backend: unbound MArrays, i.e. host data
+function MOKA.GradientOnEdge!(grad::MArray{Float64,2}, h::MArray{Float64,2}, m::Mesh; backend = grad.backend, workgroupsize = 64)
+    dm = device_mesh(m, backend)
+    check(ccall((:moka_gradient_on_edge, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dm.handle, sync_host!(h).host, grad.host), backend.ctx)
 end
-function MOKA.DivergenceOnCell!(div::Matrix{Float64}, V::Matrix{Float64}, temp::Matrix{Float64}, m::DeviceMesh; backend = m.backend, nthreads = 50)
-    check(ccall((:moka_divergence_on_cell, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), m.handle, V, temp, div), m.backend.ctx)
+function MOKA.DivergenceOnCell!(div::MArray{Float64,2}, V::MArray{Float64,2}, temp::MArray{Float64,2}, m::Mesh; backend = div.backend, nthreads = 50)
+    dm = device_mesh(m, backend)
+    check(ccall((:moka_divergence_on_cell, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), dm.handle, sync_host!(V).host, temp.host, div.host), backend.ctx)
 end
-function MOKA.CurlOnVertex!(curl::Matrix{Float64}, V::Matrix{Float64}, m::DeviceMesh; backend = m.backend)
-    check(ccall((:moka_curl_on_vertex, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), m.handle, V, curl), m.backend.ctx)
+function MOKA.CurlOnVertex!(curl::MArray{Float64,2}, V::MArray{Float64,2}, m::Mesh; backend = curl.backend)
+    dm = device_mesh(m, backend)
+    check(ccall((:moka_curl_on_vertex, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dm.handle, sync_host!(V).host, sync_host!(curl).host), backend.ctx)
 end
-function MOKA.interpolateCell2Edge!(e::Matrix{Float64}, c::Matrix{Float64}, m::DeviceMesh; backend = m.backend)
-    check(ccall((:moka_interpolate_cell2edge, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint), m.handle, c, e, 1), m.backend.ctx)
+function MOKA.interpolateCell2Edge!(e::MArray{Float64,2}, c::MArray{Float64,2}, m::Mesh; backend = e.backend)
+    dm = device_mesh(m, backend)
+    check(ccall((:moka_interpolate_cell2edge, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint), dm.handle, sync_host!(c).host, sync_host!(e).host, 1), backend.ctx)
 end
 
-# ---- state: one moka_state behind Prog / Diag / Tend ---------------------------------------------
-mutable struct State
-    handle::Ptr{Cvoid}
-    mesh::DeviceMesh
+# ---- binding Prog / Diag / Tend to one device state ---------------------------------------------------
+const MProg = PrognosticVars{<:Any,<:MArray}          # the reference's struct, parametrised by our array type
+const MDiag = DiagnosticVars{<:Any,<:MArray}
+const MTend = TendencyVars{<:Any,<:MArray}
+
+function bind!(a::MArray{Float64}, s::State, field, level; upload::Bool)
+    a.state === s && return
+    a.state === nothing || error("MokaHIP: array is already bound to another model state")
+    if upload
+        check(ccall((:moka_state_upload, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}), s.handle, field, level, a.host), s.backend.ctx)
+    end
+    a.state, a.field, a.level = s, Int32(field), Int32(level)
+    a.host_version, a.host_dirty = upload ? s.version : -1, false
+    push!(s.bound, WeakRef(a))
 end
-function State(m::DeviceMesh)
-    ref = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:moka_state_create, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), m.backend.ctx, m.handle, ref), m.backend.ctx)
-    s = State(ref[], m)
-    finalizer(x -> ccall((:moka_state_destroy, lib), Cvoid, (Ptr{Cvoid},), x.handle), s)
+
+"the state behind Prog (created and filled at the first device call); Diag / Tend join it"
+function state_of(Prog::MProg, Diag, Tend, S::ModelSetup, b::Backend)
+    s = Prog.ssh[end].state
+    if s === nothing
+        dm = device_mesh(S.mesh, b)
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:moka_state_create, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), b.ctx, dm.handle, ref), b.ctx)
+        s = State(ref[], dm, retain!(b), 0, WeakRef[])
+        finalizer(s) do x
+            ccall((:moka_state_destroy, lib), Cvoid, (Ptr{Cvoid},), x.handle)
+            release!(x.backend)
+        end
+        length(Prog.ssh) == 2 || error("nTimeLevels must be <= 2")           # time_integration.jl:23
+        for t in 1:2                                                           # Julia index 1 = previous = level 0, end = current = 1
+            bind!(Prog.ssh[t], s, F_SSH, t - 1; upload = true)
+            bind!(Prog.normalVelocity[t], s, F_U, t - 1; upload = true)
+            bind!(Prog.layerThickness[t], s, F_H, t - 1; upload = true)
+        end
+    end
+    if Diag !== nothing && Diag.layerThicknessEdge.state === nothing         # KA.zeros on the host == zero-initialised device fields
+        for (a, f) in ((Diag.layerThicknessEdge, F_HEDGE), (Diag.thicknessFlux, F_FLUX), (Diag.velocityDivCell, F_DIV), (Diag.relativeVorticity, F_VORT))
+            bind!(a, s, f, 1; upload = true)
+        end
+    end
+    if Tend !== nothing && Tend.tendNormalVelocity.state === nothing
+        bind!(Tend.tendNormalVelocity, s, F_TENDU, 1; upload = true)
+        bind!(Tend.tendLayerThickness, s, F_TENDH, 1; upload = true)
+    end
+    flush_host_writes!(s)
     s
 end
 
-# field ids of include/moka_hip.h (moka_field)
-const F_SSH, F_U, F_H, F_HEDGE, F_FLUX, F_DIV, F_VORT, F_TENDU, F_TENDH = Int32.(0:8)
-
-"Device-backed array: Adapt.adapt(KA.CPU(), a) downloads (OutPut.jl:122-124), copyto!(a, host) uploads."
-struct MArray{N} <: AbstractArray{Float64,N}
-    state::State; field::Int32; level::Int32; dims::NTuple{N,Int}
+"upload what the host changed through setindex! / copyto! since the last device call"
+function flush_host_writes!(s::State)
+    for w in s.bound
+        a = w.value
+        (a === nothing || !a.host_dirty) && continue
+        check(ccall((:moka_state_upload, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}), s.handle, a.field, a.level, a.host), s.backend.ctx)
+        a.host_dirty = false
+        a.host_version = s.version
+    end
 end
-Base.size(a::MArray) = a.dims
-function Base.Array(a::MArray{N}) where {N}
-    out = Array{Float64,N}(undef, a.dims)
-    check(ccall((:moka_state_download, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}), a.state.handle, a.field, a.level, out), a.state.mesh.backend.ctx)
-    out
-end
-Base.getindex(a::MArray, i...) = Array(a)[i...]                 # scalar indexing = @allowscalar: correct, slow
-function Base.copyto!(a::MArray, src::Array{Float64})
-    check(ccall((:moka_state_upload, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}), a.state.handle, a.field, a.level, src), a.state.mesh.backend.ctx)
-    a
-end
-Adapt.adapt_storage(::KA.CPU, a::MArray) = Array(a)
-KA.get_backend(a::MArray) = a.state.mesh.backend                 # mpas_ocean.jl:48
-
-# PrognosticVars(Config, Mesh; backend) (PrognosticVars.jl:59): read on the host as the reference does,
-# then Adapt.adapt(backend, ...) becomes "create state + upload into both time levels".
-function device_state(ssh::Vector{Float64}, u::Matrix{Float64}, h::Matrix{Float64}, m::DeviceMesh)
-    s = State(m); K, nE = size(u); nC = length(ssh); nV = m.host.HorzMesh.DualCells.nVertices
-    mk(f, lev, dims) = MArray{length(dims)}(s, f, Int32(lev), dims)
-    sshv = [mk(F_SSH, t, (nC,)) for t in 0:1]; uv = [mk(F_U, t, (K, nE)) for t in 0:1]; hv = [mk(F_H, t, (K, nC)) for t in 0:1]
-    for t in 1:2; copyto!(sshv[t], ssh); copyto!(uv[t], u); copyto!(hv[t], h); end
-    Prog = (ssh = sshv, normalVelocity = uv, layerThickness = hv, state = s)
-    Diag = (layerThicknessEdge = mk(F_HEDGE, 1, (K, nE)), thicknessFlux = mk(F_FLUX, 1, (K, nE)),
-            velocityDivCell = mk(F_DIV, 1, (K, nC)), relativeVorticity = mk(F_VORT, 1, (K, nV)), state = s)
-    Tend = (tendNormalVelocity = mk(F_TENDU, 1, (K, nE)), tendLayerThickness = mk(F_TENDH, 1, (K, nC)), state = s)
-    return Prog, Diag, Tend
-end
+device_changed!(s::State) = (s.version += 1; nothing)
 
 # ---- forward model --------------------------------------------------------------------------------
-const REFERENCE_COMPAT = Int32(7)        # MOKA_FE_STALE_HEDGE | ACCUM_VORT | LEVEL1_ONLY
+const REFERENCE_COMPAT = Int32(7)        # MOKA_FE_STALE_HEDGE | ACCUM_VORT | LEVEL1_ONLY: the live reference step, quirks included
 
 # ocn_timestep(timestep, Prog, Diag, Tend, S, ForwardEuler; backend)   time_integration.jl:150
-function MOKA.ocn_timestep(timestep, Prog, Diag, Tend, S::ModelSetup, ::Type{ForwardEuler}; backend::Backend)
-    dt = Array(timestep)[1]              # the reference's 1-element device array (mpas_ocean.jl:36-37)
-    check(ccall((:moka_step_fe, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint), Prog.state.handle, dt, REFERENCE_COMPAT), backend.ctx)
+# More specific than the reference's method in the Prog / Diag / Tend array type, so dispatch picks it for MArrays.
+function MOKA.ocn_timestep(timestep, Prog::MProg, Diag::MDiag, Tend::MTend, S::ModelSetup, ::Type{ForwardEuler}; backend = Prog.ssh[end].backend)
+    s = state_of(Prog, Diag, Tend, S, backend)
+    dt = Float64(timestep[1])             # the reference's 1-element array on the backend (mpas_ocean.jl:36-37): never bound
+    check(ccall((:moka_step_fe, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint), s.handle, dt, REFERENCE_COMPAT), backend.ctx)
+    device_changed!(s)
 end
-# ocn_timestep(Prog, Diag, Tend, S, RungeKutta4; backend)              time_integration.jl:61
-function MOKA.ocn_timestep(Prog, Diag, Tend, S::ModelSetup, ::Type{RungeKutta4}; backend::Backend)
-    dt = convert(Float64, Dates.value(Dates.Second(S.timeManager.timeStep)))
-    check(ccall((:moka_step_rk4, lib), Cint, (Ptr{Cvoid}, Cdouble), Prog.state.handle, dt), backend.ctx)
+# ocn_timestep(Prog, Diag, Tend, S, RungeKutta4; backend)              time_integration.jl:61 (dead code there: the spec)
+function MOKA.ocn_timestep(Prog::MProg, Diag::MDiag, Tend::MTend, S::ModelSetup, ::Type{RungeKutta4}; backend = Prog.ssh[end].backend)
+    s = state_of(Prog, Diag, Tend, S, backend)
+    dt = convert(Float64, Dates.value(Dates.Second(S.timeManager.timeStep)))   # :75
+    check(ccall((:moka_step_rk4, lib), Cint, (Ptr{Cvoid}, Cdouble), s.handle, dt), backend.ctx)
+    device_changed!(s)
 end
 # diagnostic_compute!(Mesh, Diag, Prog; backend)                       DiagnosticVars.jl:108
-MOKA.diagnostic_compute!(m::DeviceMesh, Diag, Prog; backend::Backend) =
-    check(ccall((:moka_diagnostic_compute, lib), Cint, (Ptr{Cvoid}, Cint), Prog.state.handle, REFERENCE_COMPAT), backend.ctx)
-# computeNormalVelocityTendency! / computeLayerThicknessTendency!      normalVelocity.jl:21, layerThickness.jl:14
-MOKA.computeNormalVelocityTendency!(Tend, Prog, Diag, m::DeviceMesh, Config; backend::Backend) =
-    check(ccall((:moka_compute_normal_velocity_tendency, lib), Cint, (Ptr{Cvoid}, Cint), Prog.state.handle, REFERENCE_COMPAT), backend.ctx)
-MOKA.computeLayerThicknessTendency!(Tend, Prog, Diag, m::DeviceMesh, Config; backend::Backend) =
-    check(ccall((:moka_compute_layer_thickness_tendency, lib), Cint, (Ptr{Cvoid}, Cint), Prog.state.handle, REFERENCE_COMPAT), backend.ctx)
-# sumArray + mycopyto! of ocn_run_loop(sumCPU, sumGPU, ...)            run_loop.jl:39-43
-function sum_sq_ssh(Prog)
-    out = Ref{Float64}(0.0)
-    check(ccall((:moka_sum_sq, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Float64}), Prog.state.handle, F_SSH, 1, out), Prog.state.mesh.backend.ctx)
-    out[]
+function MOKA.diagnostic_compute!(m::Mesh, Diag::MDiag, Prog::MProg; backend = Prog.ssh[end].backend)
+    s = state_of(Prog, Diag, nothing, ModelSetup(nothing, m, nothing), backend)
+    check(ccall((:moka_diagnostic_compute, lib), Cint, (Ptr{Cvoid}, Cint), s.handle, REFERENCE_COMPAT), backend.ctx)
+    device_changed!(s)
 end
-# ocn_run_loop itself (run_loop.jl:8-22) needs no change: it only calls advance!, ocn_timestep, isRinging, reset!.
+# computeNormalVelocityTendency! / computeLayerThicknessTendency!      normalVelocity.jl:21, layerThickness.jl:14
+function MOKA.computeNormalVelocityTendency!(Tend::MTend, Prog::MProg, Diag::MDiag, m::Mesh, Config; backend = Prog.ssh[end].backend)
+    s = state_of(Prog, Diag, Tend, ModelSetup(Config, m, nothing), backend)
+    check(ccall((:moka_compute_normal_velocity_tendency, lib), Cint, (Ptr{Cvoid}, Cint), s.handle, REFERENCE_COMPAT), backend.ctx)
+    device_changed!(s)
+end
+function MOKA.computeLayerThicknessTendency!(Tend::MTend, Prog::MProg, Diag::MDiag, m::Mesh, Config; backend = Prog.ssh[end].backend)
+    s = state_of(Prog, Diag, Tend, ModelSetup(Config, m, nothing), backend)
+    check(ccall((:moka_compute_layer_thickness_tendency, lib), Cint, (Ptr{Cvoid}, Cint), s.handle, REFERENCE_COMPAT), backend.ctx)
+    device_changed!(s)
+end
+# advanceTimeLevels!(Prog; backend)                                    time_integration.jl:10
+function MOKA.advanceTimeLevels!(Prog::MProg; backend = Prog.ssh[end].backend)
+    s = Prog.ssh[end].state
+    s === nothing && return (copyto!(Prog.ssh[1].host, Prog.ssh[2].host); copyto!(Prog.normalVelocity[1].host, Prog.normalVelocity[2].host);
+                             copyto!(Prog.layerThickness[1].host, Prog.layerThickness[2].host); nothing)
+    flush_host_writes!(s)
+    check(ccall((:moka_advance_time_levels, lib), Cint, (Ptr{Cvoid}, Cint), s.handle, 0), backend.ctx)
+    device_changed!(s)
+end
+# ocn_run_loop (run_loop.jl:8-22) needs no method: it only calls advance!, ocn_timestep, isRinging, reset!.
+# Its (sumCPU, sumGPU, ...) form (run_loop.jl:26-45) launches the one-thread KA kernel sumArray on the backend: here the
+# same strictly serial sum is a library call, placed where the reference puts it.
+function MOKA.ocn_run_loop(sumCPU, sumGPU::MArray, timestep, Prog::MProg, Diag::MDiag, Tend::MTend, Setup, ::Type{ForwardEuler},
+                           clock, simulationAlarm, outputAlarm; backend = Prog.ssh[end].backend)
+    MOKA.ocn_run_loop(timestep, Prog, Diag, Tend, Setup, ForwardEuler, clock, simulationAlarm, outputAlarm; backend = backend)
+    s = state_of(Prog, Diag, Tend, Setup, backend)
+    out = Ref{Float64}(0.0)
+    check(ccall((:moka_sum_sq, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Float64}), s.handle, F_SSH, 1, out), backend.ctx)
+    sumGPU[1] = sumGPU[1] + out[]              # sumGPU[1] = sumGPU[1] + array[j]^2 ... (run_loop.jl:47-51)
+    MOKA.mycopyto!(sumCPU, sumGPU)
+    return sumCPU[1]
+end
 
 # ---- beyond the reference's GPU path (all optional) ------------------------------------------------
 # nonlinear terms (potential-vorticity Coriolis + kinetic-energy gradient); the mesh descriptor must carry
 # kiteAreasOnVertex / fVertex.  Off by default: the reference has only the linear terms.
-set_nonlinear!(Prog, on::Bool = true) =
-    check(ccall((:moka_set_nonlinear, lib), Cint, (Ptr{Cvoid}, Cint), Prog.state.handle, on ? 1 : 0), Prog.state.mesh.backend.ctx)
+function set_nonlinear!(Prog::MProg, on::Bool = true)
+    s = Prog.ssh[end].state
+    s === nothing && error("MokaHIP: take one step (or call diagnostic_compute!) first: the model is not on the device yet")
+    check(ccall((:moka_set_nonlinear, lib), Cint, (Ptr{Cvoid}, Cint), s.handle, on ? 1 : 0), s.backend.ctx)
+end
 # Del2 momentum mixing on top of them (what horizontal_momentum_mixing.jl:53-80 sketches); 0 = off
-set_viscosity_del2!(Prog, viscDel2::Float64) =
-    check(ccall((:moka_set_viscosity_del2, lib), Cint, (Ptr{Cvoid}, Cdouble), Prog.state.handle, viscDel2), Prog.state.mesh.backend.ctx)
+function set_viscosity_del2!(Prog::MProg, viscDel2::Float64)
+    s = Prog.ssh[end].state
+    s === nothing && error("MokaHIP: the model is not on the device yet")
+    check(ccall((:moka_set_viscosity_del2, lib), Cint, (Ptr{Cvoid}, Cdouble), s.handle, viscDel2), s.backend.ctx)
+end
 
-# reverse mode: what an EnzymeRules rule for ocn_run_loop on this backend calls (ext/MPASEnzymeExt.jl registers such
-# rules for mycopyto! already, :13-38).  d sum(ssh^2) / d initial state, test/enzyme/test_Enzyme_end2end.jl.
-mutable struct Tape; handle::Ptr{Cvoid}; state::State; end
-function Tape(Prog, capacity::Integer)
+# reverse mode: the hand-written adjoint of the step loop (what Enzyme differentiates in the reference:
+# test/enzyme/test_Enzyme_end2end.jl).  MokaHIPEnzymeExt.jl registers it as the EnzymeRules rule of ocn_run_loop.
+mutable struct Tape
+    handle::Ptr{Cvoid}
+    state::State
+end
+function Tape(s::State, capacity::Integer)
     ref = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:moka_tape_create, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), Prog.state.handle, capacity, ref), Prog.state.mesh.backend.ctx)
-    t = Tape(ref[], Prog.state)
-    finalizer(x -> ccall((:moka_tape_destroy, lib), Cvoid, (Ptr{Cvoid},), x.handle), t)
+    check(ccall((:moka_tape_create, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), s.handle, capacity, ref), s.backend.ctx)
+    t = Tape(ref[], s)                 # holds the state (hence mesh and context count) alive
+    retain!(s.backend)
+    finalizer(t) do x
+        ccall((:moka_tape_destroy, lib), Cvoid, (Ptr{Cvoid},), x.handle)
+        release!(x.state.backend)
+    end
     t
 end
-step_fe!(t::Tape, dt; flags = REFERENCE_COMPAT) =
-    check(ccall((:moka_step_fe_taped, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint), t.handle, dt, flags), t.state.mesh.backend.ctx)
-step_rk4!(t::Tape, dt) =
-    check(ccall((:moka_step_rk4_taped, lib), Cint, (Ptr{Cvoid}, Cdouble), t.handle, dt), t.state.mesh.backend.ctx)
-function gradient!(t::Tape, d_ssh::Vector{Float64}, d_u::Matrix{Float64}, d_h::Matrix{Float64})   # d_Prog of the reference test
-    ctx = t.state.mesh.backend.ctx
+function step_fe!(t::Tape, dt; flags = REFERENCE_COMPAT)
+    check(ccall((:moka_step_fe_taped, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint), t.handle, dt, flags), t.state.backend.ctx)
+    device_changed!(t.state)
+end
+function step_rk4!(t::Tape, dt)
+    check(ccall((:moka_step_rk4_taped, lib), Cint, (Ptr{Cvoid}, Cdouble), t.handle, dt), t.state.backend.ctx)
+    device_changed!(t.state)
+end
+"d sum(ssh^2) / d (initial ssh, normalVelocity, layerThickness) into host arrays: `d_Prog` of the reference test"
+function gradient!(t::Tape, d_ssh::Vector{Float64}, d_u::Matrix{Float64}, d_h::Matrix{Float64})
+    ctx = t.state.backend.ctx
     check(ccall((:moka_adjoint_seed_sum_sq_ssh, lib), Cint, (Ptr{Cvoid},), t.handle), ctx)
     check(ccall((:moka_adjoint_sweep, lib), Cint, (Ptr{Cvoid},), t.handle), ctx)
     for (f, a) in ((F_SSH, d_ssh), (F_U, d_u), (F_H, d_h))

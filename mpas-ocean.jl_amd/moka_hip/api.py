@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import datetime as _dt
 import math
+import weakref
 
 import numpy as np
 
@@ -50,6 +51,7 @@ class MokaHIP:
         self._h = C.c_void_p()
         L.check(L.lib().moka_ctx_create(int(device), C.byref(self._h)))
         self.device = device
+        _own(self, L.lib().moka_ctx_destroy, self._h)
 
     def synchronize(self):           # KA.synchronize(backend)
         L.check(L.lib().moka_sync(self._h), self._h)
@@ -77,14 +79,8 @@ class MokaHIP:
 
     def close(self):
         if self._h:
-            L.lib().moka_ctx_destroy(self._h)
+            _release(self, L.lib().moka_ctx_destroy, self._h)
             self._h = C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
 
 # ---------------------------------------------------------------------------------------------
@@ -145,6 +141,7 @@ class Mesh:
             desc, keep = L.make_desc(horz.data, vert.nVertLevels, vert.restingThicknessSum,
                                      vert.maxLevelEdge.Top, ordering, patch_cells, state_bytes=state_bytes)
             L.check(L.lib().moka_mesh_create(backend._h, C.byref(desc), C.byref(self._h)), backend._h)
+            _own(self, L.lib().moka_mesh_destroy, self._h, backend)
 
     def info(self) -> dict:
         inf = L.MeshInfo()
@@ -157,8 +154,27 @@ class Mesh:
 
     def close(self):
         if self._h:
-            L.lib().moka_mesh_destroy(self._h)
+            _release(self, L.lib().moka_mesh_destroy, self._h)
             self._h = C.c_void_p()
+
+
+def _own(obj, destroy, handle, *keep_alive):
+    """Destroy the library object when its Python owner is collected (or at interpreter exit), unless close() did it
+    first.  `keep_alive` are the owners of what the object lives on (state -> mesh -> backend): the finalizer holds them,
+    so the library objects go in dependency order."""
+    h = C.c_void_p(handle.value)
+
+    def fin(h=h, keep=keep_alive):
+        destroy(h)
+    obj._fin = weakref.finalize(obj, fin)
+
+
+def _release(obj, destroy, handle):
+    fin = getattr(obj, "_fin", None)
+    if fin is not None and fin.alive:
+        fin()                       # runs destroy exactly once
+    else:
+        destroy(handle)
 
 
 class ModelSetup:        # struct ModelSetup(config, mesh, timeManager)  (ModelSetup.jl:4)
@@ -220,10 +236,11 @@ class _State:
         self.mesh = mesh
         self._h = C.c_void_p()
         L.check(L.lib().moka_state_create(mesh.backend._h, mesh._h, C.byref(self._h)), mesh.backend._h)
+        _own(self, L.lib().moka_state_destroy, self._h, mesh, mesh.backend)
 
     def close(self):
         if self._h:
-            L.lib().moka_state_destroy(self._h)
+            _release(self, L.lib().moka_state_destroy, self._h)
             self._h = C.c_void_p()
 
 
@@ -425,6 +442,7 @@ class AdjointTape:
                         "layerThicknessEdge": (m.nEdges, K)}
         self._h = C.c_void_p()
         L.check(L.lib().moka_tape_create(self._state._h, int(capacity_steps), C.byref(self._h)), self._ctx)
+        _own(self, L.lib().moka_tape_destroy, self._h, self._state, self._state.mesh, self._state.mesh.backend)
 
     def step(self, timestep, flags: int = REFERENCE_COMPAT, method=None):
         """ocn_timestep(timestep, ..., ForwardEuler) -- or RungeKutta4 with method=RungeKutta4 -- with the step recorded.
@@ -452,7 +470,7 @@ class AdjointTape:
 
     def close(self):
         if self._h:
-            L.lib().moka_tape_destroy(self._h)
+            _release(self, L.lib().moka_tape_destroy, self._h)
             self._h = C.c_void_p()
 
 
@@ -525,13 +543,21 @@ def ocn_init(Config_filepath, backend=None, multilayer: bool = True, **layout):
     return Setup, Diag, Tend, Prog
 
 
-def write_netcdf(Setup: ModelSetup, Diag, Prog):
-    """write_netcdf(Setup, Diag, Prog) (OutPut.jl:117-215): the current time level to the `output` stream's file."""
+def write_netcdf(Setup: ModelSetup, Diag, Prog, reference_compat: bool = True):
+    """write_netcdf(Setup, Diag, Prog) (OutPut.jl:117-215) to the `output` stream's file.
+
+    reference_compat (default): the file holds what the reference's file holds -- the state ONE STEP BEHIND the final one.
+    write_netcdf first pulls everything to the CPU with Adapt.adapt_structure(KA.CPU(), Prog) (OutPut.jl:124), and that
+    method rebuilds the struct from the FIRST time level, `x.ssh[1]` etc. (PrognosticVars.jl:108-113), whose deep copies
+    fill every level; `Prog.ssh[end]` written at OutPut.jl:210-212 is therefore the previous time level, i.e. the state the
+    last ocn_timestep started from (advanceTimeLevels! copied it there, time_integration.jl:163).  A quirk of the
+    reference like those of SURVEY 0.6; reference_compat=False writes the current level."""
     out_fp = ConfigGet(ConfigGet(Setup.config.streams, "output"), "filename_template")
     clock, mesh = Setup.timeManager, Setup.mesh
+    lev = 0 if reference_compat else -1
     mpasio.write_output(out_fp, mesh.HorzMesh.data, mesh.VertMesh.nVertLevels, period_seconds(clock.timeStep),
-                        (clock.currTime - clock.startTime).total_seconds(), Prog.ssh[-1].get(),
-                        Prog.layerThickness[-1].get(), Prog.normalVelocity[-1].get())
+                        (clock.currTime - clock.startTime).total_seconds(), Prog.ssh[lev].get(),
+                        Prog.layerThickness[lev].get(), Prog.normalVelocity[lev].get())
     return out_fp
 
 

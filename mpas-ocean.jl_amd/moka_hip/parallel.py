@@ -12,6 +12,7 @@ import types
 
 import numpy as np
 
+from . import api
 from . import lib as L
 
 __all__ = ["partition_cells", "build_local", "LocalMesh", "DistributedModel"]
@@ -226,7 +227,6 @@ class DistributedModel:
         (default: torch.distributed.all_gather_object on `group`); LocalCluster passes None and calls finish() itself."""
         import torch
         import torch.distributed as dist
-        from . import api
         self.torch, self.dist = torch, dist
         self.rank, self.world, self.dt, self.backend, self.transport = rank, world, float(dt), backend, transport
         self.group = group                 # process group of the gloo transport / control messages (None = default group)
@@ -247,6 +247,7 @@ class DistributedModel:
         desc.cellsOnVertex = None
         desc.verticesOnEdge = None
         L.check(L.lib().moka_mesh_create(backend._h, C.byref(desc), C.byref(self.mesh._h)), backend._h)
+        api._own(self.mesh, L.lib().moka_mesh_destroy, self.mesh._h, backend)
         self.Prog = api.PrognosticVars(np.asarray(ssh)[lm.cells_g], np.asarray(u).reshape(mesh.nEdges, K)[lm.edges_g],
                                        np.asarray(h).reshape(mesh.nCells, K)[lm.cells_g], 2, self.mesh)
         self.Diag = api.DiagnosticVars(None, self.mesh, self.Prog._state)
@@ -300,6 +301,7 @@ class DistributedModel:
                                          L.i32(self._keep[0]), i64(offs[0]), L.i32(self._keep[1]), i64(offs[1]),
                                          L.i32(self._keep[2]), i64(offs[2]), L.i32(self._keep[3]), i64(offs[3]),
                                          self.p_boundary, self.p_owned, C.byref(self._halo)), backend._h)
+        api._own(self, L.lib().moka_halo_destroy, self._halo, self.Prog._state, self.mesh, backend)
         ns, nr = C.c_int64(), C.c_int64()
         L.check(L.lib().moka_halo_buffer_elems(self._halo, C.byref(ns), C.byref(nr)))
         dev = torch.device("cuda", backend.device)
@@ -522,7 +524,7 @@ class DistributedModel:
     def close(self):
         """Release the device objects in dependency order (halo, state, mesh); the backend stays with the caller."""
         if getattr(self, "_halo", None):
-            L.lib().moka_halo_destroy(self._halo)
+            api._release(self, L.lib().moka_halo_destroy, self._halo)
             self._halo = C.c_void_p()
         self.Prog._state.close()
         self.mesh.close()
@@ -618,7 +620,6 @@ class LocalCluster:
     def __init__(self, mesh, ssh, u, h, rest, dt, world, device=0, ordering=0, patch_cells=0, state_bytes=8, direct=True,
                  devices=None):
         import torch
-        from . import api
         self.torch, self.world = torch, world
         devs = list(devices) if devices is not None else [device] * world
         self.backends = [api.MokaHIP(devs[r]) for r in range(world)]

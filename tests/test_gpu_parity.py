@@ -590,11 +590,101 @@ def test_driver_from_yaml_and_mpas_files(tmp_path):
     ds = mpasio.open_dataset(out_fp)
     try:
         assert ds.attr("dt") == dts and ds.var("time")[0] == nsteps * dts
-        assert np.array_equal(ds.var("ssh"), st.ssh[1])
-        assert np.array_equal(ds.var("layerThickness")[0], st.h[1][:, 0])
-        assert np.array_equal(ds.var("normalVelocity")[0], st.u[1][:, 0])
+        # the reference's file holds the state one step behind (adapt_structure rebuilds Prog from its FIRST time level:
+        # OutPut.jl:124, PrognosticVars.jl:108-113): index 0 = the level the last step started from
+        assert np.array_equal(ds.var("ssh"), st.ssh[0]) and not np.array_equal(st.ssh[0], st.ssh[1])
+        assert np.array_equal(ds.var("layerThickness")[0], st.h[0][:, 0])
+        assert np.array_equal(ds.var("normalVelocity")[0], st.u[0][:, 0])
     finally:
         ds.close()
+
+
+def _write_igw_case(tmp_path, hours=2):
+    from moka_hip import mpasio
+    mesh = get_mesh("igw200")
+    ssh, u, h, rest = mg.igw_initial_state(mesh)
+    mesh_fp, out_fp, cfg_fp = tmp_path / "igw_mesh.nc", tmp_path / "output.nc", tmp_path / "config.yml"
+    mpasio.write_mesh(mesh_fp, mesh, restingThickness=np.asarray(rest).reshape(mesh.nCells, 1),
+                      state=(ssh, u.reshape(mesh.nEdges, 1), h.reshape(mesh.nCells, 1)))
+    cfg_fp.write_text(f"""omega:
+  time_management:
+    config_do_restart: false
+    config_start_time: 0001-01-01_00:00:00
+    config_stop_time: none
+    config_run_duration: 0000-00-00_0{hours}:00:00
+  time_integration:
+    config_dt: 0000-00-00_00:05:00
+    config_number_of_time_levels: 2
+  streams:
+    mesh:
+      filename_template: {mesh_fp}
+    input:
+      filename_template: {mesh_fp}
+    output:
+      filename_template: {out_fp}
+      reference_time: 0001-01-01_00:00:00
+      output_interval: 0000-00-00_01:00:00
+""")
+    return mesh, (ssh, u, h, rest), cfg_fp, out_fp
+
+
+def test_driver_in_the_reference_constructor_order(tmp_path):
+    """src/driver/mpas_ocean.jl:20-53 line by line through moka_hip/shim.py, the executable transliteration of the Julia
+    shim (julia/MokaHIP.jl): the reference's OWN constructors run first -- every array adapted to the backend or made by
+    KA.zeros / KA.ones before any device state exists (init.jl:3-30, PrognosticVars.jl:59-106, DiagnosticVars.jl:75-99,
+    TendencyVars.jl:51-67), `timestep` a 1-element array on the backend written with a scalar store -- the first
+    ocn_timestep binds everything to one library state, write_netcdf gets host arrays back through
+    Adapt.adapt_structure(KA.CPU(), x).  Output file bit-identical to the oracle replaying the same sequence."""
+    from moka_hip import mpasio, shim
+    mesh, (ssh, u, h, rest), cfg_fp, out_fp = _write_igw_case(tmp_path)
+    out, arch, clock, (Setup, Diag, Tend, Prog) = shim.ocn_run(str(cfg_fp))
+    assert out == str(out_fp) and arch == "GPU"
+    dts = float(mg.igw_dt(mesh))                    # ocn_init_alarms overrides config_dt (init.jl:118): 400 s at 200 km
+    nsteps = int(2 * 3600 / dts)
+    om = orc.OracleMesh(mesh, 1, resting_thickness_sum=np.asarray(rest).reshape(mesh.nCells, -1).sum(1))
+    st = orc.OracleState(om, ssh, u, h)
+    for _ in range(nsteps):
+        st.step_fe(dts)
+    ds = mpasio.open_dataset(out_fp)
+    try:
+        assert ds.attr("dt") == dts and ds.var("time")[0] == nsteps * dts
+        # the reference's file holds the state one step behind (adapt_structure rebuilds Prog from its FIRST time level:
+        # OutPut.jl:124, PrognosticVars.jl:108-113): index 0 = the level the last step started from
+        assert np.array_equal(ds.var("ssh"), st.ssh[0]) and not np.array_equal(st.ssh[0], st.ssh[1])
+        assert np.array_equal(ds.var("layerThickness")[0], st.h[0][:, 0])
+        assert np.array_equal(ds.var("normalVelocity")[0], st.u[0][:, 0])
+    finally:
+        ds.close()
+    # what the lazily bound arrays show afterwards: every field of the three structs, both time levels
+    f = lambda a: np.asarray(a)
+    assert np.array_equal(f(Prog.ssh[0]), st.ssh[0]) and np.array_equal(f(Prog.normalVelocity[0]), st.u[0])
+    for got, exp in ((Diag.layerThicknessEdge, st.hEdge), (Diag.thicknessFlux, st.F), (Diag.velocityDivCell, st.div),
+                     (Diag.relativeVorticity, st.vort), (Tend.tendNormalVelocity, st.tendU), (Tend.tendLayerThickness, st.tendH)):
+        assert np.array_equal(f(got), exp)
+    # scalar reads of a bound array cost ONE download per device change (version stamp), scalar writes reach the device
+    # before the next step
+    s = Prog.ssh[-1].state
+    assert Prog.ssh[-1].host_version != s.version            # stale: the steps since binding changed the device
+    x = [Prog.ssh[-1][i] for i in range(5)]                  # first scalar read downloads, the rest do not
+    assert Prog.ssh[-1].host_version == s.version and x == list(st.ssh[1][:5])
+    Prog.layerThickness[-1][3] = Prog.layerThickness[-1][3] + 0.25
+    st.h[1][3] += 0.25
+    timestep = shim.zeros(Prog.ssh[-1].backend, np.float64, (1,))
+    timestep[0] = dts
+    shim.ocn_timestep(timestep, Prog, Diag, Tend, Setup, shim.ForwardEuler, backend=Prog.ssh[-1].backend)
+    st.step_fe(dts)
+    assert np.array_equal(f(Prog.layerThickness[-1]), st.h[1]) and np.array_equal(f(Prog.ssh[-1]), st.ssh[1])
+    # the (sumCPU, sumGPU, ...) form of ocn_run_loop (run_loop.jl:26-45) on one more hour
+    from moka_hip.timemanager import OneTimeAlarm, attachAlarm
+    sim2 = OneTimeAlarm("simulation_end2", clock.currTime + dt.timedelta(hours=1))
+    attachAlarm(clock, sim2)
+    sumCPU, sumGPU = np.zeros(1), shim.zeros(Prog.ssh[-1].backend, np.float64, (1,))
+    got = shim.ocn_run_loop(sumCPU, sumGPU, timestep, Prog, Diag, Tend, Setup, shim.ForwardEuler, clock, sim2,
+                            clock.alarms["outputAlarm"], backend=Prog.ssh[-1].backend)
+    for _ in range(int(3600 / dts)):
+        st.step_fe(dts)
+    assert got == st.sum_sq_ssh() == sumCPU[0]
+    s.close(); s.mesh.close()
 
 
 # ------------------------------------------------------------------------------------------------
