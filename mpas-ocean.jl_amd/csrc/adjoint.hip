@@ -53,7 +53,14 @@ __global__ __launch_bounds__(BLOCK) void k_adj_edge(const AdjMesh m, const AdjAr
                 const double lu = a.lamU1[off];
                 if constexpr (TT) {
                     const double hI = 0.5 * (a.h[(size_t)c1 * K + k] + a.h[(size_t)c2 * K + k]);    // Operators.jl:217
-                    a.lamU0[off] = hI * Fbar + cor;
+                    const double pb = hI * Fbar + cor;
+                    if (a.accOutU) {                      // fused element-wise steps of the RK4 reverse sweep
+                        const double x = a.xU[off];
+                        a.accOutU[off] = (a.accInU ? a.accInU[off] : x) + pb;
+                        if (a.kNextU) a.kNextU[off] = a.cbNext * x + a.caNext * pb;
+                    } else {
+                        a.lamU0[off] = pb;
+                    }
                 } else {
                     a.lamU0[off] = (lu + a.hEuse[off] * Fbar) + cor;
                 }
@@ -94,8 +101,19 @@ __global__ __launch_bounds__(BLOCK) void k_adj_cell(const AdjMesh m, const AdjAr
                 const int e = re[i];
                 if (e >= 0) acc += Eread[(size_t)e * K + k];
             }
-            if constexpr (TT) a.lamH0[(size_t)c * K + k] = 0.5 * acc + ls;
-            else a.lamH0[(size_t)c * K + k] = (a.lamH1[(size_t)c * K + k] + s1) + 0.5 * acc;
+            if constexpr (TT) {
+                const double pb = 0.5 * acc + ls;
+                const size_t off = (size_t)c * K + k;
+                if (a.accOutH) {
+                    const double x = a.xH[off];
+                    a.accOutH[off] = (a.accInH ? a.accInH[off] : x) + pb;
+                    if (a.kNextH) a.kNextH[off] = a.cbNext * x + a.caNext * pb;
+                } else {
+                    a.lamH0[off] = pb;
+                }
+            } else {
+                a.lamH0[(size_t)c * K + k] = (a.lamH1[(size_t)c * K + k] + s1) + 0.5 * acc;
+            }
         }
     }
 }
@@ -155,7 +173,14 @@ __global__ __launch_bounds__(BLOCK) void k_adj_edge2(const AdjMesh m, const AdjA
             if constexpr (TT) {
                 const double2 h1 = ld2(a.h, c1, K, l), h2 = ld2(a.h, c2, K, l);
                 const double2 hI = make_double2(0.5 * (h1.x + h2.x), 0.5 * (h1.y + h2.y));           // Operators.jl:217
-                st2(a.lamU0, e, K, l, make_double2(hI.x * Fbar.x + cor.x, hI.y * Fbar.y + cor.y));
+                const double2 pb = make_double2(hI.x * Fbar.x + cor.x, hI.y * Fbar.y + cor.y);
+                if (a.accOutU) {                          // fused element-wise steps of the RK4 reverse sweep
+                    const double2 x = ld2(a.xU, e, K, l), ai = a.accInU ? ld2(a.accInU, e, K, l) : x;
+                    st2(a.accOutU, e, K, l, make_double2(ai.x + pb.x, ai.y + pb.y));
+                    if (a.kNextU) st2(a.kNextU, e, K, l, make_double2(a.cbNext * x.x + a.caNext * pb.x, a.cbNext * x.y + a.caNext * pb.y));
+                } else {
+                    st2(a.lamU0, e, K, l, pb);
+                }
             } else {
                 const double2 hE = ld2(a.hEuse, e, K, l);
                 st2(a.lamU0, e, K, l, make_double2((lu.x + hE.x * Fbar.x) + cor.x, (lu.y + hE.y * Fbar.y) + cor.y));
@@ -197,7 +222,16 @@ __global__ __launch_bounds__(BLOCK) void k_adj_cell2(const AdjMesh m, const AdjA
             }
         }
         if constexpr (TT) {
-            if (act) st2(a.lamH0, c, K, l, make_double2(0.5 * acc.x + ls, 0.5 * acc.y + ls));
+            if (act) {
+                const double2 pb = make_double2(0.5 * acc.x + ls, 0.5 * acc.y + ls);
+                if (a.accOutH) {
+                    const double2 x = ld2(a.xH, c, K, l), ai = a.accInH ? ld2(a.accInH, c, K, l) : x;
+                    st2(a.accOutH, c, K, l, make_double2(ai.x + pb.x, ai.y + pb.y));
+                    if (a.kNextH) st2(a.kNextH, c, K, l, make_double2(a.cbNext * x.x + a.caNext * pb.x, a.cbNext * x.y + a.caNext * pb.y));
+                } else {
+                    st2(a.lamH0, c, K, l, pb);
+                }
+            }
         } else {
             const double s1 = a.lamS1[c];
             if (l == 0) a.lamS0[c] = ls;

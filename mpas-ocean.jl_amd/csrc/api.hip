@@ -1261,24 +1261,29 @@ int moka_adjoint_sweep(moka_tape *t)
         const int in = t->cur, o = 1 - t->cur;
         const double *XU = t->lamU[in], *XH = t->lamH[in];
         double *accU = t->lamU[o], *accH = t->lamH[o];
+        // kb of stage 4 by one scale pass; every later kb, and the running sum X + Pb4 + Pb3 + ..., come out of the two
+        // transposed kernels themselves (fused epilogues: AdjArgs.accOut / kNext), k-bar double-buffered because the
+        // current one is being gathered while the next one is written
+        double *kU[2] = {t->kbU, t->pbU}, *kH[2] = {t->kbH, t->pbH};
+        HIPCHK(st->ctx, launch_scale_copy(kU[0], XU, cb[3], (int64_t)nEK, s));
+        HIPCHK(st->ctx, launch_scale_copy(kH[0], XH, cb[3], (int64_t)nCK, s));
+        int kc = 0;
         for (int sg = 4; sg >= 1; --sg) {
-            if (sg == 4) {
-                HIPCHK(st->ctx, launch_scale_copy(t->kbU, XU, cb[3], (int64_t)nEK, s));
-                HIPCHK(st->ctx, launch_scale_copy(t->kbH, XH, cb[3], (int64_t)nCK, s));
-            } else {
-                HIPCHK(st->ctx, launch_axpby(t->kbU, cb[sg - 1], XU, ca[sg - 1], t->pbU, (int64_t)nEK, s));
-                HIPCHK(st->ctx, launch_axpby(t->kbH, cb[sg - 1], XH, ca[sg - 1], t->pbH, (int64_t)nCK, s));
-            }
             moka::AdjArgs a{};
             a.tt = 1; a.dt = 1.0;
             a.u = t->rkU + nEK * (4 * i + (sg - 1)); a.h = t->rkH + nCK * (4 * i + (sg - 1));
-            a.lamU1 = t->kbU; a.lamH1 = t->kbH;
-            a.lamU0 = t->pbU; a.lamH0 = t->pbH;
+            a.lamU1 = kU[kc]; a.lamH1 = kH[kc];
             a.Enew = t->Enew; a.csum = t->csum;
+            a.xU = XU; a.xH = XH;
+            a.accInU = sg == 4 ? nullptr : accU; a.accInH = sg == 4 ? nullptr : accH;
+            a.accOutU = accU; a.accOutH = accH;
+            if (sg > 1) {
+                a.kNextU = kU[1 - kc]; a.kNextH = kH[1 - kc];
+                a.cbNext = cb[sg - 2]; a.caNext = ca[sg - 2];
+            }
             HIPCHK(st->ctx, launch_adj_edge(t->am, a, st->mesh->lpc, s));
             HIPCHK(st->ctx, launch_adj_cell(t->am, a, st->mesh->lpc, s));
-            HIPCHK(st->ctx, launch_add(accU, sg == 4 ? XU : accU, t->pbU, (int64_t)nEK, s));
-            HIPCHK(st->ctx, launch_add(accH, sg == 4 ? XH : accH, t->pbH, (int64_t)nCK, s));
+            kc = 1 - kc;
         }
         t->cur = o;
         t->dts.pop_back(); t->flags.pop_back();

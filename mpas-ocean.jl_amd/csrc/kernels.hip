@@ -229,16 +229,16 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     bool pend = false;
     auto flush_cell = [&]() {
         if (act) {
-            if constexpr (MODE == 0) gstore2(a.tendH, pOff, pA);
+            if constexpr (MODE == 0) gstore2o(a.tendH, pOff, pA);
             if constexpr (MODE == 1 || MODE == 2) {
-                gstore2(a.ph_out, pOff, pA);
-                gstore2(a.nh_out, pOff, pB);
+                gstore2o(a.ph_out, pOff, pA);
+                gstore2o(a.nh_out, pOff, pB);
             }
-            if constexpr (MODE == 3) gstore2(a.nh_out, pOff, pB);
+            if constexpr (MODE == 3) gstore2o(a.nh_out, pOff, pB);
             if constexpr (FE) {
-                gstore2(a.ph_out, pOff, pA);
-                gstore2(a.tendH, pOff, pB);
-                gstore2(a.div, pOff, pD);
+                gstore2o(a.ph_out, pOff, pA);
+                gstore2o(a.tendH, pOff, pB);
+                gstore2o(a.div, pOff, pD);
             }
         }
         if constexpr (MODE != 0)
@@ -354,17 +354,17 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     pend = false;
     auto flush_edge = [&]() {
         if (act) {
-            if constexpr (MODE == 0) gstore2(a.tendU, pOff, pA);
+            if constexpr (MODE == 0) gstore2o(a.tendU, pOff, pA);
             if constexpr (MODE == 1 || MODE == 2) {
-                gstore2(a.pu_out, pOff, pA);
-                gstore2(a.nu_out, pOff, pB);
+                gstore2o(a.pu_out, pOff, pA);
+                gstore2o(a.nu_out, pOff, pB);
             }
-            if constexpr (MODE == 3) gstore2(a.nu_out, pOff, pB);
+            if constexpr (MODE == 3) gstore2o(a.nu_out, pOff, pB);
             if constexpr (FE) {
-                gstore2(a.pu_out, pOff, pA);
-                gstore2(a.tendU, pOff, pB);
-                gstore2(a.F, pOff, pD);
-                gstore2(a.hEdgeNew, pOff, pE);
+                gstore2o(a.pu_out, pOff, pA);
+                gstore2o(a.tendU, pOff, pB);
+                gstore2o(a.F, pOff, pD);
+                gstore2o(a.hEdgeNew, pOff, pE);
             }
         }
     };

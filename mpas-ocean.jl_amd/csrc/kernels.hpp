@@ -130,6 +130,13 @@ struct AdjArgs {
     const double *lamU1, *lamH1, *lamS1, *lamE1;
     double *lamU0, *lamH0, *lamS0;
     double *Enew, *csum;               // u*Fbar (K, nE); ksum_k dt*lamU1 (nE)
+    // RK4 reverse sweep (tt = 1): the element-wise steps around T'(P)^T fused into the two kernels.  With accOut set the
+    // result Pb = T'(P)^T k is not stored (lamU0 / lamH0 unused); instead, row by row,
+    //   accOut = (accIn ? accIn : x) + Pb          X + Pb4, then (...) + Pb3 ...   (time_integration.jl:61-148 transposed)
+    //   kNext  = cbNext * x + caNext * Pb          the next stage's k-bar (nullptr after the last stage)
+    const double *xU, *xH, *accInU, *accInH;
+    double *accOutU, *accOutH, *kNextU, *kNextH;
+    double cbNext, caNext;
 };
 hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s);
 hipError_t launch_adj_cell(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s);

@@ -91,6 +91,18 @@ __device__ __forceinline__ void gstore2(double *base, uint32_t off, double2 x)
     *reinterpret_cast<double2 *>(reinterpret_cast<char *>(base) + off) = x;
 }
 
+// Result stores of the default stage kernels.  Experiment MOKA_EXP_WT_STORES: write-through (sc1) stores, which do not
+// keep the line in the XCD's L2 (MI355X_MICROARCH.md, "stores of each flavour"): results are never re-read inside a
+// launch, so the L2 would hold gathered rows instead.
+__device__ __forceinline__ void gstore2o(double *base, uint32_t off, double2 x)
+{
+#ifdef MOKA_EXP_WT_STORES
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), make_rsrc(base, 0xFFFFFFFFu), (int)off, 0, 16);
+#else
+    gstore2(base, off, x);
+#endif
+}
+
 struct RecLds {
     uint32_t *eRec, *cRec;
     double *woe, *feoe, *g, *sdv, *invA, *rsum;

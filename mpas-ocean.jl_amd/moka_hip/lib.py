@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))     # mpas-ocean.jl_amd/
-LIB_PATH = os.path.join(PKG_DIR, "libmoka_hip.so")
+# MOKA_HIP_LIB: another build of the same library (A/B experiments: `make exp EXP=...` -> libmoka_hip_exp.so)
+LIB_PATH = os.environ.get("MOKA_HIP_LIB") or os.path.join(PKG_DIR, "libmoka_hip.so")
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
