@@ -132,7 +132,9 @@ __device__ __forceinline__ void st2(double *p, size_t row, int K, int l, double2
     reinterpret_cast<double2 *>(p + row * K)[l] = v;
 }
 
-template <bool TT>
+// WF > 0: the transposed lists have exactly WF slots (10 on hexagonal meshes): the regular-edge path is fully unrolled,
+// its index / weight loads and its WF row gathers go out as batches (no per-source maxLevelEdgeTop lookups, no masks)
+template <bool TT, int WF>
 __global__ __launch_bounds__(BLOCK) void k_adj_edge2(const AdjMesh m, const AdjArgs a)
 {
     constexpr int NG = BLOCK / 32;
@@ -146,6 +148,8 @@ __global__ __launch_bounds__(BLOCK) void k_adj_edge2(const AdjMesh m, const AdjA
         double s1 = 0.0, s2 = 0.0;
         if constexpr (!TT) { s1 = a.lamS1[c1]; s2 = a.lamS1[c2]; }
         double2 tu = make_double2(0.0, 0.0);
+        // both half-waves of the wave on regular edges: wave-uniform branch
+        const bool plain = WF > 0 && __builtin_amdgcn_ballot_w64(!m.efull[e]) == 0;
         if (act) {
             const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
             const double2 l1 = ld2(a.lamH1, c1, K, l), l2 = ld2(a.lamH1, c2, K, l);
@@ -160,14 +164,31 @@ __global__ __launch_bounds__(BLOCK) void k_adj_edge2(const AdjMesh m, const AdjA
             if (!ax) Fbar.x = 0.0;
             if (!ay) Fbar.y = 0.0;
             double2 cor = make_double2(0.0, 0.0);
-            for (int j = 0; j < m.W; ++j) {
-                const int s = m.teoe[(size_t)e * m.W + j];
-                if (s < 0) continue;
-                const int ms = m.ehdr[(size_t)s * 4 + 3];
-                const double w = m.tw[(size_t)e * m.W + j] * fe;
-                const double2 ls = ld2(a.lamU1, s, K, l);
-                if (k0 < ms) cor.x += TT ? w * ls.x : w * (a.dt * ls.x);
-                if (k0 + 1 < ms) cor.y += TT ? w * ls.y : w * (a.dt * ls.y);
+            if (plain) {
+                constexpr int WU = WF > 0 ? WF : 1;
+                int32_t src[WU];
+                double w[WU];
+                double2 ls[WU];
+#pragma unroll
+                for (int j = 0; j < WU; ++j) { src[j] = m.teoe[(size_t)e * WU + j]; w[j] = m.tw[(size_t)e * WU + j]; }
+#pragma unroll
+                for (int j = 0; j < WU; ++j) ls[j] = ld2(a.lamU1, src[j], K, l);
+#pragma unroll
+                for (int j = 0; j < WU; ++j) {
+                    const double wf = w[j] * fe;
+                    cor.x += TT ? wf * ls[j].x : wf * (a.dt * ls[j].x);
+                    cor.y += TT ? wf * ls[j].y : wf * (a.dt * ls[j].y);
+                }
+            } else {
+                for (int j = 0; j < m.W; ++j) {
+                    const int s = m.teoe[(size_t)e * m.W + j];
+                    if (s < 0) continue;
+                    const int ms = m.ehdr[(size_t)s * 4 + 3];
+                    const double w = m.tw[(size_t)e * m.W + j] * fe;
+                    const double2 ls = ld2(a.lamU1, s, K, l);
+                    if (k0 < ms) cor.x += TT ? w * ls.x : w * (a.dt * ls.x);
+                    if (k0 + 1 < ms) cor.y += TT ? w * ls.y : w * (a.dt * ls.y);
+                }
             }
             const double2 lu = ld2(a.lamU1, e, K, l);
             if constexpr (TT) {
@@ -294,8 +315,13 @@ static int grid2(int n) { return std::min(std::max((n + 7) / 8, 1), 65536); }
 hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s)
 {
     if (lpc == 64 && m.K <= 64 && !(m.K & 1)) {   // even 34 <= K <= 64: 16-byte lanes
-        if (a.tt) hipLaunchKernelGGL((k_adj_edge2<true>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
-        else hipLaunchKernelGGL((k_adj_edge2<false>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
+        if (m.W == 10) {
+            if (a.tt) hipLaunchKernelGGL((k_adj_edge2<true, 10>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
+            else hipLaunchKernelGGL((k_adj_edge2<false, 10>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
+        } else {
+            if (a.tt) hipLaunchKernelGGL((k_adj_edge2<true, 0>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
+            else hipLaunchKernelGGL((k_adj_edge2<false, 0>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
+        }
         return hipGetLastError();
     }
 #define CALL(L) launch_adj_edge_lpc<L>(m, a, s)

@@ -1128,6 +1128,18 @@ int moka_tape_create(moka_state *st, int64_t capacity_steps, moka_tape **out)
     if (rc == MOKA_OK) rc = tape_upload(t, tw, &am.tw);
     if (rc == MOKA_OK) rc = tape_upload(t, sd, &am.sd);
     if (rc == MOKA_OK) rc = tape_upload(t, csgn, &am.csgn);
+    {   // regular edges (everything but the neighbourhood of the 12 pentagons on a sphere without land): mask-free path
+        std::vector<int32_t> efull(nE, 0);
+        for (int e = 0; e < nE; ++e) {
+            bool full = p.ehdr[(size_t)e * 4 + 3] >= p.K;
+            for (int j = 0; j < W && full; ++j) {
+                const int sidx = teoe[(size_t)e * W + j];
+                full = sidx >= 0 && p.ehdr[(size_t)sidx * 4 + 3] >= p.K;
+            }
+            efull[e] = full ? 1 : 0;
+        }
+        if (rc == MOKA_OK) rc = tape_upload(t, efull, &am.efull);
+    }
     if (rc != MOKA_OK) { moka_tape_destroy(t); return rc; }
     HIPCHK(st->ctx, hipStreamSynchronize(st->ctx->stream));
     *out = t;

@@ -120,6 +120,7 @@ struct AdjMesh {
     const double *tw;                  // (W, nE) weightsOnEdge[i,s]
     const double *sd;                  // (2, nE) dvEdge*edgeSign*invArea for c1, c2
     const double *fEdge, *gInvDc;      // (nE)
+    const int32_t *efull;              // (nE) 1: all W sources exist and the edge and every source are active on all levels
 };
 struct AdjArgs {
     double dt;

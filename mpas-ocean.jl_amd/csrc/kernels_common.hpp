@@ -96,8 +96,12 @@ __device__ __forceinline__ void gstore2(double *base, uint32_t off, double2 x)
 // launch, so the L2 would hold gathered rows instead.
 __device__ __forceinline__ void gstore2o(double *base, uint32_t off, double2 x)
 {
-#ifdef MOKA_EXP_WT_STORES
+#if defined(MOKA_EXP_WT_STORES)
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), make_rsrc(base, 0xFFFFFFFFu), (int)off, 0, 16);
+#elif defined(MOKA_EXP_NT_STORES)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), make_rsrc(base, 0xFFFFFFFFu), (int)off, 0, 2);
+#elif defined(MOKA_EXP_NO_STORES)
+    if (x.x == 1.2345e300) gstore2(base, off, x);      // ablation (wrong results): what do the stores cost / displace?
 #else
     gstore2(base, off, x);
 #endif
