@@ -188,6 +188,7 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
     MeshDev dev = m->dev;                 // the launch covers patches [pBegin, pBegin + pCount) (+ the patch `tail`)
     dev.tailPatch = -1;
     hipStream_t s = on ? on : st->ctx->stream;
+    if (tail >= 0 && (st->ctx->variant == 12 || st->ctx->variant == 13)) tail = -2;   // (no tail patches since round 2)
     if (tail >= 0) {
         // One extra, non-adjacent patch in the same launch: only the default kernels can carry it.  Anything else
         // (explicit variants, fallbacks for other K, the nonlinear path) gets a launch of its own for it.
@@ -246,7 +247,7 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
     const int v = st->ctx->variant;
     // 0 = auto: rec2c (even 34 <= K <= 64, patches whose records + own rows fit the LDS), else the plain column kernel (K >= 33),
     // else the generic index kernel.  11 rec2c, 4 column, 3 generic.  Built with VARIANTS=1 only (csrc/experiments):
-    // 8 rec2, 7 rec, 1 pipelined column, 5/6 16-byte-lane column, 2 LDS-tiled, 9 tile, 10 ptile.
+    // 8 rec2, 7 rec, 1 pipelined column, 5/6 16-byte-lane column, 2 LDS-tiled, 9 tile, 10 ptile, 12/13 tile3 (LDS-DMA).
 #ifdef MOKA_VARIANTS
     if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(dev, g, m->ldsBytes, s);
     if (v == 10 && m->ptileOk) {           // persistent double-buffered tiled kernel (needs patch_cells <= ~14)
@@ -255,6 +256,12 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
     }
     if (v == 9 && m->tileOk) {             // tiled: u rows + records in LDS (needs patch_cells <= 16)
         hipError_t e = launch_stage_tile(dev, g, s);
+        if (e != hipErrorNotSupported) return e;
+    }
+#endif
+#ifdef MOKA_VARIANTS
+    if ((v == 12 || v == 13) && m->lpc == 64 && m->colOk) {  // every row of a patch staged in LDS by LDS-DMA (256 / 512 threads)
+        hipError_t e = launch_stage_tile3(dev, g, v == 13 ? 512 : 256, s);
         if (e != hipErrorNotSupported) return e;
     }
 #endif
@@ -409,7 +416,7 @@ int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
 int moka_kernel_variant_available(int variant)
 {
 #ifdef MOKA_VARIANTS
-    return variant >= 0 && variant <= 11;
+    return variant >= 0 && variant <= 13;
 #else
     return variant == 0 || variant == 3 || variant == 4 || variant == 11;
 #endif
@@ -418,7 +425,7 @@ int moka_kernel_variant_available(int variant)
 int moka_set_kernel_variant(moka_ctx *ctx, int variant)
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
-    if (variant < 0 || variant > 11) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..11");
+    if (variant < 0 || variant > 13) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..13");
     if (!moka_kernel_variant_available(variant))
         return fail(ctx, MOKA_ERR_UNSUPPORTED, "this kernel variant is an experiment: build the library with `make VARIANTS=1`");
     ctx->variant = variant;

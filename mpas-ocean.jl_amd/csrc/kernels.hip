@@ -19,97 +19,6 @@
 
 namespace moka {
 
-typedef const __attribute__((address_space(3))) unsigned char *lds_bytes_t;
-typedef const __attribute__((address_space(1))) unsigned char *glb_bytes_t;
-typedef double v2d_t __attribute__((ext_vector_type(2)));
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-// N 16-byte LDS reads issued back to back, one wait.  Inline assembly because a plain LDS load next to a global
-// load of the other branch is merged by the compiler into ONE flat_load from a selected pointer (a flat load of an LDS
-// address still occupies the texture-address unit), and a volatile LDS load is waited for individually.
-typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
-template <int N>
-__device__ __forceinline__ void lds_burst(v4u_t (&v)[N], const uint32_t (&ad)[N]);
-template <>
-__device__ __forceinline__ void lds_burst<6>(v4u_t (&v)[6], const uint32_t (&ad)[6])
-{
-    asm volatile("ds_read_b128 %[o0], %[a0]\n\t"
-                 "ds_read_b128 %[o1], %[a1]\n\t"
-                 "ds_read_b128 %[o2], %[a2]\n\t"
-                 "ds_read_b128 %[o3], %[a3]\n\t"
-                 "ds_read_b128 %[o4], %[a4]\n\t"
-                 "ds_read_b128 %[o5], %[a5]\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : [o0] "=&v"(v[0]), [o1] "=&v"(v[1]), [o2] "=&v"(v[2]), [o3] "=&v"(v[3]), [o4] "=&v"(v[4]), [o5] "=&v"(v[5])
-                 : [a0] "v"(ad[0]), [a1] "v"(ad[1]), [a2] "v"(ad[2]), [a3] "v"(ad[3]), [a4] "v"(ad[4]), [a5] "v"(ad[5])
-                 : "memory");
-}
-template <>
-__device__ __forceinline__ void lds_burst<8>(v4u_t (&v)[8], const uint32_t (&ad)[8])
-{
-    asm volatile("ds_read_b128 %[o0], %[a0]\n\t"
-                 "ds_read_b128 %[o1], %[a1]\n\t"
-                 "ds_read_b128 %[o2], %[a2]\n\t"
-                 "ds_read_b128 %[o3], %[a3]\n\t"
-                 "ds_read_b128 %[o4], %[a4]\n\t"
-                 "ds_read_b128 %[o5], %[a5]\n\t"
-                 "ds_read_b128 %[o6], %[a6]\n\t"
-                 "ds_read_b128 %[o7], %[a7]\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : [o0] "=&v"(v[0]), [o1] "=&v"(v[1]), [o2] "=&v"(v[2]), [o3] "=&v"(v[3]), [o4] "=&v"(v[4]), [o5] "=&v"(v[5]), [o6] "=&v"(v[6]), [o7] "=&v"(v[7])
-                 : [a0] "v"(ad[0]), [a1] "v"(ad[1]), [a2] "v"(ad[2]), [a3] "v"(ad[3]), [a4] "v"(ad[4]), [a5] "v"(ad[5]), [a6] "v"(ad[6]), [a7] "v"(ad[7])
-                 : "memory");
-}
-template <>
-__device__ __forceinline__ void lds_burst<10>(v4u_t (&v)[10], const uint32_t (&ad)[10])
-{
-    asm volatile("ds_read_b128 %[o0], %[a0]\n\t"
-                 "ds_read_b128 %[o1], %[a1]\n\t"
-                 "ds_read_b128 %[o2], %[a2]\n\t"
-                 "ds_read_b128 %[o3], %[a3]\n\t"
-                 "ds_read_b128 %[o4], %[a4]\n\t"
-                 "ds_read_b128 %[o5], %[a5]\n\t"
-                 "ds_read_b128 %[o6], %[a6]\n\t"
-                 "ds_read_b128 %[o7], %[a7]\n\t"
-                 "ds_read_b128 %[o8], %[a8]\n\t"
-                 "ds_read_b128 %[o9], %[a9]\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : [o0] "=&v"(v[0]), [o1] "=&v"(v[1]), [o2] "=&v"(v[2]), [o3] "=&v"(v[3]), [o4] "=&v"(v[4]), [o5] "=&v"(v[5]), [o6] "=&v"(v[6]), [o7] "=&v"(v[7]), [o8] "=&v"(v[8]), [o9] "=&v"(v[9])
-                 : [a0] "v"(ad[0]), [a1] "v"(ad[1]), [a2] "v"(ad[2]), [a3] "v"(ad[3]), [a4] "v"(ad[4]), [a5] "v"(ad[5]), [a6] "v"(ad[6]), [a7] "v"(ad[7]), [a8] "v"(ad[8]), [a9] "v"(ad[9])
-                 : "memory");
-}
-template <>
-__device__ __forceinline__ void lds_burst<14>(v4u_t (&v)[14], const uint32_t (&ad)[14])
-{
-    asm volatile("ds_read_b128 %[o0], %[a0]\n\t"
-                 "ds_read_b128 %[o1], %[a1]\n\t"
-                 "ds_read_b128 %[o2], %[a2]\n\t"
-                 "ds_read_b128 %[o3], %[a3]\n\t"
-                 "ds_read_b128 %[o4], %[a4]\n\t"
-                 "ds_read_b128 %[o5], %[a5]\n\t"
-                 "ds_read_b128 %[o6], %[a6]\n\t"
-                 "ds_read_b128 %[o7], %[a7]\n\t"
-                 "ds_read_b128 %[o8], %[a8]\n\t"
-                 "ds_read_b128 %[o9], %[a9]\n\t"
-                 "ds_read_b128 %[o10], %[a10]\n\t"
-                 "ds_read_b128 %[o11], %[a11]\n\t"
-                 "ds_read_b128 %[o12], %[a12]\n\t"
-                 "ds_read_b128 %[o13], %[a13]\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : [o0] "=&v"(v[0]), [o1] "=&v"(v[1]), [o2] "=&v"(v[2]), [o3] "=&v"(v[3]), [o4] "=&v"(v[4]), [o5] "=&v"(v[5]), [o6] "=&v"(v[6]), [o7] "=&v"(v[7]), [o8] "=&v"(v[8]), [o9] "=&v"(v[9]), [o10] "=&v"(v[10]), [o11] "=&v"(v[11]), [o12] "=&v"(v[12]), [o13] "=&v"(v[13])
-                 : [a0] "v"(ad[0]), [a1] "v"(ad[1]), [a2] "v"(ad[2]), [a3] "v"(ad[3]), [a4] "v"(ad[4]), [a5] "v"(ad[5]), [a6] "v"(ad[6]), [a7] "v"(ad[7]), [a8] "v"(ad[8]), [a9] "v"(ad[9]), [a10] "v"(ad[10]), [a11] "v"(ad[11]), [a12] "v"(ad[12]), [a13] "v"(ad[13])
-                 : "memory");
-}
-__device__ __forceinline__ double2 glb_row2(glb_bytes_t p)
-{
-    const v2d_t v = *(const __attribute__((address_space(1))) v2d_t *)p;
-    return make_double2(v.x, v.y);
-}
-__device__ __forceinline__ float4 glb_row4f(glb_bytes_t p)
-{
-    const v4f_t v = *(const __attribute__((address_space(1))) v4f_t *)p;
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-
 // ------------------------------------------------------------------------------------------------
 // rec2 + own-edge cache ("rec2c"): k_stage_rec2 with the u-rows of the patch's OWN edges copied once into LDS
 // (a contiguous range: one coalesced copy, no halo list).  ~65 % of all u gathers of a compact patch refer to

@@ -83,6 +83,9 @@ hipError_t launch_stage_colx(const MeshDev &m, const StageArgs &a, bool pipeline
 hipError_t launch_stage_colp(const MeshDev &m, const StageArgs &a, hipStream_t s);
 hipError_t launch_stage_lds(const MeshDev &m, const StageArgs &a, size_t ldsBytes, hipStream_t s);
 hipError_t prepare_stage_lds(size_t ldsBytes);
+// every row of a patch staged in LDS by LDS-DMA (csrc/experiments/stage_tile.hip); threads = 256 or 512 per patch
+bool stage_tile3_usable(const MeshDev &m);
+hipError_t launch_stage_tile3(const MeshDev &m, const StageArgs &a, int threads, hipStream_t s);
 #endif
 hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s);
 hipError_t launch_curl2(const MeshDev &m, const double *u, double *vort, bool accum, hipStream_t s);

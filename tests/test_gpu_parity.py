@@ -31,7 +31,7 @@ def backend():
 _MESH_CACHE = {}
 # kernel variants this build of the library carries: the product has 11 (default) / 4 (column) / 3 (generic); the round-1
 # experiments (csrc/experiments, `make VARIANTS=1`) add 1, 2, 5-10
-VARIANTS = [v for v in (11, 10, 9, 8, 7, 1, 2, 3, 4, 5, 6) if L.lib().moka_kernel_variant_available(v)]
+VARIANTS = [v for v in (13, 12, 11, 10, 9, 8, 7, 1, 2, 3, 4, 5, 6) if L.lib().moka_kernel_variant_available(v)]
 
 
 def get_mesh(name):
@@ -343,7 +343,9 @@ def test_reference_call_sequence_piecewise(backend):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("meshname,K,nsteps,variant", [("igw200", 1, 10, 0), ("ico16", 1, 5, 0), ("ico16", 60, 3, 1),
                                                          ("ico16", 60, 3, 2), ("ico16", 80, 2, 2), ("ico32", 60, 2, 0), ("ico32", 60, 3, 9), ("ico32", 60, 3, 10), ("ico12f", 60, 3, 0), ("ico12f", 3, 3, 0), ("ico32", 60, 3, 11),
-                                                         ("ico16", 60, 3, 4), ("ico16", 80, 2, 4), ("ico16", 60, 3, 3), ("ico16", 33, 2, 0), ("ico16", 100, 2, 0)])
+                                                         ("ico16", 60, 3, 4), ("ico16", 80, 2, 4), ("ico16", 60, 3, 3), ("ico16", 33, 2, 0), ("ico16", 100, 2, 0),
+                                                         ("ico32", 60, 3, 12), ("ico32", 60, 3, 13), ("ico12f", 60, 3, 13), ("ico16", 34, 2, 12), ("ico32", 64, 2, 13),
+                                                         ("ico16", 40, 2, 13)])
 def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
     if not L.lib().moka_kernel_variant_available(variant):
         pytest.skip("experimental kernel variant: build the library with `make VARIANTS=1`")

@@ -1,2 +1,9 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "adjoint" > gpurun_out/r02_adj_tests2.log 2>&1; tail -3 gpurun_out/r02_adj_tests2.log | cut -c1-300
-timeout -k 10 300 python tools/adjoint_timing.py 320 60 2 2>&1 | tail -2
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fused_tendency or rk4_bitwise or tiny_periodic" > gpurun_out/r02_tile_tests.log 2>&1; tail -6 gpurun_out/r02_tile_tests.log | cut -c1-300
+for v in 0 13 12; do for P in 16 12; do
+python3 bench.py --no-cpu --steps 20 --warmup 5 --variant $v --patch-cells $P > gpurun_out/tile_v${v}_P${P}.json 2> gpurun_out/tile_v${v}_P${P}.err && python3 - gpurun_out/tile_v${v}_P${P}.json $v $P <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+ps = d["roofline"].get("per_stage", [])
+print(f"v{sys.argv[2]} P{sys.argv[3]}: {d['ms_per_step']:.3f} ms/step  stages " + " ".join(f"{p['ms']:.3f}" for p in ps) + f"  tendency {d['tendency_kernel']['avg_launch_ms']:.3f}")
+PY
+done; done
