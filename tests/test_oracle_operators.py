@@ -82,3 +82,27 @@ def test_tangential_reconstruction_uniform_flow():
     ut = -U[0] * ny + U[1] * nx
     assert np.abs(tu[:, 0] - 1e-4 * ut).max() < 1e-18 + 1e-15
     assert np.abs(th).max() < 1e-15
+
+
+def test_ksum_order_against_a_plain_serial_sum():
+    """N3 (a build decision): ssh[c] = sum_k h[k,c] - restingThicknessSum[c] with the sum taken in the order a wavefront
+    reduction produces (64 strided partials, then an XOR butterfly), so that the CPU oracle and the GPU agree bit for bit.
+    A Julia restatement would more naturally write the plain serial sum over k.  This test states how far the two are
+    apart: they are identical for K <= 2, and within K/2 units in the last place of the result for layer thicknesses of
+    one sign (the case of the model: h > 0) -- far below the 1e-12 relative tolerance BASELINE.md asks for."""
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for K in (1, 2, 3, 7, 10, 33, 60, 64, 65, 80, 100, 128):
+        for _ in range(200):
+            col = rng.uniform(10.0, 70.0, K)                # layer thicknesses, metres
+            serial = 0.0
+            for x in col:
+                serial += x                                  # the plain left-to-right sum
+            got = orc.ksum(col)
+            if K <= 2:
+                assert got == serial
+            ulp = np.spacing(abs(serial))
+            worst = max(worst, abs(got - serial) / ulp)
+            assert abs(got - serial) <= 0.5 * K * ulp
+            assert abs(got - serial) <= 1e-13 * abs(serial)
+    assert worst >= 1.0                                      # they do differ in the last place: the order is a decision
