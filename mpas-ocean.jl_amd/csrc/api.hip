@@ -188,7 +188,7 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
     MeshDev dev = m->dev;                 // the launch covers patches [pBegin, pBegin + pCount) (+ the patch `tail`)
     dev.tailPatch = -1;
     hipStream_t s = on ? on : st->ctx->stream;
-    if (tail >= 0 && (st->ctx->variant == 12 || st->ctx->variant == 13)) tail = -2;   // (no tail patches since round 2)
+    if (tail >= 0 && st->ctx->variant >= 12) tail = -2;   // (no tail patches since round 2)
     if (tail >= 0) {
         // One extra, non-adjacent patch in the same launch: only the default kernels can carry it.  Anything else
         // (explicit variants, fallbacks for other K, the nonlinear path) gets a launch of its own for it.
@@ -260,6 +260,10 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
     }
 #endif
 #ifdef MOKA_VARIANTS
+    if (v == 14 && m->lpc == 64 && m->colOk) {               // persistent double-buffered LDS-DMA tile
+        hipError_t e = launch_stage_ptile2(dev, g, st->ctx->nCUs, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if ((v == 12 || v == 13) && m->lpc == 64 && m->colOk) {  // every row of a patch staged in LDS by LDS-DMA (256 / 512 threads)
         hipError_t e = launch_stage_tile3(dev, g, v == 13 ? 512 : 256, s);
         if (e != hipErrorNotSupported) return e;
@@ -416,7 +420,7 @@ int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
 int moka_kernel_variant_available(int variant)
 {
 #ifdef MOKA_VARIANTS
-    return variant >= 0 && variant <= 13;
+    return variant >= 0 && variant <= 14;
 #else
     return variant == 0 || variant == 3 || variant == 4 || variant == 11;
 #endif
@@ -425,7 +429,7 @@ int moka_kernel_variant_available(int variant)
 int moka_set_kernel_variant(moka_ctx *ctx, int variant)
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
-    if (variant < 0 || variant > 13) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..13");
+    if (variant < 0 || variant > 14) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..14");
     if (!moka_kernel_variant_available(variant))
         return fail(ctx, MOKA_ERR_UNSUPPORTED, "this kernel variant is an experiment: build the library with `make VARIANTS=1`");
     ctx->variant = variant;
@@ -471,11 +475,23 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     UP(eoc) UP(coc) UP(mltc) UP(sdv) UP(invArea) UP(areaCell) UP(rsum)
     UP(ehdr) UP(eoe) UP(woe) UP(gInvDc) UP(dcEdge) UP(dvEdge) UP(fEdge)
     UP(eov) UP(cv) UP(cellN2O) UP(edgeN2O) UP(vertN2O)
-    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(lcOff) UP(leOff) UP(patchRegular) UP(rowStart) UP(rowEdge)
+    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(lcOff) UP(leOff) UP(patchRegular) UP(rowStart) UP(rowEdge) UP(cRecT) UP(eRecT)
     if (p.nlOk) { UP(voe) UP(cov) UP(kite) UP(invAreaTri) UP(fVertex) UP(keCoef) UP(invDc) }
 #undef UP
     d.CI = p.CI; d.EI = p.EI;
     m->colOk = p.colOk;
+    d.tileRecOk = 0;
+#ifdef MOKA_VARIANTS
+    if (!p.eRecT.empty()) {        // persistent tiled kernel: the loader keeps a bounded number of row indices per lane
+        const int rpp = 1024 / (p.K * 8);
+        int worst = 0;
+        for (int q = 0; q < p.nPatches; ++q) {
+            const int rows = p.rowStart[q + 1] - p.rowStart[q], own = p.patchEdgeStart[q + 1] - p.patchEdgeStart[q];
+            worst = std::max(worst, (rows + rpp - 1) / rpp - own / rpp);
+        }
+        d.tileRecOk = worst <= stage_ptile2_halo_piece_budget() ? 1 : 0;
+    }
+#endif
 
     d.maxRows = p.maxRows; d.maxOwnE = p.maxOwnE; d.maxOwnC = p.maxOwnC;
 #ifdef MOKA_VARIANTS

@@ -86,6 +86,10 @@ hipError_t prepare_stage_lds(size_t ldsBytes);
 // every row of a patch staged in LDS by LDS-DMA (csrc/experiments/stage_tile.hip); threads = 256 or 512 per patch
 bool stage_tile3_usable(const MeshDev &m);
 hipError_t launch_stage_tile3(const MeshDev &m, const StageArgs &a, int threads, hipStream_t s);
+// persistent, double-buffered form of it (csrc/experiments/stage_ptile2.hip): one workgroup per CU, a loader wave + 8 compute waves
+int stage_ptile2_halo_piece_budget();
+bool stage_ptile2_usable(const MeshDev &m);
+hipError_t launch_stage_ptile2(const MeshDev &m, const StageArgs &a, int nCUs, hipStream_t s);
 #endif
 hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s);
 hipError_t launch_curl2(const MeshDev &m, const double *u, double *vort, bool accum, hipStream_t s);

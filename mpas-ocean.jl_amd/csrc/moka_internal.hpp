@@ -53,6 +53,7 @@ struct Plan {
     //   eRec[e][EI]: [0,ME2) u-row offsets of edgesOnEdge | c1 | c2 | valid-slot mask | maxLevelEdgeTop
     // invalid slots carry the entity's own (valid) offset.  feoe = fEdge[edgesOnEdge] per slot.
     std::vector<uint32_t> cRec, eRec;
+    std::vector<uint32_t> cRecT, eRecT;   // the same with patch-local LDS row-image offsets in the u-row slots (tiled kernels)
     std::vector<double>   feoe;       // nE*ME2
     int32_t CI = 0, EI = 0;
     bool colOk = false;               // K*stateBytes*nE < 4 GiB: offsets fit 32 bits
@@ -105,6 +106,7 @@ struct MeshDev {
     const int32_t *cellN2O, *edgeN2O, *vertN2O;
     // column kernel records
     const uint32_t *cRec, *eRec;
+    const uint32_t *cRecT, *eRecT;
     const double *feoe;
     int32_t CI, EI;
     // LDS-tiled kernel
@@ -116,6 +118,7 @@ struct MeshDev {
     // optional nonlinear terms (nullptr when the mesh did not bring them)
     const int32_t *voe, *cov;
     const double *kite, *invAreaTri, *fVertex, *keCoef, *invDc;
+    int32_t tileRecOk;    // eRecT / cRecT exist and every patch fits the loader budget of the persistent tiled kernel
     int32_t tailPatch;    // >= 0: one extra, non-adjacent patch rides in this launch (default stage kernels only)
 };
 
