@@ -18,11 +18,11 @@ struct PTileMesh {
     int32_t maxRows;
 };
 
-constexpr int PT_CW = 8;                 // compute waves
+constexpr int PT_CW = 15;                // compute waves
 constexpr int PT_NT = (PT_CW + 1) * 64;  // + one loader wave
 constexpr int PT_NG = PT_CW * 2;         // half-wave groups
 constexpr int PT_MAXHP = 48;             // halo pieces a patch may have (rows beyond the own ones, rpp per piece)
-constexpr int PT_NCI = 1, PT_NEI = 4;    // cells / edges a half-wave group handles per patch: patches of <= 16 cells, <= 64 own edges
+constexpr int PT_NCI = 1, PT_NEI = 2;    // cells / edges a half-wave group handles per patch: patches of <= 16 cells, <= 64 own edges
 
 struct PRec {                            // byte offsets of the record arrays inside a buffer's record area (all 16-byte aligned)
     uint32_t woe, feoe, g, sdv, invA, rsum, eRec, cRec, bytes;
