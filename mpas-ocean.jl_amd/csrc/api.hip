@@ -110,6 +110,8 @@ struct FieldRef {
     bool f32 = false;   // ptr is a float array (prognostic field of an fp32-storage state)
 };
 
+static bool is_tend_field_id(int f) { return f == MOKA_F_TEND_NORMAL_VELOCITY || f == MOKA_F_TEND_LAYER_THICKNESS; }
+
 int field_ref(moka_state *st, int field, int level, FieldRef *r)
 {
     const Plan &p = st->mesh->plan;
@@ -126,7 +128,7 @@ int field_ref(moka_state *st, int field, int level, FieldRef *r)
         case MOKA_F_TEND_LAYER_THICKNESS: *r = {st->tendH, MOKA_CELL, p.nC, p.K}; break;
         default: return fail(st->ctx, MOKA_ERR_ARG, "unknown field id");
     }
-    r->f32 = st->f32 && field <= MOKA_F_LAYER_THICKNESS;
+    r->f32 = st->f32 && (field <= MOKA_F_LAYER_THICKNESS || is_tend_field_id(field));
     if (!r->ptr) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "an fp32-storage state carries no DiagnosticVars arrays");
     return MOKA_OK;
 }
@@ -646,7 +648,7 @@ int moka_state_create(moka_ctx *ctx, moka_mesh *mesh, moka_state **out)
         A(&st->hEdge[0], nEK); A(&st->hEdge[1], nEK);
         A(&st->F, nEK); A(&st->div, nCK); A(&st->vort, nVK);
     }
-    A(&st->tendU, nEK); A(&st->tendH, nCK);
+    A(&st->tendU, nEK, sb); A(&st->tendH, nCK, sb);       // fp32-storage states store their tendencies fp32 as well
     A(&st->scalar, 2);
     if (rc != MOKA_OK) { moka_state_destroy(st); return rc; }
     st->phys[0] = st->lev[0]; st->phys[1] = st->lev[1];

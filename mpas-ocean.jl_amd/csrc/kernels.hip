@@ -374,8 +374,9 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
 // ssh / normalVelocity / layerThickness of every time level and RK provisional state are stored as fp32
 // (rows of K*4 bytes); a lane owns FOUR consecutive levels (one 16-byte load), K/4 lanes one entity and a wave
 // 64/(K/4) entities (K <= 128, K % 4 == 0).  Every load widens to fp64, the arithmetic is that of k_stage_rec2c in the
-// same order, stores round to nearest fp32; tendencies (MODE 0) are written as fp64.  The StageArgs pointers
-// of state arrays are float arrays in disguise (the host keeps one argument block for both storage types).
+// same order, stores round to nearest fp32 -- the tendencies of MODE 0 too (accumulated in fp64, stored fp32 like the
+// state: inside an RK step they never leave the registers).  The StageArgs pointers of state and tendency arrays are float
+// arrays in disguise (the host keeps one argument block for both storage types).
 // The byte-offset records of such a mesh are built for K*4-byte rows (moka_mesh_desc.stateBytes = 4).
 // ssh column sum: oracle_ksum order -- lanes l and l^16 hold levels k and k^64, then k^32 ... k^4, and the four
 // levels of a lane combine as (x+z)+(y+w), i.e. k^2 then k^1.
@@ -425,7 +426,6 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         return pl < K4 ? o : 0.0;
     };
     const uint32_t voff = (uint32_t)l * 16u, rowB = (uint32_t)K * 4u;      // fp32 rows
-    const uint32_t voffD = (uint32_t)l * 32u, rowBD = (uint32_t)K * 8u;    // fp64 rows (tendency outputs)
     const RecLds L = rec_carve(smem, m, ME, ME2, maxOwnE, maxOwnC);
     const size_t recBytes = ((size_t)maxOwnE * (2 * ME2 + 1) * 8 + (size_t)maxOwnC * (ME + 2) * 8 +
                              ((size_t)maxOwnE * m.EI + (size_t)maxOwnC * m.CI) * 4 + 15) & ~(size_t)15;
@@ -575,11 +575,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         }
         d4 hs = zero;
         if (act) {
-            if constexpr (MODE == 0) {
-                const uint32_t ownD = (uint32_t)c * rowBD + voffD;
-                gstore2(a.tendH, ownD, make_double2(t.x, t.y));
-                gstore2(a.tendH, ownD + 16u, make_double2(t.z, t.w));
-            }
+            if constexpr (MODE == 0) gstore4(a.tendH, own, t);          // the sum was formed in fp64; stored like the state, fp32
             if constexpr (MODE == 1 || MODE == 2) {
                 const d4 hcur = MODE == 2 ? widen4(curf) : hc;
                 const d4 nb = MODE == 2 ? widen4(ninf) : hcur;
@@ -672,11 +668,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
                     if (on && aw) t.w += pw;
                 }
             }
-            if constexpr (MODE == 0) {
-                const uint32_t ownD = (uint32_t)e * rowBD + voffD;
-                gstore2(a.tendU, ownD, make_double2(t.x, t.y));
-                gstore2(a.tendU, ownD + 16u, make_double2(t.z, t.w));
-            }
+            if constexpr (MODE == 0) gstore4(a.tendU, own, t);
             if constexpr (MODE == 1) {
                 const d4 up = widen4(ubuf4[(size_t)ei * K4 + l]);       // own row is in the cache
                 gstore4(a.pu_out, own, axpy4(up, a.a, t));              // time_integration.jl:124

@@ -333,7 +333,8 @@ void oracle_step_rk4(const oracle_mesh *m, oracle_state *s, double dt, double *w
  * hard-codes Float64: PrognosticVars.jl:91-93): a storage option of this build, so PARITY UNPINNED beyond
  * agreeing with the fp64 path to fp32 round-off.  Semantics: ssh, normalVelocity, layerThickness of every
  * time level and RK provisional state are STORED as fp32; every load widens to fp64; all arithmetic is the
- * fp64 arithmetic above, in the same order; a store rounds to nearest fp32.  Tendencies stay fp64.
+ * fp64 arithmetic above, in the same order; a store rounds to nearest fp32.  The tendency ARRAYS (what moka_tendencies
+ * leaves in Tend) are stored fp32 too -- oracle.py rounds them; inside an RK step the fp64 tendency is used unrounded.
  * The oracle keeps double arrays whose values are fp32-representable (rnd32 at each store).
  * --------------------------------------------------------------------------------------------- */
 static inline double rnd32(double x) { return (double)(float)x; }

@@ -174,6 +174,8 @@ class OracleMesh:
         s1, s2 = np.zeros_like(u), np.zeros_like(u)
         fn = lib().oracle_tendencies_mixed if mixed else lib().oracle_tendencies_clean
         fn(self.ref, _p(tu), _p(th), _p(u), _p(h), _p(ssh), _p(s1), _p(s2))
+        if mixed:          # accumulated in fp64, STORED like the state: fp32
+            tu, th = tu.astype(np.float32).astype(np.float64), th.astype(np.float32).astype(np.float64)
         return tu, th, ssh
 
 
@@ -215,6 +217,9 @@ class OracleState:
             self._work = np.zeros(2 * K * (m.nEdges + m.nCells) + m.nCells)
         fn = lib().oracle_step_rk4_mixed if self.mixed else lib().oracle_step_rk4
         fn(self.om.ref, C.byref(self.c), float(dt), _p(self._work))
+        if self.mixed:     # the stage-4 tendencies left in Tend: fp64 inside the step, stored fp32
+            self.tendU[...] = self.tendU.astype(np.float32)
+            self.tendH[...] = self.tendH.astype(np.float32)
 
     def sum_sq_ssh(self):
         return lib().oracle_sum_sq(_p(self.ssh[1]), self.ssh[1].size)

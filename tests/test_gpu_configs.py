@@ -189,10 +189,11 @@ def test_config5_full_size_properties(backend):
     mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
     th = Tend.tendLayerThickness.get()
     assert np.all(np.isfinite(th))
-    # (a) flux form: sum_c areaCell * tendH[k,c] = 0 for every level, to round-off of the (fp64) summands
+    # (a) flux form: sum_c areaCell * tendH[k,c] = 0 for every level, to round-off of the summands -- which are stored
+    #     fp32 on such a state (accumulated in fp64): 2^-24 relative each
     tot = (mesh.areaCell[:, None] * th).sum(0)
     scale = (mesh.areaCell[:, None] * np.abs(th)).sum(0)
-    assert np.all(np.abs(tot) <= 1e-11 * scale)
+    assert np.all(np.abs(tot) <= 6e-8 * scale)
     # (b) a sample of whole columns against the storage-emulating oracle would need the full oracle run (minutes);
     #     the same kernel is compared bit for bit at m = 32 / 64 above.  Here: the stored state widens exactly
     f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)

@@ -1,10 +1,8 @@
-export MOKA_HIP_LIB=$PWD/mpas-ocean.jl_amd/libmoka_hip_exp.so
-timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "rk4_bitwise" > gpurun_out/r02_ptile_tests.log 2>&1; tail -3 gpurun_out/r02_ptile_tests.log | cut -c1-300
-for v in 14 0 14; do for P in 14; do
-timeout -k 10 200 python3 bench.py --no-cpu --steps 20 --warmup 5 --variant $v --patch-cells $P > gpurun_out/ptile_v${v}_P${P}.json 2> gpurun_out/ptile_v${v}_P${P}.err && python3 - gpurun_out/ptile_v${v}_P${P}.json $v $P <<'PY'
-import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
-ps = d["roofline"].get("per_stage", [])
-print(f"v{sys.argv[2]} P{sys.argv[3]}: {d['ms_per_step']:.3f} ms/step  stages " + " ".join(f"{p['ms']:.3f}" for p in ps) + f"  tendency {d['tendency_kernel']['avg_launch_ms']:.3f}  FE {d['forward_euler_compat']['ms_per_step']:.3f}")
+timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "fp32 or config5 or stream_ordered" > gpurun_out/r02_f32_tests.log 2>&1; tail -3 gpurun_out/r02_f32_tests.log | cut -c1-300
+timeout -k 10 300 python3 bench.py --workload config5_3.7M_x80_f32 --no-cpu > gpurun_out/r02_bench_c5.json 2> gpurun_out/r02_bench_c5.err; python3 - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r02_bench_c5.json").read().strip().split("\n")[-1])
+print(d["ms_per_step"], [round(p["ms"],3) for p in d["roofline"]["per_stage"]], d["tendency_kernel"], d["roofline"]["frac"])
 PY
-done; done
+timeout -k 10 200 python tools/fuzz_cluster.py 60 3 2>&1 | tail -2
+timeout -k 10 200 python tools/fuzz_parity.py 60 5 2>&1 | tail -2

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""GPU box helper: randomized sweep of the distributed RK4 step (all ranks of a partition in one process, stream-ordered
-device copies as halo transport: parallel.LocalCluster) against the single-domain oracle, bit for bit.
+"""GPU box helper: randomized sweep of the distributed steps (all ranks of a partition in one process: parallel.LocalCluster,
+direct transport -- push kernels into the neighbours' fields + flag words -- or buffered transport with stream-ordered device
+copies, chosen at random; RK4 steps, and on fp64 states also the reference's Forward-Euler step with random compat flags)
+against the single-domain oracle, bit for bit.
    python tools/fuzz_cluster.py [seconds=120] [seed=0]"""
 import os
 import sys
@@ -31,8 +33,11 @@ while time.time() - t0 < budget:
     u = r.uniform(-1, 1, (mesh.nEdges, K))
     ssh = h.sum(1) - rest.sum(1)
     tag = f"case {n}: m {m} world {world} K {K} P {P} f32 {f32}"
+    direct = bool(rng.integers(0, 4) != 0)
+    fe_flags = int(rng.choice([3, 2, 1, 0])) if K > 1 else int(rng.choice([7, 0]))
+    tag += f" direct {direct} fe_flags {fe_flags}"
     try:
-        cl = par.LocalCluster(mesh, ssh, u, h, rest, 20.0, world, patch_cells=P, state_bytes=4 if f32 else 8)
+        cl = par.LocalCluster(mesh, ssh, u, h, rest, 20.0, world, patch_cells=P, state_bytes=4 if f32 else 8, direct=direct)
     except Exception as exc:               # noqa: BLE001  shapes the library refuses (e.g. fp32 with a huge straddling patch)
         skipped += 1
         continue
@@ -46,6 +51,15 @@ while time.time() - t0 < budget:
     assert np.array_equal(gu, ref.u[1]), tag + " u"
     assert np.array_equal(gh, ref.h[1]), tag + " h"
     assert np.array_equal(gs, ref.ssh[1]), tag + " ssh"
+    if not f32:
+        for _ in range(2):
+            cl.step_fe(fe_flags)
+            ref.step_fe(20.0, fe_flags)
+        gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
+        assert np.array_equal(gu, ref.u[1]) and np.array_equal(gh, ref.h[1]) and np.array_equal(gs, ref.ssh[1]), tag + " FE"
+        d = cl.gather_diagnostics(mesh, K)
+        for name, exp in (("hEdge", ref.hEdge), ("F", ref.F), ("div", ref.div), ("vort", ref.vort), ("tendU", ref.tendU), ("tendH", ref.tendH)):
+            assert np.array_equal(d[name], exp), tag + " FE " + name
     cl.close()
     n += 1
     if n % 10 == 0:
