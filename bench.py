@@ -143,19 +143,24 @@ def cpu_baseline_1t(mesh, K, ssh, u, h, rest, dts, budget_s=12.0, mixed=False):
             "ms_per_step": t * 1e3}
 
 
-def rccl_probe_child():
+def rccl_probe_child(backend="nccl"):
     """Child process of probe_rccl: bring RCCL up between the ranks and move a few bytes the two ways the halo transports
-    do (all_to_all_single with uneven splits, batched isend / irecv).  Exit code 0 = it works on this node."""
+    do (all_to_all_single with uneven splits, batched isend / irecv).  Exit code 0 = it works on this node.
+    (backend = "gloo" runs the same exchange on CPU tensors: the rendezvous logic can then be tested without a GPU.)"""
     import torch
     import torch.distributed as dist
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
-    ndev = max(torch.cuda.device_count(), 1)
-    if ndev < world:
-        print(f"[rccl-probe] {world} ranks on {ndev} device(s): RCCL needs one device per rank", file=sys.stderr)
-        sys.exit(3)
-    torch.cuda.set_device(local % ndev)
-    dev = torch.device("cuda", local % ndev)
-    dist.init_process_group("nccl", device_id=dev, timeout=dt.timedelta(seconds=60))
+    if backend == "nccl":
+        ndev = max(torch.cuda.device_count(), 1)
+        if ndev < world:
+            print(f"[rccl-probe] {world} ranks on {ndev} device(s): RCCL needs one device per rank", file=sys.stderr)
+            sys.exit(3)
+        torch.cuda.set_device(local % ndev)
+        dev = torch.device("cuda", local % ndev)
+        dist.init_process_group("nccl", device_id=dev, timeout=dt.timedelta(seconds=60))
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo", timeout=dt.timedelta(seconds=60))
     ins = [(rank + q) % 3 + 1 if q != rank else 0 for q in range(world)]
     outs = [(q + rank) % 3 + 1 if q != rank else 0 for q in range(world)]
     send = torch.full((sum(ins),), float(rank), device=dev, dtype=torch.float64)
@@ -167,14 +172,15 @@ def rccl_probe_child():
     a, b = torch.full((5,), float(rank), device=dev), torch.zeros(5, device=dev)
     for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, prv), dist.P2POp(dist.isend, a, nxt)]):
         w.wait()
-    torch.cuda.synchronize()
+    if backend == "nccl":
+        torch.cuda.synchronize()
     ok = ok and bool((b.cpu() == float(prv)).all())
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 4)
 
 
-def probe_rccl(timeout_s=120):
+def probe_rccl(timeout_s=120, backend="nccl"):
     """Does RCCL work between the ranks of this launch?  Answered by a CHILD process per rank (its own rendezvous port),
     started before this process has touched the GPU: a wedged RCCL collective does not raise, it hangs until a watchdog
     kills the process -- so the risk is taken by a process whose only job is to take it.  True = every step ran."""
@@ -182,8 +188,12 @@ def probe_rccl(timeout_s=120):
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 23)
     env["MASTER_ADDR"] = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    # under torch.distributed.run the ranks are told to use the AGENT's store at MASTER_PORT; the children rendezvous among
+    # themselves on another port, where child rank 0 has to host the store
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+        env.pop(k)
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-probe"], env=env, timeout=timeout_s,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-probe", backend], env=env, timeout=timeout_s,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             log(f"[bench] RCCL probe failed (exit {r.returncode}): {r.stdout.strip().splitlines()[-1:] }")
@@ -195,7 +205,7 @@ def probe_rccl(timeout_s=120):
 
 def main():
     if "--rccl-probe" in sys.argv:
-        rccl_probe_child()
+        rccl_probe_child(sys.argv[sys.argv.index("--rccl-probe") + 1] if len(sys.argv) > sys.argv.index("--rccl-probe") + 1 else "nccl")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

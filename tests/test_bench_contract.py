@@ -21,3 +21,22 @@ def test_default_workload_is_config4():
     m, K = bench.WORKLOADS["config4_1M_x60"]
     assert 10 * m * m + 2 == 1024002 and K == 60
     assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_rccl_probe_rendezvous_in_child_processes():
+    """bench.py asks a CHILD process per rank whether RCCL works (a wedged collective hangs rather than raises).  The
+    children rendezvous on their own port, outside the launcher's agent store.  Run that logic under torch.distributed.run
+    with the probe's exchange on gloo / CPU tensors: two ranks, both must report success."""
+    import subprocess
+    import sys
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    code = ("import importlib.util, os, sys; spec = importlib.util.spec_from_file_location('bench', %r); "
+            "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b); "
+            "ok = b.probe_rccl(timeout_s=90, backend='gloo'); print('PROBE', os.environ['RANK'], ok); sys.exit(0 if ok else 1)"
+            % os.path.join(ROOT, "bench.py"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "--no-python", sys.executable, "-c", code],
+                       capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "PROBE 0 True" in r.stdout and "PROBE 1 True" in r.stdout
