@@ -234,9 +234,11 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
         if (pCount >= 0) return hipErrorNotSupported;
         const bool del2 = st->viscDel2 != 0.0;
         const NlArgs nl{st->nlQv, st->nlQe, st->nlKe, del2 ? st->nlZv : nullptr, del2 ? st->nlDiv : nullptr, st->viscDel2};
-        hipError_t e = launch_nl_prepare(dev, g.pu, g.ph, nl, m->lpc, s);
+        // kernel variants 4 / 3 select the plainer forms of the nonlinear kernels too (tests run every form against the oracle)
+        const int form = st->ctx->variant == 4 ? 1 : st->ctx->variant == 3 ? 3 : 0;
+        hipError_t e = launch_nl_prepare(dev, g.pu, g.ph, nl, m->lpc, form, s);
         if (e != hipSuccess) return e;
-        return launch_stage_nl(dev, g, nl, m->lpc, s);
+        return launch_stage_nl(dev, g, nl, m->lpc, m->plan.ldsOk, form, s);
     }
     if (st->f32) {   // the one fp32-storage kernel (checked at state creation against the patches that are ever launched)
         if (pCount < 0 && m->plan.nPatchesLaunch < m->plan.nPatches) {

@@ -114,8 +114,11 @@ struct NlArgs {
     double *divc;   // (K, nC) velocityDivCell
     double visc;
 };
-hipError_t launch_nl_prepare(const MeshDev &m, const double *u, const double *h, const NlArgs &nl, int lpc, hipStream_t s);
-hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &nl, int lpc, hipStream_t s);
+// form: 0 = best available, 1 = patch kernels without the LDS q_e rows, 2 = 16-byte-lane entity kernels, 3 = generic lane-group kernels
+// (prepare and stage must be called with the same form: forms 0 / 1 keep F alone in NlArgs.fq, forms 2 / 3 {F, q_e} pairs)
+hipError_t launch_nl_prepare(const MeshDev &m, const double *u, const double *h, const NlArgs &nl, int lpc, int form, hipStream_t s);
+// rowsOk: the plan built the patch row lists (rowStart / rowEdge / leoe; Plan.ldsOk)
+hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &nl, int lpc, bool rowsOk, int form, hipStream_t s);
 
 // ---- reverse mode of one Forward-Euler step: gather form, the oracle's summation order ----
 struct AdjMesh {

@@ -862,6 +862,46 @@ def test_nonlinear_tendency_and_rk4_bitwise(backend, meshname, K, nsteps):
     Prog._state.close(); Setup.mesh.close()
 
 
+@pytest.mark.parametrize("variant", [0, 4, 3])
+@pytest.mark.parametrize("meshname,K,visc", [("ico16", 60, 0.0), ("planar", 64, 1.0), ("ico32", 34, 0.0)])
+def test_nonlinear_kernel_forms_with_partial_edge_masks(backend, meshname, K, visc, variant):
+    """The three forms of the nonlinear kernels (variant 0: patch kernels with q_e rows in LDS; 4: patch kernels gathering
+    the vertex potential vorticity; 3: generic lane-group kernels) against the oracle, with maxLevelEdgeTop < K on a third of
+    the edges (the masks of horizontal_advection.jl:63 and the edge loop) and, on one mesh, Del2 mixing on top."""
+    mesh = get_mesh(meshname)
+    ssh, u, h, rest = random_state(mesh, K, 91 + K)
+    dtv = 2.0 if meshname == "planar" else 20.0
+    rng = np.random.default_rng(7)
+    mlt = np.where(rng.random(mesh.nEdges) < 0.33, rng.integers(0, K + 1, mesh.nEdges), K).astype(np.int32)
+    hm = mk.HorzMesh(mesh)
+    vm = mk.VerticalMesh(hm, nVertLevels=K, restingThickness=rest)
+    vm.maxLevelEdge.Top[:] = mlt
+    backend.set_kernel_variant(variant)
+    try:
+        M = mk.Mesh(hm, vm, backend=backend)
+        Prog = mk.PrognosticVars(ssh, u, h, 2, M)
+        Diag, Tend = mk.DiagnosticVars(None, M, Prog._state), mk.TendencyVars(None, M, Prog._state)
+        om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=mlt)
+        v = visc * 0.01 * float(mesh.dcEdge.min()) ** 2 / dtv
+        nl = orc.OracleNonlinear(om, visc_del2=v) if v else orc.OracleNonlinear(om)
+        mk.set_nonlinear(Prog, True, visc_del2=v)
+        tu, th, ossh, _ = nl.tendencies(u, h)
+        mk.computeTendency(M, Diag, Prog, Tend)
+        assert np.array_equal(Tend.tendNormalVelocity.get(), tu)
+        assert np.array_equal(Tend.tendLayerThickness.get(), th)
+        assert np.array_equal(Prog.ssh[-1].get(), ossh)
+        st = orc.OracleState(om, ssh, u, h)
+        mk.run_steps(Prog, mk.RungeKutta4, dtv, 3)
+        for _ in range(3):
+            nl.step_rk4(st, dtv)
+        assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1])
+        assert np.array_equal(Prog.layerThickness[-1].get(), st.h[1])
+        assert np.array_equal(Prog.ssh[-1].get(), st.ssh[1])
+        Prog._state.close(); M.close()
+    finally:
+        backend.set_kernel_variant(0)
+
+
 @pytest.mark.parametrize("meshname,K,nsteps", [("ico16", 1, 3), ("ico16", 60, 2), ("planar", 4, 3), ("ico12f", 5, 2), ("ico16", 70, 2),
                                                ("ico12f", 40, 2), ("planar", 34, 2)])
 def test_del2_mixing_bitwise(backend, meshname, K, nsteps):
