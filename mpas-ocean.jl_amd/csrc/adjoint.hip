@@ -220,6 +220,117 @@ __global__ __launch_bounds__(BLOCK) void k_adj_edge2(const AdjMesh m, const AdjA
     }
 }
 
+// k_adj_edge2<TT, 10> with a workgroup per chunk of 64 consecutive edges (plan order: a compact piece of the mesh; chunks are
+// dealt to the XCDs like the forward kernels' patches): the chunk's records -- transposed lists, weights, headers, metric
+// factors -- are staged in LDS in one round trip, so that an edge's 18 row loads all go out together instead of behind
+// three dependent record loads.  Same sums in the same order.
+constexpr int ADJ_CH = 64;
+
+template <bool TT>
+__global__ __launch_bounds__(BLOCK, TT ? 3 : 4) void k_adj_edge3(const AdjMesh m, const AdjArgs a)
+{
+    constexpr int NG = BLOCK / 32, WU = 10;
+    __shared__ int sSrc[ADJ_CH * WU];
+    __shared__ double sW[ADJ_CH * WU];
+    __shared__ int4 sHd[ADJ_CH];
+    __shared__ double2 sSd[ADJ_CH];
+    __shared__ double sFe[ADJ_CH];
+    __shared__ int sFull[ADJ_CH];
+    const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int K = m.K, k0 = 2 * l;
+    const bool act = k0 < K;
+    const int nCh = (m.nE + ADJ_CH - 1) / ADJ_CH, ch = patch_of_block(nCh);
+    if (ch >= nCh) return;
+    const int e0 = ch * ADJ_CH, ne = min(ADJ_CH, m.nE - e0);
+    for (int i = threadIdx.x; i < ne * WU; i += BLOCK) { sSrc[i] = m.teoe[(size_t)e0 * WU + i]; sW[i] = m.tw[(size_t)e0 * WU + i]; }
+    for (int i = threadIdx.x; i < ne; i += BLOCK) {
+        sHd[i] = reinterpret_cast<const int4 *>(m.ehdr)[e0 + i];
+        sSd[i] = reinterpret_cast<const double2 *>(m.sd)[e0 + i];
+        sFe[i] = m.fEdge[e0 + i];
+        sFull[i] = m.efull[e0 + i];
+    }
+    __syncthreads();
+    for (int le = grp; le < ne; le += NG) {
+        const int e = e0 + le;
+        const int4 hd = sHd[le];
+        const int c1 = hd.x, c2 = hd.y, mlt = hd.w;
+        const double sd1 = sSd[le].x, sd2 = sSd[le].y;
+        const double fe = sFe[le];
+        double s1 = 0.0, s2 = 0.0;
+        if constexpr (!TT) { s1 = a.lamS1[c1]; s2 = a.lamS1[c2]; }
+        double2 tu = make_double2(0.0, 0.0);
+        const bool plain = __builtin_amdgcn_ballot_w64(!sFull[le]) == 0;      // both half-waves of the wave on regular edges
+        if (act) {
+            const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
+            const double2 l1 = ld2(a.lamH1, c1, K, l), l2 = ld2(a.lamH1, c2, K, l);
+            double2 cor = make_double2(0.0, 0.0);
+            double2 ls[WU];
+            if (plain) {
+#pragma unroll
+                for (int j = 0; j < WU; ++j) ls[j] = ld2(a.lamU1, sSrc[le * WU + j], K, l);
+            }
+            const double2 lu = ld2(a.lamU1, e, K, l);
+            const double2 uu = ld2(a.u, e, K, l);
+            double2 h1, h2, x, ai, hE;
+            if constexpr (TT) {
+                h1 = ld2(a.h, c1, K, l); h2 = ld2(a.h, c2, K, l);
+                if (a.accOutU) { x = ld2(a.xU, e, K, l); ai = a.accInU ? ld2(a.accInU, e, K, l) : x; }
+            } else {
+                hE = ld2(a.hEuse, e, K, l);
+            }
+            double2 Fbar;
+            if constexpr (TT) {
+                Fbar = make_double2(sd1 * l1.x + sd2 * l2.x, sd1 * l1.y + sd2 * l2.y);
+            } else {
+                const double2 tH1 = make_double2(a.dt * (l1.x + s1), a.dt * (l1.y + s1));
+                const double2 tH2 = make_double2(a.dt * (l2.x + s2), a.dt * (l2.y + s2));
+                Fbar = make_double2(sd1 * tH1.x + sd2 * tH2.x, sd1 * tH1.y + sd2 * tH2.y);
+            }
+            if (!ax) Fbar.x = 0.0;
+            if (!ay) Fbar.y = 0.0;
+            if (plain) {
+#pragma unroll
+                for (int j = 0; j < WU; ++j) {
+                    const double wf = sW[le * WU + j] * fe;
+                    cor.x += TT ? wf * ls[j].x : wf * (a.dt * ls[j].x);
+                    cor.y += TT ? wf * ls[j].y : wf * (a.dt * ls[j].y);
+                }
+            } else {
+                for (int j = 0; j < WU; ++j) {
+                    const int sx = sSrc[le * WU + j];
+                    if (sx < 0) continue;
+                    const int ms = m.ehdr[(size_t)sx * 4 + 3];
+                    const double w = sW[le * WU + j] * fe;
+                    const double2 lv = ld2(a.lamU1, sx, K, l);
+                    if (k0 < ms) cor.x += TT ? w * lv.x : w * (a.dt * lv.x);
+                    if (k0 + 1 < ms) cor.y += TT ? w * lv.y : w * (a.dt * lv.y);
+                }
+            }
+            if constexpr (TT) {
+                const double2 hI = make_double2(0.5 * (h1.x + h2.x), 0.5 * (h1.y + h2.y));           // Operators.jl:217
+                const double2 pb = make_double2(hI.x * Fbar.x + cor.x, hI.y * Fbar.y + cor.y);
+                if (a.accOutU) {                          // fused element-wise steps of the RK4 reverse sweep
+                    st2(a.accOutU, e, K, l, make_double2(ai.x + pb.x, ai.y + pb.y));
+                    if (a.kNextU) st2(a.kNextU, e, K, l, make_double2(a.cbNext * x.x + a.caNext * pb.x, a.cbNext * x.y + a.caNext * pb.y));
+                } else {
+                    st2(a.lamU0, e, K, l, pb);
+                }
+            } else {
+                st2(a.lamU0, e, K, l, make_double2((lu.x + hE.x * Fbar.x) + cor.x, (lu.y + hE.y * Fbar.y) + cor.y));
+            }
+            st2(a.Enew, e, K, l, make_double2(uu.x * Fbar.x, uu.y * Fbar.y));
+            if (ax) tu.x = TT ? lu.x : a.dt * lu.x;
+            if (ay) tu.y = TT ? lu.y : a.dt * lu.y;
+        }
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) {                       // oracle_ksum order
+            const double ox = __shfl_xor(tu.x, sft, 32), oy = __shfl_xor(tu.y, sft, 32);
+            tu = make_double2(tu.x + ox, tu.y + oy);
+        }
+        if (l == 0) a.csum[e] = tu.x + tu.y;
+    }
+}
+
 template <bool TT>
 __global__ __launch_bounds__(BLOCK) void k_adj_cell2(const AdjMesh m, const AdjArgs a)
 {
@@ -316,8 +427,9 @@ hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStrea
 {
     if (lpc == 64 && m.K <= 64 && !(m.K & 1)) {   // even 34 <= K <= 64: 16-byte lanes
         if (m.W == 10) {
-            if (a.tt) hipLaunchKernelGGL((k_adj_edge2<true, 10>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
-            else hipLaunchKernelGGL((k_adj_edge2<false, 10>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
+            const unsigned g = 8u * (unsigned)(((m.nE + ADJ_CH - 1) / ADJ_CH + 7) / 8);
+            if (a.tt) hipLaunchKernelGGL((k_adj_edge3<true>), dim3(g), dim3(BLOCK), 0, s, m, a);
+            else hipLaunchKernelGGL((k_adj_edge3<false>), dim3(g), dim3(BLOCK), 0, s, m, a);
         } else {
             if (a.tt) hipLaunchKernelGGL((k_adj_edge2<true, 0>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
             else hipLaunchKernelGGL((k_adj_edge2<false, 0>), dim3(grid2(m.nE)), dim3(BLOCK), 0, s, m, a);
