@@ -262,15 +262,17 @@ __global__ __launch_bounds__(BLOCK, TT ? 3 : 4) void k_adj_edge3(const AdjMesh m
         const bool plain = __builtin_amdgcn_ballot_w64(!sFull[le]) == 0;      // both half-waves of the wave on regular edges
         if (act) {
             const bool ax = k0 < mlt, ay = k0 + 1 < mlt;
-            const double2 l1 = ld2(a.lamH1, c1, K, l), l2 = ld2(a.lamH1, c2, K, l);
+            double2 l1 = ld2(a.lamH1, c1, K, l), l2 = ld2(a.lamH1, c2, K, l);
             double2 cor = make_double2(0.0, 0.0);
             double2 ls[WU];
             if (plain) {
 #pragma unroll
                 for (int j = 0; j < WU; ++j) ls[j] = ld2(a.lamU1, sSrc[le * WU + j], K, l);
             }
-            const double2 lu = ld2(a.lamU1, e, K, l);
-            const double2 uu = ld2(a.u, e, K, l);
+            double2 lu = ld2(a.lamU1, e, K, l);
+            const bool storeE = !(TT && a.fuseE);
+            double2 uu = make_double2(0.0, 0.0);
+            if (storeE) uu = ld2(a.u, e, K, l);
             double2 h1, h2, x, ai, hE;
             if constexpr (TT) {
                 h1 = ld2(a.h, c1, K, l); h2 = ld2(a.h, c2, K, l);
@@ -280,6 +282,12 @@ __global__ __launch_bounds__(BLOCK, TT ? 3 : 4) void k_adj_edge3(const AdjMesh m
             }
             double2 Fbar;
             if constexpr (TT) {
+                const double sc = a.lamScale;                        // k-bar = lamScale * stored rows (1.0 except in stage 4)
+                l1 = make_double2(sc * l1.x, sc * l1.y); l2 = make_double2(sc * l2.x, sc * l2.y); lu = make_double2(sc * lu.x, sc * lu.y);
+                if (plain) {
+#pragma unroll
+                    for (int j = 0; j < WU; ++j) ls[j] = make_double2(sc * ls[j].x, sc * ls[j].y);
+                }
                 Fbar = make_double2(sd1 * l1.x + sd2 * l2.x, sd1 * l1.y + sd2 * l2.y);
             } else {
                 const double2 tH1 = make_double2(a.dt * (l1.x + s1), a.dt * (l1.y + s1));
@@ -301,7 +309,8 @@ __global__ __launch_bounds__(BLOCK, TT ? 3 : 4) void k_adj_edge3(const AdjMesh m
                     if (sx < 0) continue;
                     const int ms = m.ehdr[(size_t)sx * 4 + 3];
                     const double w = sW[le * WU + j] * fe;
-                    const double2 lv = ld2(a.lamU1, sx, K, l);
+                    double2 lv = ld2(a.lamU1, sx, K, l);
+                    if constexpr (TT) lv = make_double2(a.lamScale * lv.x, a.lamScale * lv.y);
                     if (k0 < ms) cor.x += TT ? w * lv.x : w * (a.dt * lv.x);
                     if (k0 + 1 < ms) cor.y += TT ? w * lv.y : w * (a.dt * lv.y);
                 }
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(BLOCK, TT ? 3 : 4) void k_adj_edge3(const AdjMesh m
             } else {
                 st2(a.lamU0, e, K, l, make_double2((lu.x + hE.x * Fbar.x) + cor.x, (lu.y + hE.y * Fbar.y) + cor.y));
             }
-            st2(a.Enew, e, K, l, make_double2(uu.x * Fbar.x, uu.y * Fbar.y));
+            if (storeE) st2(a.Enew, e, K, l, make_double2(uu.x * Fbar.x, uu.y * Fbar.y));
             if (ax) tu.x = TT ? lu.x : a.dt * lu.x;
             if (ay) tu.y = TT ? lu.y : a.dt * lu.y;
         }
@@ -328,6 +337,75 @@ __global__ __launch_bounds__(BLOCK, TT ? 3 : 4) void k_adj_edge3(const AdjMesh m
             tu = make_double2(tu.x + ox, tu.y + oy);
         }
         if (l == 0) a.csum[e] = tu.x + tu.y;
+    }
+}
+
+// The cell half of a transposed tendency evaluation (tt) with u*Fbar recomputed instead of read: a workgroup per chunk of 64
+// cells, per (cell, slot) the edge's header and metric factors staged in LDS (two dependent round trips per chunk), then per
+// cell one batch of 15 row loads: the k-bar rows of the cell and of the cells across its edges, the stage's u rows, x and the
+// running sum.  Fbar = sd1 * kbar[c1] + sd2 * kbar[c2] with the edge's own (c1, c2) order and mask: the value the edge
+// kernel used, so the sums equal k_adj_cell2's bit for bit.  The edge kernel then neither loads u nor stores u*Fbar.
+constexpr int ADJ_CCH = 64;
+
+template <int ME_>
+__global__ __launch_bounds__(BLOCK, 4) void k_adj_cell3(const AdjMesh m, const AdjArgs a)
+{
+    constexpr int NG = BLOCK / 32;
+    __shared__ int4 sI[ADJ_CCH * ME_];        // edge (-1 none), the cell across, maxLevelEdgeTop of the edge, 1 if this cell is the edge's c1
+    __shared__ double4 sD[ADJ_CCH * ME_];     // sd1, sd2 of the edge, -sign * g / dcEdge, csum of the edge
+    const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int K = m.K, k0 = 2 * l;
+    const bool act = k0 < K;
+    const int nCh = (m.nC + ADJ_CCH - 1) / ADJ_CCH, ch = patch_of_block(nCh);
+    if (ch >= nCh) return;
+    const int c0 = ch * ADJ_CCH, nc = min(ADJ_CCH, m.nC - c0);
+    for (int i = threadIdx.x; i < nc * ME_; i += BLOCK) {
+        const int c = c0 + i / ME_;
+        const int e = m.eoc[(size_t)c0 * ME_ + i];
+        const int es = e < 0 ? 0 : e;
+        const int4 hd = reinterpret_cast<const int4 *>(m.ehdr)[es];
+        const double2 sd = reinterpret_cast<const double2 *>(m.sd)[es];
+        sI[i] = make_int4(e, hd.x == c ? hd.y : hd.x, hd.w, hd.x == c ? 1 : 0);
+        sD[i] = make_double4(sd.x, sd.y, (-(double)m.csgn[(size_t)c0 * ME_ + i]) * m.gInvDc[es], a.csum[es]);
+    }
+    __syncthreads();
+    if (!act) return;
+    const double sc = a.lamScale;
+    for (int lc = grp; lc < nc; lc += NG) {
+        const int c = c0 + lc;
+        double2 own = ld2(a.lamH1, c, K, l);
+        double2 oth[ME_], uu[ME_];
+#pragma unroll
+        for (int i = 0; i < ME_; ++i) {
+            const int4 r = sI[lc * ME_ + i];
+            oth[i] = ld2(a.lamH1, r.x < 0 ? c : r.y, K, l);
+            uu[i] = ld2(a.u, r.x < 0 ? 0 : r.x, K, l);
+        }
+        const double2 x = ld2(a.xH, c, K, l), ai = a.accInH ? ld2(a.accInH, c, K, l) : x;
+        own = make_double2(sc * own.x, sc * own.y);
+        double ls = 0.0;
+        double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < ME_; ++i) {
+            const int4 r = sI[lc * ME_ + i];
+            const double4 d = sD[lc * ME_ + i];
+            if (r.x < 0) continue;
+            ls += d.z * d.w;
+            const double2 o = make_double2(sc * oth[i].x, sc * oth[i].y);
+            const double2 l1 = r.w ? own : o, l2 = r.w ? o : own;
+            double2 Fbar = make_double2(d.x * l1.x + d.y * l2.x, d.x * l1.y + d.y * l2.y);
+            if (!(k0 < r.z)) Fbar.x = 0.0;
+            if (!(k0 + 1 < r.z)) Fbar.y = 0.0;
+            acc.x += uu[i].x * Fbar.x;
+            acc.y += uu[i].y * Fbar.y;
+        }
+        const double2 pb = make_double2(0.5 * acc.x + ls, 0.5 * acc.y + ls);
+        if (a.accOutH) {
+            st2(a.accOutH, c, K, l, make_double2(ai.x + pb.x, ai.y + pb.y));
+            if (a.kNextH) st2(a.kNextH, c, K, l, make_double2(a.cbNext * x.x + a.caNext * pb.x, a.cbNext * x.y + a.caNext * pb.y));
+        } else {
+            st2(a.lamH0, c, K, l, pb);
+        }
     }
 }
 
@@ -423,8 +501,11 @@ static hipError_t launch_adj_cell_lpc(const AdjMesh &m, const AdjArgs &a, hipStr
 
 static int grid2(int n) { return std::min(std::max((n + 7) / 8, 1), 65536); }
 
+bool adj_fused_available(const AdjMesh &m, int lpc) { return lpc == 64 && m.K <= 64 && !(m.K & 1) && m.W == 10 && m.ME == 6; }
+
 hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s)
 {
+    if (a.tt && (a.fuseE || a.lamScale != 1.0) && !adj_fused_available(m, lpc)) return hipErrorNotSupported;
     if (lpc == 64 && m.K <= 64 && !(m.K & 1)) {   // even 34 <= K <= 64: 16-byte lanes
         if (m.W == 10) {
             const unsigned g = 8u * (unsigned)(((m.nE + ADJ_CH - 1) / ADJ_CH + 7) / 8);
@@ -443,6 +524,12 @@ hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStrea
 
 hipError_t launch_adj_cell(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s)
 {
+    if (a.tt && a.fuseE) {
+        if (!adj_fused_available(m, lpc)) return hipErrorNotSupported;
+        const unsigned g = 8u * (unsigned)(((m.nC + ADJ_CCH - 1) / ADJ_CCH + 7) / 8);
+        hipLaunchKernelGGL((k_adj_cell3<6>), dim3(g), dim3(BLOCK), 0, s, m, a);
+        return hipGetLastError();
+    }
     if (lpc == 64 && m.K <= 64 && !(m.K & 1)) {
         if (a.tt) hipLaunchKernelGGL((k_adj_cell2<true>), dim3(grid2(m.nC)), dim3(BLOCK), 0, s, m, a);
         else hipLaunchKernelGGL((k_adj_cell2<false>), dim3(grid2(m.nC)), dim3(BLOCK), 0, s, m, a);

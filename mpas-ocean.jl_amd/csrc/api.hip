@@ -1304,14 +1304,21 @@ int moka_adjoint_sweep(moka_tape *t)
         // transposed kernels themselves (fused epilogues: AdjArgs.accOut / kNext), k-bar double-buffered because the
         // current one is being gathered while the next one is written
         double *kU[2] = {t->kbU, t->pbU}, *kH[2] = {t->kbH, t->pbH};
-        HIPCHK(st->ctx, launch_scale_copy(kU[0], XU, cb[3], (int64_t)nEK, s));
-        HIPCHK(st->ctx, launch_scale_copy(kH[0], XH, cb[3], (int64_t)nCK, s));
+        // chunk kernels (even K <= 64, hexagon-width lists): stage 4 reads X scaled on the fly (kb4 is never stored) and
+        // u*Fbar is recomputed by the cell kernel instead of travelling through memory
+        const bool fused = moka::adj_fused_available(t->am, st->mesh->lpc);
+        if (!fused) {
+            HIPCHK(st->ctx, launch_scale_copy(kU[0], XU, cb[3], (int64_t)nEK, s));
+            HIPCHK(st->ctx, launch_scale_copy(kH[0], XH, cb[3], (int64_t)nCK, s));
+        }
         int kc = 0;
         for (int sg = 4; sg >= 1; --sg) {
             moka::AdjArgs a{};
             a.tt = 1; a.dt = 1.0;
             a.u = t->rkU + nEK * (4 * i + (sg - 1)); a.h = t->rkH + nCK * (4 * i + (sg - 1));
             a.lamU1 = kU[kc]; a.lamH1 = kH[kc];
+            a.lamScale = 1.0; a.fuseE = fused ? 1 : 0;
+            if (fused && sg == 4) { a.lamU1 = XU; a.lamH1 = XH; a.lamScale = cb[3]; }
             a.Enew = t->Enew; a.csum = t->csum;
             a.xU = XU; a.xH = XH;
             a.accInU = sg == 4 ? nullptr : accU; a.accInH = sg == 4 ? nullptr : accH;

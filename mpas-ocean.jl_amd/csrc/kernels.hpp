@@ -148,7 +148,14 @@ struct AdjArgs {
     const double *xU, *xH, *accInU, *accInH;
     double *accOutU, *accOutH, *kNextU, *kNextH;
     double cbNext, caNext;
+    // tt only.  lamScale: the k-bar actually used is lamScale * lamU1 / lamH1 (stage 4 reads X itself: kb4 = b4 * X is never
+    // stored).  fuseE: u*Fbar is not stored by the edge kernel; the cell kernel recomputes it from the stage's u rows and the
+    // k-bar rows of the edge's two cells (same products, same order) -- set only when adj_fused_available() says so.
+    double lamScale;
+    int fuseE;
 };
+// both fused forms (lamScale != 1, fuseE) need the 16-byte-lane chunk kernels: even K <= 64, hexagon-width lists
+bool adj_fused_available(const AdjMesh &m, int lpc);
 hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s);
 hipError_t launch_adj_cell(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s);
 hipError_t launch_scale_copy(double *dst, const double *src, double f, int64_t n, hipStream_t s);   // dst = f*src
