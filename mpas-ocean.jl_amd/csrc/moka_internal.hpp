@@ -86,6 +86,8 @@ struct Plan {
     std::vector<double>  kite;     // nV*VD  kiteAreasOnVertex
     std::vector<double>  invAreaTri, fVertex;   // nV
     std::vector<double>  keCoef, invDc;         // nE  0.25*dcEdge*dvEdge ; 1/dcEdge
+    std::vector<double>  keoc;     // nC*ME  keCoef of the cell's edge in slot i (0 for padding): no dependent load in the kernels
+    std::vector<int32_t> rowVoe;   // 2 per entry of rowEdge: verticesOnEdge of that row's edge (patch row lists only)
 };
 
 int build_plan(const moka_mesh_desc *d, Plan &out);   // returns moka_status
@@ -117,7 +119,8 @@ struct MeshDev {
     int32_t maxRows, maxOwnE, maxOwnC;
     // optional nonlinear terms (nullptr when the mesh did not bring them)
     const int32_t *voe, *cov;
-    const double *kite, *invAreaTri, *fVertex, *keCoef, *invDc;
+    const double *kite, *invAreaTri, *fVertex, *keCoef, *invDc, *keoc;
+    const int32_t *rowVoe;
     int32_t tileRecOk;    // eRecT / cRecT exist and every patch fits the loader budget of the persistent tiled kernel
     int32_t tailPatch;    // >= 0: one extra, non-adjacent patch rides in this launch (default stage kernels only)
 };

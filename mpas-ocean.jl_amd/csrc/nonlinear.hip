@@ -355,7 +355,7 @@ __global__ __launch_bounds__(BLOCK) void k_nl_prep4(const MeshDev m, const doubl
             const int e = m.eoc[(size_t)cb * ME_ + i];
             sCi[i] = e;
             sCd[c * (2 * ME_ + 2) + j] = m.sdv[(size_t)cb * ME_ + i];
-            sCd[c * (2 * ME_ + 2) + ME_ + j] = m.keCoef[e < 0 ? 0 : e];
+            sCd[c * (2 * ME_ + 2) + ME_ + j] = m.keoc[(size_t)cb * ME_ + i];
         }
         for (int i = threadIdx.x; i < nc; i += BLOCK) {
             sCd[i * (2 * ME_ + 2) + 2 * ME_] = m.invArea[cb + i]; sCd[i * (2 * ME_ + 2) + 2 * ME_ + 1] = m.areaCell[cb + i];
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(NT, 4) void k_stage_nl4(const MeshDev m, const Stag
     const double *__restrict__ F = nl.fq;
     const int e0 = m.patchEdgeStart[p], e1 = m.patchEdgeStart[p + 1], nOwn = e1 - e0;
     const int r0 = m.rowStart[p], nRows = m.rowStart[p + 1] - r0;
-    for (int i = threadIdx.x; i < nRows; i += NT) sV[i] = reinterpret_cast<const int2 *>(m.voe)[m.rowEdge[r0 + i]];
+    for (int i = threadIdx.x; i < nRows; i += NT) sV[i] = reinterpret_cast<const int2 *>(m.rowVoe)[r0 + i];
     for (int i = threadIdx.x; i < nOwn * ME2_; i += NT) { sX[i] = m.eoe[(size_t)e0 * ME2_ + i]; sW[i] = m.woe[(size_t)e0 * ME2_ + i]; }
     for (int i = threadIdx.x; i < nOwn * 4; i += NT) reinterpret_cast<int *>(sL)[i] = reinterpret_cast<const int *>(m.leoe)[(size_t)e0 * 4 + i];
     const int c0 = m.patchCellStart[p], nC = m.patchCellStart[p + 1] - c0;

@@ -593,6 +593,16 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
         }
     }
     p.rowEdge.push_back(0);
+    if (p.nlOk) {
+        p.rowVoe.resize(2 * p.rowEdge.size());
+        for (size_t r = 0; r < p.rowEdge.size(); ++r) {
+            p.rowVoe[2 * r] = p.voe[2 * (size_t)p.rowEdge[r]]; p.rowVoe[2 * r + 1] = p.voe[2 * (size_t)p.rowEdge[r] + 1];
+        }
+        p.keoc.assign((size_t)nC * ME, 0.0);
+        for (int c = 0; c < nC; ++c)
+            for (int i = 0; i < ME; ++i)
+                if (p.eoc[IX(i, c, ME)] >= 0) p.keoc[IX(i, c, ME)] = p.keCoef[p.eoc[IX(i, c, ME)]];
+    }
     // records of the LDS-DMA tiled kernels: eRec / cRec with the u-row slots replaced by the byte offset of the row inside a
     // patch's LDS row image (pieces of 1 KiB holding 1024 / rowBytes whole rows; csrc/experiments/stage_tile.hip)
     p.eRecT.clear(); p.cRecT.clear();
