@@ -211,7 +211,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config4_1M_x60", choices=list(WORKLOADS))
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant: 0 auto, 1 direct, 2 LDS patch")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (moka_set_kernel_variant): 0 auto, 11 default stage kernel, 4 column kernel, 3 generic index kernel")
     ap.add_argument("--patch-cells", type=int, default=0)
     ap.add_argument("--ordering", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")

@@ -1,14 +1,12 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "nonlinear or del2" -x > gpurun_out/nl_tests.log 2>&1 || { tail -40 gpurun_out/nl_tests.log; exit 1; }
-tail -3 gpurun_out/nl_tests.log
-rm -rf gpurun_out/nlprof
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/nlprof -- python3 tools/nonlinear_timing.py 320 60 > gpurun_out/nlprof.log 2>&1
-grep "ms per" gpurun_out/nlprof.log
-f=$(ls -t gpurun_out/nlprof/*/*kernel_stats.csv | head -1)
-python3 - "$f" <<'PY'
-import csv,sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:4]:
-    print(r["Name"][:70].ljust(70), r["Calls"], "%.1f us"%(float(r["AverageNs"])/1e3))
+mkdir -p gpurun_out/pitch; export TMPDIR=/tmp
+for r in 1 2; do for w in config4_1M_x60 exp_1M_x64; do
+  timeout -k 10 300 python3 bench.py --workload $w --no-cpu --steps 20 --warmup 5 > gpurun_out/pitch/${w}_$r.json 2> gpurun_out/pitch/${w}_$r.err || { echo "$w failed"; tail -3 gpurun_out/pitch/${w}_$r.err; continue; }
+  python3 - gpurun_out/pitch/${w}_$r.json $w <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+ps = d["roofline"].get("per_stage", [])
+print(f"{sys.argv[2]}: {d['ms_per_step']:.3f} ms/step  stages " + " ".join(f"{p['ms']:.3f}" for p in ps) + f"  tendency {d.get('tendency_kernel', {}).get('avg_launch_ms', float('nan')):.3f} ms  FE {d.get('forward_euler_compat', {}).get('ms_per_step', float('nan')):.3f}")
 PY
+done; done
