@@ -274,6 +274,11 @@ typedef struct {
     int32_t  slot;               /* the neighbour's slot in the flag block */
     int32_t  nNeighbors, pid, device, stateBytes, nVertLevels;
 } moka_halo_peer_info;
+/* How a distributed RK4 stage queues its two launches.  0: boundary patches, then interior patches, on the compute stream
+ * (the exchange starts behind the first).  1: boundary patches on the high-priority communication stream, interior patches
+ * on the compute stream, in flight together (a small boundary launch no longer leaves the chip idle).  -1 (default):
+ * chosen from the size of the interior launch.  Takes effect at the next moka_rk4_dist_begin.  Results are identical. */
+int  moka_halo_set_overlap(moka_halo *h, int mode);
 int  moka_halo_direct_available(const moka_halo *h);   /* 1: the receive lists are contiguous ranges (see above) */
 int  moka_halo_export(moka_halo *h, int32_t nbr, int32_t shared, moka_halo_peer_info *out);
 int  moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer, int32_t shared);

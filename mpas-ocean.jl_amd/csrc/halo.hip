@@ -80,6 +80,9 @@ struct moka_halo {
     std::string shmName;                  // non-empty: the block is a POSIX shared-memory object (multi-process)
     uint64_t seq = 0;                     // exchanges started so far
     hipEvent_t evPush = nullptr;
+    hipEvent_t evB[2] = {nullptr, nullptr};   // boundary launch of an odd / even stage done (comm stream)
+    bool overlapB = false;                    // boundary patches on the comm stream, in flight together with the interior launch
+    bool overlapNow = false;                  // ... as the running step was begun
     std::vector<void *> allocs;           // device allocations of this object
 };
 
@@ -230,7 +233,21 @@ int dist_stage_part(moka_halo *h, int stage, int part)
     moka_state *st = h->st;
     const StageArgs g = rk4_stage_args(st, stage, h->dt, h->ssh0);
     const int p0 = part == 0 ? 0 : h->pFirst, cnt = part == 0 ? h->pFirst : h->pOwned - h->pFirst;
-    HIPCHK(st->ctx, run_stage(st, g, p0, cnt));
+    moka_ctx *c = st->ctx;
+    if (!h->overlapNow) {
+        // boundary group first, interior right behind it on the same (compute) stream
+        HIPCHK(c, run_stage(st, g, p0, cnt));
+    } else if (part == 0) {
+        // boundary patches on the (high-priority) comm stream, interior patches on the compute stream, in flight together:
+        // B_s waits for I_(s-1) (it gathers rows of interior patches), I_s waits for B_(s-1), never for B_s
+        HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
+        HIPCHK(c, run_stage(st, g, p0, cnt, c->comm));
+        HIPCHK(c, hipEventRecord(h->evB[stage & 1], c->comm));
+    } else {
+        if (stage > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, h->evB[(stage - 1) & 1], 0));
+        HIPCHK(c, run_stage(st, g, p0, cnt));
+        HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
+    }
     return MOKA_OK;
 }
 
@@ -269,6 +286,10 @@ int moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCell
     // generation of workgroups -- 4 per CU -- so that its ~30 us do more work was measured and is slower: 1024 workgroups
     // that start together also stage and gather together; 8-rank share of config 4 0.97 -> 1.04 ms per step.)
     h->pFirst = nPatchesBoundary;
+    // Small interior launches (an 8-way share of config 4: 7 800 patches) run together with the boundary launch, which alone
+    // fills an eighth of the chip for ~30 us; measured -6 % per step there, +3 % on a 2-way share (32 000 patches): see
+    // moka_halo_set_overlap
+    h->overlapB = nPatchesBoundary > 0 && nPatchesOwned - nPatchesBoundary < 12000;
     int rc = MOKA_OK;
     try {
         if ((rc = build_halo_map(h, nNeighbors, sendCells, sendCellOff, sendEdges, sendEdgeOff, &h->sendMap, &h->nSend)) ||
@@ -325,6 +346,7 @@ int moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCell
         moka_halo_destroy(h);
         return fail(st->ctx, MOKA_ERR_ALLOC, "out of host memory building the halo maps");
     }
+    for (hipEvent_t &e : h->evB) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     if (hipEventCreateWithFlags(&h->evPush, hipEventDisableTiming) != hipSuccess) {
         moka_halo_destroy(h);
         return fail(st->ctx, MOKA_ERR_HIP, "hipEventCreate failed");
@@ -350,6 +372,7 @@ void moka_halo_destroy(moka_halo *h)
         else free((void *)h->flags);
     }
     if (h->evPush) (void)hipEventDestroy(h->evPush);
+    for (hipEvent_t e : h->evB) if (e) (void)hipEventDestroy(e);
     for (void *q : h->allocs) (void)hipFree(q);
     delete h;
 }
@@ -412,6 +435,14 @@ int moka_halo_unpack(moka_halo *h, int what, const void *recvbuf)
 // ---------------------------------------------------------------------------------------------
 // direct transport
 // ---------------------------------------------------------------------------------------------
+int moka_halo_set_overlap(moka_halo *h, int mode)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    if (mode < -1 || mode > 1) return hfail(h, MOKA_ERR_ARG, "mode must be -1 (automatic), 0 or 1");
+    h->overlapB = mode < 0 ? (h->pBoundary > 0 && h->pOwned - h->pBoundary < 12000) : mode == 1;
+    return MOKA_OK;
+}
+
 int moka_halo_direct_available(const moka_halo *h)
 {
     return h && h->directOk ? 1 : 0;
@@ -579,7 +610,10 @@ int moka_rk4_dist_begin(moka_halo *h, double dt)
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     // like moka_step_rk4: lazily pending diagnostics / stage-4 tendencies of the previous step are superseded, not computed
     h->dt = dt;
-    return rk4_begin(st, &h->ssh0);
+    if (int rc = rk4_begin(st, &h->ssh0)) return rc;
+    h->overlapNow = h->overlapB;              // fixed for the step: the two forms order their launches by different events
+    if (h->overlapNow) HIPCHK(st->ctx, hipEventRecord(st->ctx->evInterior, st->ctx->stream));
+    return MOKA_OK;
 }
 
 // part 0: patches [0, first) = the boundary patches (their rows are what other ranks need); part 1: [first, owned).
@@ -611,6 +645,7 @@ int moka_rk4_dist_stage_launch(moka_halo *h, int stage)
 int moka_rk4_dist_end(moka_halo *h)
 {
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    if (h->overlapNow) HIPCHK(h->st->ctx, hipStreamWaitEvent(h->st->ctx->stream, h->evB[0], 0));    // stage 4's boundary launch
     rk4_end(h->st);
     return MOKA_OK;
 }

@@ -331,6 +331,11 @@ class DistributedModel:
         self._cb = L.TRANSPORT_FN(_cb)
         self._ready = True
 
+    def set_overlap(self, mode: int):
+        """How an RK4 stage queues its boundary and interior launches (moka_halo_set_overlap): -1 automatic, 0 one behind
+        the other on the compute stream, 1 together on two streams.  Same results either way."""
+        L.check(L.lib().moka_halo_set_overlap(self._halo, int(mode)), self.backend._h)
+
     # ---- direct transport: tell the neighbours where to push ----
     def export_peer_info(self, shared: bool):
         """{neighbour rank: bytes} -- what each neighbour needs to push its rows into this rank's fields."""
@@ -618,7 +623,7 @@ class LocalCluster:
     send and receive buffers, ordered by stream events only."""
 
     def __init__(self, mesh, ssh, u, h, rest, dt, world, device=0, ordering=0, patch_cells=0, state_bytes=8, direct=True,
-                 devices=None):
+                 devices=None, overlap=-1):
         import torch
         self.torch, self.world = torch, world
         devs = list(devices) if devices is not None else [device] * world
@@ -629,6 +634,8 @@ class LocalCluster:
                        for r in range(world)]
         for r, m in enumerate(self.models):        # every rank learns the order its neighbours want their rows in
             m.finish({q: self.models[q]._wants[r] for q in m.lm.neighbors})
+        for m in self.models:
+            m.set_overlap(overlap)
         self.direct = bool(direct) and all(m.direct_available for m in self.models)
         if self.direct:
             exported = [m.export_peer_info(False) for m in self.models]

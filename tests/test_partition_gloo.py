@@ -120,17 +120,19 @@ def test_rccl_collectives_on_the_library_comm_stream():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [1, 0])
 @pytest.mark.parametrize("world,K,P,nsteps,sbytes,direct", [(2, 60, 0, 4, 8, True), (4, 60, 0, 4, 8, True), (8, 60, 0, 3, 8, True),
                                                             (3, 1, 0, 5, 8, True), (4, 60, 8, 3, 8, True), (5, 80, 0, 2, 8, True),
                                                             (4, 80, 0, 3, 4, True), (3, 60, 0, 2, 4, True),
                                                             (2, 60, 0, 4, 8, False), (8, 60, 0, 3, 8, False), (3, 1, 0, 5, 8, False),
                                                             (4, 80, 0, 3, 4, False)])
-def test_stream_ordered_exchange_in_one_process(world, K, P, nsteps, sbytes, direct):
+def test_stream_ordered_exchange_in_one_process(world, K, P, nsteps, sbytes, direct, overlap):
     """All ranks in one process on one GPU.  direct: the library's direct transport (push kernels store into the neighbours'
     fields, flag words complete the exchange) exactly as between processes; otherwise the buffered transport with
     stream-ordered device copies and no host synchronisation anywhere in the step -- the ordering RCCL gives.  Exercises
     the two-stream / event choreography of the distributed RK4 step (boundary patches, exchange on the comm stream,
-    interior on the compute stream): any missing dependency shows up as a mismatch against the single-domain oracle."""
+    interior on the compute stream): any missing dependency shows up as a mismatch against the single-domain oracle.
+    overlap: the boundary launch beside the interior launch on two streams (1) or in front of it on one (0)."""
     import oracle as orc
     mesh = mg.icosahedral_mesh(24)
     rng = np.random.default_rng(17 + world)
@@ -141,7 +143,7 @@ def test_stream_ordered_exchange_in_one_process(world, K, P, nsteps, sbytes, dir
     dt = 20.0
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     ref = orc.OracleState(om, ssh, u, h, mixed=sbytes == 4)          # fp32-storage states exchange fp32 halos
-    cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, world, patch_cells=P, state_bytes=sbytes, direct=direct)
+    cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, world, patch_cells=P, state_bytes=sbytes, direct=direct, overlap=overlap)
     assert cl.direct == direct
     cl.exchange_state()
     for rep in range(3):                      # several rounds: timing-dependent races get more than one chance to show

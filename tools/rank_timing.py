@@ -3,7 +3,7 @@
 traffic itself left out: the per-rank GPU time an N-GPU run cannot beat -- for the stage launches alone, with the one
 gather kernel per stage the direct transport adds (its push kernel does the same reads; the stores go over xGMI), and
 with the pack + unpack pair of the buffered transports.
-   python tools/rank_timing.py [world=8] [rank=0]"""
+   python tools/rank_timing.py [world=8] [rank=0] [overlap=-1]"""
 import os
 import sys
 import time
@@ -15,7 +15,7 @@ from moka_hip import lib as L              # noqa: E402
 from moka_hip import meshgen as mg         # noqa: E402
 from moka_hip import parallel as par       # noqa: E402
 
-world, rank = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 8), (2, 0)))
+world, rank, overlap = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 8), (2, 0), (3, -1)))
 mesh = mg.icosahedral_mesh(320)
 K = 60
 ssh, u, h, rest, dts = mg.sphere_synthetic_state(mesh, K)
@@ -27,6 +27,7 @@ asked = {q: (lm0.cells_g[lm0.send_cells[lm0.send_cell_off[i]:lm0.send_cell_off[i
              lm0.edges_g[lm0.send_edges[lm0.send_edge_off[i]:lm0.send_edge_off[i + 1]]]) for i, q in enumerate(lm0.neighbors)}
 m = par.DistributedModel(mesh, ssh, u, h, rest, dts, b, rank, world, transport="local", part=part, exchange_lists=lambda w: asked)
 lib = L.lib()
+L.check(lib.moka_halo_set_overlap(m._halo, overlap), b._h)     # -1 automatic, 0 / 1: boundary launch beside the interior launch
 
 
 def step(pack, unpack):
@@ -53,7 +54,7 @@ def timed(pack, unpack, N=50):
 
 info = m.info()
 t_stage, t_direct, t_buf = timed(False, False), timed(True, False), timed(True, True)
-print(f"world {world} rank {rank}: {info['rank_cells_owned']} owned cells, {info['patches_boundary']} boundary / "
+print(f"world {world} rank {rank} overlap {overlap}: {info['rank_cells_owned']} owned cells, {info['patches_boundary']} boundary / "
       f"{info['patches_owned']} owned patches, halo {info['halo_bytes_per_stage'] / 1e6:.2f} MB/stage, ms per step: "
       f"boundary + interior launches only {t_stage:.3f}; + one gather kernel per stage (= the direct transport's push) {t_direct:.3f}; "
       f"+ unpack (buffered transport without the copies) {t_buf:.3f}")
