@@ -92,8 +92,9 @@ typedef struct moka_mesh_desc {
      * 2 = halo, so that patch ranges [0,pb) / [pb,po) / [po,nPatches) are boundary / interior / halo. */
     const int32_t *cellClass;
     /* bytes per real of the prognostic state this mesh will carry: 0 or 8 = Float64 (the reference,
-     * PrognosticVars.jl:91-93); 4 = fp32 STORAGE of ssh / normalVelocity / layerThickness (every time level and RK
-     * provisional state) with fp64 arithmetic and fp64 tendencies (BASELINE config 5; not a reference feature).
+     * PrognosticVars.jl:91-93); 4 = fp32 STORAGE of every array of PrognosticVars (every time level and RK provisional
+     * state), DiagnosticVars and TendencyVars, with fp64 arithmetic: an element is accumulated in fp64 and rounded once
+     * when it is stored (BASELINE config 5; not a reference feature).
      * It fixes the byte offsets baked into the gather records, so a mesh serves states of one storage type. */
     int32_t stateBytes;
     /* (opt) only for the optional nonlinear terms (moka_set_nonlinear): MPAS mesh files carry both, the reference
@@ -192,9 +193,11 @@ int moka_interpolate_cell2edge(moka_mesh *mesh, const double *cellValue, double 
 /* PrognosticVars/DiagnosticVars/TendencyVars constructors with KA.zeros on the backend
  * (PrognosticVars.jl:59-106, DiagnosticVars.jl:75-99, TendencyVars.jl:51-67); nTimeLevels = 2 */
 /* A mesh created with stateBytes = 4 yields an fp32-STORAGE state: host arrays stay double (upload rounds to fp32,
- * download widens), moka_tendencies / moka_step_rk4 / moka_run(RK4) / moka_sum_sq / the halo API work on it, the
- * Forward-Euler sequence and DiagnosticVars do not (MOKA_ERR_UNSUPPORTED: the reference sequence is Float64).
- * Needs nVertLevels % 4 == 0 and <= 128. */
+ * download widens); moka_tendencies / moka_step_rk4 / moka_step_fe / moka_run / moka_sum_sq / the halo API work on it.
+ * moka_step_fe steps all levels of a whole mesh (no MOKA_FE_LEVEL1_ONLY, no partitions).  DiagnosticVars come out of
+ * Forward-Euler steps only: after an RK4 step they are unavailable (MOKA_ERR_UNSUPPORTED on download), and the next
+ * Forward-Euler step must carry none over (flags 0).  The piecewise calls (moka_diagnostic_compute, moka_compute_*_tendency,
+ * moka_advance_time_levels with level-1-only flags) stay Float64-only.  Needs nVertLevels % 4 == 0 and <= 128. */
 int  moka_state_create(moka_ctx *ctx, moka_mesh *mesh, moka_state **out);
 void moka_state_destroy(moka_state *st);
 /* Adapt.adapt(backend, array) / Adapt.adapt_structure(KA.CPU(), x) (OutPut.jl:122-124).

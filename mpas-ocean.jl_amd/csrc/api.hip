@@ -110,8 +110,6 @@ struct FieldRef {
     bool f32 = false;   // ptr is a float array (prognostic field of an fp32-storage state)
 };
 
-static bool is_tend_field_id(int f) { return f == MOKA_F_TEND_NORMAL_VELOCITY || f == MOKA_F_TEND_LAYER_THICKNESS; }
-
 int field_ref(moka_state *st, int field, int level, FieldRef *r)
 {
     const Plan &p = st->mesh->plan;
@@ -128,8 +126,8 @@ int field_ref(moka_state *st, int field, int level, FieldRef *r)
         case MOKA_F_TEND_LAYER_THICKNESS: *r = {st->tendH, MOKA_CELL, p.nC, p.K}; break;
         default: return fail(st->ctx, MOKA_ERR_ARG, "unknown field id");
     }
-    r->f32 = st->f32 && (field <= MOKA_F_LAYER_THICKNESS || is_tend_field_id(field));
-    if (!r->ptr) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "an fp32-storage state carries no DiagnosticVars arrays");
+    r->f32 = st->f32;     // every field of an fp32-storage state is a float array
+    if (!r->ptr) return fail(st->ctx, MOKA_ERR_ARG, "field not allocated");
     return MOKA_OK;
 }
 
@@ -301,7 +299,9 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
 
 int flush_lazy(moka_state *st, bool diag, bool tend)
 {
-    if (st->f32) st->diagDirty = false;    // no DiagnosticVars on an fp32-storage state
+    if (diag && st->diagDirty && st->f32)   // no diagnostics-only kernel for float arrays: they come out of Forward-Euler steps
+        return fail(st->ctx, MOKA_ERR_UNSUPPORTED,
+                    "fp32-storage state: DiagnosticVars exist after Forward-Euler steps only (not after RK4 steps or uploads)");
     if (diag && st->diagDirty) {
         // clean diagnostics of the current state: hEdge = interp(h); F = u*hEdge; div; vort zeroed + curl
         FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE, 0, 0.0);
@@ -646,10 +646,8 @@ int moka_state_create(moka_ctx *ctx, moka_mesh *mesh, moka_state **out)
     int rc = MOKA_OK;
     auto A = [&](double **q, size_t n, size_t eb = 8) { if (rc == MOKA_OK) rc = alloc_field(st, q, n, eb); };
     for (auto &l : st->lev) { A(&l.ssh, p.nC, sb); A(&l.u, nEK, sb); A(&l.h, nCK, sb); }
-    if (!st->f32) {
-        A(&st->hEdge[0], nEK); A(&st->hEdge[1], nEK);
-        A(&st->F, nEK); A(&st->div, nCK); A(&st->vort, nVK);
-    }
+    A(&st->hEdge[0], nEK, sb); A(&st->hEdge[1], nEK, sb);     // DiagnosticVars arrays have the state's storage type
+    A(&st->F, nEK, sb); A(&st->div, nCK, sb); A(&st->vort, nVK, sb);
     A(&st->tendU, nEK, sb); A(&st->tendH, nCK, sb);       // fp32-storage states store their tendencies fp32 as well
     A(&st->scalar, 2);
     if (rc != MOKA_OK) { moka_state_destroy(st); return rc; }
@@ -676,7 +674,8 @@ int moka_state_upload(moka_state *st, int field, int time_level, const double *h
     if (rc) return rc;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     const bool prog1 = field <= MOKA_F_LAYER_THICKNESS && time_level == 1;   // pending lazy results refer to the old state
-    if ((rc = flush_lazy(st, prog1 || is_diag_field(field), prog1 || is_tend_field(field)))) return rc;
+    // (an fp32-storage state cannot materialise pending diagnostics: they stay pending, i.e. unavailable)
+    if ((rc = flush_lazy(st, (prog1 && !st->f32) || is_diag_field(field), prog1 || is_tend_field(field)))) return rc;
     if ((rc = field_ref(st, field, time_level, &r))) return rc;   // flush may have swapped buffers
     if (time_level == 1 && (field == MOKA_F_SSH || field == MOKA_F_LAYER_THICKNESS)) st->sshConsistent = false;
     return put_rows(st->mesh, r.ptr, host, r.kind, r.n, r.K, r.f32);
@@ -720,7 +719,7 @@ int moka_diagnostic_compute(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
     if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms: moka_tendencies / RK4 only");
-    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
+    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: moka_step_fe, moka_step_rk4 and moka_tendencies only (the piecewise reference calls are Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rcl = flush_lazy(st, true, false)) return rcl;
     FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE, flags, 0.0);
@@ -733,7 +732,7 @@ int moka_compute_normal_velocity_tendency(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
     if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms: moka_tendencies / RK4 only");
-    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
+    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: moka_step_fe, moka_step_rk4 and moka_tendencies only (the piecewise reference calls are Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rcl = flush_lazy(st, false, true)) return rcl;
     FeArgs a = fe_args(st, FE_TENDU, flags, 0.0);
@@ -745,7 +744,7 @@ int moka_compute_layer_thickness_tendency(moka_state *st, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
     if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms: moka_tendencies / RK4 only");
-    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
+    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: moka_step_fe, moka_step_rk4 and moka_tendencies only (the piecewise reference calls are Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rcl = flush_lazy(st, true, true)) return rcl;
     FeArgs a = fe_args(st, FE_TENDH | FE_TENDH_FROM_F, flags, 0.0);
@@ -785,12 +784,36 @@ int moka_step_fe(moka_state *st, double dt, int flags)
 {
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
     if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms: moka_tendencies / RK4 only");
-    if (st->f32) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: RK4 and moka_tendencies only (the reference sequence is Float64)");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    // an fp32-storage state after an RK4 step has no current DiagnosticVars: a step that carries none over (flags 0) may follow
+    if (st->f32 && st->diagDirty && !(flags & (MOKA_FE_STALE_HEDGE | MOKA_FE_ACCUM_VORT))) st->diagDirty = false;
     if (int rcl = flush_lazy(st, true, true)) return rcl;
     // advanceTimeLevels! + diagnostic_compute! + both tendencies + updates (time_integration.jl:163-189)
     // in one launch: new values are written into the previous level's buffers, then the levels swap.
     FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE | FE_TENDU | FE_TENDH | FE_UPDATE, flags, dt);
+    if (st->f32) {
+        // fp32-storage state: the step exists in the stage kernel's Forward-Euler modes only (all levels, whole mesh)
+        const moka_mesh *mf = st->mesh;
+        if ((flags & MOKA_FE_LEVEL1_ONLY) || mf->plan.nPatchesLaunch != mf->plan.nPatches)
+            return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: Forward Euler steps all levels of a whole mesh (no MOKA_FE_LEVEL1_ONLY, no partitions)");
+        StageArgs g{};
+        g.pu = a.u; g.ph = a.h; g.ssh = a.ssh;
+        g.pu_out = a.u_new; g.ph_out = a.h_new; g.ssh_out = a.ssh_new;
+        g.tendU = a.tendU; g.tendH = a.tendH; g.a = dt;
+        g.hEdgeOld = (flags & MOKA_FE_STALE_HEDGE) ? a.hEdgeOld : nullptr;
+        g.hEdgeNew = a.hEdgeNew; g.F = a.F; g.div = a.div; g.areaCell = mf->dev.areaCell;
+        MeshDev dev = mf->dev;
+        dev.tailPatch = -1;
+        dev.maxOwnE = std::max(mf->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(mf->plan.maxOwnCLaunch, 1);
+        HIPCHK(st->ctx, launch_stage_rec2c_f32(dev, g, st->ctx->stream));      // ssh as stored, like the Float64 step
+        HIPCHK(st->ctx, launch_curl_f32(dev, reinterpret_cast<const float *>(a.u), reinterpret_cast<float *>(a.vort),
+                                        flags & MOKA_FE_ACCUM_VORT, st->ctx->stream));
+        st->feFast = 1;
+        std::swap(st->lev[0], st->lev[1]);
+        std::swap(st->hEdge[0], st->hEdge[1]);
+        st->sshConsistent = true;
+        return MOKA_OK;
+    }
     // All levels on a whole mesh with the default kernel choice: the step runs in the tuned stage kernel (modes 4 / 5 of
     // k_stage_rec2c: everything but relativeVorticity) plus the vertex pass of the generic kernel.  Anything else --
     // MOKA_FE_LEVEL1_ONLY, odd or large K, explicit kernel variants, partitioned meshes -- takes the generic one-launch kernel.
@@ -953,7 +976,9 @@ int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flag
         if ((rc = one())) return rc;
         ++done;
         HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
-        if ((rc = flush_lazy(st, true, true))) return rc;      // nothing lazy may fire inside the capture
+        // nothing lazy may fire inside the capture (pending diagnostics of an fp32-storage state cannot be produced: they
+        // stay pending -- an RK4 run leaves them pending anyway, a Forward-Euler step has none)
+        if ((rc = flush_lazy(st, !st->f32, true))) return rc;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipStream_t s = st->ctx->stream;

@@ -505,6 +505,9 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         return ldsU + (cached ? loc : 0u);
     };
     const d4 zero{0.0, 0.0, 0.0, 0.0};
+    // MODE 4 / 5: one Forward-Euler step with the diagnostics of diagnostic_compute! except relativeVorticity, as in
+    // k_stage_rec2c; layerThicknessEdge, thicknessFlux, velocityDivCell and the tendencies are float arrays like the state
+    constexpr bool FE = MODE >= 4, STALE = MODE == 4;
 
     // ---------------- cells ----------------
     for (int ci = grp; ci < nOwnC; ci += NG) {
@@ -526,8 +529,8 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
             hcf = gload4f(a.ph, own);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
-                hf[i] = gload4f(a.ph, r[ME + i] + voff);
                 const uint32_t off = r[i];
+                hf[i] = STALE ? gload4f(a.hEdgeOld, off + voff) : gload4f(a.ph, r[ME + i] + voff);
                 ad[i] = urow_addr(off, cached[i]);
                 goff[i] = off + voff;
                 asm("" : "+v"(goff[i]));               // stays in a VGPR (see k_stage_rec2c).  The deferred stores of that kernel
@@ -541,20 +544,27 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
                 if (!cached[i]) uf[i] = glb_row4f(puG + goff[i]);
             }
             if constexpr (MODE == 2) curf = gload4f(a.ch, own);
-            if constexpr (MODE >= 2) ninf = gload4f(a.nh_in, own);
+            if constexpr (MODE == 2 || MODE == 3) ninf = gload4f(a.nh_in, own);
         }
+        double area = 0.0;
+        if constexpr (FE) area = a.areaCell[c];
         const d4 hc = widen4(hcf);
-        d4 t = zero;
+        d4 t = zero, dv = zero;                                         // dv: velocityDivCell (FE), Operators.jl:18,39
+        // thickness at the edge: interpolated (Operators.jl:217) or, MODE 4, what the previous step stored
+        auto hE = [&](const d4 &hvi) { return STALE ? hvi : d4{0.5 * (hc.x + hvi.x), 0.5 * (hc.y + hvi.y), 0.5 * (hc.z + hvi.z), 0.5 * (hc.w + hvi.w)}; };
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME) - 1u && all)) == 0;   // see k_stage_rec2c
         if (plain) {
             if (act) {
 #pragma unroll
                 for (int i = 0; i < ME; ++i) {
-                    const d4 uvi = widen4(uf[i]), hvi = widen4(hf[i]);
-                    t.x += uvi.x * (0.5 * (hc.x + hvi.x)) * rs[i] * invA;
-                    t.y += uvi.y * (0.5 * (hc.y + hvi.y)) * rs[i] * invA;
-                    t.z += uvi.z * (0.5 * (hc.z + hvi.z)) * rs[i] * invA;
-                    t.w += uvi.w * (0.5 * (hc.w + hvi.w)) * rs[i] * invA;
+                    const d4 uvi = widen4(uf[i]), he = hE(widen4(hf[i]));
+                    t.x += uvi.x * he.x * rs[i] * invA;
+                    t.y += uvi.y * he.y * rs[i] * invA;
+                    t.z += uvi.z * he.z * rs[i] * invA;
+                    t.w += uvi.w * he.w * rs[i] * invA;
+                    if constexpr (FE) {
+                        dv.x -= uvi.x * rs[i]; dv.y -= uvi.y * rs[i]; dv.z -= uvi.z * rs[i]; dv.w -= uvi.w * rs[i];
+                    }
                 }
             }
         } else if (act) {
@@ -562,15 +572,18 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
             for (int i = 0; i < ME; ++i) {
                 const int ml = all ? K : cptr(m.mltc)[(size_t)c * ME + i];
                 const bool on = (mask >> i) & 1u;
-                const d4 uvi = widen4(uf[i]), hvi = widen4(hf[i]);
-                const double dx = uvi.x * (0.5 * (hc.x + hvi.x)) * rs[i] * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
-                const double dy = uvi.y * (0.5 * (hc.y + hvi.y)) * rs[i] * invA;   // horizontal_advection.jl:63
-                const double dz = uvi.z * (0.5 * (hc.z + hvi.z)) * rs[i] * invA;
-                const double dw = uvi.w * (0.5 * (hc.w + hvi.w)) * rs[i] * invA;
+                const d4 uvi = widen4(uf[i]), he = hE(widen4(hf[i]));
+                const double dx = uvi.x * he.x * rs[i] * invA;   // Operators.jl:217, DiagnosticVars.jl:165,
+                const double dy = uvi.y * he.y * rs[i] * invA;   // horizontal_advection.jl:63
+                const double dz = uvi.z * he.z * rs[i] * invA;
+                const double dw = uvi.w * he.w * rs[i] * invA;
                 if (on && k0 < ml) t.x += dx;
                 if (on && k0 + 1 < ml) t.y += dy;
                 if (on && k0 + 2 < ml) t.z += dz;
                 if (on && k0 + 3 < ml) t.w += dw;
+                if constexpr (FE) {
+                    if (on) { dv.x -= uvi.x * rs[i]; dv.y -= uvi.y * rs[i]; dv.z -= uvi.z * rs[i]; dv.w -= uvi.w * rs[i]; }
+                }
             }
         }
         d4 hs = zero;
@@ -586,6 +599,12 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
             if constexpr (MODE == 3) {
                 hs = round4(axpy4(widen4(ninf), a.b, t));
                 gstore4(a.nh_out, own, hs);
+            }
+            if constexpr (FE) {
+                hs = round4(axpy4(hc, a.a, t));                                               // time_integration.jl:199
+                gstore4(a.ph_out, own, hs);
+                gstore4(a.tendH, own, t);
+                gstore4(a.div, own, d4{dv.x / area, dv.y / area, dv.z / area, dv.w / area});  // Operators.jl:41
             }
         }
         if constexpr (MODE != 0) {
@@ -610,6 +629,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         const uint32_t own = (uint32_t)e * rowB + voff;
         float sA = 0.f, sB = 0.f;
         d4 uv[ME2], cur = zero, nin = zero;
+        float4 hxf = make_float4(0.f, 0.f, 0.f, 0.f), hyf = hxf, hEof = hxf;
         if (act) {
             bool cached[ME2];
             uint32_t ad[ME2];
@@ -630,7 +650,12 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
                 if (!cached[i]) uf[i] = glb_row4f(puG + goff[i]);
             }
             if constexpr (MODE == 2) cur = gload4(a.cu, own);
-            if constexpr (MODE >= 2) nin = gload4(a.nu_in, own);
+            if constexpr (MODE == 2 || MODE == 3) nin = gload4(a.nu_in, own);
+            if constexpr (FE) {
+                hxf = gload4f(a.ph, r[ME2] * rowB + voff);             // layerThickness of cellsOnEdge[1], [2]
+                hyf = gload4f(a.ph, r[ME2 + 1] * rowB + voff);
+                if constexpr (STALE) hEof = gload4f(a.hEdgeOld, own);
+            }
             if (l == 0) {                                              // behind the gathers in the queue: nothing waits for these two alone
                 sA = sshf[r[ME2]];
                 sB = sshf[r[ME2 + 1]];
@@ -679,6 +704,16 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
                 gstore4(a.nu_out, own, axpy4(nin, a.b, t));
             }
             if constexpr (MODE == 3) gstore4(a.nu_out, own, axpy4(nin, a.b, t));
+            if constexpr (FE) {
+                const d4 up = widen4(ubuf4[(size_t)ei * K4 + l]);       // own row is in the cache
+                const d4 hx = widen4(hxf), hy = widen4(hyf);
+                const d4 pE{0.5 * (hx.x + hy.x), 0.5 * (hx.y + hy.y), 0.5 * (hx.z + hy.z), 0.5 * (hx.w + hy.w)};   // layerThicknessEdge, Operators.jl:217
+                const d4 hF = STALE ? widen4(hEof) : pE;
+                gstore4(a.F, own, d4{up.x * hF.x, up.y * hF.y, up.z * hF.z, up.w * hF.w});                            // thicknessFlux, DiagnosticVars.jl:165
+                gstore4(a.hEdgeNew, own, pE);
+                gstore4(a.pu_out, own, axpy4(up, a.a, t));              // time_integration.jl:199
+                gstore4(a.tendU, own, t);
+            }
         }
     }
 }
@@ -883,6 +918,51 @@ __global__ __launch_bounds__(BLOCK) void k_curl3(const MeshDev m, const double *
                     c[q].y += w * uv[q][j].y;
                 }
                 gstore2(vort, (uint32_t)(vb + v) * rowB + voff, c[q]);
+            }
+        }
+    }
+}
+
+// relativeVorticity of an fp32-storage state (float rows, K % 4 == 0): a lane owns four levels of one vertex, the sum is
+// formed in fp64 in edgesOnVertex order and stored fp32 (accum: on top of the stored value, widened)
+template <int VD_>
+__global__ __launch_bounds__(BLOCK) void k_curl3_f32(const MeshDev m, const float *u, float *vort, int accum)
+{
+    constexpr int VCH = 64;
+    __shared__ int sE[VCH * VD_];
+    __shared__ double sWt[VCH * VD_];
+    const int pl_ = patch_of_block(m.nPatches);
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
+    const int K = m.K, K4 = K >> 2;
+    const int v0 = m.patchVertStart[p], v1 = m.patchVertStart[p + 1];
+    for (int vb = v0; vb < v1; vb += VCH) {
+        const int nv = min(VCH, v1 - vb), items = nv * K4;
+        if (vb != v0) __syncthreads();
+        for (int i = threadIdx.x; i < nv * VD_; i += BLOCK) { sE[i] = m.eov[(size_t)vb * VD_ + i]; sWt[i] = m.cv[(size_t)vb * VD_ + i]; }
+        __syncthreads();
+        for (int it = threadIdx.x; it < items; it += 2 * BLOCK) {
+            float4 uf[2][VD_], cf[2];
+            int vq[2], lq[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int item = it + q * BLOCK < items ? it + q * BLOCK : it;
+                vq[q] = item / K4; lq[q] = item - vq[q] * K4;
+#pragma unroll
+                for (int j = 0; j < VD_; ++j) uf[q][j] = reinterpret_cast<const float4 *>(u + (size_t)sE[vq[q] * VD_ + j] * K)[lq[q]];
+                cf[q] = accum ? reinterpret_cast<const float4 *>(vort + (size_t)(vb + vq[q]) * K)[lq[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (it + q * BLOCK >= items) break;
+                d4 c = widen4(cf[q]);
+#pragma unroll
+                for (int j = 0; j < VD_; ++j) {
+                    const double w = sWt[vq[q] * VD_ + j];
+                    const d4 uv = widen4(uf[q][j]);
+                    c.x += w * uv.x; c.y += w * uv.y; c.z += w * uv.z; c.w += w * uv.w;
+                }
+                reinterpret_cast<float4 *>(vort + (size_t)(vb + vq[q]) * K)[lq[q]] = narrow4(c);
             }
         }
     }
@@ -1113,6 +1193,8 @@ static bool launch_rec2c_f32(const ColMesh &m, const StageArgs &a, int mode, dim
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised = true;
     }
     switch (mode) {
@@ -1120,6 +1202,8 @@ static bool launch_rec2c_f32(const ColMesh &m, const StageArgs &a, int mode, dim
         case 1: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 1>), g, b, lds, s, m, a, mE, mC); return true;
         case 2: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 2>), g, b, lds, s, m, a, mE, mC); return true;
         case 3: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 3>), g, b, lds, s, m, a, mE, mC); return true;
+        case 4: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 4>), g, b, lds, s, m, a, mE, mC); return true;
+        case 5: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 5>), g, b, lds, s, m, a, mE, mC); return true;
     }
     return false;
 }
@@ -1156,6 +1240,14 @@ hipError_t launch_curl2(const MeshDev &m, const double *u, double *vort, bool ac
     if (m.K > 64 || (m.K & 1) || (size_t)std::max(m.nE, m.nV) * m.K * 8 >= ((size_t)1 << 32)) return hipErrorNotSupported;
     if (m.VD == 3) hipLaunchKernelGGL((k_curl3<3>), dim3(patch_grid(m)), dim3(BLOCK), 0, s, m, u, vort, accum ? 1 : 0);
     else hipLaunchKernelGGL(k_curl2, dim3(patch_grid(m)), dim3(BLOCK), 0, s, m, u, vort, accum ? 1 : 0);
+    return hipGetLastError();
+}
+
+// fp32-storage states (float rows, K % 4 == 0, vertexDegree 3)
+hipError_t launch_curl_f32(const MeshDev &m, const float *u, float *vort, bool accum, hipStream_t s)
+{
+    if ((m.K & 3) || m.VD != 3) return hipErrorNotSupported;
+    hipLaunchKernelGGL((k_curl3_f32<3>), dim3(patch_grid(m)), dim3(BLOCK), 0, s, m, u, vort, accum ? 1 : 0);
     return hipGetLastError();
 }
 

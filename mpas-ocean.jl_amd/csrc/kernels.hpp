@@ -93,6 +93,7 @@ hipError_t launch_stage_ptile2(const MeshDev &m, const StageArgs &a, int nCUs, h
 #endif
 hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s);
 hipError_t launch_curl2(const MeshDev &m, const double *u, double *vort, bool accum, hipStream_t s);
+hipError_t launch_curl_f32(const MeshDev &m, const float *u, float *vort, bool accum, hipStream_t s);   // fp32-storage states
 hipError_t launch_operator(const MeshDev &m, const OpArgs &a, int lpc, hipStream_t s);
 hipError_t launch_update_ssh(const MeshDev &m, const double *h, double *ssh, int nlev, int lpc, hipStream_t s);
 hipError_t launch_permute_rows(double *dst, const double *src, const int32_t *n2o, int64_t n, int K, int to_device,

@@ -227,7 +227,7 @@ static inline int patch_grid(const MeshDev &m) { return 8 * ((m.nPatches + 7) / 
 // which pipelined specialisation serves this argument block (-1: none, use the plain column kernel)
 inline int colp_mode(const StageArgs &a)
 {
-    if (a.hEdgeNew) {     // Forward-Euler step (k_stage_rec2c only)
+    if (a.hEdgeNew) {     // Forward-Euler step (k_stage_rec2c and k_stage_rec2c_f32)
         const bool ok = a.pu_out && a.ph_out && a.ssh_out && a.tendU && a.tendH && a.F && a.div && a.areaCell && !a.cu && !a.ch &&
                         !a.nu_in && !a.nh_in && !a.nu_out && !a.nh_out;
         return ok ? (a.hEdgeOld ? 4 : 5) : -1;

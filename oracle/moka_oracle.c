@@ -398,6 +398,28 @@ void oracle_step_rk4_mixed(const oracle_mesh *m, oracle_state *s, double dt, dou
     oracle_round_f32(s->ssh[1], m->nCells);
 }
 
+/* oracle_step_fe with fp32 storage of every array of Prog, Diag and Tend (all levels; not a reference feature -- the
+ * reference is Float64 throughout).  Inputs must already be fp32-representable.  Every array element is computed in fp64
+ * from the stored (fp32) inputs exactly as oracle_step_fe computes it and rounded ONCE when it is stored: within the step
+ * thicknessFlux feeds the thickness tendency unrounded, the tendencies feed the updates unrounded; ssh is the column sum of
+ * the STORED (rounded) new layerThickness, like the provisional ssh of oracle_step_rk4_mixed. */
+void oracle_step_fe_mixed(const oracle_mesh *m, oracle_state *s, double dt, int flags)
+{
+    const int K = m->nVertLevels;
+    const int64_t nu = (int64_t)K * m->nEdges, nh = (int64_t)K * m->nCells, nv = (int64_t)K * m->nVertices;
+    oracle_step_fe(m, s, dt, flags & ~ORACLE_FE_LEVEL1_ONLY);
+    oracle_round_f32(s->u[1], nu);
+    oracle_round_f32(s->h[1], nh);
+    oracle_update_ssh(m, s->ssh[1], s->h[1], K);
+    oracle_round_f32(s->ssh[1], m->nCells);
+    oracle_round_f32(s->hEdge, nu);
+    oracle_round_f32(s->F, nu);
+    oracle_round_f32(s->div, nh);
+    oracle_round_f32(s->vort, nv);
+    oracle_round_f32(s->tendU, nu);
+    oracle_round_f32(s->tendH, nh);
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Reverse mode of one Forward-Euler step.  The reference obtains it from Enzyme
  * (ext/MPASEnzymeExt.jl; test/enzyme/test_Enzyme_end2end.jl differentiates sum(ssh^2) after ocn_run_loop with

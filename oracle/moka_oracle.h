@@ -94,6 +94,7 @@ void oracle_round_f32(double *a, int64_t n);
 void oracle_tendencies_mixed(const oracle_mesh *m, double *tendU, double *tendH, const double *u, const double *h,
                              double *ssh_out, double *hEdge, double *F);
 void oracle_step_rk4_mixed(const oracle_mesh *m, oracle_state *s, double dt, double *work);
+void oracle_step_fe_mixed(const oracle_mesh *m, oracle_state *s, double dt, int flags);
 double oracle_sum_sq(const double *a, int64_t n);   /* sumArray, run_loop.jl:47-51 */
 
 /* nonlinear (vector-invariant TRiSK) tendencies and RK4 step: an extension, NOT in the reference -- parity unpinned */

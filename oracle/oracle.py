@@ -77,6 +77,7 @@ def lib():
         L.oracle_step_fe.argtypes = [mp, sp, C.c_double, C.c_int]
         L.oracle_step_rk4.argtypes = [mp, sp, C.c_double, _f64p]
         L.oracle_step_rk4_mixed.argtypes = [mp, sp, C.c_double, _f64p]
+        L.oracle_step_fe_mixed.argtypes = [mp, sp, C.c_double, C.c_int]
         L.oracle_tendencies_mixed.argtypes = [mp] + [_f64p] * 7
         L.oracle_round_f32.argtypes = [_f64p, C.c_int64]
         L.oracle_sum_sq.argtypes = [_f64p, C.c_int64]
@@ -183,7 +184,7 @@ class OracleState:
     """Two time levels of PrognosticVars + DiagnosticVars + TendencyVars, reference layout."""
 
     def __init__(self, om: OracleMesh, ssh, u, h, mixed=False):
-        """mixed=True: fp32-stored state (inputs are rounded to fp32), fp64 arithmetic; RK4 only."""
+        """mixed=True: fp32-stored state (inputs are rounded to fp32), fp64 arithmetic."""
         m, K = om.mesh, om.K
         self.om, self.mixed = om, bool(mixed)
         sd = np.float32 if mixed else np.float64
@@ -208,7 +209,10 @@ class OracleState:
 
     def step_fe(self, dt, flags=FE_REFERENCE_COMPAT):
         if self.mixed:
-            raise ValueError("fp32-state oracle: RK4 only")
+            if flags & FE_LEVEL1_ONLY:
+                raise ValueError("fp32-state oracle: Forward Euler steps all levels")
+            lib().oracle_step_fe_mixed(self.om.ref, C.byref(self.c), float(dt), int(flags))
+            return
         lib().oracle_step_fe(self.om.ref, C.byref(self.c), float(dt), int(flags))
 
     def step_rk4(self, dt):

@@ -168,10 +168,21 @@ def test_config5_stretched_fp32_reduced_size_bitwise(backend, m, P):
     for _ in range(2):
         mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)
         st.step_rk4(dts)
+    got, exp = prog_fields(Prog), oracle_prog(st)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    assert np.array_equal(Tend.tendNormalVelocity.get(), st.tendU) and np.array_equal(Tend.tendLayerThickness.get(), st.tendH)
+    # the reference's live integrator on the same state: a Forward-Euler step that carries nothing over from the RK4 steps,
+    # then two with the reference's stale layerThicknessEdge and accumulating vorticity (all levels)
+    for flags in (0, 3, 3):
+        mk.ocn_timestep(np.array([dts]), Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=flags)
+        st.step_fe(dts, flags)
     orc.set_threads(1)
     got, exp = prog_fields(Prog), oracle_prog(st)
     for k in exp:
         assert np.array_equal(got[k], exp[k]), k
+    assert np.array_equal(Diag.layerThicknessEdge.get(), st.hEdge) and np.array_equal(Diag.thicknessFlux.get(), st.F)
+    assert np.array_equal(Diag.velocityDivCell.get(), st.div) and np.array_equal(Diag.relativeVorticity.get(), st.vort)
     assert np.array_equal(Tend.tendNormalVelocity.get(), st.tendU) and np.array_equal(Tend.tendLayerThickness.get(), st.tendH)
     Prog._state.close(); Setup.mesh.close()
 

@@ -431,11 +431,51 @@ def test_fp32_state_tendency_and_rk4_bitwise(backend, meshname, K, P, nsteps):
     for _ in range(nsteps + 7):
         s64.step_rk4(dtv)
     assert np.abs(st.h[1] - s64.h[1]).max() <= 64 * np.finfo(np.float32).eps * np.abs(s64.h[1]).max()
-    # what the fp32 form does not carry fails loudly
+    # what the fp32 form does not carry fails loudly: level-1-only steps (the reference's default flags at K > 1), and
+    # DiagnosticVars after an RK4 step (they come out of Forward-Euler steps only), hence steps that would carry them over
     with pytest.raises(mk.MokaError):
         mk.ocn_timestep(np.array([dtv]), Prog, Diag, Tend, Setup, mk.ForwardEuler)
     with pytest.raises(mk.MokaError):
         Diag.layerThicknessEdge.get()
+    with pytest.raises(mk.MokaError):
+        mk.ocn_timestep(np.array([dtv]), Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=3)
+    Prog._state.close(); Setup.mesh.close()
+
+
+@pytest.mark.parametrize("meshname,K,P,flags,nsteps", [("ico16", 80, 0, 3, 4), ("ico16", 60, 12, 0, 3), ("ico32", 80, 0, 1, 3), ("ico16", 4, 0, 2, 4),
+                                                        ("ico12f", 80, 0, 3, 3), ("planar", 8, 0, 3, 5), ("ico16", 128, 8, 3, 2)])
+def test_fp32_state_forward_euler_bitwise(backend, meshname, K, P, flags, nsteps):
+    """The reference's live step (time_integration.jl:150-193: advanceTimeLevels!, diagnostic_compute!, both tendencies,
+    updates) on an fp32-storage state, all levels: every array of Prog, Diag and Tend against the storage-emulating oracle
+    (oracle_step_fe_mixed), bit for bit -- stale layerThicknessEdge (1) and accumulating vorticity (2) included; then an RK4
+    step, then a Forward-Euler step without carried diagnostics."""
+    mesh = get_mesh(meshname)
+    ssh, u, h, rest = random_state(mesh, K, 31 + K)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True,
+                                                       patch_cells=P, state_bytes=4)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h, mixed=True)
+    dtv = 2.0 if meshname == "planar" else 20.0
+    for i in range(nsteps):
+        mk.ocn_timestep(np.array([dtv]), Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=flags)
+        st.step_fe(dtv, flags)
+        got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+        for k in exp:
+            assert np.array_equal(got[k], exp[k]), (k, i)
+    mk.run_steps(Prog, mk.ForwardEuler, dtv, 5, flags=flags)           # graph replay
+    for _ in range(5):
+        st.step_fe(dtv, flags)
+    got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dtv))      # integrators mix: RK4, then a step that carries nothing over
+    mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)
+    st.step_rk4(dtv)
+    mk.ocn_timestep(np.array([dtv]), Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=0)
+    st.step_fe(dtv, 0)
+    got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
     Prog._state.close(); Setup.mesh.close()
 
 

@@ -1,6 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out; export TMPDIR=/tmp
-for o in 0 1 0 1 0 1; do
-  timeout -k 10 300 python3 tools/rank_timing.py 8 0 $o 2>&1 | grep "world" | sed 's/owned cells.*ms per step://' || exit 1
-done
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "fp32" -x > gpurun_out/f32_tests.log 2>&1 || { tail -40 gpurun_out/f32_tests.log; exit 1; }
+tail -3 gpurun_out/f32_tests.log
