@@ -1,5 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "fp32" -x > gpurun_out/f32_tests.log 2>&1 || { tail -40 gpurun_out/f32_tests.log; exit 1; }
-tail -3 gpurun_out/f32_tests.log
+rm -rf gpurun_out/prof_r02f
+bash tools/profile.sh r02f > gpurun_out/profile_r02f.log 2>&1 || { tail -20 gpurun_out/profile_r02f.log; exit 1; }
+tail -5 gpurun_out/profile_r02f.log
