@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """GPU box helper: randomized parity sweep of the tuned kernels against the oracle (bit for bit).
 Random meshes (icosahedral with edge flips, planar periodic), even K in 34..64 (Float64) or K % 4 == 0 (fp32 storage),
-patch sizes, level masks, Forward-Euler flags; RK4 + FE + tendencies.   python tools/fuzz_parity.py [seconds=150] [seed=0]"""
+patch sizes, level masks, Forward-Euler flags; RK4 + FE (both storage types) + tendencies, reverse mode of FE and RK4 runs,
+the three forms of the nonlinear kernels.   python tools/fuzz_parity.py [seconds=150] [seed=0]"""
 import datetime as dt
 import os
 import sys
@@ -20,7 +21,7 @@ budget, seed = (float(sys.argv[1]) if len(sys.argv) > 1 else 150.0), (int(sys.ar
 rng = np.random.default_rng(seed)
 b = mk.MokaHIP(0)
 t0, n = time.time(), 0
-stats = {"f32": 0, "fe_tuned": 0, "fe_generic": 0, "masked": 0, "cells_max": 0, "adjoint": 0, "nonlinear": 0}
+stats = {"f32": 0, "f32_fe": 0, "fe_tuned": 0, "fe_generic": 0, "masked": 0, "cells_max": 0, "adjoint": 0, "adjoint_rk4": 0, "nonlinear": 0}
 while time.time() - t0 < budget:
     kind = rng.integers(0, 3)
     if kind == 0:
@@ -55,13 +56,25 @@ while time.time() - t0 < budget:
     tag = f"case {n}: kind {kind} cells {mesh.nCells} K {K} P {P} f32 {f32} masks {int((mlt < K).sum())}"
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=mlt)
     st = orc.OracleState(om, ssh, u, h, mixed=f32)
-    Diag, Tend = (None, None) if f32 else (mk.DiagnosticVars(None, M, Prog._state), mk.TendencyVars(None, M, Prog._state))
+    Diag, Tend = mk.DiagnosticVars(None, M, Prog._state), mk.TendencyVars(None, M, Prog._state)
     for _ in range(2):
         L.check(L.lib().moka_step_rk4(Prog._state._h, dtv), b._h)
         st.step_rk4(dtv)
     assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]), tag + " rk4 u"
     assert np.array_equal(Prog.layerThickness[-1].get(), st.h[1]), tag + " rk4 h"
     assert np.array_equal(Prog.ssh[-1].get(), st.ssh[1]), tag + " rk4 ssh"
+    if f32:     # the Forward-Euler step of an fp32-storage state: nothing carried over right after RK4, then random flags
+        flags = int(rng.choice([0, 1, 2, 3]))
+        for fl in (0, flags, flags):
+            L.check(L.lib().moka_step_fe(Prog._state._h, dtv, fl), b._h)
+            st.step_fe(dtv, fl)
+        for name, got, exp in (("u", Prog.normalVelocity[-1].get(), st.u[1]), ("h", Prog.layerThickness[-1].get(), st.h[1]),
+                               ("ssh", Prog.ssh[-1].get(), st.ssh[1]), ("hEdge", Diag.layerThicknessEdge.get(), st.hEdge),
+                               ("F", Diag.thicknessFlux.get(), st.F), ("div", Diag.velocityDivCell.get(), st.div),
+                               ("vort", Diag.relativeVorticity.get(), st.vort), ("tendU", Tend.tendNormalVelocity.get(), st.tendU),
+                               ("tendH", Tend.tendLayerThickness.get(), st.tendH)):
+            assert np.array_equal(got, exp), f"{tag} f32 fe flags {flags} {name}"
+        stats["f32_fe"] += 1
     if not f32:
         flags = int(rng.choice([0, 1, 2, 3]))
         for _ in range(2):
@@ -89,16 +102,32 @@ while time.time() - t0 < budget:
                 np.array_equal(g["layerThickness"], gH), tag + f" adjoint flags {fl}"
             tape.close(); Prog2._state.close()
             stats["adjoint"] += 1
-        if n % 4 == 3 and not (mlt < K).any() and mesh.kiteAreasOnVertex is not None:   # nonlinear terms + Del2, one RK4 step
+        if n % 4 == 2 and not (mlt < K).any():                      # reverse mode of two RK4 steps (chunk kernels, fused cell pass)
+            Prog2 = mk.PrognosticVars(st.ssh[1], st.u[1], st.h[1], 2, M)
+            tape = mk.AdjointTape(Prog2, 2)
+            st2 = orc.OracleState(om, st.ssh[1], st.u[1], st.h[1])
+            adj = orc.OracleAdjointRK4(st2)
+            for _ in range(2):
+                tape.step(dtv, method=mk.RungeKutta4)
+                adj.step_rk4(dtv)
+            g = tape.gradient()
+            gU, gH = adj.gradient_sum_sq_ssh()
+            assert np.array_equal(g["normalVelocity"], gU) and np.array_equal(g["layerThickness"], gH), tag + " adjoint rk4"
+            tape.close(); Prog2._state.close()
+            stats["adjoint_rk4"] += 1
+        if n % 4 == 3 and mesh.kiteAreasOnVertex is not None:      # nonlinear terms + Del2, one RK4 step, any of the three kernel forms
             visc = float(rng.choice([0.0, 0.01 * float(mesh.dcEdge.min()) ** 2 / dtv]))
+            form = int(rng.choice([0, 0, 4, 3]))
+            b.set_kernel_variant(form)
             Prog3 = mk.PrognosticVars(st.ssh[1], st.u[1], st.h[1], 2, M)
             mk.set_nonlinear(Prog3, True, visc_del2=visc)
             nl = orc.OracleNonlinear(om, visc_del2=visc)
             st3 = orc.OracleState(om, st.ssh[1], st.u[1], st.h[1])
             L.check(L.lib().moka_step_rk4(Prog3._state._h, dtv), b._h)
+            b.set_kernel_variant(0)
             nl.step_rk4(st3, dtv)
             assert np.array_equal(Prog3.normalVelocity[-1].get(), st3.u[1]) and np.array_equal(Prog3.layerThickness[-1].get(), st3.h[1]), \
-                tag + f" nonlinear visc {visc}"
+                tag + f" nonlinear visc {visc} form {form}"
             Prog3._state.close()
             stats["nonlinear"] += 1
     stats["f32"] += int(f32); stats["masked"] += int((mlt < K).any()); stats["cells_max"] = max(stats["cells_max"], mesh.nCells)
