@@ -877,6 +877,52 @@ __global__ __launch_bounds__(BLOCK) void k_curl2(const MeshDev m, const double *
     }
 }
 
+// The same for vertexDegree 3 with the patch's vertex records (edges, weights) staged in LDS in one round trip and two
+// vertices per half-wave round: 1 + 2 dependent round trips per patch instead of one per (vertex, edge).
+template <int VD_>
+__global__ __launch_bounds__(BLOCK) void k_curl3(const MeshDev m, const double *u, double *vort, int accum)
+{
+    constexpr int NG = BLOCK / 32, VCH = 64;
+    __shared__ int sE[VCH * VD_];
+    __shared__ double sWt[VCH * VD_];
+    const int pl_ = patch_of_block(m.nPatches);
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;
+    const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const bool act = 2 * l < m.K;
+    const uint32_t rowB = (uint32_t)m.K * 8u, voff = (uint32_t)l * 16u;
+    const int v0 = m.patchVertStart[p], v1 = m.patchVertStart[p + 1];
+    for (int vb = v0; vb < v1; vb += VCH) {
+        const int nv = min(VCH, v1 - vb);
+        if (vb != v0) __syncthreads();
+        for (int i = threadIdx.x; i < nv * VD_; i += BLOCK) { sE[i] = m.eov[(size_t)vb * VD_ + i]; sWt[i] = m.cv[(size_t)vb * VD_ + i]; }
+        __syncthreads();
+        if (!act) continue;
+        for (int vi = grp; vi < nv; vi += 2 * NG) {
+            double2 uv[2][VD_], c[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int v = vi + q * NG < nv ? vi + q * NG : vi;
+#pragma unroll
+                for (int j = 0; j < VD_; ++j) uv[q][j] = gload2(u, (uint32_t)sE[v * VD_ + j] * rowB + voff);
+                c[q] = accum ? gload2(vort, (uint32_t)(vb + v) * rowB + voff) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int v = vi + q * NG;
+                if (v >= nv) break;
+#pragma unroll
+                for (int j = 0; j < VD_; ++j) {
+                    const double w = sWt[v * VD_ + j];
+                    c[q].x += w * uv[q][j].x;
+                    c[q].y += w * uv[q][j].y;
+                }
+                gstore2(vort, (uint32_t)(vb + v) * rowB + voff, c[q]);
+            }
+        }
+    }
+}
+
 // relativeVorticity of an fp32-storage state (float rows, K % 4 == 0): a lane owns four levels of one vertex, the sum is
 // formed in fp64 in edgesOnVertex order and stored fp32 (accum: on top of the stored value, widened)
 template <int VD_>
@@ -1192,7 +1238,8 @@ hipError_t launch_stage_rec2c_f32(const MeshDev &md, const StageArgs &a, hipStre
 hipError_t launch_curl2(const MeshDev &m, const double *u, double *vort, bool accum, hipStream_t s)
 {
     if (m.K > 64 || (m.K & 1) || (size_t)std::max(m.nE, m.nV) * m.K * 8 >= ((size_t)1 << 32)) return hipErrorNotSupported;
-    hipLaunchKernelGGL(k_curl2, dim3(patch_grid(m)), dim3(BLOCK), 0, s, m, u, vort, accum ? 1 : 0);
+    if (m.VD == 3) hipLaunchKernelGGL((k_curl3<3>), dim3(patch_grid(m)), dim3(BLOCK), 0, s, m, u, vort, accum ? 1 : 0);
+    else hipLaunchKernelGGL(k_curl2, dim3(patch_grid(m)), dim3(BLOCK), 0, s, m, u, vort, accum ? 1 : 0);
     return hipGetLastError();
 }
 
