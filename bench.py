@@ -321,8 +321,11 @@ def main():
         if world > 1:
             dist.barrier(group=gloo_group)
 
+    import gc
     for _ in range(args.warmup):
         step()
+    gc.collect()
+    gc.disable()          # no collector pause between the launches of the timed region (one was seen to cost 24 ms of 136)
     sync(); torch.cuda.synchronize(); barrier()
     backend.timer_start()
     t0 = time.perf_counter()
@@ -331,6 +334,7 @@ def main():
     ev_ms = backend.timer_stop()
     sync(); torch.cuda.synchronize(); barrier()
     t1 = time.perf_counter()
+    gc.enable()
     elapsed = t1 - t0
     if world > 1:
         tt = torch.tensor([elapsed, ev_ms], dtype=torch.float64)
