@@ -325,7 +325,8 @@ def main():
     for _ in range(args.warmup):
         step()
     gc.collect()
-    gc.disable()          # no collector pause between the launches of the timed region (one was seen to cost 24 ms of 136)
+    gc.disable()          # a 24 ms host-side pause was seen once inside a 136 ms timed region: the collector is the one
+                          # source of such pauses this process controls
     sync(); torch.cuda.synchronize(); barrier()
     backend.timer_start()
     t0 = time.perf_counter()
