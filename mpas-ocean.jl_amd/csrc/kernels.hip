@@ -1187,15 +1187,13 @@ static bool launch_rec2c_f32(const ColMesh &m, const StageArgs &a, int mode, dim
 {
     // a launch that carries a halo-straddling patch of a partitioned mesh (up to 6 own edges per cell) may need more than
     // the default 64 KB of dynamic LDS; such launches are small (the boundary group), occupancy does not matter there
-    static bool raised = false;
-    if (lds > 64 * 1024 && !raised) {
+    if (lds > 64 * 1024 && lds_attr_needed(ME == 6 ? (ME2 == 10 ? 0 : 1) : 2)) {
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
     }
     switch (mode) {
         case 0: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 0>), g, b, lds, s, m, a, mE, mC); return true;

@@ -1,6 +1,7 @@
 // kernels_common.hpp -- device helpers and launch macros shared by the kernel translation units of libmoka_hip
 // (kernels.hip: stage / Forward-Euler / utility kernels; nonlinear.hip; adjoint.hip).
 #pragma once
+#include <atomic>
 #include <algorithm>
 #include <hip/hip_runtime.h>
 
@@ -239,6 +240,18 @@ inline int colp_mode(const StageArgs &a)
     if (a.cu && a.ch && a.nu_in && a.nh_in && a.pu_out && a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 2;
     if (a.nu_in && a.nh_in && !a.pu_out && !a.ph_out && a.nu_out && a.nh_out && a.ssh_out) return 3;
     return -1;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: remember per device (a process may
+// drive several, e.g. LocalCluster over a device list) whether `slot` (one bit per kernel family) has been raised there
+inline bool lds_attr_needed(int slot)
+{
+    static std::atomic<uint32_t> done[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return true;
+    const uint32_t bit = 1u << slot;
+    return !(done[dev].fetch_or(bit) & bit);
 }
 
 inline size_t rec_lds_bytes(const MeshDev &md)

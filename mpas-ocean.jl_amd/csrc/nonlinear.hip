@@ -753,12 +753,10 @@ hipError_t launch_nl_prepare(const MeshDev &m, const double *u, const double *h,
 hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &nl, int lpc, bool rowsOk, int form, hipStream_t s)
 {
     if (lpc == 64 && nl3_ok(m) && rowsOk && form == 0 && nl4_lds_bytes(m) <= 80 * 1024) {     // two 512-thread workgroups per CU
-        static bool attr = false;
         const size_t lds = nl4_lds_bytes(m);
-        if (!attr) {
+        if (lds_attr_needed(3)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage_nl4<6, 10, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             if (e != hipSuccess) return e;
-            attr = true;
         }
         hipLaunchKernelGGL((k_stage_nl4<6, 10, 512>), dim3(nl_grid(m.nPatches)), dim3(512), lds, s, m, a, nl);
         return hipGetLastError();
