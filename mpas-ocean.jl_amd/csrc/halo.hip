@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cerrno>
 #include <cstring>
 #include <new>
 #include <string>
@@ -209,7 +210,11 @@ int ensure_flags(moka_halo *h, bool shared)
     if (shared) {
         char name[64];
         snprintf(name, sizeof name, "/moka_halo_%d_%llx", (int)getpid(), (unsigned long long)(uintptr_t)h);
-        const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 && errno == EEXIST) {      // left behind by a killed process that had this pid and address: it is ours now
+            shm_unlink(name);
+            fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        }
         if (fd < 0) return hfail(h, MOKA_ERR_COMM, std::string("shm_open(") + name + ") failed");
         if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); return hfail(h, MOKA_ERR_COMM, "ftruncate on the flag block failed"); }
         void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
