@@ -41,6 +41,36 @@ def partition_cells(mesh, nparts: int) -> np.ndarray:
     return part
 
 
+def edge_cut(mesh, part) -> int:
+    """Number of edges whose two cells lie in different parts (the halo surface a partition costs)."""
+    c = np.asarray(mesh.cellsOnEdge).reshape(mesh.nEdges, 2) - 1
+    ok = (c[:, 0] >= 0) & (c[:, 1] >= 0)
+    return int((part[c[ok, 0]] != part[c[ok, 1]]).sum())
+
+
+def write_graph_info(mesh, path: str):
+    """The cell graph in the METIS format MPAS tools use (`graph.info`: "nCells nAdjacencies", then the 1-based neighbour
+    cells of every cell): `gpmetis graph.info N` gives `graph.info.part.N`, which read_partition() / the `part=` argument of
+    DistributedModel take."""
+    c = np.asarray(mesh.cellsOnEdge).reshape(mesh.nEdges, 2)
+    ok = (c[:, 0] >= 1) & (c[:, 1] >= 1)
+    nbrs = [[] for _ in range(mesh.nCells)]
+    for a, b in c[ok]:
+        nbrs[a - 1].append(int(b)); nbrs[b - 1].append(int(a))
+    with open(path, "w") as f:
+        f.write(f"{mesh.nCells} {int(ok.sum())}\n")
+        for lst in nbrs:
+            f.write(" ".join(str(x) for x in lst) + "\n")
+
+
+def read_partition(path: str, nCells: int) -> np.ndarray:
+    """`graph.info.part.N` (one 0-based part number per cell)."""
+    part = np.loadtxt(path, dtype=np.int64).reshape(-1)
+    if part.size != nCells or part.min() < 0:
+        raise ValueError(f"{path}: expected {nCells} non-negative part numbers, found {part.size}")
+    return part.astype(np.int32)
+
+
 class LocalMesh:
     """A rank's local mesh (owned cells + one ring of halo cells, every edge of those cells) in reference
     conventions, plus the maps needed for the exchange."""

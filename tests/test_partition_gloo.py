@@ -192,3 +192,31 @@ def test_forward_euler_on_a_partitioned_mesh(world, K, flags, direct):
     gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
     assert np.array_equal(gu, ref.u[1]) and np.array_equal(gh, ref.h[1]) and np.array_equal(gs, ref.ssh[1])
     cl.close()
+
+
+def test_metis_workflow_files(tmp_path):
+    """The cell graph in the METIS format MPAS tools use (graph.info) and a part file read back (graph.info.part.N): the
+    route to a METIS partition where gpmetis exists (it does not in this image; recursive coordinate bisection is the
+    built-in partitioner).  The file is checked against the mesh: symmetric, every adjacency once per direction."""
+    mesh = mg.icosahedral_mesh(8)
+    gpath = str(tmp_path / "graph.info")
+    par.write_graph_info(mesh, gpath)
+    lines = open(gpath).read().splitlines()
+    nC, nAdj = (int(x) for x in lines[0].split())
+    assert nC == mesh.nCells and nAdj == mesh.nEdges and len(lines) == nC + 1
+    nb = [set(int(x) for x in ln.split()) for ln in lines[1:]]
+    assert sum(len(x) for x in nb) == 2 * nAdj
+    assert all((c + 1) in nb[d - 1] for c in range(nC) for d in nb[c])
+    part = par.partition_cells(mesh, 4)
+    ppath = gpath + ".part.4"
+    np.savetxt(ppath, part, fmt="%d")
+    back = par.read_partition(ppath, mesh.nCells)
+    assert np.array_equal(back, part)
+    # a partition is what it costs: the cut of the bisection equals the number of edges between parts, and every part is
+    # within one cell of the mean
+    assert par.edge_cut(mesh, part) == int(sum(1 for e in range(mesh.nEdges)
+                                               if part[mesh.cellsOnEdge.reshape(-1, 2)[e, 0] - 1] != part[mesh.cellsOnEdge.reshape(-1, 2)[e, 1] - 1]))
+    sizes = np.bincount(part)
+    assert sizes.max() - sizes.min() <= 1
+    with pytest.raises(ValueError):
+        par.read_partition(ppath, mesh.nCells + 1)
