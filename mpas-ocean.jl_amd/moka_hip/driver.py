@@ -28,7 +28,14 @@ def ocn_run(config_fp, device: int = 0, method=mk.ForwardEuler):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and os.path.isfile(sys.argv[1]):
-        ocn_run(sys.argv[1])
+    # python -m moka_hip.driver config.yml [--integrator fe|rk4] [--device N]
+    # (the reference's driver takes the config file only and always steps with ForwardEuler, mpas_ocean.jl:40,56-60)
+    args = sys.argv[1:]
+    opts = {"--integrator": "fe", "--device": "0"}
+    while len(args) >= 3 and args[-2] in opts:
+        opts[args[-2]] = args[-1]
+        args = args[:-2]
+    if len(args) == 1 and os.path.isfile(args[0]) and opts["--integrator"] in ("fe", "rk4") and opts["--device"].isdigit():
+        ocn_run(args[0], device=int(opts["--device"]), method=mk.RungeKutta4 if opts["--integrator"] == "rk4" else mk.ForwardEuler)
     else:
         raise SystemExit("yaml config file invalid")                   # mpas_ocean.jl:58
