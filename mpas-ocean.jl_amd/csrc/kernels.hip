@@ -1147,18 +1147,29 @@ static hipError_t launch_fe_lpc(const MeshDev &m, const FeArgs &a, hipStream_t s
 }
 
 
-template <int ME, int ME2>
-static bool launch_rec2c(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3 b, size_t lds, int mE, int mC, hipStream_t s)
+template <int ME, int ME2, int NT>
+static bool launch_rec2c_nt(const ColMesh &m, const StageArgs &a, int mode, dim3 g, size_t lds, int mE, int mC, hipStream_t s)
 {
+    const dim3 b(NT);
     switch (mode) {
-        case 0: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 0>), g, b, lds, s, m, a, mE, mC); return true;
-        case 1: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 1>), g, b, lds, s, m, a, mE, mC); return true;
-        case 2: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 2>), g, b, lds, s, m, a, mE, mC); return true;
-        case 3: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 3>), g, b, lds, s, m, a, mE, mC); return true;
-        case 4: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 4>), g, b, lds, s, m, a, mE, mC); return true;
-        case 5: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 5>), g, b, lds, s, m, a, mE, mC); return true;
+        case 0: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 0, NT>), g, b, lds, s, m, a, mE, mC); return true;
+        case 1: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 1, NT>), g, b, lds, s, m, a, mE, mC); return true;
+        case 2: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 2, NT>), g, b, lds, s, m, a, mE, mC); return true;
+        case 3: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 3, NT>), g, b, lds, s, m, a, mE, mC); return true;
+        case 4: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 4, NT>), g, b, lds, s, m, a, mE, mC); return true;
+        case 5: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 5, NT>), g, b, lds, s, m, a, mE, mC); return true;
     }
     return false;
+}
+
+// A launch of at most two workgroups per CU (the boundary patches of a partitioned mesh: ~180 of them, alone on the chip) is
+// as long as ONE workgroup lives: 512 threads per patch halve the number of entity rounds it makes (1 + 3 + 1 instead of
+// 1 + 6 + 2).  Whole-mesh launches keep 256 (four workgroups per CU; 512 threads tie there, profiles/r01_variants.txt).
+template <int ME, int ME2>
+static bool launch_rec2c(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3, size_t lds, int mE, int mC, hipStream_t s)
+{
+    if (m.nPatches <= 512) return launch_rec2c_nt<ME, ME2, 512>(m, a, mode, g, lds, mE, mC, s);
+    return launch_rec2c_nt<ME, ME2, BLOCK>(m, a, mode, g, lds, mE, mC, s);
 }
 
 size_t rec2c_lds_bytes(const MeshDev &md)
