@@ -312,10 +312,11 @@ int flush_lazy(moka_state *st, bool diag, bool tend)
     }
     if (tend && st->tendDirty) {
         StageArgs g{};
-        g.pu = st->rk[0].u; g.ph = st->rk[0].h; g.ssh = st->rk[0].ssh;
+        g.pu = st->lazyPu ? st->lazyPu : st->rk[0].u; g.ph = st->lazyPh ? st->lazyPh : st->rk[0].h; g.ssh = st->rk[0].ssh;
         g.tendU = st->tendU; g.tendH = st->tendH;
         HIPCHK(st->ctx, run_stage(st, g));
         st->tendDirty = false;
+        st->lazyPu = st->lazyPh = nullptr; st->lazyOwner = nullptr;
     }
     return MOKA_OK;
 }
@@ -900,6 +901,7 @@ void rk4_end(moka_state *st)
     st->sshConsistent = true;
     st->diagDirty = true;
     st->tendDirty = true;
+    st->lazyPu = st->lazyPh = nullptr; st->lazyOwner = nullptr;
 }
 }  // namespace mk
 extern "C" {
@@ -1202,6 +1204,10 @@ void moka_tape_destroy(moka_tape *t)
 {
     if (!t) return;
     (void)hipSetDevice(t->st->ctx->device);
+    if (t->st->lazyOwner == t) {        // the stage-4 tendencies of the last taped step would be produced from a slot of this tape
+        if (t->st->tendDirty) (void)flush_lazy(t->st, false, true);
+        t->st->lazyPu = t->st->lazyPh = nullptr; t->st->lazyOwner = nullptr;
+    }
     (void)hipStreamSynchronize(t->st->ctx->stream);
     for (void *q : t->allocs) (void)hipFree(q);
     delete t;
@@ -1255,24 +1261,21 @@ int moka_step_rk4_taped(moka_tape *t, double dt)
     if ((rc = rk4_begin(st, &ssh0))) return rc;
     hipStream_t s = st->ctx->stream;
     double *tu = t->rkU + nEK * 4 * t->n, *th = t->rkH + nCK * 4 * t->n;
-    // The tape needs the provisional states P1..P4 the four tendencies are evaluated at.  P1 (the current level) and P4
-    // (stage 3's output, which also has to stay in the RK buffer for the lazily produced stage-4 tendencies) are copied;
-    // P2 and P3 are written by stages 1 and 2 straight into their tape slots and read from there by stages 2 and 3.
+    // The tape needs the provisional states P1..P4 the four tendencies are evaluated at.  P1 (the current level) is copied;
+    // P2, P3 and P4 are written by stages 1, 2 and 3 straight into their tape slots and read from there by the next stage
+    // (and, P4, by the lazily produced stage-4 tendencies: moka_state.lazyPu / lazyPh).
     auto slotU = [&](int i) { return tu + nEK * i; };
     auto slotH = [&](int i) { return th + nCK * i; };
     HIPCHK(st->ctx, hipMemcpyAsync(slotU(0), st->lev[1].u, nEK * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHK(st->ctx, hipMemcpyAsync(slotH(0), st->lev[1].h, nCK * sizeof(double), hipMemcpyDeviceToDevice, s));
     for (int sg = 1; sg <= 4; ++sg) {
         StageArgs g = rk4_stage_args(st, sg, dt, ssh0);
-        if (sg == 2 || sg == 3) { g.pu = slotU(sg - 1); g.ph = slotH(sg - 1); }
-        if (sg == 1 || sg == 2) { g.pu_out = slotU(sg); g.ph_out = slotH(sg); }
+        if (sg >= 2) { g.pu = slotU(sg - 1); g.ph = slotH(sg - 1); }
+        if (sg <= 3) { g.pu_out = slotU(sg); g.ph_out = slotH(sg); }
         HIPCHK(st->ctx, run_stage(st, g));
-        if (sg == 3) {
-            HIPCHK(st->ctx, hipMemcpyAsync(slotU(3), g.pu_out, nEK * sizeof(double), hipMemcpyDeviceToDevice, s));
-            HIPCHK(st->ctx, hipMemcpyAsync(slotH(3), g.ph_out, nCK * sizeof(double), hipMemcpyDeviceToDevice, s));
-        }
     }
     rk4_end(st);
+    st->lazyPu = slotU(3); st->lazyPh = slotH(3); st->lazyOwner = t;
     t->kind = 1;
     t->dts.push_back(dt);
     t->flags.push_back(0);

@@ -62,7 +62,9 @@ struct moka_state {
     // lazily -- on the first read (download, Forward-Euler step, reference-sequenced calls) -- with
     // results identical to computing them at the end of the step.
     bool diagDirty = false;
-    bool tendDirty = false;           // stage-4 provisional state still sits in rk[0]
+    bool tendDirty = false;           // stage-4 provisional state still sits in rk[0] -- or, after a taped step, in the tape:
+    const double *lazyPu = nullptr, *lazyPh = nullptr;   // where (nullptr: rk[0]); ssh of it is rk[0].ssh either way
+    const void *lazyOwner = nullptr;                     // the tape those rows belong to (it materialises them before it goes away)
     // fp32 storage of the prognostic fields (mesh stateBytes == 4): lev[] / rk[] then point at float arrays
     // (the pointer type stays double* so that one StageArgs block serves both), Diag arrays do not exist.
     bool f32 = false;

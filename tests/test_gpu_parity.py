@@ -852,7 +852,21 @@ def test_rk4_adjoint_bitwise(backend, meshname, K, nsteps):
     a2 = orc.OracleAdjoint(st)
     a2.step_fe(dtv, 0)
     assert np.array_equal(tape.gradient()["layerThickness"], a2.gradient_sum_sq_ssh()[2])
-    tape.close(); Prog._state.close(); Setup.mesh.close()
+    tape.close()
+    # The stage-4 tendencies of a taped RK4 step are produced lazily from the TAPE's copy of the last provisional state
+    # (stage 3 writes it into the tape, not into the RK buffer): read them (a) while the tape lives, (b) after it is gone.
+    for close_first in (False, True):
+        t2 = mk.AdjointTape(Prog, 2)
+        t2.step(dtv, method=mk.RungeKutta4)
+        t2.step(dtv, method=mk.RungeKutta4)
+        st.step_rk4(dtv); st.step_rk4(dtv)
+        if close_first:
+            t2.close()
+        assert np.array_equal(Tend.tendNormalVelocity.get(), st.tendU) and np.array_equal(Tend.tendLayerThickness.get(), st.tendH)
+        assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.layerThickness[-1].get(), st.h[1])
+        if not close_first:
+            t2.close()
+    Prog._state.close(); Setup.mesh.close()
 
 
 # ------------------------------------------------------------------------------------------------
