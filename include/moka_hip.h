@@ -282,6 +282,10 @@ typedef struct {
  * on the compute stream, in flight together (a small boundary launch no longer leaves the chip idle).  -1 (default):
  * chosen from the size of the interior launch.  Takes effect at the next moka_rk4_dist_begin.  Results are identical. */
 int  moka_halo_set_overlap(moka_halo *h, int mode);
+/* the same exchange for arbitrary device fields of the state's shapes and storage type (u-like, h-like, ssh-like), library
+ * numbering: pack waits for the compute stream, unpack makes the compute stream wait for the received rows */
+int  moka_halo_pack_fields(moka_halo *h, const void *uField, const void *hField, const void *sField, void *sendbuf);
+int  moka_halo_unpack_fields(moka_halo *h, void *uField, void *hField, void *sField, const void *recvbuf);
 int  moka_halo_direct_available(const moka_halo *h);   /* 1: the receive lists are contiguous ranges (see above) */
 int  moka_halo_export(moka_halo *h, int32_t nbr, int32_t shared, moka_halo_peer_info *out);
 int  moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer, int32_t shared);
@@ -359,6 +363,18 @@ int  moka_step_rk4_taped(moka_tape *t, double dt);
 /* lambda := d sum(ssh^2) / d state at the current state (the objective of run_loop.jl:26-45) */
 int  moka_adjoint_seed_sum_sq_ssh(moka_tape *t);
 int  moka_adjoint_sweep(moka_tape *t);                                              /* reverse over (and pop) every recorded step */
+/* Reverse mode of a PARTITIONED RK4 run (one rank's part; the host layer moves the halo rows between the calls):
+ *   taping   -- the caller runs the distributed step itself and records, halo rows included, the four provisional states:
+ *               slot 0 := the current level before the step (what = 0), slot s := the output of stage s after its exchange
+ *               (what = s = 1..3); moka_tape_commit_rk4 closes the step.
+ *   reversal -- per recorded step, for sg = 4, 3, 2, 1: exchange the halo rows of the fields moka_adjoint_rk4_stage_fields
+ *               names (moka_halo_pack_fields / unpack_fields; sg = 4: the adjoint state itself), then moka_adjoint_rk4_stage.
+ * The transposed lists are sorted by the caller's edge ids: a local mesh whose edges keep the order of their global ids
+ * (moka_hip.parallel.build_local) reproduces the single-domain sums bit for bit. */
+int  moka_tape_record_rk4(moka_tape *t, int slot, int what);
+int  moka_tape_commit_rk4(moka_tape *t, double dt);
+int  moka_adjoint_rk4_stage_fields(moka_tape *t, int stage, void **fieldU, void **fieldH, void **scratchS);
+int  moka_adjoint_rk4_stage(moka_tape *t, int stage);
 /* field: MOKA_F_SSH, MOKA_F_NORMAL_VELOCITY, MOKA_F_LAYER_THICKNESS (d_Prog of the reference test) or
  * MOKA_F_LAYER_THICKNESS_EDGE (the carried diagnostic of the reference_compat sequence); caller's numbering */
 int  moka_adjoint_download(moka_tape *t, int field, double *host);

@@ -1094,6 +1094,8 @@ struct moka_tape {
     double *kbU = nullptr, *kbH = nullptr, *pbU = nullptr, *pbH = nullptr;
     int kind = -1;                                   // -1 empty, 0 Forward Euler, 1 RK4 (one integrator per tape)
     int cur = 0;                                     // index of the adjoint state that is current
+    int revNext = 4;                                 // stage-wise reverse RK4 step (moka_adjoint_rk4_stage): the stage that comes next
+    int recMask = 0;                                 // piecewise taping (moka_tape_record_rk4): slots of the open step already filled
     bool seeded = false;
     moka::AdjMesh am{};
     std::vector<void *> allocs;
@@ -1157,7 +1159,8 @@ int moka_tape_create(moka_state *st, int64_t capacity_steps, moka_tape **out)
             if (p.eoc[(size_t)c * ME + i] >= 0) csgn[(size_t)c * ME + i] = p.sdv[(size_t)c * ME + i] < 0.0 ? -1 : 1;
     for (int e = 0; e < nE; ++e) {
         const int cc[2] = {p.ehdr[(size_t)e * 4], p.ehdr[(size_t)e * 4 + 1]};
-        if (cc[0] == cc[1]) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode: rank-local (partitioned) meshes are not supported");
+        // (cc[0] == cc[1]: an outermost edge of a rank-local mesh, both sides set to the inside halo cell.  Its adjoint is never
+        //  computed here -- it arrives by exchange, like its forward value -- so its factors may be anything finite.)
         for (int q = 0; q < 2; ++q) {
             double sgn = 0.0;
             for (int i = 0; i < ME; ++i)
@@ -1284,6 +1287,51 @@ int moka_step_rk4_taped(moka_tape *t, double dt)
     return MOKA_OK;
 }
 
+// Piecewise taping for a step the caller runs itself (the distributed RK4 step, whose stages are separated by halo
+// exchanges): slot 0..3 of the step being recorded := (normalVelocity, layerThickness) of buffer set `what` (0 = the current
+// level, 1..3 = the output of RK stage `what`), halo rows included; moka_tape_commit_rk4 closes the step.
+int moka_tape_record_rk4(moka_tape *t, int slot, int what)
+{
+    if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
+    moka_state *st = t->st;
+    const Plan &p = st->mesh->plan;
+    if (slot < 0 || slot > 3 || what < 0 || what > 3) return fail(st->ctx, MOKA_ERR_ARG, "slot and what must be 0..3");
+    if (t->n >= t->capacity) return fail(st->ctx, MOKA_ERR_ARG, "tape is full");
+    if (t->n > 0 && t->kind != 1) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode: one integrator per tape");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    const size_t nEK = (size_t)p.K * p.nE, nCK = (size_t)p.K * p.nC;
+    int rc = MOKA_OK;
+    if (!t->rkU) {
+        auto A = [&](double **q, size_t n) { if (rc == MOKA_OK) { void *d = nullptr; rc = tape_alloc(t, &d, n * sizeof(double)); *q = static_cast<double *>(d); } };
+        A(&t->rkU, nEK * 4 * (size_t)t->capacity); A(&t->rkH, nCK * 4 * (size_t)t->capacity);
+        A(&t->kbU, nEK); A(&t->kbH, nCK); A(&t->pbU, nEK); A(&t->pbH, nCK);
+        if (rc) return rc;
+    }
+    if ((rc = ensure_rk_bufs(st))) return rc;
+    const LevelBufs &o = rk4_stage_output(st, what);
+    hipStream_t s = st->ctx->stream;
+    // the rows may have been produced on either stream (boundary patches, halo unpack): the copy waits for both
+    HIPCHK(st->ctx, hipEventRecord(st->ctx->evHalo, st->ctx->comm));
+    HIPCHK(st->ctx, hipStreamWaitEvent(s, st->ctx->evHalo, 0));
+    HIPCHK(st->ctx, hipMemcpyAsync(t->rkU + nEK * (4 * t->n + slot), o.u, nEK * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(st->ctx, hipMemcpyAsync(t->rkH + nCK * (4 * t->n + slot), o.h, nCK * sizeof(double), hipMemcpyDeviceToDevice, s));
+    t->recMask |= 1 << slot;
+    return MOKA_OK;
+}
+
+int moka_tape_commit_rk4(moka_tape *t, double dt)
+{
+    if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
+    if (t->recMask != 15) return fail(t->st->ctx, MOKA_ERR_ARG, "moka_tape_commit_rk4: record the four provisional states first");
+    t->recMask = 0;
+    t->kind = 1;
+    t->dts.push_back(dt);
+    t->flags.push_back(0);
+    ++t->n;
+    t->seeded = false;
+    return MOKA_OK;
+}
+
 int moka_adjoint_seed_sum_sq_ssh(moka_tape *t)
 {
     if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
@@ -1310,6 +1358,90 @@ int moka_adjoint_seed_sum_sq_ssh(moka_tape *t)
     return MOKA_OK;
 }
 
+// one stage (sg = 4, 3, 2, 1) of one RK4 step backwards (time_integration.jl:61-148 transposed):
+//   kb4 = b4*X; Pb = T'(P4)^T kb4; acc = X + Pb;  for s = 3,2,1: kb = b_s*X + a_s*Pb; Pb = T'(P_s)^T kb; acc += Pb;  X = acc
+// sg == 1 completes the step (the adjoint states swap, the step is popped).  Between two stages the host layer of a partitioned
+// run exchanges the halo rows of the k-bar the next stage gathers from (rk4_reverse_fields).
+static void rk4_reverse_fields(moka_tape *t, int sg, double **fU, double **fH)
+{
+    double *kU[2] = {t->kbU, t->pbU}, *kH[2] = {t->kbH, t->pbH};
+    const int kc = (4 - sg) & 1;                      // stage 4 reads k-bar 0 (or X itself), 3 reads 1, 2 reads 0, 1 reads 1
+    *fU = sg == 4 ? t->lamU[t->cur] : kU[kc];
+    *fH = sg == 4 ? t->lamH[t->cur] : kH[kc];
+}
+
+static int rk4_reverse_stage(moka_tape *t, int sg)
+{
+    moka_state *st = t->st;
+    const Plan &p = st->mesh->plan;
+    hipStream_t s = st->ctx->stream;
+    const size_t nEK = (size_t)p.K * p.nE, nCK = (size_t)p.K * p.nC;
+    const int64_t i = t->n - 1;
+    const double dt = t->dts[i];
+    const double ca[3] = {dt / 2., dt / 2., dt}, cb[4] = {dt / 6., dt / 3., dt / 3., dt / 6.};
+    const int in = t->cur, o = 1 - t->cur;
+    const double *XU = t->lamU[in], *XH = t->lamH[in];
+    double *accU = t->lamU[o], *accH = t->lamH[o];
+    // every k-bar after the first, and the running sum X + Pb4 + Pb3 + ..., come out of the two transposed kernels themselves
+    // (fused epilogues: AdjArgs.accOut / kNext), k-bar double-buffered because the current one is being gathered while the
+    // next one is written
+    double *kU[2] = {t->kbU, t->pbU}, *kH[2] = {t->kbH, t->pbH};
+    // chunk kernels (even K <= 64, hexagon-width lists): stage 4 reads X scaled on the fly (kb4 is never stored) and
+    // u*Fbar is recomputed by the cell kernel instead of travelling through memory
+    const bool fused = moka::adj_fused_available(t->am, st->mesh->lpc);
+    if (sg == 4 && !fused) {
+        HIPCHK(st->ctx, launch_scale_copy(kU[0], XU, cb[3], (int64_t)nEK, s));
+        HIPCHK(st->ctx, launch_scale_copy(kH[0], XH, cb[3], (int64_t)nCK, s));
+    }
+    const int kc = (4 - sg) & 1;
+    moka::AdjArgs a{};
+    a.tt = 1; a.dt = 1.0;
+    a.u = t->rkU + nEK * (4 * i + (sg - 1)); a.h = t->rkH + nCK * (4 * i + (sg - 1));
+    a.lamU1 = kU[kc]; a.lamH1 = kH[kc];
+    a.lamScale = 1.0; a.fuseE = fused ? 1 : 0;
+    if (fused && sg == 4) { a.lamU1 = XU; a.lamH1 = XH; a.lamScale = cb[3]; }
+    a.Enew = t->Enew; a.csum = t->csum;
+    a.xU = XU; a.xH = XH;
+    a.accInU = sg == 4 ? nullptr : accU; a.accInH = sg == 4 ? nullptr : accH;
+    a.accOutU = accU; a.accOutH = accH;
+    if (sg > 1) {
+        a.kNextU = kU[1 - kc]; a.kNextH = kH[1 - kc];
+        a.cbNext = cb[sg - 2]; a.caNext = ca[sg - 2];
+    }
+    HIPCHK(st->ctx, launch_adj_edge(t->am, a, st->mesh->lpc, s));
+    HIPCHK(st->ctx, launch_adj_cell(t->am, a, st->mesh->lpc, s));
+    if (sg == 1) {
+        t->cur = o;
+        t->dts.pop_back(); t->flags.pop_back();
+        --t->n;
+    }
+    return MOKA_OK;
+}
+
+int moka_adjoint_rk4_stage_fields(moka_tape *t, int sg, void **fieldU, void **fieldH, void **scratchS)
+{
+    if (!t || !fieldU || !fieldH) return fail(t ? t->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (sg < 1 || sg > 4 || t->kind != 1 || t->n <= 0) return fail(t->st->ctx, MOKA_ERR_ARG, "no recorded RK4 step / stage must be 4..1");
+    double *fU, *fH;
+    rk4_reverse_fields(t, sg, &fU, &fH);
+    *fieldU = fU; *fieldH = fH;
+    if (scratchS) *scratchS = t->lamS[1 - t->cur];     // an (nCells) array nothing reads: stands in for ssh in the exchange maps
+    return MOKA_OK;
+}
+
+int moka_adjoint_rk4_stage(moka_tape *t, int sg)
+{
+    if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
+    moka_state *st = t->st;
+    if (!t->seeded) return fail(st->ctx, MOKA_ERR_ARG, "seed the adjoint first (moka_adjoint_seed_sum_sq_ssh)");
+    if (sg < 1 || sg > 4 || t->kind != 1 || t->n <= 0) return fail(st->ctx, MOKA_ERR_ARG, "no recorded RK4 step / stage must be 4..1");
+    if (sg != t->revNext) return fail(st->ctx, MOKA_ERR_ARG, "reverse RK4 stages run 4, 3, 2, 1");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (int rc = rk4_reverse_stage(t, sg)) return rc;
+    t->revNext = sg == 1 ? 4 : sg - 1;
+    return MOKA_OK;
+}
+
 int moka_adjoint_sweep(moka_tape *t)
 {
     if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
@@ -1318,51 +1450,11 @@ int moka_adjoint_sweep(moka_tape *t)
     const Plan &p = st->mesh->plan;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     hipStream_t s = st->ctx->stream;
-    const size_t nEK = (size_t)p.K * p.nE, nCK = (size_t)p.K * p.nC;
-    while (t->n > 0 && t->kind == 1) {
-        // one RK4 step backwards (time_integration.jl:61-148 transposed):
-        //   kb4 = b4*X; Pb = T'(P4)^T kb4; acc = X + Pb;  for s = 3,2,1: kb = b_s*X + a_s*Pb; Pb = T'(P_s)^T kb; acc += Pb;  X = acc
-        const int64_t i = t->n - 1;
-        const double dt = t->dts[i];
-        const double ca[3] = {dt / 2., dt / 2., dt}, cb[4] = {dt / 6., dt / 3., dt / 3., dt / 6.};
-        const int in = t->cur, o = 1 - t->cur;
-        const double *XU = t->lamU[in], *XH = t->lamH[in];
-        double *accU = t->lamU[o], *accH = t->lamH[o];
-        // kb of stage 4 by one scale pass; every later kb, and the running sum X + Pb4 + Pb3 + ..., come out of the two
-        // transposed kernels themselves (fused epilogues: AdjArgs.accOut / kNext), k-bar double-buffered because the
-        // current one is being gathered while the next one is written
-        double *kU[2] = {t->kbU, t->pbU}, *kH[2] = {t->kbH, t->pbH};
-        // chunk kernels (even K <= 64, hexagon-width lists): stage 4 reads X scaled on the fly (kb4 is never stored) and
-        // u*Fbar is recomputed by the cell kernel instead of travelling through memory
-        const bool fused = moka::adj_fused_available(t->am, st->mesh->lpc);
-        if (!fused) {
-            HIPCHK(st->ctx, launch_scale_copy(kU[0], XU, cb[3], (int64_t)nEK, s));
-            HIPCHK(st->ctx, launch_scale_copy(kH[0], XH, cb[3], (int64_t)nCK, s));
-        }
-        int kc = 0;
-        for (int sg = 4; sg >= 1; --sg) {
-            moka::AdjArgs a{};
-            a.tt = 1; a.dt = 1.0;
-            a.u = t->rkU + nEK * (4 * i + (sg - 1)); a.h = t->rkH + nCK * (4 * i + (sg - 1));
-            a.lamU1 = kU[kc]; a.lamH1 = kH[kc];
-            a.lamScale = 1.0; a.fuseE = fused ? 1 : 0;
-            if (fused && sg == 4) { a.lamU1 = XU; a.lamH1 = XH; a.lamScale = cb[3]; }
-            a.Enew = t->Enew; a.csum = t->csum;
-            a.xU = XU; a.xH = XH;
-            a.accInU = sg == 4 ? nullptr : accU; a.accInH = sg == 4 ? nullptr : accH;
-            a.accOutU = accU; a.accOutH = accH;
-            if (sg > 1) {
-                a.kNextU = kU[1 - kc]; a.kNextH = kH[1 - kc];
-                a.cbNext = cb[sg - 2]; a.caNext = ca[sg - 2];
-            }
-            HIPCHK(st->ctx, launch_adj_edge(t->am, a, st->mesh->lpc, s));
-            HIPCHK(st->ctx, launch_adj_cell(t->am, a, st->mesh->lpc, s));
-            kc = 1 - kc;
-        }
-        t->cur = o;
-        t->dts.pop_back(); t->flags.pop_back();
-        --t->n;
-    }
+    const size_t nEK = (size_t)p.K * p.nE;
+    if (t->kind == 1 && t->revNext != 4) return fail(st->ctx, MOKA_ERR_ARG, "a stage-wise reverse step is in progress");
+    while (t->n > 0 && t->kind == 1)
+        for (int sg = 4; sg >= 1; --sg)
+            if (int rc = rk4_reverse_stage(t, sg)) return rc;
     while (t->n > 0) {
         const int64_t i = t->n - 1;
         const int in = t->cur, o = 1 - t->cur;

@@ -437,6 +437,45 @@ int moka_halo_unpack(moka_halo *h, int what, const void *recvbuf)
     return MOKA_OK;
 }
 
+// The same exchange for arbitrary fields with the state's shapes (u-like (K, nEdges), h-like (K, nCells), ssh-like (nCells), in
+// the library's numbering and the state's storage type): the adjoint state of a partitioned run (moka_adjoint_rk4_stage_fields).
+// Whatever ran on the compute stream before is waited for; whatever comes next on it sees the received rows.
+int moka_halo_pack_fields(moka_halo *h, const void *uField, const void *hField, const void *sField, void *sendbuf)
+{
+    if (!h || !uField || !hField || !sField || (!sendbuf && h->nSend)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    moka_state *st = h->st;
+    moka_ctx *c = st->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->evBoundary, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm, c->evBoundary, 0));
+    if (st->f32)
+        HIPCHK(c, launch_halo_map_f32(static_cast<float *>(sendbuf), (float *)const_cast<void *>(hField), (float *)const_cast<void *>(sField),
+                                      (float *)const_cast<void *>(uField), h->sendMap, h->nSend, 0, c->comm));
+    else
+        HIPCHK(c, launch_halo_map(static_cast<double *>(sendbuf), (double *)const_cast<void *>(hField), (double *)const_cast<void *>(sField),
+                                  (double *)const_cast<void *>(uField), h->sendMap, h->nSend, 0, c->comm));
+    return MOKA_OK;
+}
+
+int moka_halo_unpack_fields(moka_halo *h, void *uField, void *hField, void *sField, const void *recvbuf)
+{
+    if (!h || !uField || !hField || !sField || (!recvbuf && h->nRecv)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    moka_state *st = h->st;
+    moka_ctx *c = st->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->evInterior, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
+    if (st->f32)
+        HIPCHK(c, launch_halo_map_f32(static_cast<float *>(const_cast<void *>(recvbuf)), (float *)hField, (float *)sField, (float *)uField,
+                                      h->recvMap, h->nRecv, 1, c->comm));
+    else
+        HIPCHK(c, launch_halo_map(static_cast<double *>(const_cast<void *>(recvbuf)), (double *)hField, (double *)sField, (double *)uField,
+                                  h->recvMap, h->nRecv, 1, c->comm));
+    HIPCHK(c, hipEventRecord(c->evHalo, c->comm));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evHalo, 0));
+    return MOKA_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // direct transport
 // ---------------------------------------------------------------------------------------------

@@ -131,8 +131,8 @@ class Mesh:
 
     def __init__(self, horz: HorzMesh, vert: VerticalMesh, backend: MokaHIP | None = None,
                  ordering: int = L.ORDER_DEFAULT, patch_cells: int = 0, state_bytes: int = 8):
-        """state_bytes=4: the states on this mesh store ssh / normalVelocity / layerThickness as fp32 (fp64 arithmetic,
-        fp64 tendencies; RK4 only) -- BASELINE config 5, not a reference feature."""
+        """state_bytes=4: the states on this mesh store every array of Prog, Diag and Tend as fp32 (fp64 arithmetic; RK4 and
+        the one-call Forward-Euler step) -- BASELINE config 5, not a reference feature."""
         self.HorzMesh, self.VertMesh = horz, vert
         self.backend = backend
         self.state_bytes = int(state_bytes)
@@ -460,6 +460,11 @@ class AdjointTape:
         lib = L.lib()
         L.check(lib.moka_adjoint_seed_sum_sq_ssh(self._h), self._ctx)
         L.check(lib.moka_adjoint_sweep(self._h), self._ctx)
+        return self.download()
+
+    def download(self) -> dict:
+        """The adjoint state as it stands (after a sweep: the gradient), caller's numbering."""
+        lib = L.lib()
         out = {}
         for name, fid in (("ssh", L.F_SSH), ("normalVelocity", L.F_NORMAL_VELOCITY), ("layerThickness", L.F_LAYER_THICKNESS),
                           ("layerThicknessEdge", L.F_LAYER_THICKNESS_EDGE)):

@@ -429,6 +429,18 @@ class DistributedModel:
             self.recvbuf.copy_(recv_cpu)
             torch.cuda.synchronize()
 
+    def _transport_buffered(self):
+        """sendbuf -> the neighbours' recvbuf for the paths that exist in buffered form only (tape recording, the adjoint
+        fields): the model's own transport, or host-staged gloo when that is the direct one."""
+        t = self.transport
+        if t != "ipc":
+            return self._transport()
+        self.transport = "gloo"
+        try:
+            self._transport()
+        finally:
+            self.transport = t
+
     def received_bytes(self):
         """The halo rows of the current time level as this rank holds them now, in message order: what a transport has
         to have delivered."""
@@ -532,6 +544,66 @@ class DistributedModel:
             L.check(lib.moka_halo_unpack(h, s, self.recvbuf.data_ptr()), ctx)
         L.check(lib.moka_rk4_dist_end(h), ctx)
 
+    # ---- reverse mode of a partitioned RK4 run: d sum(ssh^2 over ALL ranks' owned cells) / d initial state ----
+    def tape(self, capacity_steps: int):
+        """A tape on this rank's state.  step_rk4_taped() records, adjoint_gradient() reverses (RK4 only)."""
+        self._tape = api.AdjointTape(self.Prog, capacity_steps)
+        return self._tape
+
+    def _record(self, slot, what):
+        L.check(L.lib().moka_tape_record_rk4(self._tape._h, slot, what), self.backend._h)
+
+    def step_rk4_taped(self):
+        """step_rk4 with the four provisional states recorded, halo rows included (piecewise entry points: every stage
+        output is complete only after its exchange)."""
+        lib, h, ctx = L.lib(), self._halo, self.backend._h
+        L.check(lib.moka_rk4_dist_begin(h, self.dt), ctx)
+        self._record(0, 0)
+        for s in (1, 2, 3, 4):
+            L.check(lib.moka_rk4_dist_stage(h, s, 0), ctx)
+            L.check(lib.moka_halo_pack(h, s, self.sendbuf.data_ptr()), ctx)
+            L.check(lib.moka_rk4_dist_stage(h, s, 1), ctx)
+            self._transport_buffered()
+            L.check(lib.moka_halo_unpack(h, s, self.recvbuf.data_ptr()), ctx)
+            if s <= 3:
+                self._record(s, s)
+        L.check(lib.moka_rk4_dist_end(h), ctx)
+        L.check(lib.moka_tape_commit_rk4(self._tape._h, self.dt), ctx)
+
+    def _adjoint_fields(self, sg):
+        fu, fh, fs = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.check(L.lib().moka_adjoint_rk4_stage_fields(self._tape._h, sg, C.byref(fu), C.byref(fh), C.byref(fs)), self.backend._h)
+        return fu, fh, fs
+
+    def adjoint_seed(self):
+        L.check(L.lib().moka_adjoint_seed_sum_sq_ssh(self._tape._h), self.backend._h)
+
+    def adjoint_pack(self, sg):
+        fu, fh, fs = self._adjoint_fields(sg)
+        L.check(L.lib().moka_halo_pack_fields(self._halo, fu, fh, fs, self.sendbuf.data_ptr()), self.backend._h)
+
+    def adjoint_unpack_and_stage(self, sg):
+        fu, fh, fs = self._adjoint_fields(sg)
+        L.check(L.lib().moka_halo_unpack_fields(self._halo, fu, fh, fs, self.recvbuf.data_ptr()), self.backend._h)
+        L.check(L.lib().moka_adjoint_rk4_stage(self._tape._h, sg), self.backend._h)
+
+    def adjoint_gradient(self, nsteps: int):
+        """Seeds with d sum(ssh^2) at the current state and reverses the `nsteps` recorded steps, exchanging the halo rows of
+        the adjoint fields before every transposed stage; returns owned_gradient()."""
+        self.adjoint_seed()
+        for _ in range(nsteps):
+            for sg in (4, 3, 2, 1):
+                self.adjoint_pack(sg)
+                self._transport_buffered()
+                self.adjoint_unpack_and_stage(sg)
+        return self.owned_gradient()
+
+    def owned_gradient(self):
+        """(global cell ids, d/d layerThickness), (global edge ids, d/d normalVelocity) of the entities this rank owns."""
+        lm, g = self.lm, self._tape.download()
+        cm, em = lm.owned_cell_mask, lm.owned_edge_mask
+        return (lm.cells_g[cm], g["layerThickness"][cm]), (lm.edges_g[em], g["normalVelocity"][em])
+
     def owned_state(self):
         """(global cell ids, ssh, h), (global edge ids, u) of the entities this rank owns."""
         lm = self.lm
@@ -557,7 +629,10 @@ class DistributedModel:
         return d
 
     def close(self):
-        """Release the device objects in dependency order (halo, state, mesh); the backend stays with the caller."""
+        """Release the device objects in dependency order (tape, halo, state, mesh); the backend stays with the caller."""
+        if getattr(self, "_tape", None) is not None:
+            self._tape.close()
+            self._tape = None
         if getattr(self, "_halo", None):
             api._release(self, L.lib().moka_halo_destroy, self._halo)
             self._halo = C.c_void_p()
@@ -742,6 +817,65 @@ class LocalCluster:
             self._exchange(s, pack=False)
         for m in self.models:
             L.check(lib.moka_rk4_dist_end(m._halo), m.backend._h)
+
+    # ---- reverse mode across the ranks (buffered exchange: the adjoint fields are not among the IPC-registered buffers) ----
+    def tape(self, capacity_steps: int):
+        for m in self.models:
+            m.tape(capacity_steps)
+
+    def _move(self):
+        """sendbuf -> recvbuf of the neighbours, ordered by stream events (the middle part of _exchange)."""
+        torch = self.torch
+        for r, m in enumerate(self.models):
+            self.events[r].record(m.comm_stream)
+        for r, a, b, src, c, d in self.moves:
+            mr, ms = self.models[r], self.models[src]
+            mr.comm_stream.wait_event(self.events[src])
+            with torch.cuda.stream(mr.comm_stream):
+                mr.recvbuf[a:b].copy_(ms.sendbuf[c:d], non_blocking=True)
+        done = [torch.cuda.Event() for _ in self.models]
+        for r, m in enumerate(self.models):
+            done[r].record(m.comm_stream)
+        for r, a, b, src, c, d in self.moves:
+            self.models[src].comm_stream.wait_event(done[r])
+
+    def step_rk4_taped(self):
+        lib = L.lib()
+        for m in self.models:
+            L.check(lib.moka_rk4_dist_begin(m._halo, m.dt), m.backend._h)
+            m._record(0, 0)
+        for s in (1, 2, 3, 4):
+            for m in self.models:
+                L.check(lib.moka_rk4_dist_stage(m._halo, s, 0), m.backend._h)
+            for m in self.models:
+                L.check(lib.moka_halo_pack(m._halo, s, m.sendbuf.data_ptr()), m.backend._h)
+            for m in self.models:
+                L.check(lib.moka_rk4_dist_stage(m._halo, s, 1), m.backend._h)
+            self._exchange(s, pack=False)
+            if s <= 3:
+                for m in self.models:
+                    m._record(s, s)
+        for m in self.models:
+            L.check(lib.moka_rk4_dist_end(m._halo), m.backend._h)
+            L.check(lib.moka_tape_commit_rk4(m._tape._h, m.dt), m.backend._h)
+
+    def adjoint_gradient(self, nsteps: int, nCells: int, nEdges: int, K: int):
+        """d sum(ssh^2 over the whole mesh) / d (normalVelocity, layerThickness) at the state the tapes started from,
+        assembled from the ranks' owned rows."""
+        for m in self.models:
+            m.adjoint_seed()
+        for _ in range(nsteps):
+            for sg in (4, 3, 2, 1):
+                for m in self.models:
+                    m.adjoint_pack(sg)
+                self._move()
+                for m in self.models:
+                    m.adjoint_unpack_and_stage(sg)
+        gu, gh = np.full((nEdges, K), np.nan), np.full((nCells, K), np.nan)
+        for m in self.models:
+            (cg, hh), (eg, uu) = m.owned_gradient()
+            gh[cg], gu[eg] = hh, uu
+        return gu, gh
 
     def step_fe(self, flags=L.FE_REFERENCE_COMPAT & ~L.FE_LEVEL1_ONLY):
         """The reference's Forward-Euler step on the partition: boundary patches, exchange of the new level (what = 4),

@@ -163,6 +163,23 @@ def main():
                 ids, vals = diag[name]
                 assert np.array_equal(vals, exp[ids]), name
             got = (model.Prog.ssh[-1].get(), model.Prog.normalVelocity[-1].get(), model.Prog.layerThickness[-1].get())
+        if K % 2 == 0 and transport != "nccl":
+            # reverse mode between processes: two taped RK4 steps from the state reached so far, d sum(ssh^2) / d that state;
+            # every rank's owned rows against the single-domain oracle adjoint
+            model.exchange_state()
+            st2 = orc.OracleState(om, ref.ssh[1], ref.u[1], ref.h[1])
+            adj = orc.OracleAdjointRK4(st2)
+            model.tape(2)
+            for _ in range(2):
+                model.step_rk4_taped()
+                adj.step_rk4(dt)
+            gU, gH = adj.gradient_sum_sq_ssh()
+            (cg, gh), (eg, gu) = model.adjoint_gradient(2)
+            assert np.array_equal(gh, gH[cg]) and np.array_equal(gu, gU[eg]), "partitioned reverse mode"
+            assert np.abs(gH).max() > 0
+            for _ in range(2):
+                ref.step_rk4(dt)
+            got = (model.Prog.ssh[-1].get(), model.Prog.normalVelocity[-1].get(), model.Prog.layerThickness[-1].get())
         dist.barrier()               # nobody pushes into fields that are about to be freed
         model.close()
     assert np.array_equal(got[0][cm], ref.ssh[1][lm.cells_g[cm]]), "ssh"
