@@ -375,6 +375,13 @@ int  moka_tape_record_rk4(moka_tape *t, int slot, int what);
 int  moka_tape_commit_rk4(moka_tape *t, double dt);
 int  moka_adjoint_rk4_stage_fields(moka_tape *t, int stage, void **fieldU, void **fieldH, void **scratchS);
 int  moka_adjoint_rk4_stage(moka_tape *t, int stage);
+/* Forward-Euler runs on a partitioned mesh: record before (after = 0) and behind (after = 1) the distributed step, commit;
+ * reversal per recorded step: exchange the halo rows of the three fields moka_adjoint_fe_step_fields names (the adjoints of
+ * normalVelocity, layerThickness and ssh; that of the carried layerThicknessEdge needs none), then moka_adjoint_fe_step. */
+int  moka_tape_record_fe(moka_tape *t, int flags, int after);
+int  moka_tape_commit_fe(moka_tape *t, double dt, int flags);
+int  moka_adjoint_fe_step_fields(moka_tape *t, void **fieldU, void **fieldH, void **fieldS);
+int  moka_adjoint_fe_step(moka_tape *t);
 /* field: MOKA_F_SSH, MOKA_F_NORMAL_VELOCITY, MOKA_F_LAYER_THICKNESS (d_Prog of the reference test) or
  * MOKA_F_LAYER_THICKNESS_EDGE (the carried diagnostic of the reference_compat sequence); caller's numbering */
 int  moka_adjoint_download(moka_tape *t, int field, double *host);

@@ -1319,6 +1319,50 @@ int moka_tape_record_rk4(moka_tape *t, int slot, int what)
     return MOKA_OK;
 }
 
+// The same for a Forward-Euler step the caller runs itself (moka_fe_dist_step): after = 0 before the step (normalVelocity and,
+// with MOKA_FE_STALE_HEDGE, the carried layerThicknessEdge the flux is about to use), after = 1 behind it (without the flag:
+// the refreshed layerThicknessEdge the flux used, Diag's after the step); moka_tape_commit_fe closes the step.
+int moka_tape_record_fe(moka_tape *t, int flags, int after)
+{
+    if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
+    moka_state *st = t->st;
+    const Plan &p = st->mesh->plan;
+    if (t->n >= t->capacity) return fail(st->ctx, MOKA_ERR_ARG, "tape is full");
+    if ((flags & MOKA_FE_LEVEL1_ONLY) && p.K != 1)
+        return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode: level-1-only stepping is supported for nVertLevels = 1 only");
+    if (t->n > 0 && t->kind != 0) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse mode: one integrator per tape");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    hipStream_t s = st->ctx->stream;
+    const size_t nEK = (size_t)p.K * p.nE, bytes = nEK * sizeof(double);
+    const bool stale = flags & MOKA_FE_STALE_HEDGE;
+    HIPCHK(st->ctx, hipEventRecord(st->ctx->evHalo, st->ctx->comm));       // rows produced on either stream
+    HIPCHK(st->ctx, hipStreamWaitEvent(s, st->ctx->evHalo, 0));
+    if (!after) {
+        if (int rc = flush_lazy(st, true, true)) return rc;
+        HIPCHK(st->ctx, hipMemcpyAsync(t->uTape + nEK * t->n, st->lev[1].u, bytes, hipMemcpyDeviceToDevice, s));
+        if (stale) HIPCHK(st->ctx, hipMemcpyAsync(t->hTape + nEK * t->n, st->hEdge[0], bytes, hipMemcpyDeviceToDevice, s));
+        t->recMask = 1;
+    } else {
+        if (t->recMask != 1) return fail(st->ctx, MOKA_ERR_ARG, "moka_tape_record_fe: record before the step first");
+        if (!stale) HIPCHK(st->ctx, hipMemcpyAsync(t->hTape + nEK * t->n, st->hEdge[0], bytes, hipMemcpyDeviceToDevice, s));
+        t->recMask = 3;
+    }
+    return MOKA_OK;
+}
+
+int moka_tape_commit_fe(moka_tape *t, double dt, int flags)
+{
+    if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
+    if (t->recMask != 3) return fail(t->st->ctx, MOKA_ERR_ARG, "moka_tape_commit_fe: record before and after the step first");
+    t->recMask = 0;
+    t->kind = 0;
+    t->dts.push_back(dt);
+    t->flags.push_back(flags);
+    ++t->n;
+    t->seeded = false;
+    return MOKA_OK;
+}
+
 int moka_tape_commit_rk4(moka_tape *t, double dt)
 {
     if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
@@ -1418,6 +1462,50 @@ static int rk4_reverse_stage(moka_tape *t, int sg)
     return MOKA_OK;
 }
 
+// one Forward-Euler step backwards (the transposition of oracle_step_fe: see oracle_step_fe_adjoint)
+static int fe_reverse_step(moka_tape *t)
+{
+    moka_state *st = t->st;
+    const Plan &p = st->mesh->plan;
+    hipStream_t s = st->ctx->stream;
+    const size_t nEK = (size_t)p.K * p.nE;
+    const int64_t i = t->n - 1;
+    const int in = t->cur, o = 1 - t->cur;
+    moka::AdjArgs a{};
+    a.dt = t->dts[i];
+    a.stale = (t->flags[i] & MOKA_FE_STALE_HEDGE) ? 1 : 0;
+    a.u = t->uTape + nEK * i; a.hEuse = t->hTape + nEK * i;
+    a.lamU1 = t->lamU[in]; a.lamH1 = t->lamH[in]; a.lamS1 = t->lamS[in]; a.lamE1 = t->lamE[in];
+    a.lamU0 = t->lamU[o]; a.lamH0 = t->lamH[o]; a.lamS0 = t->lamS[o];
+    a.Enew = a.stale ? t->lamE[o] : t->Enew;        // stale: u*Fbar IS the adjoint of the carried hEdge
+    a.csum = t->csum;
+    HIPCHK(st->ctx, launch_adj_edge(t->am, a, st->mesh->lpc, s));
+    HIPCHK(st->ctx, launch_adj_cell(t->am, a, st->mesh->lpc, s));
+    if (!a.stale) HIPCHK(st->ctx, hipMemsetAsync(t->lamE[o], 0, nEK * sizeof(double), s));
+    t->cur = o;
+    t->dts.pop_back(); t->flags.pop_back();
+    --t->n;
+    return MOKA_OK;
+}
+
+int moka_adjoint_fe_step_fields(moka_tape *t, void **fieldU, void **fieldH, void **fieldS)
+{
+    if (!t || !fieldU || !fieldH || !fieldS) return fail(t ? t->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (t->kind != 0 || t->n <= 0) return fail(t->st->ctx, MOKA_ERR_ARG, "no recorded Forward-Euler step");
+    *fieldU = t->lamU[t->cur]; *fieldH = t->lamH[t->cur]; *fieldS = t->lamS[t->cur];
+    return MOKA_OK;
+}
+
+int moka_adjoint_fe_step(moka_tape *t)
+{
+    if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
+    moka_state *st = t->st;
+    if (!t->seeded) return fail(st->ctx, MOKA_ERR_ARG, "seed the adjoint first (moka_adjoint_seed_sum_sq_ssh)");
+    if (t->kind != 0 || t->n <= 0) return fail(st->ctx, MOKA_ERR_ARG, "no recorded Forward-Euler step");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    return fe_reverse_step(t);
+}
+
 int moka_adjoint_rk4_stage_fields(moka_tape *t, int sg, void **fieldU, void **fieldH, void **scratchS)
 {
     if (!t || !fieldU || !fieldH) return fail(t ? t->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
@@ -1447,32 +1535,13 @@ int moka_adjoint_sweep(moka_tape *t)
     if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
     moka_state *st = t->st;
     if (!t->seeded) return fail(st->ctx, MOKA_ERR_ARG, "seed the adjoint first (moka_adjoint_seed_sum_sq_ssh)");
-    const Plan &p = st->mesh->plan;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
-    hipStream_t s = st->ctx->stream;
-    const size_t nEK = (size_t)p.K * p.nE;
     if (t->kind == 1 && t->revNext != 4) return fail(st->ctx, MOKA_ERR_ARG, "a stage-wise reverse step is in progress");
     while (t->n > 0 && t->kind == 1)
         for (int sg = 4; sg >= 1; --sg)
             if (int rc = rk4_reverse_stage(t, sg)) return rc;
-    while (t->n > 0) {
-        const int64_t i = t->n - 1;
-        const int in = t->cur, o = 1 - t->cur;
-        moka::AdjArgs a{};
-        a.dt = t->dts[i];
-        a.stale = (t->flags[i] & MOKA_FE_STALE_HEDGE) ? 1 : 0;
-        a.u = t->uTape + nEK * i; a.hEuse = t->hTape + nEK * i;
-        a.lamU1 = t->lamU[in]; a.lamH1 = t->lamH[in]; a.lamS1 = t->lamS[in]; a.lamE1 = t->lamE[in];
-        a.lamU0 = t->lamU[o]; a.lamH0 = t->lamH[o]; a.lamS0 = t->lamS[o];
-        a.Enew = a.stale ? t->lamE[o] : t->Enew;        // stale: u*Fbar IS the adjoint of the carried hEdge
-        a.csum = t->csum;
-        HIPCHK(st->ctx, launch_adj_edge(t->am, a, st->mesh->lpc, s));
-        HIPCHK(st->ctx, launch_adj_cell(t->am, a, st->mesh->lpc, s));
-        if (!a.stale) HIPCHK(st->ctx, hipMemsetAsync(t->lamE[o], 0, nEK * sizeof(double), s));
-        t->cur = o;
-        t->dts.pop_back(); t->flags.pop_back();
-        --t->n;
-    }
+    while (t->n > 0)
+        if (int rc = fe_reverse_step(t)) return rc;
     return MOKA_OK;
 }
 

@@ -79,6 +79,7 @@ EXPORTS = [
     "moka_halo_unpack", "moka_rk4_dist_begin", "moka_rk4_dist_stage", "moka_rk4_dist_end",
     "moka_plan_class_ranges", "moka_mesh_class_ranges", "moka_mesh_permutation", "moka_halo_direct_available", "moka_halo_set_overlap", "moka_halo_pack_fields", "moka_halo_unpack_fields",
     "moka_tape_record_rk4", "moka_tape_commit_rk4", "moka_adjoint_rk4_stage_fields", "moka_adjoint_rk4_stage",
+    "moka_tape_record_fe", "moka_tape_commit_fe", "moka_adjoint_fe_step_fields", "moka_adjoint_fe_step",
     "moka_halo_export", "moka_halo_connect", "moka_halo_push_begin", "moka_halo_push_signal", "moka_halo_push_wait",
     "moka_rk4_dist_stage_launch", "moka_rk4_dist_step", "moka_fe_dist_launch", "moka_fe_dist_end", "moka_fe_dist_step",
     "moka_set_nonlinear", "moka_last_fe_path", "moka_set_viscosity_del2", "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
@@ -177,6 +178,10 @@ def lib():
     L.moka_tape_commit_rk4.argtypes = [vp, C.c_double]
     L.moka_adjoint_rk4_stage_fields.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.moka_adjoint_rk4_stage.argtypes = [vp, C.c_int]
+    L.moka_tape_record_fe.argtypes = [vp, C.c_int, C.c_int]
+    L.moka_tape_commit_fe.argtypes = [vp, C.c_double, C.c_int]
+    L.moka_adjoint_fe_step_fields.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.moka_adjoint_fe_step.argtypes = [vp]
     L.moka_halo_export.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(HaloPeerInfo)]
     L.moka_halo_connect.argtypes = [vp, C.c_int32, C.POINTER(HaloPeerInfo), C.c_int32]
     L.moka_halo_push_begin.argtypes = [vp, C.c_int]

@@ -604,6 +604,42 @@ class DistributedModel:
         cm, em = lm.owned_cell_mask, lm.owned_edge_mask
         return (lm.cells_g[cm], g["layerThickness"][cm]), (lm.edges_g[em], g["normalVelocity"][em])
 
+    # ---- the same for Forward-Euler runs (the integrator the reference differentiates, test_Enzyme_end2end.jl) ----
+    def step_fe_taped(self, flags=L.FE_REFERENCE_COMPAT & ~L.FE_LEVEL1_ONLY):
+        lib, t, ctx = L.lib(), self._tape._h, self.backend._h
+        L.check(lib.moka_tape_record_fe(t, int(flags), 0), ctx)
+        self.step_fe(flags)
+        L.check(lib.moka_tape_record_fe(t, int(flags), 1), ctx)
+        L.check(lib.moka_tape_commit_fe(t, self.dt, int(flags)), ctx)
+
+    def _adjoint_fe_fields(self):
+        fu, fh, fs = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.check(L.lib().moka_adjoint_fe_step_fields(self._tape._h, C.byref(fu), C.byref(fh), C.byref(fs)), self.backend._h)
+        return fu, fh, fs
+
+    def adjoint_fe_pack(self):
+        L.check(L.lib().moka_halo_pack_fields(self._halo, *self._adjoint_fe_fields(), self.sendbuf.data_ptr()), self.backend._h)
+
+    def adjoint_fe_unpack_and_step(self):
+        L.check(L.lib().moka_halo_unpack_fields(self._halo, *self._adjoint_fe_fields(), self.recvbuf.data_ptr()), self.backend._h)
+        L.check(L.lib().moka_adjoint_fe_step(self._tape._h), self.backend._h)
+
+    def adjoint_gradient_fe(self, nsteps: int):
+        self.adjoint_seed()
+        for _ in range(nsteps):
+            self.adjoint_fe_pack()
+            self._transport_buffered()
+            self.adjoint_fe_unpack_and_step()
+        return self.owned_gradient_fe()
+
+    def owned_gradient_fe(self):
+        """{name: (global ids, rows)} of d / d (ssh, normalVelocity, layerThickness, carried layerThicknessEdge), owned entities."""
+        lm, g = self.lm, self._tape.download()
+        cm, em = lm.owned_cell_mask, lm.owned_edge_mask
+        return {"ssh": (lm.cells_g[cm], g["ssh"][cm]), "layerThickness": (lm.cells_g[cm], g["layerThickness"][cm]),
+                "normalVelocity": (lm.edges_g[em], g["normalVelocity"][em]),
+                "layerThicknessEdge": (lm.edges_g[em], g["layerThicknessEdge"][em])}
+
     def owned_state(self):
         """(global cell ids, ssh, h), (global edge ids, u) of the entities this rank owns."""
         lm = self.lm
@@ -876,6 +912,33 @@ class LocalCluster:
             (cg, hh), (eg, uu) = m.owned_gradient()
             gh[cg], gu[eg] = hh, uu
         return gu, gh
+
+    def step_fe_taped(self, flags=L.FE_REFERENCE_COMPAT & ~L.FE_LEVEL1_ONLY):
+        lib = L.lib()
+        for m in self.models:
+            L.check(lib.moka_tape_record_fe(m._tape._h, int(flags), 0), m.backend._h)
+        self.step_fe(flags)
+        for m in self.models:
+            L.check(lib.moka_tape_record_fe(m._tape._h, int(flags), 1), m.backend._h)
+            L.check(lib.moka_tape_commit_fe(m._tape._h, m.dt, int(flags)), m.backend._h)
+
+    def adjoint_gradient_fe(self, nsteps: int, mesh, K: int):
+        """d sum(ssh^2 over the whole mesh) / d (ssh, normalVelocity, layerThickness, carried layerThicknessEdge) of a taped
+        Forward-Euler run, assembled from the ranks' owned rows."""
+        for m in self.models:
+            m.adjoint_seed()
+        for _ in range(nsteps):
+            for m in self.models:
+                m.adjoint_fe_pack()
+            self._move()
+            for m in self.models:
+                m.adjoint_fe_unpack_and_step()
+        out = {"ssh": np.full(mesh.nCells, np.nan), "layerThickness": np.full((mesh.nCells, K), np.nan),
+               "normalVelocity": np.full((mesh.nEdges, K), np.nan), "layerThicknessEdge": np.full((mesh.nEdges, K), np.nan)}
+        for m in self.models:
+            for name, (ids, rows) in m.owned_gradient_fe().items():
+                out[name][ids] = rows
+        return out
 
     def step_fe(self, flags=L.FE_REFERENCE_COMPAT & ~L.FE_LEVEL1_ONLY):
         """The reference's Forward-Euler step on the partition: boundary patches, exchange of the new level (what = 4),

@@ -179,6 +179,25 @@ def main():
             assert np.abs(gH).max() > 0
             for _ in range(2):
                 ref.step_rk4(dt)
+            # and of a Forward-Euler run with the reference's stale layerThicknessEdge and accumulating vorticity
+            st3 = orc.OracleState(om, ref.ssh[1], ref.u[1], ref.h[1])
+            st3.hEdge[...] = 0.0; ref.hEdge[...] = 0.0; ref.vort[...] = 0.0
+            model.Diag.layerThicknessEdge.set(np.zeros((lm.mesh.nEdges, K)))
+            model.Diag.relativeVorticity.set(np.zeros((lm.mesh.nVertices, K)))
+            afe = orc.OracleAdjoint(st3)
+            model._tape.close()
+            model.tape(2)
+            for _ in range(2):
+                model.step_fe_taped(3)
+                afe.step_fe(dt, 3)
+                ref.step_fe(dt, 3)
+            gS, gU, gH, gE = afe.gradient_sum_sq_ssh()
+            g = model.adjoint_gradient_fe(2)
+            for name, exp in (("ssh", gS), ("normalVelocity", np.asarray(gU).reshape(mesh.nEdges, K)),
+                              ("layerThickness", np.asarray(gH).reshape(mesh.nCells, K)),
+                              ("layerThicknessEdge", np.asarray(gE).reshape(mesh.nEdges, K))):
+                ids, rows = g[name]
+                assert np.array_equal(rows, exp[ids]), "partitioned reverse mode (FE) " + name
             got = (model.Prog.ssh[-1].get(), model.Prog.normalVelocity[-1].get(), model.Prog.layerThickness[-1].get())
         dist.barrier()               # nobody pushes into fields that are about to be freed
         model.close()

@@ -253,3 +253,40 @@ def test_reverse_mode_on_a_partitioned_mesh(world, K, nsteps):
     assert np.array_equal(gh, gH)
     assert np.abs(gU).max() > 0 and np.abs(gH).max() > 0
     cl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,K,flags,nsteps,direct", [(2, 60, 3, 3, True), (4, 60, 0, 2, False), (3, 34, 1, 3, True), (8, 60, 3, 2, True),
+                                                         (5, 1, 7, 4, False), (4, 60, 2, 3, True)])
+def test_reverse_mode_of_a_partitioned_forward_euler_run(world, K, flags, nsteps, direct):
+    """The computation the reference differentiates with Enzyme (test/enzyme/test_Enzyme_end2end.jl): d sum(ssh^2) / d initial
+    state of a Forward-Euler run, here on 2-8 ranks with the reference's quirk flags: the adjoints of normalVelocity,
+    layerThickness, ssh and of the carried layerThicknessEdge, assembled from the ranks, equal the single-domain oracle adjoint
+    (oracle_step_fe_adjoint) bit for bit."""
+    import oracle as orc
+    mesh = mg.icosahedral_mesh(20)
+    rng = np.random.default_rng(43 + world)
+    rest = np.full((mesh.nCells, K), 1000.0 / K) + rng.uniform(0, 0.1, (mesh.nCells, K))
+    h = rest + rng.uniform(-1, 1, (mesh.nCells, K))
+    u = rng.uniform(-1, 1, (mesh.nEdges, K))
+    ssh = h.sum(1) - rest.sum(1)
+    dt = 20.0
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    adj = orc.OracleAdjoint(st)
+    cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, world, direct=direct)
+    cl.exchange_state()
+    cl.tape(nsteps)
+    for _ in range(nsteps):
+        cl.step_fe_taped(flags)
+        adj.step_fe(dt, flags)
+    gs, gu_, gh_ = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
+    assert np.array_equal(gu_, st.u[1].reshape(mesh.nEdges, K)) and np.array_equal(gh_, st.h[1].reshape(mesh.nCells, K))
+    gS, gU, gH, gE = adj.gradient_sum_sq_ssh()
+    g = cl.adjoint_gradient_fe(nsteps, mesh, K)
+    assert np.array_equal(g["ssh"], gS)
+    assert np.array_equal(g["normalVelocity"], np.asarray(gU).reshape(mesh.nEdges, K))
+    assert np.array_equal(g["layerThickness"], np.asarray(gH).reshape(mesh.nCells, K))
+    assert np.array_equal(g["layerThicknessEdge"], np.asarray(gE).reshape(mesh.nEdges, K))
+    assert np.abs(gU).max() > 0
+    cl.close()
