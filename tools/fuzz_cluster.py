@@ -2,7 +2,7 @@
 """GPU box helper: randomized sweep of the distributed steps (all ranks of a partition in one process: parallel.LocalCluster,
 direct transport -- push kernels into the neighbours' fields + flag words -- or buffered transport with stream-ordered device
 copies, chosen at random; RK4 steps, and on fp64 states also the reference's Forward-Euler step with random compat flags)
-against the single-domain oracle, bit for bit.
+against the single-domain oracle, bit for bit; every third fp64 case also tapes two steps and reverses them across the ranks.
    python tools/fuzz_cluster.py [seconds=120] [seed=0]"""
 import os
 import sys
@@ -19,6 +19,7 @@ from moka_hip import parallel as par       # noqa: E402
 budget, seed = (float(sys.argv[1]) if len(sys.argv) > 1 else 120.0), (int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 rng = np.random.default_rng(seed)
 t0, n, skipped = time.time(), 0, 0
+n_rev = {"rk4": 0, "fe": 0}
 meshes = {}
 while time.time() - t0 < budget:
     m = int(rng.integers(8, 28))
@@ -60,8 +61,35 @@ while time.time() - t0 < budget:
         d = cl.gather_diagnostics(mesh, K)
         for name, exp in (("hEdge", ref.hEdge), ("F", ref.F), ("div", ref.div), ("vort", ref.vort), ("tendU", ref.tendU), ("tendH", ref.tendH)):
             assert np.array_equal(d[name], exp), tag + " FE " + name
+    if not f32 and (K % 2 == 0 or K == 1) and n % 3 == 0:
+        # reverse mode across the ranks from the state reached: two taped steps of a random integrator, the assembled gradient
+        # of sum(ssh^2) against the single-domain oracle adjoint
+        st2 = orc.OracleState(om, ref.ssh[1], ref.u[1], ref.h[1])
+        st2.hEdge[...] = ref.hEdge; st2.vort[...] = ref.vort
+        cl.tape(2)
+        if rng.integers(0, 2):
+            adj = orc.OracleAdjointRK4(st2)
+            for _ in range(2):
+                cl.step_rk4_taped()
+                adj.step_rk4(20.0)
+            gU, gH = adj.gradient_sum_sq_ssh()
+            gu, gh = cl.adjoint_gradient(2, mesh.nCells, mesh.nEdges, K)
+            assert np.array_equal(gu, gU) and np.array_equal(gh, gH), tag + " reverse RK4"
+            n_rev["rk4"] += 1
+        else:
+            adj = orc.OracleAdjoint(st2)
+            for _ in range(2):
+                cl.step_fe_taped(fe_flags)
+                adj.step_fe(20.0, fe_flags)
+            gS, gU, gH, gE = adj.gradient_sum_sq_ssh()
+            g = cl.adjoint_gradient_fe(2, mesh, K)
+            assert np.array_equal(g["ssh"], gS) and np.array_equal(g["normalVelocity"], np.asarray(gU).reshape(mesh.nEdges, K)) and \
+                np.array_equal(g["layerThickness"], np.asarray(gH).reshape(mesh.nCells, K)) and \
+                np.array_equal(g["layerThicknessEdge"], np.asarray(gE).reshape(mesh.nEdges, K)), tag + " reverse FE"
+            n_rev["fe"] += 1
     cl.close()
     n += 1
     if n % 10 == 0:
         print(f"{n} cases, {time.time() - t0:.0f}s", flush=True)
-print(f"fuzz_cluster: {n} random partitions bit-identical to the single-domain oracle (seed {seed}, {skipped} refused)")
+print(f"fuzz_cluster: {n} random partitions bit-identical to the single-domain oracle (seed {seed}, {skipped} refused; "
+      f"reverse mode across the ranks: {n_rev})")
