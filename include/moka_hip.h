@@ -295,7 +295,9 @@ int  moka_halo_push_wait(moka_halo *h, double timeout_s); /* host: wait for ever
 
 /* distributed form of moka_step_rk4, piecewise: begin; for stage 1..4 { stage(s,0) boundary patches; pack(s) or
  * push_begin(s); stage(s,1) interior patches (overlaps the exchange); transport + unpack(s), or push_signal + push_wait };
- * end.  moka_rk4_dist_stage_launch(s) = stage(s,0) + push_begin(s) + stage(s,1). */
+ * end.  moka_rk4_dist_stage_launch(s) = stage(s,0) + push_begin(s) + stage(s,1).
+ * part = 2: the whole local mesh in one launch, halo entities included (redundantly), exchange behind it -- the form the
+ * optional nonlinear terms run in on a partitioned mesh (their stencil needs a halo two cells deep: build_local(rings = 2)). */
 int  moka_rk4_dist_begin(moka_halo *h, double dt);
 int  moka_rk4_dist_stage(moka_halo *h, int stage, int part);
 int  moka_rk4_dist_stage_launch(moka_halo *h, int stage);

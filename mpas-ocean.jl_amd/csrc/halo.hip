@@ -665,10 +665,17 @@ int moka_rk4_dist_begin(moka_halo *h, double dt)
 int moka_rk4_dist_stage(moka_halo *h, int stage, int part)
 {
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
-    if (stage < 1 || stage > 4 || part < 0 || part > 1) return hfail(h, MOKA_ERR_ARG, "stage must be 1..4, part 0 or 1");
+    if (stage < 1 || stage > 4 || part < 0 || part > 2) return hfail(h, MOKA_ERR_ARG, "stage must be 1..4, part 0, 1 or 2");
     moka_state *st = h->st;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
-    if (st->nonlinear) return hfail(h, MOKA_ERR_UNSUPPORTED, "nonlinear terms are not available on partitioned meshes");
+    if (part == 2) {
+        // the whole local mesh in one launch, halo entities included (redundantly: the exchange behind the stage overwrites
+        // them): the form the optional nonlinear terms run in -- their two-ring halo makes every owned stencil local
+        const StageArgs g = rk4_stage_args(st, stage, h->dt, h->ssh0);
+        HIPCHK(st->ctx, run_stage(st, g));
+        return MOKA_OK;
+    }
+    if (st->nonlinear) return hfail(h, MOKA_ERR_UNSUPPORTED, "nonlinear terms on a partitioned mesh: whole-mesh stages only (part = 2)");
     // Boundary group first, interior right behind it on the same (compute) stream: in-order, no cross-queue wait in the
     // compute chain.  Launched concurrently the two kernels share the CUs and the ~130 boundary workgroups finish no
     // earlier than the thousands of interior ones (measured 290 us instead of 35 us), which would push the exchange

@@ -77,8 +77,9 @@ class LocalMesh:
     pass
 
 
-def _halo_sets(mesh, part, r):
-    """(ring cells of rank r, local cell mask, local edge mask, edges rank r must receive, the rank that sends each edge).
+def _halo_sets(mesh, part, r, rings=1):
+    """(halo cells of rank r -- `rings` rings around its cells --, local cell mask, local edge mask, edges rank r must receive,
+    the rank that sends each edge).
 
     An edge without an r-owned cell cannot be computed on r and arrives by exchange.  Its sender is the LOWEST rank
     among the owners of those of its cells that are local on r: every such owner computes the edge (it owns one of
@@ -90,6 +91,11 @@ def _halo_sets(mesh, part, r):
     ring = np.zeros(mesh.nCells, dtype=bool)
     ring[coe[o1 & ~o2, 1]] = True
     ring[coe[o2 & ~o1, 0]] = True
+    for _ in range(int(rings) - 1):                   # the optional nonlinear terms reach two cells deep
+        inn = own | ring
+        i1, i2 = inn[coe[:, 0]], inn[coe[:, 1]]
+        ring[coe[i1 & ~i2, 1]] = True
+        ring[coe[i2 & ~i1, 0]] = True
     local_c = own | ring
     l1, l2 = local_c[coe[:, 0]], local_c[coe[:, 1]]
     local_e = l1 | l2
@@ -101,10 +107,13 @@ def _halo_sets(mesh, part, r):
     return ring, local_c, local_e, recv_e, sender
 
 
-def build_local(mesh, part: np.ndarray, rank: int, world: int) -> LocalMesh:
+def build_local(mesh, part: np.ndarray, rank: int, world: int, rings: int = 1, vertex_fields: bool = False) -> LocalMesh:
+    """rings: depth of the halo in cells (1: the reference's linear terms; 2: the optional nonlinear terms, whose stencil --
+    kinetic energy and potential vorticity of the cells / vertices around an edge's two cells -- reaches one ring further).
+    vertex_fields: carry verticesOnEdge, cellsOnVertex, kiteAreasOnVertex and fVertex too (the nonlinear terms read them)."""
     coe = mesh.cellsOnEdge.astype(np.int64) - 1
     own = part == rank
-    ring, local_c, local_e, recv_e, sender = _halo_sets(mesh, part, rank)
+    ring, local_c, local_e, recv_e, sender = _halo_sets(mesh, part, rank, rings)
 
     # ---- exchange lists (global ids, sorted: both sides derive the same order) ----
     recv_cells = {q: np.nonzero(ring & (part == q))[0] for q in range(world) if q != rank}
@@ -113,7 +122,7 @@ def build_local(mesh, part: np.ndarray, rank: int, world: int) -> LocalMesh:
     for q in range(world):
         if q == rank:
             continue
-        ring_q, _, _, recv_e_q, sender_q = _halo_sets(mesh, part, q)
+        ring_q, _, _, recv_e_q, sender_q = _halo_sets(mesh, part, q, rings)
         send_cells[q] = np.nonzero(ring_q & own)[0]
         send_edges[q] = np.nonzero(recv_e_q & (sender_q == rank))[0]
     nbrs = [q for q in range(world) if q != rank and
@@ -164,9 +173,27 @@ def build_local(mesh, part: np.ndarray, rank: int, world: int) -> LocalMesh:
     m.cellsOnVertex = np.zeros((m.nVertices, mesh.vertexDegree), dtype=np.int32)   # 0: let the library derive it
     m.edgeSignOnVertex = np.ascontiguousarray(mesh.edgeSignOnVertex[verts_g])
     m.areaTriangle = np.ascontiguousarray(mesh.areaTriangle[verts_g])
+    if vertex_fields:
+        # Every vertex whose potential vorticity an owned entity reads (the vertices of the cells up to one ring out) has its
+        # three cells and edges inside a two-ring halo.  Rim vertices / edges get a valid local stand-in: what is computed
+        # from it is never read by an owned entity.
+        g2l_v = -np.ones(mesh.nVertices, dtype=np.int64)
+        g2l_v[verts_g] = np.arange(verts_g.size)
+        cov = g2l_c[mesh.cellsOnVertex[verts_g].astype(np.int64) - 1]                 # (nVl, 3), -1 = outside
+        first = np.where(cov >= 0, cov, cov.max(axis=1, keepdims=True))
+        m.cellsOnVertex = (first + 1).astype(np.int32)
+        m.kiteAreasOnVertex = np.ascontiguousarray(mesh.kiteAreasOnVertex[verts_g])
+        m.fVertex = np.ascontiguousarray(mesh.fVertex[verts_g])
+        voe = g2l_v[mesh.verticesOnEdge[edges_g].astype(np.int64) - 1]                # (nEl, 2), -1 = outside
+        stand = np.where(voe.max(axis=1, keepdims=True) >= 0, voe.max(axis=1, keepdims=True), 0)
+        m.verticesOnEdge = (np.where(voe >= 0, voe, stand) + 1).astype(np.int32)
+        lm_complete_v = np.all(cov >= 0, axis=1)
+    else:
+        m.kiteAreasOnVertex = None
 
     lm = LocalMesh()
     lm.rank, lm.world, lm.mesh = rank, world, m
+    lm.rings, lm.vertex_fields = int(rings), bool(vertex_fields)
     lm.cells_g, lm.edges_g, lm.verts_g = cells_g, edges_g, verts_g
     lm.g2l_c, lm.g2l_e = g2l_c, g2l_e
     lm.n_owned_cells = int(own.sum())
@@ -252,7 +279,8 @@ class DistributedModel:
       "local"     driven by LocalCluster (all ranks in one process)."""
 
     def __init__(self, mesh, ssh, u, h, rest, dt, backend, rank, world, ordering=0, patch_cells=0,
-                 transport="nccl", part=None, group=None, state_bytes=8, exchange_lists=None, timeout_s=30.0):
+                 transport="nccl", part=None, group=None, state_bytes=8, exchange_lists=None, timeout_s=30.0, nonlinear=False,
+                 visc_del2=0.0):
         """exchange_lists(wants: {rank: obj}) -> {rank: obj}: all-to-all of small Python objects between the ranks
         (default: torch.distributed.all_gather_object on `group`); LocalCluster passes None and calls finish() itself."""
         import torch
@@ -264,7 +292,10 @@ class DistributedModel:
         K = np.asarray(u).reshape(mesh.nEdges, -1).shape[1]
         self.K, self.state_bytes = K, int(state_bytes)
         self.part = partition_cells(mesh, world) if part is None else np.asarray(part, dtype=np.int32)
-        lm = self.lm = build_local(mesh, self.part, rank, world)
+        # the optional nonlinear terms: a two-ring halo (their stencil reaches one ring further) carrying the vertex-side fields;
+        # the whole local mesh is computed every stage (step_rk4_whole), the halo's share redundantly
+        self.nonlinear = bool(nonlinear)
+        lm = self.lm = build_local(mesh, self.part, rank, world, rings=2 if nonlinear else 1, vertex_fields=self.nonlinear)
         rest = np.asarray(rest).reshape(mesh.nCells, -1)
         h_mesh = api.HorzMesh(lm.mesh)
         v_mesh = api.VerticalMesh(h_mesh, nVertLevels=K, restingThickness=rest[lm.cells_g], multilayer=True)
@@ -274,14 +305,17 @@ class DistributedModel:
         self.mesh._h = C.c_void_p()
         desc, keep = L.make_desc(lm.mesh, K, v_mesh.restingThicknessSum, v_mesh.maxLevelEdge.Top, ordering,
                                  patch_cells, cell_class=lm.cell_class, state_bytes=state_bytes)
-        desc.cellsOnVertex = None
-        desc.verticesOnEdge = None
+        if not self.nonlinear:
+            desc.cellsOnVertex = None
+            desc.verticesOnEdge = None
         L.check(L.lib().moka_mesh_create(backend._h, C.byref(desc), C.byref(self.mesh._h)), backend._h)
         api._own(self.mesh, L.lib().moka_mesh_destroy, self.mesh._h, backend)
         self.Prog = api.PrognosticVars(np.asarray(ssh)[lm.cells_g], np.asarray(u).reshape(mesh.nEdges, K)[lm.edges_g],
                                        np.asarray(h).reshape(mesh.nCells, K)[lm.cells_g], 2, self.mesh)
         self.Diag = api.DiagnosticVars(None, self.mesh, self.Prog._state)
         self.Tend = api.TendencyVars(None, self.mesh, self.Prog._state)
+        if self.nonlinear:
+            api.set_nonlinear(self.Prog, True, visc_del2=visc_del2)
         # launch ranges and receive order come from the plan: class 0 = boundary patches, 1 = interior, 2 + i = what
         # neighbour i sends, contiguous and in the library's order
         pS, cS, eS = L.class_ranges(self.mesh._h, True)
@@ -532,6 +566,18 @@ class DistributedModel:
         self._check_cb(L.lib().moka_fe_dist_step(self._halo, self.dt, int(flags), cb, None, self.sendbuf.data_ptr(),
                                                  self.recvbuf.data_ptr(), self.timeout_s))
 
+    def step_rk4_whole(self):
+        """An RK4 step with every stage as ONE launch over the whole local mesh (halo entities included, redundantly) and the
+        exchange behind it -- no overlap; the form the optional nonlinear terms run in on a partitioned mesh."""
+        lib, h, ctx = L.lib(), self._halo, self.backend._h
+        L.check(lib.moka_rk4_dist_begin(h, self.dt), ctx)
+        for s in (1, 2, 3, 4):
+            L.check(lib.moka_rk4_dist_stage(h, s, 2), ctx)
+            L.check(lib.moka_halo_pack(h, s, self.sendbuf.data_ptr()), ctx)
+            self._transport_buffered()
+            L.check(lib.moka_halo_unpack(h, s, self.recvbuf.data_ptr()), ctx)
+        L.check(lib.moka_rk4_dist_end(h), ctx)
+
     def step_rk4_piecewise(self):
         """The same step through the piecewise entry points (17 library calls): kept for tests and host-overhead timing."""
         lib, h, ctx = L.lib(), self._halo, self.backend._h
@@ -764,14 +810,15 @@ class LocalCluster:
     send and receive buffers, ordered by stream events only."""
 
     def __init__(self, mesh, ssh, u, h, rest, dt, world, device=0, ordering=0, patch_cells=0, state_bytes=8, direct=True,
-                 devices=None, overlap=-1):
+                 devices=None, overlap=-1, nonlinear=False, visc_del2=0.0):
         import torch
         self.torch, self.world = torch, world
         devs = list(devices) if devices is not None else [device] * world
         self.backends = [api.MokaHIP(devs[r]) for r in range(world)]
         part = partition_cells(mesh, world)
         self.models = [DistributedModel(mesh, ssh, u, h, rest, dt, self.backends[r], r, world, ordering=ordering,
-                                        patch_cells=patch_cells, transport="local", part=part, state_bytes=state_bytes)
+                                        patch_cells=patch_cells, transport="local", part=part, state_bytes=state_bytes,
+                                        nonlinear=nonlinear, visc_del2=visc_del2)
                        for r in range(world)]
         for r, m in enumerate(self.models):        # every rank learns the order its neighbours want their rows in
             m.finish({q: self.models[q]._wants[r] for q in m.lm.neighbors})
@@ -874,6 +921,18 @@ class LocalCluster:
             done[r].record(m.comm_stream)
         for r, a, b, src, c, d in self.moves:
             self.models[src].comm_stream.wait_event(done[r])
+
+    def step_rk4_whole(self):
+        """Every stage one launch over each rank's whole local mesh, then the exchange (the nonlinear terms' form)."""
+        lib = L.lib()
+        for m in self.models:
+            L.check(lib.moka_rk4_dist_begin(m._halo, m.dt), m.backend._h)
+        for s in (1, 2, 3, 4):
+            for m in self.models:
+                L.check(lib.moka_rk4_dist_stage(m._halo, s, 2), m.backend._h)
+            self._exchange(s)
+        for m in self.models:
+            L.check(lib.moka_rk4_dist_end(m._halo), m.backend._h)
 
     def step_rk4_taped(self):
         lib = L.lib()

@@ -199,6 +199,18 @@ def main():
                 ids, rows = g[name]
                 assert np.array_equal(rows, exp[ids]), "partitioned reverse mode (FE) " + name
             got = (model.Prog.ssh[-1].get(), model.Prog.normalVelocity[-1].get(), model.Prog.layerThickness[-1].get())
+        if K % 2 == 0 and transport != "nccl":
+            # the optional nonlinear terms between processes: a model of its own (two-ring halo, whole-mesh stages)
+            nlm = par.DistributedModel(mesh, ssh, u, h, rest, dt, backend, rank, world, transport="gloo", part=part, nonlinear=True)
+            nlm.exchange_state()
+            onl, stn = orc.OracleNonlinear(om), orc.OracleState(om, ssh, u, h)
+            for _ in range(2):
+                nlm.step_rk4_whole()
+                onl.step_rk4(stn, dt)
+            (cg, s_, hh), (eg, uu) = nlm.owned_state()
+            assert np.array_equal(hh, stn.h[1][cg]) and np.array_equal(uu, stn.u[1][eg]) and np.array_equal(s_, stn.ssh[1][cg]), "nonlinear"
+            dist.barrier()
+            nlm.close()
         dist.barrier()               # nobody pushes into fields that are about to be freed
         model.close()
     assert np.array_equal(got[0][cm], ref.ssh[1][lm.cells_g[cm]]), "ssh"

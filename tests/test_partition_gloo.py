@@ -290,3 +290,46 @@ def test_reverse_mode_of_a_partitioned_forward_euler_run(world, K, flags, nsteps
     assert np.array_equal(g["layerThicknessEdge"], np.asarray(gE).reshape(mesh.nEdges, K))
     assert np.abs(gU).max() > 0
     cl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,K,visc,nsteps", [(2, 60, 0.0, 3), (4, 60, 1.0, 2), (3, 34, 0.0, 2), (8, 60, 0.0, 2), (4, 3, 0.0, 3)])
+def test_nonlinear_terms_on_a_partitioned_mesh(world, K, visc, nsteps):
+    """The optional nonlinear terms (potential-vorticity Coriolis, kinetic-energy gradient, Del2 mixing) on 2-8 ranks: a halo
+    two cells deep with the vertex-side fields, every stage one launch over the whole local mesh, the exchange behind it;
+    owned rows equal the single-domain restatement (OracleNonlinear; parity unpinned: the reference has no such terms) bit
+    for bit.  Also: the same two-ring local meshes under the reference's linear terms."""
+    import oracle as orc
+    mesh = mg.icosahedral_mesh(20)
+    rng = np.random.default_rng(53 + world)
+    rest = np.full((mesh.nCells, K), 1000.0 / K) + rng.uniform(0, 0.1, (mesh.nCells, K))
+    h = rest + rng.uniform(-1, 1, (mesh.nCells, K))
+    u = rng.uniform(-1, 1, (mesh.nEdges, K))
+    ssh = h.sum(1) - rest.sum(1)
+    dt = 20.0
+    v = visc * 0.01 * float(mesh.dcEdge.min()) ** 2 / dt
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    nl = orc.OracleNonlinear(om, visc_del2=v) if v else orc.OracleNonlinear(om)
+    st = orc.OracleState(om, ssh, u, h)
+    cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, world, direct=False, nonlinear=True, visc_del2=v)
+    assert all(m.lm.rings == 2 for m in cl.models)
+    cl.exchange_state()
+    for _ in range(nsteps):
+        cl.step_rk4_whole()
+        nl.step_rk4(st, dt)
+    gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
+    assert np.array_equal(gu, st.u[1])
+    assert np.array_equal(gh, st.h[1])
+    assert np.array_equal(gs, st.ssh[1])
+    # back to the reference's terms on the same (two-ring) local meshes: the ordinary distributed step
+    from moka_hip import api as mk
+    for m in cl.models:
+        mk.set_nonlinear(m.Prog, False)
+    lin = orc.OracleState(om, st.ssh[1], st.u[1], st.h[1])
+    cl.exchange_state()
+    for _ in range(2):
+        cl.step_rk4()
+        lin.step_rk4(dt)
+    gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
+    assert np.array_equal(gu, lin.u[1]) and np.array_equal(gh, lin.h[1]) and np.array_equal(gs, lin.ssh[1])
+    cl.close()
