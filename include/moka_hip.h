@@ -194,7 +194,7 @@ int moka_interpolate_cell2edge(moka_mesh *mesh, const double *cellValue, double 
  * (PrognosticVars.jl:59-106, DiagnosticVars.jl:75-99, TendencyVars.jl:51-67); nTimeLevels = 2 */
 /* A mesh created with stateBytes = 4 yields an fp32-STORAGE state: host arrays stay double (upload rounds to fp32,
  * download widens); moka_tendencies / moka_step_rk4 / moka_step_fe / moka_run / moka_sum_sq / the halo API work on it.
- * moka_step_fe steps all levels of a whole mesh (no MOKA_FE_LEVEL1_ONLY, no partitions).  DiagnosticVars come out of
+ * moka_step_fe steps all levels of a whole mesh (no MOKA_FE_LEVEL1_ONLY; on a partitioned mesh: moka_fe_dist_step).  DiagnosticVars come out of
  * Forward-Euler steps only: after an RK4 step they are unavailable (MOKA_ERR_UNSUPPORTED on download), and the next
  * Forward-Euler step must carry none over (flags 0).  The piecewise calls (moka_diagnostic_compute, moka_compute_*_tendency,
  * moka_advance_time_levels with level-1-only flags) stay Float64-only.  Needs nVertLevels % 4 == 0 and <= 128. */

@@ -760,12 +760,15 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
     if (part < 0 || part > 2) return hfail(h, MOKA_ERR_ARG, "part must be 0 (boundary), 1 (interior) or 2 (vertices)");
     moka_state *st = h->st;
     moka_ctx *c = st->ctx;
-    if (st->nonlinear || st->f32) return hfail(h, MOKA_ERR_UNSUPPORTED, "distributed Forward Euler: Float64 states with the reference's linear terms");
+    if (st->nonlinear) return hfail(h, MOKA_ERR_UNSUPPORTED, "distributed Forward Euler: the reference's linear terms only");
     if (flags & MOKA_FE_LEVEL1_ONLY && st->mesh->plan.K > 1)
         return hfail(h, MOKA_ERR_UNSUPPORTED, "distributed Forward Euler steps all levels (MOKA_FE_LEVEL1_ONLY is for nVertLevels = 1)");
     HIPCHK(c, hipSetDevice(c->device));
-    if (part == 0)
+    if (part == 0) {
+        // an fp32-storage state after an RK4 step has no current DiagnosticVars: a step that carries none over may follow
+        if (st->f32 && st->diagDirty && !(flags & (MOKA_FE_STALE_HEDGE | MOKA_FE_ACCUM_VORT))) st->diagDirty = false;
         if (int rc = flush_lazy(st, true, true)) return rc;
+    }
     StageArgs g;
     FeArgs a;
     fe_stage_args(st, dt, flags, &g, &a);
@@ -773,6 +776,11 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
     const moka_mesh *mm = st->mesh;
     if (part == 2) {
         // relativeVorticity of the OLD state (DiagnosticVars.jl:108-117 runs before the update): every local vertex
+        if (st->f32) {
+            HIPCHK(c, launch_curl_f32(mm->dev, reinterpret_cast<const float *>(a.u), reinterpret_cast<float *>(a.vort),
+                                      flags & MOKA_FE_ACCUM_VORT, c->stream));
+            return MOKA_OK;
+        }
         const hipError_t ec = launch_curl2(mm->dev, a.u, a.vort, flags & MOKA_FE_ACCUM_VORT, c->stream);
         if (ec == hipErrorNotSupported) {
             a.ops = FE_CURL;
@@ -796,6 +804,10 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
         dev.maxOwnE = mE; dev.maxOwnC = mC;
     }
     hipError_t e = hipErrorNotSupported;
+    if (st->f32) {                         // the Forward-Euler modes of the fp32-storage kernel: no generic form behind them
+        HIPCHK(c, launch_stage_rec2c_f32(dev, g, c->stream));
+        return MOKA_OK;
+    }
     if ((c->variant == 0 || c->variant == 11) && mm->lpc == 64 && mm->colOk) e = launch_stage_rec2c(dev, g, c->stream);
     if (e == hipErrorNotSupported) {
         a.ops &= ~FE_CURL;                 // the generic one-launch kernel over the same patch range, vertices in part 2

@@ -194,6 +194,39 @@ def test_forward_euler_on_a_partitioned_mesh(world, K, flags, direct):
     cl.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,K,flags,direct", [(2, 80, 3, True), (4, 60, 0, False), (3, 36, 1, True), (8, 80, 3, True)])
+def test_forward_euler_of_fp32_storage_states_on_a_partitioned_mesh(world, K, flags, direct):
+    """The reference's live step on fp32-storage states across 2-8 ranks (halo messages carry floats): every array of Prog, Diag
+    and Tend equals the storage-emulating single-domain oracle (oracle_step_fe_mixed) bit for bit."""
+    import oracle as orc
+    mesh = mg.icosahedral_mesh(20)
+    rng = np.random.default_rng(61 + world)
+    rest = np.full((mesh.nCells, K), 1000.0 / K) + rng.uniform(0, 0.1, (mesh.nCells, K))
+    h = rest + rng.uniform(-1, 1, (mesh.nCells, K))
+    u = rng.uniform(-1, 1, (mesh.nEdges, K))
+    ssh = h.sum(1) - rest.sum(1)
+    dt = 15.0
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    ref = orc.OracleState(om, ssh, u, h, mixed=True)
+    cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, world, direct=direct, state_bytes=4)
+    cl.exchange_state()
+    for step in range(4):
+        cl.step_fe(flags)
+        ref.step_fe(dt, flags)
+        gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
+        assert np.array_equal(gu, ref.u[1]) and np.array_equal(gh, ref.h[1]) and np.array_equal(gs, ref.ssh[1]), step
+    d = cl.gather_diagnostics(mesh, K)
+    for name, exp in (("hEdge", ref.hEdge), ("F", ref.F), ("div", ref.div), ("vort", ref.vort), ("tendU", ref.tendU),
+                      ("tendH", ref.tendH)):
+        assert np.array_equal(d[name], exp), name
+    cl.step_rk4(); ref.step_rk4(dt)                 # RK4, then a Forward-Euler step that carries nothing over
+    cl.step_fe(0); ref.step_fe(dt, 0)
+    gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
+    assert np.array_equal(gu, ref.u[1]) and np.array_equal(gh, ref.h[1]) and np.array_equal(gs, ref.ssh[1])
+    cl.close()
+
+
 def test_metis_workflow_files(tmp_path):
     """The cell graph in the METIS format MPAS tools use (graph.info) and a part file read back (graph.info.part.N): the
     route to a METIS partition where gpmetis exists (it does not in this image; recursive coordinate bisection is the
