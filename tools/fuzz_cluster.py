@@ -88,8 +88,21 @@ while time.time() - t0 < budget:
                 np.array_equal(g["layerThicknessEdge"], np.asarray(gE).reshape(mesh.nEdges, K)), tag + " reverse FE"
             n_rev["fe"] += 1
     cl.close()
+    if not f32 and n % 5 == 4:
+        # the optional nonlinear terms on the same partition (two-ring halo, whole-mesh stages), random Del2 viscosity
+        visc = float(rng.choice([0.0, 0.01 * float(mesh.dcEdge.min()) ** 2 / 20.0]))
+        cn = par.LocalCluster(mesh, ssh, u, h, rest, 20.0, world, patch_cells=P, direct=False, nonlinear=True, visc_del2=visc)
+        onl, stn = (orc.OracleNonlinear(om, visc_del2=visc) if visc else orc.OracleNonlinear(om)), orc.OracleState(om, ssh, u, h)
+        cn.exchange_state()
+        for _ in range(2):
+            cn.step_rk4_whole()
+            onl.step_rk4(stn, 20.0)
+        gs, gu, gh = cn.gather_owned(mesh.nCells, mesh.nEdges, K)
+        assert np.array_equal(gu, stn.u[1]) and np.array_equal(gh, stn.h[1]) and np.array_equal(gs, stn.ssh[1]), tag + f" nonlinear visc {visc}"
+        cn.close()
+        n_rev["nonlinear"] = n_rev.get("nonlinear", 0) + 1
     n += 1
     if n % 10 == 0:
         print(f"{n} cases, {time.time() - t0:.0f}s", flush=True)
 print(f"fuzz_cluster: {n} random partitions bit-identical to the single-domain oracle (seed {seed}, {skipped} refused; "
-      f"reverse mode across the ranks: {n_rev})")
+      f"reverse mode / nonlinear terms across the ranks: {n_rev})")
