@@ -237,9 +237,15 @@ class _State:
         self._h = C.c_void_p()
         L.check(L.lib().moka_state_create(mesh.backend._h, mesh._h, C.byref(self._h)), mesh.backend._h)
         _own(self, L.lib().moka_state_destroy, self._h, mesh, mesh.backend)
+        self._dependents = []          # weak references to tapes on this state: they dereference it when they are destroyed
 
     def close(self):
         if self._h:
+            for ref in self._dependents:      # an explicit close() takes what lives on the state with it, in order
+                dep = ref()
+                if dep is not None:
+                    dep.close()
+            self._dependents = []
             _release(self, L.lib().moka_state_destroy, self._h)
             self._h = C.c_void_p()
 
@@ -443,6 +449,7 @@ class AdjointTape:
         self._h = C.c_void_p()
         L.check(L.lib().moka_tape_create(self._state._h, int(capacity_steps), C.byref(self._h)), self._ctx)
         _own(self, L.lib().moka_tape_destroy, self._h, self._state, self._state.mesh, self._state.mesh.backend)
+        self._state._dependents.append(weakref.ref(self))
 
     def step(self, timestep, flags: int = REFERENCE_COMPAT, method=None):
         """ocn_timestep(timestep, ..., ForwardEuler) -- or RungeKutta4 with method=RungeKutta4 -- with the step recorded.

@@ -805,6 +805,22 @@ def test_fe_adjoint_central_difference_through_the_c_abi(backend):
         assert abs(fd - g[name][k, 0]) <= atol, (name, fd, g[name][k, 0])
 
 
+def test_closing_a_state_takes_its_tapes_along(backend):
+    """An explicit close() of the state while a tape on it is alive: the tape is destroyed first (its destructor dereferences
+    the state), not later by the garbage collector."""
+    mesh = get_mesh("ico16")
+    ssh, u, h, rest = random_state(mesh, 8, 3)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    tape = mk.AdjointTape(Prog, 2)
+    tape.step(20.0, method=mk.RungeKutta4)
+    Prog._state.close()
+    assert not tape._h
+    tape.close()                     # idempotent
+    Setup.mesh.close()
+    import gc
+    gc.collect()
+
+
 def test_adjoint_refuses_what_it_does_not_cover(backend):
     mesh = get_mesh("ico16")
     ssh, u, h, rest = random_state(mesh, 4, 2)
