@@ -366,3 +366,40 @@ def test_nonlinear_terms_on_a_partitioned_mesh(world, K, visc, nsteps):
     gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
     assert np.array_equal(gu, lin.u[1]) and np.array_equal(gh, lin.h[1]) and np.array_equal(gs, lin.ssh[1])
     cl.close()
+
+
+def test_two_ring_local_meshes_for_the_nonlinear_terms():
+    """build_local(rings=2, vertex_fields=True): every cell within two rings of an owned cell is local, the exchange lists of
+    the ranks match pairwise, and every vertex whose potential vorticity an owned entity can read -- the vertices of the
+    owned cells and of their neighbours -- is local with its three cells and three edges (no stand-ins there)."""
+    mesh = mg.icosahedral_mesh(10)
+    coe = mesh.cellsOnEdge.astype(np.int64) - 1
+    nbrs = [set() for _ in range(mesh.nCells)]
+    for a, b in coe:
+        nbrs[a].add(b); nbrs[b].add(a)
+    for world in (2, 5):
+        part = par.partition_cells(mesh, world)
+        lms = [par.build_local(mesh, part, r, world, rings=2, vertex_fields=True) for r in range(world)]
+        for r, lm in enumerate(lms):
+            own = set(np.nonzero(part == r)[0].tolist())
+            ring1 = set().union(*(nbrs[c] for c in own)) - own
+            ring2 = set().union(*(nbrs[c] for c in ring1)) - own - ring1
+            assert set(lm.cells_g.tolist()) == own | ring1 | ring2
+            assert lm.rings == 2 and lm.mesh.kiteAreasOnVertex is not None
+            # what r receives from q is exactly what q sends to r (global ids; the order is agreed later, in finish())
+            for i, q in enumerate(lm.neighbors):
+                j = lms[q].neighbors.index(r)
+                rc = lm.cells_g[lm.recv_cells[lm.recv_cell_off[i]:lm.recv_cell_off[i + 1]]]
+                sc = lms[q].cells_g[lms[q].send_cells[lms[q].send_cell_off[j]:lms[q].send_cell_off[j + 1]]]
+                assert np.array_equal(np.sort(rc), np.sort(sc))
+                re_ = lm.edges_g[lm.recv_edges[lm.recv_edge_off[i]:lm.recv_edge_off[i + 1]]]
+                se = lms[q].edges_g[lms[q].send_edges[lms[q].send_edge_off[j]:lms[q].send_edge_off[j + 1]]]
+                assert np.array_equal(np.sort(re_), np.sort(se))
+            # vertices of the owned cells and of ring 1: local, complete, in the reference's slot order
+            g2l_v = -np.ones(mesh.nVertices, dtype=np.int64); g2l_v[lm.verts_g] = np.arange(lm.verts_g.size)
+            need = np.nonzero(np.isin(mesh.cellsOnVertex - 1, list(own | ring1)).any(axis=1))[0]
+            assert np.all(g2l_v[need] >= 0)
+            lv = g2l_v[need]
+            assert np.array_equal(lm.cells_g[lm.mesh.cellsOnVertex[lv] - 1], mesh.cellsOnVertex[need] - 1)
+            assert np.array_equal(lm.edges_g[lm.mesh.edgesOnVertex[lv] - 1], mesh.edgesOnVertex[need] - 1)
+            assert np.array_equal(lm.mesh.kiteAreasOnVertex[lv], mesh.kiteAreasOnVertex[need])
