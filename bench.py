@@ -7,13 +7,25 @@ A "step" is one full 4-stage RK4 step of the shallow-water dycore over the whole
 (BASELINE.json metric).  Default workload = BASELINE config 4: ~1 M-cell (1 024 002) icosahedral
 sphere x 60 layers, fp64, inputs resident in HBM before the timed region starts.
 For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU); the mesh is
-partitioned across ranks (strong scaling) and halos are exchanged over RCCL.
+partitioned across ranks (strong scaling) and halos are exchanged once per RK stage.
 Prints ONE JSON line on rank 0.
+
+What the line carries beyond the contract:
+  * `value` / `ms_per_step` come from the MEDIAN of the K per-step times (one HIP event per step on the library's compute
+    stream, max over ranks per step); the mean over the barrier-bracketed wall region is kept as `ms_per_step_wall_mean`;
+  * `calibration`: a plain 16-byte-per-lane copy and a read-only sweep of a 4 GiB buffer timed with HIP events on the same
+    stream right before the warm-up and right after the timed region, plus the device's clock / power files from sysfs --
+    so a slow box and a slow build can be told apart (`roofline.frac_of_copy_this_run`);
+  * `config5`: BASELINE config 5 (3 696 642 cells x 80 layers, fp32 storage / fp64 arithmetic) timed in the same default run;
+  * `n_gpus` = DISTINCT devices the ranks use (`ranks`, `n_devices_visible`, `ranks_per_device`, `rehearsal`).
 """
 import argparse
 import datetime as dt
+import glob
 import json
 import os
+import socket
+import statistics
 import sys
 import time
 
@@ -24,10 +36,11 @@ for p in (os.path.join(ROOT, "mpas-ocean.jl_amd"), os.path.join(ROOT, "oracle"))
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
+import numpy as np  # noqa: E402,F401
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-HBM_COPY_GBS = 6290.0          # measured float4 copy ceiling, same guide
+HBM_COPY_GBS = 6290.0          # the guide's float4 copy ceiling; the same-run probe is what frac_of_copy_this_run uses
+PROBE_BYTES = 4 << 30          # footprint of the same-run bandwidth probe (2 GiB source + 2 GiB destination)
 
 WORKLOADS = {
     # name: (icosahedral frequency m, layers[, state bytes, Schmidt stretch])  -- SURVEY.md section 8 size table
@@ -85,6 +98,77 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MOKA_BENCH_THREADS", "16"))))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# clock / power state (plain sysfs reads; nothing here touches the GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except Exception:
+        return None
+
+
+def _dpm_current(text):
+    """'0: 500Mhz\\n1: 2394Mhz *\\n2: 2400Mhz' -> 2394 (MHz of the starred line), None when unreadable."""
+    if not text:
+        return None
+    for line in text.splitlines():
+        if line.rstrip().endswith("*"):
+            for tok in line.replace("*", " ").split():
+                t = tok.lower()
+                if t.endswith("mhz"):
+                    try:
+                        return float(t[:-3])
+                    except ValueError:
+                        return None
+    return None
+
+
+def _power_watts(devdir):
+    for name in ("power1_average", "power1_input"):
+        for f in glob.glob(os.path.join(devdir, "hwmon", "hwmon*", name)):
+            t = _read(f)
+            if t:
+                try:
+                    return float(t.strip()) / 1e6
+                except ValueError:
+                    pass
+    return None
+
+
+def device_sysfs(pci_bus_id):
+    """sclk / mclk / fclk (MHz, the current DPM level) and package power (W) of the device at `pci_bus_id`, plus the power of
+    the OTHER GPUs of the host (a one-GPU box is a slice of an 8-GPU machine whose other cards may be busy)."""
+    base = "/sys/bus/pci/devices"
+    dev = os.path.join(base, pci_bus_id)
+    out = {"pci_bus_id": pci_bus_id}
+    if not os.path.isdir(dev):
+        out["note"] = "device not found in sysfs"
+        return out
+    for k in ("sclk", "mclk", "fclk"):
+        out[k + "_mhz"] = _dpm_current(_read(os.path.join(dev, "pp_dpm_" + k)))
+    out["power_w"] = _power_watts(dev)
+    busy = _read(os.path.join(dev, "gpu_busy_percent"))
+    if busy and busy.strip().isdigit():
+        out["busy_percent"] = int(busy.strip())
+    others = []
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+        if "-" in os.path.basename(card):
+            continue
+        d = os.path.realpath(os.path.join(card, "device"))
+        if os.path.basename(d).lower() == pci_bus_id.lower():
+            continue
+        w = _power_watts(d)
+        if w is not None:
+            others.append(round(w, 1))
+    out["other_gpus_power_w"] = others
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline legs (the oracle as the timed thing: the only place bench.py uses it)
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(mesh, K, ssh, u, h, rest, dts, budget_s=25.0, mixed=False):
     """Oracle (C restatement of the reference loop nests) timed on this box's host cores: clean RK4 step,
     all cores (OpenMP), on the same mesh when one step fits the budget, else on a smaller sphere."""
@@ -143,6 +227,9 @@ def cpu_baseline_1t(mesh, K, ssh, u, h, rest, dts, budget_s=12.0, mixed=False):
             "ms_per_step": t * 1e3}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# RCCL probe (child process)
+# ---------------------------------------------------------------------------------------------------------------------
 def rccl_probe_child(backend="nccl"):
     """Child process of probe_rccl: bring RCCL up between the ranks and move a few bytes the two ways the halo transports
     do (all_to_all_single with uneven splits, batched isend / irecv).  Exit code 0 = it works on this node.
@@ -183,7 +270,9 @@ def rccl_probe_child(backend="nccl"):
 def probe_rccl(timeout_s=120, backend="nccl"):
     """Does RCCL work between the ranks of this launch?  Answered by a CHILD process per rank (its own rendezvous port),
     started before this process has touched the GPU: a wedged RCCL collective does not raise, it hangs until a watchdog
-    kills the process -- so the risk is taken by a process whose only job is to take it.  True = every step ran."""
+    kills the process -- so the risk is taken by a process whose only job is to take it.  True = every step ran.
+    (A child that does not finish is killed and reported; this process goes on with the other transports -- nothing is
+    ever re-exec'ed.)"""
     import subprocess
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 23)
@@ -203,6 +292,135 @@ def probe_rccl(timeout_s=120, backend="nccl"):
         return False
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# measurement helpers
+# ---------------------------------------------------------------------------------------------------------------------
+def step_stats(ms):
+    s = sorted(ms)
+    return {"median": statistics.median(s), "min": s[0], "max": s[-1], "mean": sum(s) / len(s), "n": len(s)}
+
+
+def calibrate(backend, tag):
+    """One probe of the device as it is right now: copy / read rates (HIP events on the compute stream) + sysfs state."""
+    t0 = time.time()
+    cal = backend.bw_probe(PROBE_BYTES, 5)
+    cal["sysfs"] = device_sysfs(backend.pci_bus_id())
+    cal["probe_s"] = round(time.time() - t0, 2)
+    log(f"[bench] calibration {tag}: copy {cal['copy_GBs']:.0f} GB/s (mean {cal['copy_GBs_mean']:.0f}), read {cal['read_GBs']:.0f} GB/s, "
+        f"sclk {cal['sysfs'].get('sclk_mhz')} MHz, {cal['sysfs'].get('power_w')} W")
+    return cal
+
+
+def timed_steps(backend, step, steps, warmup, sync_all):
+    """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides, with one HIP event per step on
+    the compute stream.  Returns (wall seconds, [ms per step])."""
+    import gc
+    for _ in range(warmup):
+        step()
+    gc.collect()
+    gc.disable()          # a 24 ms host-side pause was seen once inside a 136 ms timed region: the collector is the one
+                          # source of such pauses this process controls
+    backend.marks_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    backend.mark()
+    for _ in range(steps):
+        step()
+        backend.mark()
+    sync_all()
+    t1 = time.perf_counter()
+    gc.enable()
+    return t1 - t0, backend.marks_read()
+
+
+def stage_rooflines(backend, step, nrec, stream_bytes, b_mesh, modes=(1, 2, 2, 3)):
+    """Per-stage launch durations: a pass of the same steps with one HIP event between the launches."""
+    backend.stage_timing(True)
+    for _ in range(nrec):
+        step()
+    ms4, nst = backend.stage_timing_read()
+    backend.stage_timing(False)
+    per_stage = []
+    for sidx, ms in enumerate(ms4):
+        bc = STAGE_CONTRACT_STREAMS[sidx] * stream_bytes + b_mesh
+        bm = STAGE_MIN_STREAMS[sidx] * stream_bytes + b_mesh
+        per_stage.append({"stage": sidx + 1, "kernel_mode": modes[sidx], "ms": ms,
+                          "bytes_contract": bc, "frac_contract": bc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "bytes_minimum": bm, "frac_minimum": bm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    return per_stage, nst, sum(ms4)
+
+
+def single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, iters):
+    """The pure tendency launch (north_star's 40 % target is quoted on it) and the reference's live integrator."""
+    out = {}
+    mesh = Setup.mesh
+    for _ in range(3):
+        mk.computeTendency(mesh, Diag, Prog, Tend)
+    backend.synchronize()
+    backend.timer_start()
+    for _ in range(iters):
+        mk.computeTendency(mesh, Diag, Prog, Tend)
+    tms = backend.timer_stop() / iters
+    out["tendency_kernel"] = {"avg_launch_ms": tms, "algorithmic_bytes": b_tend,
+                              "achieved_GBs": b_tend / (tms * 1e-3) / 1e9,
+                              "frac_of_peak": b_tend / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # the reference's live integrator: reference_compat Forward-Euler step, for the record
+    fe_flags = mk.REFERENCE_COMPAT if K == 1 else (mk.REFERENCE_COMPAT & ~4)
+    if sbytes == 4:     # an fp32-storage state has no DiagnosticVars to carry over right after RK4 steps
+        mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=0)
+    for _ in range(2):
+        mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=fe_flags)
+    backend.synchronize()
+    backend.timer_start()
+    for _ in range(iters):
+        mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=fe_flags)
+    fms = backend.timer_stop() / iters
+    nC = mesh.HorzMesh.data.nCells
+    out["forward_euler_compat"] = {"ms_per_step": fms, "value": nC * K / (fms * 1e-3), "unit": "cell-updates/s",
+                                   "note": "moka_step_fe, reference_compat flags, all levels"}
+    return out
+
+
+def config5_leg(mk, backend, args, copy_gbs):
+    """BASELINE config 5 inside the same run: RK4 ms/step (median), per stage, the tendency launch and
+    the reference_compat Forward-Euler step on the 3 696 642-cell x 80-layer fp32-storage workload.  No CPU leg for it."""
+    from moka_hip import meshgen as mg
+    name = "config5_3.7M_x80_f32"
+    m, K, sbytes, stretch = WORKLOADS[name]
+    mesh = get_mesh(m, stretch)
+    ssh, u, h, rest, dts = mg.sphere_synthetic_state(mesh, K)
+    cfg = {"time_management": {"config_start_time": dt.datetime(1, 1, 1), "config_run_duration": dt.timedelta(hours=1)},
+           "time_integration": {"config_dt": dt.timedelta(seconds=dts), "config_number_of_time_levels": 2}}
+    t0 = time.time()
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, cfg, backend, multilayer=True,
+                                                       state_bytes=sbytes)
+    log(f"[bench] config 5 plan + upload: {time.time() - t0:.1f}s")
+    info = Setup.mesh.info()
+    step = lambda: mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)  # noqa: E731
+    steps, warmup = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
+    wall, ms = timed_steps(backend, step, steps, warmup, backend.synchronize)
+    st = step_stats(ms)
+    b_mesh, b_tend, b_step = algorithmic_bytes(mesh.nCells, mesh.nEdges, K, S=sbytes)
+    stream_bytes = sbytes * K * (mesh.nEdges + mesh.nCells)
+    per_stage, nst, ssum = stage_rooflines(backend, step, min(steps, 10), stream_bytes, b_mesh)
+    out = {"workload": name, "mesh": f"icosahedral m={m}, Schmidt stretch {stretch}", "nCells": mesh.nCells, "nEdges": mesh.nEdges,
+           "nVertLevels": K, "dtype": "f64 arithmetic on f32-stored state", "patch_cells": info.get("patch_cells"),
+           "steps": steps, "warmup": warmup, "ms_per_step": st["median"], "step_ms": st,
+           "ms_per_step_wall_mean": wall / steps * 1e3, "value": mesh.nCells * K / (st["median"] * 1e-3), "unit": "cell-updates/s",
+           "roofline": {"bound": "hbm", "achieved": b_step / (st["median"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": b_step / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "frac_of_copy_this_run": b_step / (st["median"] * 1e-3) / 1e9 / copy_gbs if copy_gbs else None,
+                        "formula": "contract: 18 state streams per step + 4 B_mesh, S = 4",
+                        "per_stage": per_stage, "per_stage_steps": nst, "per_stage_sum_ms": ssum},
+           "cpu_baseline": None, "cpu_baseline_note": "skipped for this leg: the CPU baseline belongs to the headline (config 4) line"}
+    out.update(single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, max(5, min(args.tend_iters, 10))))
+    out["tendency"] = out["tendency_kernel"]
+    backend.synchronize()
+    Prog._state.close()
+    Setup.mesh.close()
+    return out
+
+
 def main():
     if "--rccl-probe" in sys.argv:
         rccl_probe_child(sys.argv[sys.argv.index("--rccl-probe") + 1] if len(sys.argv) > sys.argv.index("--rccl-probe") + 1 else "nccl")
@@ -215,6 +433,7 @@ def main():
     ap.add_argument("--patch-cells", type=int, default=0)
     ap.add_argument("--ordering", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg of the default single-GPU run")
     ap.add_argument("--tend-iters", type=int, default=20)
     ap.add_argument("--transport", default="auto", choices=["auto", "ipc", "nccl", "nccl-a2a", "nccl-p2p", "nccl-default-stream", "gloo"],
                     help="halo transport for N > 1: auto = the fastest of those that qualify on this node -- ipc (direct stores "
@@ -238,6 +457,7 @@ def main():
     device_index = local_rank % ndev            # rehearsals may put several ranks on one GPU (ipc and gloo transports)
     gloo_group = None
     rccl_ok = False
+    dist = None
     if world > 1:
         import torch.distributed as dist
         want_rccl = args.transport in ("auto", "nccl", "nccl-a2a", "nccl-p2p", "nccl-default-stream")
@@ -277,7 +497,20 @@ def main():
     if args.variant:
         backend.set_kernel_variant(args.variant)
 
+    # which physical devices do the ranks of this launch really use?  (host, PCI bus id) per rank
+    my_dev = (socket.gethostname(), backend.pci_bus_id())
+    devs = [my_dev]
+    if world > 1:
+        devs = [None] * world
+        dist.all_gather_object(devs, my_dev, group=gloo_group)
+    n_distinct = len(set(devs))
+    ranks_per_device = max(devs.count(d) for d in set(devs))
+    rehearsal = n_distinct < world
+    if rehearsal:
+        log(f"[bench] rank {rank}: {world} ranks on {n_distinct} distinct device(s): this line is a REHEARSAL, not an {world}-GPU result")
+
     transport_trials = {}
+    model = None
     if world > 1:
         from moka_hip import parallel as mp
         t0 = time.time()
@@ -286,26 +519,22 @@ def main():
                                     state_bytes=sbytes)
         log(f"[bench] rank {rank}: partition + local plan + upload: {time.time() - t0:.1f}s  {model.info()}")
         # Choose the halo transport on this node.  Every candidate must, on every rank, (1) set up, (2) deliver exactly the
-        # bytes the host-staged gloo exchange delivers for the same state, (3) run a step; the ranks agree after each phase
-        # over the gloo group so nobody is left waiting in a collective.  The fastest qualifying candidate is kept.
+        # bytes the host-staged gloo exchange delivers for the same state, (3) run steps whose owned state equals the same
+        # steps over gloo bit for bit; the ranks agree after each phase over the gloo group so nobody is left waiting in a
+        # collective.  The fastest qualifying candidate is kept.
         rccl_forms = ("nccl-a2a", "nccl") if rccl_ok else ()
         cands = {"auto": ("ipc",) + rccl_forms, "nccl": rccl_forms, "ipc": ("ipc",), "nccl-a2a": rccl_forms[:1],
                  "nccl-p2p": rccl_forms[1:], "nccl-default-stream": (), "gloo": ()}[args.transport]
         fallbacks = (("nccl-default-stream",) if rccl_ok else ()) + ("gloo",)
-        model.transport = "gloo"
+        model.set_transport("gloo")
         model.exchange_state()
         cand, times = mp.choose_transport(model, cands, fallbacks, gloo_group, lambda msg: log(f"[bench] rank {rank}: {msg}"))
-        model.transport = cand
+        model.set_transport(cand)
         # the trials advanced the state: start the timed run from the initial state again
-        lm = model.lm
-        for f, a in ((model.Prog.ssh, ssh[lm.cells_g]), (model.Prog.normalVelocity, u[lm.edges_g]),
-                     (model.Prog.layerThickness, h[lm.cells_g])):
-            f[0].set(a); f[-1].set(a)
-        model.exchange_state()
+        model.reset_state(ssh, u, h)
         args.transport = {"nccl": "nccl-p2p"}.get(cand, cand)
         transport_trials = times
         step = model.step_rk4
-        sync = backend.synchronize
         info = model.info()
     else:
         t0 = time.time()
@@ -315,42 +544,37 @@ def main():
         log(f"[bench] plan + upload: {time.time() - t0:.1f}s")
         info = Setup.mesh.info()
         step = lambda: mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)  # noqa: E731
-        sync = backend.synchronize
 
-    def barrier():
+    def sync_all():
+        backend.synchronize(); torch.cuda.synchronize()
         if world > 1:
             dist.barrier(group=gloo_group)
 
-    import gc
-    for _ in range(args.warmup):
-        step()
-    gc.collect()
-    gc.disable()          # a 24 ms host-side pause was seen once inside a 136 ms timed region: the collector is the one
-                          # source of such pauses this process controls
-    sync(); torch.cuda.synchronize(); barrier()
-    backend.timer_start()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ev_ms = backend.timer_stop()
-    sync(); torch.cuda.synchronize(); barrier()
-    t1 = time.perf_counter()
-    gc.enable()
-    elapsed = t1 - t0
+    # ---- same-run calibration, before: right in front of the warm-up ----
+    cal_before = calibrate(backend, "before")
+    wall, step_ms = timed_steps(backend, step, args.steps, args.warmup, sync_all)
+    # ---- ... and after: right behind the timed region ----
+    cal_after = calibrate(backend, "after")
     if world > 1:
-        tt = torch.tensor([elapsed, ev_ms], dtype=torch.float64)
+        # per step: the slowest rank's time (the step is over when the last rank is done); wall: max over ranks
+        tt = torch.tensor(step_ms + [wall], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=gloo_group)
-        elapsed, ev_ms = float(tt[0]), float(tt[1])
-    ms_per_step = elapsed / args.steps * 1e3
-    value = mesh.nCells * K / (elapsed / args.steps)
+        step_ms, wall = [float(x) for x in tt[:-1]], float(tt[-1])
+        cc = torch.tensor([cal_before["copy_GBs"], cal_after["copy_GBs"], cal_before["read_GBs"]], dtype=torch.float64)
+        dist.all_reduce(cc, op=dist.ReduceOp.MIN, group=gloo_group)
+        copy_min_over_ranks = [float(x) for x in cc]
+    st = step_stats(step_ms)
+    ms_per_step = st["median"]
+    value = mesh.nCells * K / (ms_per_step * 1e-3)
+    copy_this_run = 0.5 * (cal_before["copy_GBs"] + cal_after["copy_GBs"])
 
     b_mesh, b_tend, b_step = algorithmic_bytes(mesh.nCells, mesh.nEdges, K, S=sbytes)
     stream_bytes = sbytes * K * (mesh.nEdges + mesh.nCells)
-    # dominant kernel = the fused RK-stage kernel (k_stage_rec2c): 4 launches per step.  Average launch duration from HIP
-    # events on the library's compute stream over the timed region (the four launches of a step run back to back on that
-    # stream, nothing else does); algorithmic bytes per launch = B_step / 4 (contract formula).
-    launches = 4 * args.steps
-    avg_launch_ms = ev_ms / launches
+    # dominant kernel = the fused RK-stage kernel (k_stage_rec2c): 4 launches per step, back to back on the compute stream
+    # (nothing else runs there), so the average launch duration over the timed region is (sum of the step times) / (4 K);
+    # algorithmic bytes per launch = B_step / 4 (contract formula).
+    launches = 4 * len(step_ms)
+    avg_launch_ms = sum(step_ms) / launches
     per_rank_bytes = b_step / 4 / world
     achieved = per_rank_bytes / (avg_launch_ms * 1e-3) / 1e9
     # the same with the bytes the four launches really have to move (stage 1 aliases Provis = Curr = New): 16 streams
@@ -374,32 +598,39 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "kernel": "k_stage_rec2c (fused TRiSK tendency + RK4 stage update), mean of the 4 launches of a step",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "frac_of_copy_this_run": achieved / copy_this_run, "copy_GBs_this_run": copy_this_run,
+                "frac_of_guide_copy_ceiling": achieved / HBM_COPY_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": per_rank_bytes, "avg_launch_ms": avg_launch_ms,
                 "launches_timed": launches, "formula": "contract: 18 state streams per step (5, 5, 5, 3) + 4 B_mesh",
                 "frac_kernel_minimum_bytes": achieved_min / HBM_PEAK_GBS,
+                "frac_kernel_minimum_bytes_of_copy_this_run": achieved_min / copy_this_run,
                 "kernel_minimum_note": "16 state streams per step (3, 5, 5, 3): stage 1 aliases Provis = Curr = New"}
     if world == 1:
-        # per-stage launch durations: a second pass of the same steps with one HIP event between the launches
-        nrec = max(5, min(args.steps, 20))
-        backend.stage_timing(True)
-        for _ in range(nrec):
-            step()
-        ms4, nst = backend.stage_timing_read()
-        backend.stage_timing(False)
-        per_stage = []
-        for sidx, ms in enumerate(ms4):
-            bc = STAGE_CONTRACT_STREAMS[sidx] * stream_bytes + b_mesh
-            bm = STAGE_MIN_STREAMS[sidx] * stream_bytes + b_mesh
-            per_stage.append({"stage": sidx + 1, "kernel_mode": (1, 2, 2, 3)[sidx], "ms": ms,
-                              "bytes_contract": bc, "frac_contract": bc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "bytes_minimum": bm, "frac_minimum": bm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        per_stage, nst, ssum = stage_rooflines(backend, step, max(5, min(args.steps, 20)), stream_bytes, b_mesh)
         roofline["per_stage"] = per_stage
         roofline["per_stage_steps"] = nst
-        roofline["per_stage_sum_ms"] = sum(ms4)
+        roofline["per_stage_sum_ms"] = ssum
+
+    calibration = {"copy_GBs_before": cal_before["copy_GBs"], "copy_GBs_after": cal_after["copy_GBs"],
+                   "copy_GBs_mean_before": cal_before["copy_GBs_mean"], "copy_GBs_mean_after": cal_after["copy_GBs_mean"],
+                   "read_GBs": cal_before["read_GBs"], "read_GBs_after": cal_after["read_GBs"],
+                   "probe": f"{PROBE_BYTES >> 30} GiB footprint (half source, half destination), 16 bytes per lane, best of 5 launches, "
+                            "HIP events on the compute stream; before = in front of the warm-up, after = behind the timed region",
+                   "guide_copy_ceiling_GBs": HBM_COPY_GBS,
+                   "ms_per_step_at_guide_ceiling": ms_per_step * copy_this_run / HBM_COPY_GBS,
+                   "clocks_power_before": cal_before["sysfs"], "clocks_power_after": cal_after["sysfs"]}
+    if world > 1:
+        calibration["min_over_ranks"] = {"copy_GBs_before": copy_min_over_ranks[0], "copy_GBs_after": copy_min_over_ranks[1],
+                                         "read_GBs": copy_min_over_ranks[2]}
 
     out = {"metric": "cell-updates/sec per RK4 step", "value": value, "unit": "cell-updates/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+           "n_gpus": n_distinct, "ranks": world, "n_devices_visible": ndev, "ranks_per_device": ranks_per_device,
+           "rehearsal": rehearsal,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+           "step_ms": st, "ms_per_step_wall_mean": wall / args.steps * 1e3,
+           "value_wall_mean": mesh.nCells * K / (wall / args.steps),
+           "value_note": "value and ms_per_step = median of the per-step times (HIP events, max over ranks per step; SURVEY 8d); "
+                         "the *_wall_mean fields = the barrier-bracketed wall region / K",
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f64" if sbytes == 8 else "f64 arithmetic on f32-stored state", "data": "synthetic",
            "config": {"workload": args.workload,
@@ -408,43 +639,33 @@ def main():
                       "ordering": info.get("ordering"), "patch_cells": info.get("patch_cells"),
                       "kernel_variant": args.variant,
                       "parallelism": "single GPU" if world == 1 else
-                      f"mesh partitioned over {world} GPUs (RCB), 1-deep halo exchanged per RK stage over {args.transport}, "
-                      f"overlapped with the interior patches; halo {info.get('halo_bytes_per_stage', 0) / 1e6:.1f} MB/stage/rank",
+                      f"mesh partitioned over {world} ranks on {n_distinct} distinct GPU(s) (RCB), 1-deep halo exchanged per RK stage over "
+                      f"{args.transport}, overlapped with the interior patches; halo {info.get('halo_bytes_per_stage', 0) / 1e6:.1f} MB/stage/rank"
+                      + (" -- REHEARSAL: ranks share a device" if rehearsal else ""),
                       **({"halo_transport": args.transport, "halo_transport_trials_ms_per_step": transport_trials,
                           "rccl_usable": rccl_ok} if world > 1 else {})},
-           "roofline": roofline}
+           "roofline": roofline, "calibration": calibration}
 
     if world == 1:
-        # the pure tendency kernel (north_star's 40 % target is quoted on it): B_tend / t
-        for _ in range(3):
-            mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
-        backend.synchronize()
-        backend.timer_start()
-        for _ in range(args.tend_iters):
-            mk.computeTendency(Setup.mesh, Diag, Prog, Tend)
-        tms = backend.timer_stop() / args.tend_iters
-        out["tendency_kernel"] = {"avg_launch_ms": tms, "algorithmic_bytes": b_tend,
-                                  "achieved_GBs": b_tend / (tms * 1e-3) / 1e9,
-                                  "frac_of_peak": b_tend / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if True:
-            # the reference's live integrator: reference_compat Forward-Euler step (one fused launch), for the record
-            fe_flags = mk.REFERENCE_COMPAT if K == 1 else (mk.REFERENCE_COMPAT & ~4)
-            if sbytes == 4:     # an fp32-storage state has no DiagnosticVars to carry over right after RK4 steps
-                mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=0)
-            for _ in range(2):
-                mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=fe_flags)
+        out.update(single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, args.tend_iters))
+        if args.workload == "config4_1M_x60" and not args.no_config5:
+            # free the headline workload's device objects, then time config 5 on the same device in the same run
             backend.synchronize()
-            backend.timer_start()
-            for _ in range(args.tend_iters):
-                mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=fe_flags)
-            fms = backend.timer_stop() / args.tend_iters
-            out["forward_euler_compat"] = {"ms_per_step": fms, "value": mesh.nCells * K / (fms * 1e-3),
-                                           "unit": "cell-updates/s", "note": "moka_step_fe, reference_compat flags, all levels"}
+            Prog._state.close()
+            Setup.mesh.close()
+            try:
+                out["config5"] = config5_leg(mk, backend, args, copy_this_run)
+            except Exception as exc:                 # noqa: BLE001  (the headline line must not be lost to its appendix)
+                out["config5"] = {"error": f"{type(exc).__name__}: {exc}"}
+                log(f"[bench] config 5 leg failed: {exc!r}")
+            cal_end = calibrate(backend, "end of run")
+            calibration["copy_GBs_end_of_run"] = cal_end["copy_GBs"]
+            calibration["clocks_power_end_of_run"] = cal_end["sysfs"]
+    backend.bw_probe(0)
     if rank == 0 and world == 1 and not args.no_cpu:       # the CPU leg belongs to the N = 1 line only
         t0 = time.time()
         mixed = sbytes == 4
         if mesh.nCells * K > 1.5e8:        # bounded sample: the same workload family on a quarter of the cells
-            from moka_hip import meshgen as mg
             cm = get_mesh(m // 2, stretch)
             cssh, cu, ch, crest, cdts = mg.sphere_synthetic_state(cm, K)
             out["cpu_baseline"] = cpu_baseline(cm, K, cssh, cu, ch, crest, cdts, mixed=mixed)

@@ -282,6 +282,11 @@ typedef struct {
  * on the compute stream, in flight together (a small boundary launch no longer leaves the chip idle).  -1 (default):
  * chosen from the size of the interior launch.  Takes effect at the next moka_rk4_dist_begin.  Results are identical. */
 int  moka_halo_set_overlap(moka_halo *h, int mode);
+/* on != 0: a system-scope acquire (cache invalidate on every XCD) is launched in front of every launch that reads received
+ * rows (the boundary patches of a stage, the Forward-Euler vertex pass).  Default off: the acquire of a kernel dispatch makes
+ * peer-written rows visible (csrc/halo.hip header); the transport selection falls back to this form ("ipc-acq") when whole steps
+ * over the plain direct transport do not reproduce the host-staged exchange bit for bit. */
+int  moka_halo_set_acquire(moka_halo *h, int on);
 /* the same exchange for arbitrary device fields of the state's shapes and storage type (u-like, h-like, ssh-like), library
  * numbering: pack waits for the compute stream, unpack makes the compute stream wait for the received rows */
 int  moka_halo_pack_fields(moka_halo *h, const void *uField, const void *hField, const void *sField, void *sendbuf);
@@ -302,15 +307,18 @@ int  moka_rk4_dist_begin(moka_halo *h, double dt);
 int  moka_rk4_dist_stage(moka_halo *h, int stage, int part);
 int  moka_rk4_dist_stage_launch(moka_halo *h, int stage);
 int  moka_rk4_dist_end(moka_halo *h);
-/* ... and as ONE call per step.  Direct when every neighbour is connected; otherwise `transport` moves the packed send
- * buffer of a stage to the neighbours and fills the receive buffer (stream-ordered on the comm stream, or synchronously;
- * returns 0 on success).  timeout_s bounds every wait of the direct form. */
+/* ... and as ONE call per step.  transport == NULL: the direct exchange (every neighbour must be connected, MOKA_ERR_ARG
+ * otherwise); a callback, when given, is always used, connected or not: it moves the packed send buffer of a stage to the
+ * neighbours and fills the receive buffer (stream-ordered on the comm stream, or synchronously; returns 0 on success).
+ * timeout_s bounds every wait of the direct form. */
 typedef int (*moka_transport_fn)(void *user, int what, void *sendbuf_device, void *recvbuf_device);
 int  moka_rk4_dist_step(moka_halo *h, double dt, moka_transport_fn transport, void *user, void *sendbuf_device,
                         void *recvbuf_device, double timeout_s);
 /* distributed form of moka_step_fe (ocn_timestep(..., ForwardEuler), time_integration.jl:150-193) with the same flags:
  * part 0 boundary patches, 1 interior patches, 2 relativeVorticity; the new level is exchanged as `what` = 4 between
- * part 0 and the end; moka_fe_dist_end swaps the time levels.  moka_fe_dist_step does all of it in one call. */
+ * part 0 and the end; moka_fe_dist_end swaps the time levels.  Order with the direct transport: part 2 FIRST (it reads
+ * old-level rows of halo edges, which a neighbour's next step overwrites once this rank's push has been signalled), then
+ * part 0, push, part 1.  moka_fe_dist_step does all of it in one call, in that order. */
 int  moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part);
 int  moka_fe_dist_end(moka_halo *h);
 int  moka_fe_dist_step(moka_halo *h, double dt, int flags, moka_transport_fn transport, void *user, void *sendbuf_device,
@@ -330,6 +338,20 @@ int moka_set_kernel_variant(moka_ctx *ctx, int variant);
  * moka_stage_timing_read: ms[s-1] = mean duration of the stage-s launch over the *steps recorded steps. */
 int moka_stage_timing(moka_ctx *ctx, int enable);
 int moka_stage_timing_read(moka_ctx *ctx, double ms[4], int64_t *steps);
+/* PCI bus id of the context's device ("0000:c5:00.0"; buf of >= 16 bytes): the key to its clock / power files in sysfs and to
+ * counting the distinct devices the ranks of a launch really use (measurement). */
+int moka_ctx_pci_bus_id(moka_ctx *ctx, char *buf, int32_t len);
+/* Per-step statistics of a timed region (measurement: bench.py's median / min / max): moka_mark records one HIP event on the
+ * compute stream, n marks give n - 1 intervals; moka_marks_read: ms[i] = time between marks i and i + 1 (at most `capacity`
+ * of them), *n = how many exist; moka_marks_reset forgets them. */
+int moka_mark(moka_ctx *ctx);
+int moka_marks_reset(moka_ctx *ctx);
+int moka_marks_read(moka_ctx *ctx, int64_t capacity, double *ms, int64_t *n);
+/* Same-run bandwidth calibration (measurement): a plain 16-byte-per-lane copy and a read-only sweep over a buffer of `bytes`
+ * (two halves), each launch timed with HIP events on the compute stream; gbs[0] = best copy rate (bytes read + written, GB/s),
+ * gbs[1] = best read-only rate, gbs[2] = mean copy rate over the `iters` launches.  The buffer is kept for the next probe;
+ * bytes = 0 frees it.  (MI355X_MICROARCH.md quotes 6.29 TB/s for such a copy; SURVEY.md 8d asks for both figures.) */
+int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[3]);
 /* which kernel the last moka_step_fe of this state used: 1 = the tuned stage kernel (+ vertex pass), 0 = the generic
  * one-launch kernel, -1 = no Forward-Euler step yet.  For tests and measurement; results are identical either way. */
 int moka_last_fe_path(const moka_state *st);

@@ -386,6 +386,8 @@ void moka_ctx_destroy(moka_ctx *ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);
+    if (ctx->bwBuf) (void)hipFree(ctx->bwBuf);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -419,6 +421,98 @@ int moka_timer_stop(moka_ctx *ctx, float *elapsed_ms)
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return MOKA_OK;
+}
+
+// PCI bus id ("0000:c5:00.0") of the context's device: lets a caller find the device's clock / power files in sysfs
+// (/sys/bus/pci/devices/<id>/pp_dpm_sclk ...) and count distinct devices among the ranks of a launch.
+int moka_ctx_pci_bus_id(moka_ctx *ctx, char *buf, int32_t len)
+{
+    if (!ctx || !buf || len < 16) return fail(ctx, MOKA_ERR_ARG, "buf is NULL or shorter than 16 bytes");
+    HIPCHK(ctx, hipDeviceGetPCIBusId(buf, len, ctx->device));
+    return MOKA_OK;
+}
+
+// Per-step statistics of a timed region (bench.py: median / min / max of the step times).  moka_mark records one event on the
+// compute stream; n marks give n - 1 intervals.  moka_marks_reset forgets them (the events are kept for reuse).
+int moka_mark(moka_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
+    if (ctx->marksUsed == ctx->marks.size()) {
+        hipEvent_t e = nullptr;
+        HIPCHK(ctx, hipEventCreate(&e));
+        ctx->marks.push_back(e);
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->marks[ctx->marksUsed++], ctx->stream));
+    return MOKA_OK;
+}
+
+int moka_marks_reset(moka_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->marksUsed = 0;
+    return MOKA_OK;
+}
+
+// ms[i] = time between mark i and mark i + 1 (at most `capacity` intervals); *n = number of intervals available
+int moka_marks_read(moka_ctx *ctx, int64_t capacity, double *ms, int64_t *n)
+{
+    if (!ctx || !n || (capacity > 0 && !ms)) return fail(ctx, MOKA_ERR_ARG, "NULL argument");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t have = ctx->marksUsed > 0 ? (int64_t)ctx->marksUsed - 1 : 0;
+    *n = have;
+    for (int64_t i = 0; i < have && i < capacity; ++i) {
+        float t = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&t, ctx->marks[i], ctx->marks[i + 1]));
+        ms[i] = t;
+    }
+    return MOKA_OK;
+}
+
+// Same-run bandwidth calibration: what this device, in the state it is in NOW, moves with a plain 16-byte-per-lane copy and a
+// read-only sweep (MI355X_MICROARCH.md quotes 6.29 TB/s for the copy).  `bytes` = total footprint (two halves: source and
+// destination); every launch is timed on its own with HIP events on the compute stream, the best of `iters` is reported
+// (the first launch also faults the pages in).  gbs[0] = copy, bytes read + written per second; gbs[1] = read-only sweep of both
+// halves; gbs[2] = mean copy rate over the launches.  bytes = 0 releases the buffers.
+int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[3])
+{
+    if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (bytes <= 0) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->bwBuf) HIPCHK(ctx, hipFree(ctx->bwBuf));
+        ctx->bwBuf = nullptr; ctx->bwBytes = 0;
+        return MOKA_OK;
+    }
+    if (!gbs || iters < 1) return fail(ctx, MOKA_ERR_ARG, "gbs is NULL or iters < 1");
+    const size_t half = ((size_t)bytes / 2) & ~(size_t)4095;
+    if (half < ((size_t)1 << 20)) return fail(ctx, MOKA_ERR_ARG, "bandwidth probe: at least 2 MiB");
+    hipStream_t s = ctx->stream;
+    if (ctx->bwBytes != 2 * half) {
+        if (ctx->bwBuf) { HIPCHK(ctx, hipStreamSynchronize(s)); HIPCHK(ctx, hipFree(ctx->bwBuf)); ctx->bwBuf = nullptr; ctx->bwBytes = 0; }
+        hipError_t e = hipMalloc(&ctx->bwBuf, 2 * half + 64);
+        if (e != hipSuccess) return fail(ctx, MOKA_ERR_ALLOC, std::string("bandwidth probe: hipMalloc: ") + hipGetErrorString(e));
+        ctx->bwBytes = 2 * half;
+        HIPCHK(ctx, hipMemsetAsync(ctx->bwBuf, 0x5A, 2 * half + 64, s));
+    }
+    unsigned char *a = static_cast<unsigned char *>(ctx->bwBuf), *b = a + half;
+    uint32_t *sink = reinterpret_cast<uint32_t *>(a + 2 * half);
+    double bestCopy = 0.0, bestRead = 0.0, sumCopy = 0.0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < iters; ++i) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+            if (pass == 0) HIPCHK(ctx, launch_bw_copy(b, a, (int64_t)half, ctx->nCUs, s));
+            else HIPCHK(ctx, launch_bw_read(a, (int64_t)(2 * half), sink, ctx->nCUs, s));
+            HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
+            HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+            float ms = 0.f;
+            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            const double r = (double)(2 * half) / ((double)ms * 1e-3) / 1e9;
+            if (pass == 0) { bestCopy = std::max(bestCopy, r); sumCopy += r; }
+            else bestRead = std::max(bestRead, r);
+        }
+    gbs[0] = bestCopy; gbs[1] = bestRead; gbs[2] = sumCopy / iters;
     return MOKA_OK;
 }
 

@@ -18,9 +18,26 @@
 //              stage's boundary patches.  All of that happens while the interior patches of the stage run on the compute
 //              stream, so the host never sits on the critical path unless the exchange is later than the interior launch.
 //              No kernel ever spins on the device (a spinning kernel can starve whatever shares its hardware queue).
-// Why the direct form needs no back-pressure: halo rows are read only by boundary launches; the rows a neighbour
-// overwrites at stage s+1 (its output set) were last read by my boundary launch of an earlier stage, which precedes my
-// push of that stage, whose flag the neighbour has waited for before it computed what it now pushes.
+// Why the direct form needs no back-pressure: a rank signals exchange n only when its push kernel of exchange n is done, and
+// that kernel is queued behind EVERY launch of this rank that reads halo rows of the buffer set a neighbour overwrites next:
+//   RK4: halo rows are read only by boundary launches; the rows a neighbour overwrites at stage s+1 (its output set) were
+//        last read by my boundary launch of an earlier stage, which precedes my push of that stage;
+//   Forward Euler: besides the boundary launch, the vertex pass (relativeVorticity over every local vertex) reads
+//        old-level normalVelocity rows of halo edges -- the very buffer the neighbours' NEXT step pushes into.  It is
+//        therefore launched FIRST, ahead of the boundary launch and the push (moka_fe_dist_step; round 3: launched behind the
+//        interior patches it could still be reading when a neighbour that was a step ahead overwrote those rows).
+// A neighbour has waited for that flag before it computed what it now pushes.
+//
+// Visibility of peer-written rows (the fields are ordinary, coarse-grained hipMalloc memory): a push kernel ends with
+// __threadfence_system() and its completion event precedes the flag store (release) the reader's host thread acquires
+// before it LAUNCHES the kernel that reads the rows.  Peer stores arrive through the fabric at the owner's memory, not
+// through the owner's L2s; a line of a halo row that an earlier launch left in one of the owner's eight L2s is dropped by
+// the acquire every kernel dispatch performs (the same mechanism that lets launch N + 1 on XCD j read what launch N stored
+// through XCD i's L2 -- the per-XCD L2s are not coherent with each other either, MI355X_MICROARCH.md "Correctness
+// boundaries").  For a platform where that should not hold, moka_halo_set_acquire(h, 1) puts an explicit system-scope
+// acquire (a grid of small workgroups across all XCDs, each executing a system-scope fence = cache invalidate) in front of
+// every launch that reads received rows; moka_hip.parallel.choose_transport qualifies "ipc" by comparing whole steps with the
+// host-staged exchange bit for bit and tries "ipc-acq" (the same transport with that fence) when the plain form fails.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -82,6 +99,7 @@ struct moka_halo {
     uint64_t seq = 0;                     // exchanges started so far
     hipEvent_t evPush = nullptr;
     hipEvent_t evB[2] = {nullptr, nullptr};   // boundary launch of an odd / even stage done (comm stream)
+    bool acquireFence = false;                // moka_halo_set_acquire: system-scope acquire in front of launches that read received rows
     bool overlapB = false;                    // boundary patches on the comm stream, in flight together with the interior launch
     bool overlapNow = false;                  // ... as the running step was begun
     std::vector<void *> allocs;           // device allocations of this object
@@ -169,6 +187,22 @@ __global__ __launch_bounds__(256) void k_halo_push(const uint32_t *rows, int64_t
     __threadfence_system();          // the rows are in the peer's memory before the kernel (hence its event) completes
 }
 
+// System-scope acquire on every XCD: 64 single-wave workgroups (the dispatcher deals consecutive workgroups round-robin over
+// the eight XCDs), each invalidating the caches it sits behind.  Nothing is loaded: the launch that follows does that.
+__global__ __launch_bounds__(64) void k_halo_acquire(uint32_t *sink)
+{
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);                      // system scope: buffer_inv sc0 sc1
+    if (sink && threadIdx.x == 0xFFFF) *sink = blockIdx.x;        // (never true: keeps the kernel from being empty)
+}
+
+int launch_acquire(moka_halo *h, hipStream_t s)
+{
+    if (!h->acquireFence) return MOKA_OK;
+    hipLaunchKernelGGL(k_halo_acquire, dim3(64), dim3(64), 0, s, (uint32_t *)nullptr);
+    HIPCHK(h->st->ctx, hipGetLastError());
+    return MOKA_OK;
+}
+
 int upload_peer_tab(moka_halo *h)
 {
     if (!h->tabDirty) return MOKA_OK;
@@ -241,11 +275,13 @@ int dist_stage_part(moka_halo *h, int stage, int part)
     moka_ctx *c = st->ctx;
     if (!h->overlapNow) {
         // boundary group first, interior right behind it on the same (compute) stream
+        if (part == 0) if (int rc = launch_acquire(h, c->stream)) return rc;
         HIPCHK(c, run_stage(st, g, p0, cnt));
     } else if (part == 0) {
         // boundary patches on the (high-priority) comm stream, interior patches on the compute stream, in flight together:
         // B_s waits for I_(s-1) (it gathers rows of interior patches), I_s waits for B_(s-1), never for B_s
         HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));
+        if (int rc = launch_acquire(h, c->comm)) return rc;
         HIPCHK(c, run_stage(st, g, p0, cnt, c->comm));
         HIPCHK(c, hipEventRecord(h->evB[stage & 1], c->comm));
     } else {
@@ -487,6 +523,13 @@ int moka_halo_set_overlap(moka_halo *h, int mode)
     return MOKA_OK;
 }
 
+int moka_halo_set_acquire(moka_halo *h, int on)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    h->acquireFence = on != 0;
+    return MOKA_OK;
+}
+
 int moka_halo_direct_available(const moka_halo *h)
 {
     return h && h->directOk ? 1 : 0;
@@ -558,12 +601,19 @@ int moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer
             }
             pl.mapped[i] = q;
         }
+        auto unmap_all = [&]() { for (void *m : pl.mapped) if (m) (void)hipIpcCloseMemHandle(m); };
         const int fd = shm_open(peer->shmName, O_RDWR, 0600);
-        if (fd < 0) return hfail(h, MOKA_ERR_COMM, std::string("shm_open(") + peer->shmName + ") of the peer's flag block failed");
+        if (fd < 0) {
+            unmap_all();
+            return hfail(h, MOKA_ERR_COMM, std::string("shm_open(") + peer->shmName + ") of the peer's flag block failed");
+        }
         pl.flagsBytes = sizeof(uint64_t) * (size_t)std::max(peer->nNeighbors, 1);
         void *q = mmap(nullptr, pl.flagsBytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         close(fd);
-        if (q == MAP_FAILED) return hfail(h, MOKA_ERR_COMM, "mmap of the peer's flag block failed");
+        if (q == MAP_FAILED) {
+            unmap_all();
+            return hfail(h, MOKA_ERR_COMM, "mmap of the peer's flag block failed");
+        }
         pl.flags = static_cast<volatile uint64_t *>(q);
     } else {
         for (int i = 0; i < 12; ++i) pl.mapped[i] = (void *)(uintptr_t)peer->ptr[i];
@@ -577,6 +627,11 @@ int moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer
     }
     if (!pl.flags) return hfail(h, MOKA_ERR_ARG, "peer info carries no flag block");
     pl.connected = true;
+    PeerLink &old = h->peers[nbr];
+    if (old.connected && old.ipc) {                   // connected before: release the earlier mappings
+        for (void *m : old.mapped) if (m) (void)hipIpcCloseMemHandle(m);
+        if (old.flags) munmap((void *)old.flags, old.flagsBytes);
+    }
     h->peers[nbr] = pl;
     h->tabDirty = true;
     return MOKA_OK;
@@ -710,8 +765,11 @@ int moka_rk4_dist_step(moka_halo *h, double dt, moka_transport_fn transport, voi
 {
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
     int rc;
-    const bool direct = all_connected(h) && h->nNbr > 0;
-    if (!direct && h->nNbr > 0 && !transport) return hfail(h, MOKA_ERR_ARG, "no transport callback and not every neighbour is connected");
+    // the caller chooses: transport == NULL is the direct exchange (every neighbour must be connected), a callback is ALWAYS
+    // used when given -- a connected halo does not override it (round 2 did: the buffered candidates of the transport
+    // selection were then never exercised)
+    const bool direct = h->nNbr > 0 && !transport;
+    if (direct && !all_connected(h)) return hfail(h, MOKA_ERR_ARG, "no transport callback and not every neighbour is connected");
     if ((rc = moka_rk4_dist_begin(h, dt))) return rc;
     for (int s = 1; s <= 4; ++s) {
         if ((rc = moka_rk4_dist_stage(h, s, 0))) return rc;
@@ -764,7 +822,7 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
     if (flags & MOKA_FE_LEVEL1_ONLY && st->mesh->plan.K > 1)
         return hfail(h, MOKA_ERR_UNSUPPORTED, "distributed Forward Euler steps all levels (MOKA_FE_LEVEL1_ONLY is for nVertLevels = 1)");
     HIPCHK(c, hipSetDevice(c->device));
-    if (part == 0) {
+    {   // whichever part of a step is launched first finds pending lazy results (after it: nothing is pending, a no-op)
         // an fp32-storage state after an RK4 step has no current DiagnosticVars: a step that carries none over may follow
         if (st->f32 && st->diagDirty && !(flags & (MOKA_FE_STALE_HEDGE | MOKA_FE_ACCUM_VORT))) st->diagDirty = false;
         if (int rc = flush_lazy(st, true, true)) return rc;
@@ -776,6 +834,7 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
     const moka_mesh *mm = st->mesh;
     if (part == 2) {
         // relativeVorticity of the OLD state (DiagnosticVars.jl:108-117 runs before the update): every local vertex
+        if (int rc = launch_acquire(h, c->stream)) return rc;          // it reads received rows (old normalVelocity of halo edges)
         if (st->f32) {
             HIPCHK(c, launch_curl_f32(mm->dev, reinterpret_cast<const float *>(a.u), reinterpret_cast<float *>(a.vort),
                                       flags & MOKA_FE_ACCUM_VORT, c->stream));
@@ -792,6 +851,7 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
     }
     const int p0 = part == 0 ? 0 : h->pFirst, cnt = part == 0 ? h->pFirst : h->pOwned - h->pFirst;
     if (cnt <= 0) return MOKA_OK;
+    if (part == 0) if (int rc = launch_acquire(h, c->stream)) return rc;
     MeshDev dev = mm->dev;
     dev.patchBegin = p0; dev.nPatches = cnt; dev.tailPatch = -1;
     {
@@ -833,8 +893,12 @@ int moka_fe_dist_step(moka_halo *h, double dt, int flags, moka_transport_fn tran
 {
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
     int rc;
-    const bool direct = all_connected(h) && h->nNbr > 0;
-    if (!direct && h->nNbr > 0 && !transport) return hfail(h, MOKA_ERR_ARG, "no transport callback and not every neighbour is connected");
+    const bool direct = h->nNbr > 0 && !transport;          // the caller chooses, as in moka_rk4_dist_step
+    if (direct && !all_connected(h)) return hfail(h, MOKA_ERR_ARG, "no transport callback and not every neighbour is connected");
+    // The vertex pass goes FIRST: it reads old-level normalVelocity rows of halo edges, i.e. rows of the buffer set the
+    // neighbours' next step pushes into.  Ahead of the boundary launch it is also ahead of this rank's push, whose completion
+    // is what lets a neighbour run on (see the header of this file).
+    if ((rc = moka_fe_dist_launch(h, dt, flags, 2))) return rc;
     if ((rc = moka_fe_dist_launch(h, dt, flags, 0))) return rc;
     if (direct) {
         if ((rc = moka_halo_push_begin(h, 4))) return rc;
@@ -842,7 +906,6 @@ int moka_fe_dist_step(moka_halo *h, double dt, int flags, moka_transport_fn tran
         if ((rc = moka_halo_pack(h, 4, sendbuf))) return rc;
     }
     if ((rc = moka_fe_dist_launch(h, dt, flags, 1))) return rc;
-    if ((rc = moka_fe_dist_launch(h, dt, flags, 2))) return rc;
     if (direct) {
         if ((rc = moka_halo_push_signal(h))) return rc;
         if ((rc = moka_halo_push_wait(h, timeout_s))) return rc;

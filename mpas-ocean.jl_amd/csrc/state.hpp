@@ -23,6 +23,12 @@ struct moka_ctx {
     bool stageTiming = false;
     std::vector<hipEvent_t> evPool;          // events owned by the context (reused between measurements)
     size_t evUsed = 0;
+    // per-step statistics of a timed region (moka_mark / moka_marks_read): one event per mark on the compute stream
+    std::vector<hipEvent_t> marks;
+    size_t marksUsed = 0;
+    // same-run bandwidth calibration (moka_bw_probe): two halves of one allocation, kept between the probes of a run
+    void *bwBuf = nullptr;
+    size_t bwBytes = 0;
 };
 
 struct moka_mesh {

@@ -74,6 +74,32 @@ class MokaHIP:
         L.check(L.lib().moka_stage_timing_read(self._h, ms, C.byref(n)), self._h)
         return [float(x) for x in ms], int(n.value)
 
+    def mark(self):
+        """One HIP event on the compute stream (moka_mark): n marks give n - 1 step times."""
+        L.check(L.lib().moka_mark(self._h), self._h)
+
+    def marks_reset(self):
+        L.check(L.lib().moka_marks_reset(self._h), self._h)
+
+    def marks_read(self):
+        """ms between consecutive marks (synchronises the compute stream)."""
+        n = C.c_int64()
+        L.check(L.lib().moka_marks_read(self._h, 0, None, C.byref(n)), self._h)
+        ms = (C.c_double * max(n.value, 1))()
+        L.check(L.lib().moka_marks_read(self._h, n.value, ms, C.byref(n)), self._h)
+        return [float(ms[i]) for i in range(n.value)]
+
+    def bw_probe(self, nbytes=4 << 30, iters=5):
+        """Same-run bandwidth calibration (moka_bw_probe): {copy_GBs, read_GBs, copy_GBs_mean} of this device right now."""
+        g = (C.c_double * 3)()
+        L.check(L.lib().moka_bw_probe(self._h, int(nbytes), int(iters), g), self._h)
+        return {"copy_GBs": float(g[0]), "read_GBs": float(g[1]), "copy_GBs_mean": float(g[2])} if nbytes > 0 else {}
+
+    def pci_bus_id(self) -> str:
+        buf = C.create_string_buffer(32)
+        L.check(L.lib().moka_ctx_pci_bus_id(self._h, buf, 32), self._h)
+        return buf.value.decode().lower()
+
     def set_kernel_variant(self, v: int):
         L.check(L.lib().moka_set_kernel_variant(self._h, int(v)), self._h)
 

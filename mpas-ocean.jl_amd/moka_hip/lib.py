@@ -84,6 +84,7 @@ EXPORTS = [
     "moka_rk4_dist_stage_launch", "moka_rk4_dist_step", "moka_fe_dist_launch", "moka_fe_dist_end", "moka_fe_dist_step",
     "moka_set_nonlinear", "moka_last_fe_path", "moka_set_viscosity_del2", "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
     "moka_adjoint_download",
+    "moka_mark", "moka_marks_reset", "moka_marks_read", "moka_bw_probe", "moka_ctx_pci_bus_id", "moka_halo_set_acquire",
 ]
 
 
@@ -172,6 +173,7 @@ def lib():
     L.moka_mesh_permutation.argtypes = [vp, C.c_int, _i32p]
     L.moka_halo_direct_available.argtypes = [vp]
     L.moka_halo_set_overlap.argtypes = [vp, C.c_int]
+    L.moka_halo_set_acquire.argtypes = [vp, C.c_int]
     L.moka_halo_pack_fields.argtypes = [vp, vp, vp, vp, vp]
     L.moka_halo_unpack_fields.argtypes = [vp, vp, vp, vp, vp]
     L.moka_tape_record_rk4.argtypes = [vp, C.c_int, C.c_int]
@@ -203,6 +205,11 @@ def lib():
     L.moka_adjoint_seed_sum_sq_ssh.argtypes = [vp]
     L.moka_adjoint_sweep.argtypes = [vp]
     L.moka_adjoint_download.argtypes = [vp, C.c_int, _f64p]
+    L.moka_mark.argtypes = [vp]
+    L.moka_marks_reset.argtypes = [vp]
+    L.moka_marks_read.argtypes = [vp, C.c_int64, _f64p, C.POINTER(C.c_int64)]
+    L.moka_bw_probe.argtypes = [vp, C.c_int64, C.c_int, _f64p]
+    L.moka_ctx_pci_bus_id.argtypes = [vp, C.c_char_p, C.c_int32]
     _lib = L
     return L
 

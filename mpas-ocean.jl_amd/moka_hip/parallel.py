@@ -418,12 +418,56 @@ class DistributedModel:
         self.connected = True
 
     def connect_ipc(self):
-        """Multi-process set-up of the direct transport: IPC handles and flag-block names travel over `group`."""
-        mine = self.export_peer_info(True)
+        """Multi-process set-up of the direct transport: IPC handles and flag-block names travel over `group`.
+        Collective, and failure-safe as one: a rank whose export or connect fails still takes part in every collective of this
+        method (with a failure marker), so no rank is left waiting; all ranks then raise together."""
+        err = None
+        try:
+            mine = self.export_peer_info(True)
+        except Exception as exc:                     # noqa: BLE001
+            mine, err = None, exc
         everyone = [None] * self.world
         self.dist.all_gather_object(everyone, mine, group=self.group)
-        self.connect_peers({q: everyone[q][self.rank] for q in self.lm.neighbors}, True)
-        self.dist.barrier(group=self.group)
+        bad = [q for q in range(self.world) if everyone[q] is None]
+        if not bad:
+            try:
+                self.connect_peers({q: everyone[q][self.rank] for q in self.lm.neighbors}, True)
+            except Exception as exc:                 # noqa: BLE001
+                err = exc
+        ok = self.torch.tensor([0.0 if (err is not None or bad) else 1.0], dtype=self.torch.float64)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)      # doubles as the closing barrier
+        if float(ok[0]) != 1.0:
+            self.connected = False
+            raise RuntimeError(f"direct halo transport: set-up failed on rank(s) {bad or '(connect)'}"
+                               + (f"; this rank: {err!r}" if err is not None else ""))
+
+    def set_transport(self, name: str):
+        """Select the halo transport of the steps that follow.  "ipc" = direct; "ipc-acq" = direct with an explicit
+        system-scope acquire in front of every launch that reads received rows (moka_halo_set_acquire)."""
+        self.transport = name
+        if getattr(self, "_halo", None):
+            L.check(L.lib().moka_halo_set_acquire(self._halo, 1 if name == "ipc-acq" else 0), self.backend._h)
+
+    def snapshot(self):
+        """The local prognostic state (current level, halo rows included) as host arrays."""
+        self.sync_device()
+        return (self.Prog.ssh[-1].get(), self.Prog.normalVelocity[-1].get(), self.Prog.layerThickness[-1].get())
+
+    def restore(self, snap):
+        """Both time levels := a snapshot() (halo rows included: no exchange needed)."""
+        for f, a in zip((self.Prog.ssh, self.Prog.normalVelocity, self.Prog.layerThickness), snap):
+            f[0].set(a); f[-1].set(a)
+
+    def reset_state(self, ssh, u, h):
+        """Both time levels := the given GLOBAL arrays' local rows, halo rows included."""
+        lm = self.lm
+        u, h = np.asarray(u).reshape(-1, self.K), np.asarray(h).reshape(-1, self.K)
+        self.restore((np.asarray(ssh)[lm.cells_g], u[lm.edges_g], h[lm.cells_g]))
+
+    def sync_device(self):
+        """Everything this rank has queued on its device is done (the library's streams and torch's)."""
+        self.backend.synchronize()
+        self.torch.cuda.synchronize()
 
     # ---- transport of the packed buffers ----
     def _transport(self):
@@ -449,7 +493,7 @@ class DistributedModel:
                     [dist.P2POp(dist.isend, self.sendbuf[a:b], q) for q, a, b in self.send_slices if b > a]):
                 w.wait()
             torch.cuda.synchronize()
-        elif self.transport in ("local", "ipc"):
+        elif self.transport in ("local", "ipc", "ipc-acq"):
             raise RuntimeError(f"transport {self.transport!r} has no buffered form")
         elif self.transport != "gloo":
             raise ValueError(f"unknown halo transport {self.transport!r}")
@@ -467,7 +511,7 @@ class DistributedModel:
         """sendbuf -> the neighbours' recvbuf for the paths that exist in buffered form only (tape recording, the adjoint
         fields): the model's own transport, or host-staged gloo when that is the direct one."""
         t = self.transport
-        if t != "ipc":
+        if t not in ("ipc", "ipc-acq"):
             return self._transport()
         self.transport = "gloo"
         try:
@@ -493,7 +537,7 @@ class DistributedModel:
         the same bytes on this rank (callers combine the ranks' answers)."""
         lib = L.lib()
         mine = self.transport
-        if mine == "ipc":
+        if mine in ("ipc", "ipc-acq"):
             lm = self.lm
             # wipe the halo rows, exchange directly, read them back
             hh, ssh, uu = self.Prog.layerThickness[-1].get(), self.Prog.ssh[-1].get(), self.Prog.normalVelocity[-1].get()
@@ -531,7 +575,7 @@ class DistributedModel:
         return bool(self.torch.equal(got, self.recvbuf))
 
     def _direct(self):
-        return self.transport == "ipc" and self.connected
+        return self.transport in ("ipc", "ipc-acq") and self.connected
 
     def exchange_state(self):
         """Halo exchange of the current time level (e.g. after an upload).  Collective: every rank calls it."""
@@ -722,16 +766,24 @@ class DistributedModel:
         self.mesh.close()
 
 
-def choose_transport(model: DistributedModel, candidates, fallbacks, control_group, log=lambda msg: None, trial_steps=5):
+def choose_transport(model, candidates, fallbacks, control_group, log=lambda msg: None, trial_steps=5, check_steps=3):
     """Pick the halo transport of `model` on this node; every rank calls this and all return the same name.
 
     A candidate qualifies in three phases, each closed by an agreement of all ranks over `control_group` (gloo), so that
     nobody runs ahead into a collective the others will never post: (1) it can be set up on every rank, (2) on every
-    rank it moves the current state's halo to exactly the bytes the host-staged gloo exchange delivers, (3) a full RK4
-    step with it runs on every rank.  Any failure makes ALL ranks drop the candidate.  Of the qualifying `candidates`
-    the fastest over `trial_steps` steps is kept (max over ranks); otherwise the first qualifying one of `fallbacks`.
+    rank it moves the current state's halo to exactly the bytes the host-staged gloo exchange delivers, (3) `check_steps`
+    full RK4 steps with it leave every rank's local state (halo rows included) equal, bit for bit, to the same steps over
+    the host-staged gloo exchange from the same start -- which catches a timing-dependent stale read of peer-written rows
+    that a single exchange or a single step can miss.  Any failure on any rank makes ALL ranks drop the candidate, at once:
+    a failing rank takes part in the agreement with a 0, it never leaves the others waiting for a timeout.  "ipc" failing
+    is followed by "ipc-acq" (the same transport with an explicit system-scope acquire in front of the launches that read
+    received rows).  Of the qualifying `candidates` the fastest over `trial_steps` steps is kept (max over ranks);
+    otherwise the first qualifying one of `fallbacks`.
     Candidates whose failure mode is a hang rather than an exception (an RCCL collective that never completes) must be
-    screened BEFORE this function, in a child process (bench.py: probe_rccl).  Returns (name, {candidate: ms/step})."""
+    screened BEFORE this function, in a child process (bench.py: probe_rccl).  Returns (name, {candidate: ms/step}).
+
+    `model` needs: dist, torch, set_transport, direct_available, connected, connect_ipc, verify_transport, step_rk4,
+    snapshot, restore, sync_device (DistributedModel; the CPU tests pass a stand-in)."""
     import time
     torch, dist = model.torch, model.dist
 
@@ -741,7 +793,7 @@ def choose_transport(model: DistributedModel, candidates, fallbacks, control_gro
         return float(t[0])
 
     def sync_all():
-        model.backend.synchronize(); torch.cuda.synchronize()
+        model.sync_device()
         dist.barrier(group=control_group)
 
     def phase(cand, what, fn):
@@ -755,26 +807,43 @@ def choose_transport(model: DistributedModel, candidates, fallbacks, control_gro
             ok = 0.0
         return agree(ok, dist.ReduceOp.MIN) == 1.0
 
-    def works(cand):
-        model.transport = cand
+    start = model.snapshot()                    # every trial starts from, and the function returns with, this state
+    reference = []                               # the local state after check_steps steps over gloo (computed on first use)
 
+    def run_steps(name, n):
+        model.restore(start)
+        model.set_transport(name)
+        sync_all()                               # nobody pushes into a state another rank is still restoring
+        for _ in range(n):
+            model.step_rk4()
+        model.sync_device()
+        return model.snapshot()
+
+    def steps_match(cand):
+        if not reference:
+            reference.append(run_steps("gloo", check_steps))
+        got = run_steps(cand, check_steps)
+        return all(np.array_equal(a, b) for a, b in zip(got, reference[0]))
+
+    def works(cand):
         def setup():
-            if cand == "ipc":
-                if not model.direct_available:
+            if cand in ("ipc", "ipc-acq") and not model.connected:
+                # every rank must be able to go direct BEFORE anyone enters connect_ipc's collectives
+                if agree(1.0 if model.direct_available else 0.0, dist.ReduceOp.MIN) != 1.0:
                     return False
-                if not model.connected:
-                    model.connect_ipc()
+                model.connect_ipc()              # collective and failure-safe: raises on every rank or on none
+            model.set_transport(cand)
             return True
 
-        def step():
-            model.transport = cand
-            model.step_rk4()
-            model.backend.synchronize(); torch.cuda.synchronize()
-        return (phase(cand, "set-up", setup) and phase(cand, "byte comparison with gloo", lambda: model.verify_transport("gloo"))
-                and phase(cand, "one RK4 step", step))
+        ok = (phase(cand, "set-up", setup) and
+              phase(cand, "byte comparison with gloo", lambda: model.verify_transport("gloo")) and
+              (cand == "gloo" or phase(cand, f"{check_steps} RK4 steps against the same steps over gloo", lambda: steps_match(cand))))
+        model.set_transport("gloo")
+        return ok
 
     def trial_ms(cand):
-        model.transport = cand
+        model.restore(start)
+        model.set_transport(cand)
         sync_all()
         t0 = time.perf_counter()
         for _ in range(trial_steps):
@@ -783,7 +852,12 @@ def choose_transport(model: DistributedModel, candidates, fallbacks, control_gro
         return agree((time.perf_counter() - t0) / trial_steps * 1e3, dist.ReduceOp.MAX)
 
     times = {}
-    good = [c for c in candidates if works(c)]
+    good = []
+    for c in candidates:
+        if works(c):
+            good.append(c)
+        elif c == "ipc" and "ipc-acq" not in candidates and works("ipc-acq"):
+            good.append("ipc-acq")
     if good:
         times = {c: trial_ms(c) for c in good}
         cand = min(good, key=lambda c: times[c])
@@ -795,7 +869,9 @@ def choose_transport(model: DistributedModel, candidates, fallbacks, control_gro
         else:
             raise RuntimeError("no halo transport works on this node")
         log(f"using halo transport {cand}")
-    model.transport = cand
+    model.restore(start)
+    model.set_transport(cand)
+    sync_all()
     return cand, times
 
 
@@ -810,12 +886,12 @@ class LocalCluster:
     send and receive buffers, ordered by stream events only."""
 
     def __init__(self, mesh, ssh, u, h, rest, dt, world, device=0, ordering=0, patch_cells=0, state_bytes=8, direct=True,
-                 devices=None, overlap=-1, nonlinear=False, visc_del2=0.0):
+                 devices=None, overlap=-1, nonlinear=False, visc_del2=0.0, part=None):
         import torch
         self.torch, self.world = torch, world
         devs = list(devices) if devices is not None else [device] * world
         self.backends = [api.MokaHIP(devs[r]) for r in range(world)]
-        part = partition_cells(mesh, world)
+        part = partition_cells(mesh, world) if part is None else np.asarray(part, dtype=np.int32)
         self.models = [DistributedModel(mesh, ssh, u, h, rest, dt, self.backends[r], r, world, ordering=ordering,
                                         patch_cells=patch_cells, transport="local", part=part, state_bytes=state_bytes,
                                         nonlinear=nonlinear, visc_del2=visc_del2)
@@ -1000,10 +1076,12 @@ class LocalCluster:
         return out
 
     def step_fe(self, flags=L.FE_REFERENCE_COMPAT & ~L.FE_LEVEL1_ONLY):
-        """The reference's Forward-Euler step on the partition: boundary patches, exchange of the new level (what = 4),
-        interior patches and relativeVorticity meanwhile."""
+        """The reference's Forward-Euler step on the partition: relativeVorticity first (it reads old-level rows of halo edges,
+        which the neighbours' next step overwrites once this rank's push is signalled: csrc/halo.hip), boundary patches,
+        exchange of the new level (what = 4), interior patches meanwhile."""
         lib = L.lib()
         for m in self.models:
+            L.check(lib.moka_fe_dist_launch(m._halo, m.dt, int(flags), 2), m.backend._h)
             L.check(lib.moka_fe_dist_launch(m._halo, m.dt, int(flags), 0), m.backend._h)
         for m in self.models:
             if self.direct:
@@ -1012,7 +1090,6 @@ class LocalCluster:
                 L.check(lib.moka_halo_pack(m._halo, 4, m.sendbuf.data_ptr()), m.backend._h)
         for m in self.models:
             L.check(lib.moka_fe_dist_launch(m._halo, m.dt, int(flags), 1), m.backend._h)
-            L.check(lib.moka_fe_dist_launch(m._halo, m.dt, int(flags), 2), m.backend._h)
         if self.direct:
             self._finish_direct()
         else:

@@ -142,6 +142,29 @@ def main():
             model.connect_ipc()
             model.exchange_state()
             assert model.verify_transport("gloo")
+            # the caller chooses: a CONNECTED model whose transport is "gloo" runs its steps through the buffered callback, four
+            # times per RK4 step and once per Forward-Euler step -- the library does not override it with the direct exchange
+            # (it did, so the buffered candidates of the selection were never exercised)
+            calls = []
+            real_transport = model._transport
+            model._transport = lambda: (calls.append(1), real_transport())[1]
+            before = model.snapshot()
+            model.set_transport("gloo")
+            model.step_rk4()
+            assert len(calls) == 4, calls
+            model.step_fe(3 if K > 1 else 7)
+            assert len(calls) == 5, calls
+            via_gloo = model.snapshot()
+            model.restore(before)
+            model.set_transport("ipc-acq")          # the direct form with the explicit acquire: same results, no callback
+            dist.barrier()
+            model.step_rk4()
+            model.step_fe(3 if K > 1 else 7)
+            assert len(calls) == 5, calls
+            assert all(np.array_equal(a, b) for a, b in zip(model.snapshot(), via_gloo)), "ipc-acq vs gloo"
+            model._transport = real_transport
+            model.set_transport("ipc")
+            dist.barrier()
             model.Prog.ssh[-1].set(ssh[lm.cells_g]); model.Prog.layerThickness[-1].set(h[lm.cells_g])
             model.Prog.normalVelocity[-1].set(u[lm.edges_g])
             for f in (model.Prog.ssh, model.Prog.layerThickness, model.Prog.normalVelocity):

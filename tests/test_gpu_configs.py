@@ -140,6 +140,35 @@ def test_config4_full_size_two_rk4_steps_bitwise(backend):
     assert np.array_equal(Tend.tendNormalVelocity.get(), st.tendU)
     assert np.array_equal(Tend.tendLayerThickness.get(), st.tendH)
     Prog._state.close(); Setup.mesh.close()
+
+
+def test_config4_full_size_eight_way_partition_direct(backend):
+    """BASELINE config 4 as the 8-GPU run partitions it: 1 024 002 cells x 60 layers, RCB into 8 parts, one
+    context per rank on this one GPU, the DIRECT transport (push kernels storing into the neighbours' fields, flag words) --
+    two RK4 steps, every rank's owned rows bit for bit against the single-domain oracle."""
+    from moka_hip import parallel as par
+    mesh = sphere(320)
+    K = 60
+    ssh, u, h, rest, dts = mg.sphere_synthetic_state(mesh, K)
+    orc.set_threads(host_threads())
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    cl = par.LocalCluster(mesh, ssh, u, h, rest, dts, 8, direct=True)
+    assert cl.direct
+    # the shares are what bench.py --gpus 8 gives its ranks: balanced, each with a boundary and an interior launch
+    owned = [m.lm.n_owned_cells for m in cl.models]
+    assert sum(owned) == mesh.nCells and max(owned) - min(owned) <= 8
+    assert all(0 < m.p_boundary < m.p_owned for m in cl.models)
+    cl.exchange_state()
+    for _ in range(2):
+        cl.step_rk4()
+        st.step_rk4(dts)
+    orc.set_threads(1)
+    gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
+    assert np.array_equal(gu, st.u[1]), "normalVelocity"
+    assert np.array_equal(gh, st.h[1]), "layerThickness"
+    assert np.array_equal(gs, st.ssh[1]), "ssh"
+    cl.close()
     _MESHES.pop((320, 1.0), None)        # ~1 GB of host arrays
 
 

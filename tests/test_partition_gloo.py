@@ -37,6 +37,15 @@ def test_distributed_rk4_with_oracle_compute_gloo(world):
     run_workers(world, "cpu")
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_transport_selection_agrees_on_failures(world):
+    """choose_transport with a candidate that fails on ONE rank in phase 1 (set-up), 2 (bytes) or 3 (whole steps against the
+    same steps over gloo): every rank drops it at once and ends on the same transport, nobody waits on a timeout
+    (tests/transport_worker.py; gloo, no GPU)."""
+    out = run_workers(world, worker="transport_worker.py", timeout=120)
+    assert "transport_worker: OK" in out
+
+
 def test_partition_and_local_mesh_properties():
     mesh = mg.icosahedral_mesh(10)
     for world in (2, 4, 8):
@@ -191,6 +200,41 @@ def test_forward_euler_on_a_partitioned_mesh(world, K, flags, direct):
     cl.step_fe(flags); ref.step_fe(dt, flags)
     gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
     assert np.array_equal(gu, ref.u[1]) and np.array_equal(gh, ref.h[1]) and np.array_equal(gs, ref.ssh[1])
+    cl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,sbytes", [(60, 8), (80, 4)])
+def test_forward_euler_with_unbalanced_ranks(K, sbytes):
+    """Direct transport, Forward Euler, ranks of very different size (the vertex pass reads old-level rows of halo
+    edges, and a small rank that runs a step ahead pushes its next level into exactly those rows).  Rank 0 owns ~85 % of the
+    cells, so ranks 1 and 2 finish every step long before rank 0's vertex pass is through; no synchronisation between the
+    steps.  Accumulating relativeVorticity would carry a mixed-level read into every later step."""
+    import oracle as orc
+    mesh = mg.icosahedral_mesh(40)
+    rng = np.random.default_rng(97)
+    rest = np.full((mesh.nCells, K), 1000.0 / K) + rng.uniform(0, 0.1, (mesh.nCells, K))
+    h = rest + rng.uniform(-1, 1, (mesh.nCells, K))
+    u = rng.uniform(-1, 1, (mesh.nEdges, K))
+    ssh = h.sum(1) - rest.sum(1)
+    dt, flags = 10.0, 3
+    # a thin slab for rank 1, a thinner one for rank 2, the rest for rank 0
+    z = mesh.zCell / np.abs(mesh.zCell).max()
+    part = np.where(z > 0.80, 1, np.where(z < -0.88, 2, 0)).astype(np.int32)
+    assert np.bincount(part)[0] > 0.8 * mesh.nCells
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    ref = orc.OracleState(om, ssh, u, h, mixed=sbytes == 4)
+    cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, 3, direct=True, part=part, state_bytes=sbytes)
+    assert cl.direct
+    cl.exchange_state()
+    for rep in range(3):
+        for _ in range(6):
+            cl.step_fe(flags)
+            ref.step_fe(dt, flags)
+        gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
+        assert np.array_equal(gu, ref.u[1]) and np.array_equal(gh, ref.h[1]) and np.array_equal(gs, ref.ssh[1]), rep
+        d = cl.gather_diagnostics(mesh, K)
+        assert np.array_equal(d["vort"], ref.vort), rep
     cl.close()
 
 
