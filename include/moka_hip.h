@@ -257,9 +257,9 @@ int  moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCel
                       int32_t nPatchesBoundary, int32_t nPatchesOwned, moka_halo **out);
 void moka_halo_destroy(moka_halo *h);
 int  moka_halo_buffer_elems(const moka_halo *h, int64_t *sendElems, int64_t *recvElems);
-/* what: 0 = current time level, 1..4 = output of RK4 stage `what` (4 = also the new level of a distributed
- * Forward-Euler step).  pack runs on the comm stream after the work already queued on the compute stream; unpack makes
- * later compute-stream work wait for it. */
+/* what: 0 = current time level, 1..4 = output of RK4 stage `what`, 5 = the new level of a distributed Forward-Euler step
+ * (before moka_fe_dist_end rotates the levels).  pack runs on the comm stream after the work already queued on the compute
+ * stream; unpack makes later compute-stream work wait for it. */
 int  moka_halo_pack(moka_halo *h, int what, void *sendbuf_device);
 int  moka_halo_unpack(moka_halo *h, int what, const void *recvbuf_device);
 
@@ -268,8 +268,9 @@ int  moka_halo_unpack(moka_halo *h, int what, const void *recvbuf_device);
  * there.  shared = 1: the two ranks are different processes (IPC handles + a POSIX shared-memory flag block);
  * shared = 0: same process (raw pointers; several devices are mapped with hipDeviceEnablePeerAccess). */
 typedef struct {
-    unsigned char ipc[12][64];   /* hipIpcMemHandle_t of the four buffer sets x (normalVelocity, layerThickness, ssh) */
-    uint64_t ptr[12];            /* the same allocations as raw device pointers */
+    unsigned char ipc[15][64];   /* hipIpcMemHandle_t of the five buffer sets (two time levels, two RK provisional states, the
+                                    Forward-Euler spare level) x (normalVelocity, layerThickness, ssh) */
+    uint64_t ptr[15];            /* the same allocations as raw device pointers */
     uint64_t flagPtr;            /* the rank's flag block as a raw host pointer */
     char     shmName[64];        /* ... and as a POSIX shared-memory object (shared = 1) */
     int32_t  dstCell, dstEdge;   /* first cell / edge (library numbering) of the ranges the neighbour's rows go to */
@@ -315,8 +316,9 @@ typedef int (*moka_transport_fn)(void *user, int what, void *sendbuf_device, voi
 int  moka_rk4_dist_step(moka_halo *h, double dt, moka_transport_fn transport, void *user, void *sendbuf_device,
                         void *recvbuf_device, double timeout_s);
 /* distributed form of moka_step_fe (ocn_timestep(..., ForwardEuler), time_integration.jl:150-193) with the same flags:
- * part 0 boundary patches, 1 interior patches, 2 relativeVorticity; the new level is exchanged as `what` = 4 between
- * part 0 and the end; moka_fe_dist_end swaps the time levels.  Order with the direct transport: part 2 FIRST (it reads
+ * part 0 boundary patches, 1 interior patches, 2 relativeVorticity; the new level is exchanged as `what` = 5 between
+ * part 0 and the end; moka_fe_dist_end rotates the time levels (previous <- current <- new: a third level set takes the new
+ * level, so the step can form the reference's stale layerThicknessEdge from the previous level's layerThickness).  Order with the direct transport: part 2 FIRST (it reads
  * old-level rows of halo edges, which a neighbour's next step overwrites once this rank's push has been signalled), then
  * part 0, push, part 1.  moka_fe_dist_step does all of it in one call, in that order. */
 int  moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part);
@@ -333,6 +335,11 @@ int  moka_fe_dist_step(moka_halo *h, double dt, int flags, moka_transport_fn tra
  * in a library built with `make VARIANTS=1`; moka_set_kernel_variant returns MOKA_ERR_UNSUPPORTED for them otherwise. */
 int moka_kernel_variant_available(int variant);
 int moka_set_kernel_variant(moka_ctx *ctx, int variant);
+/* Process-wide launch-shape switches for A/B measurements (every setting gives identical results).  key 1: bit mask of the
+ * modes (0 tendency, 1..3 RK4 stages, 4..6 Forward Euler) of the fp32-storage stage kernel that run as 512-thread workgroups
+ * bounded to 128 registers = 4 waves per SIMD instead of 3 (default: modes 0 and 1, the two that fit without spilling). */
+int moka_set_tuning(int key, int value);
+int moka_get_tuning(int key, int *value);
 /* Per-stage durations of moka_step_rk4 from HIP events on the compute stream (measurement: bench.py's per-mode roofline
  * lines).  moka_stage_timing(ctx, 1) forgets earlier samples and records 5 events per step from now on; (ctx, 0) stops.
  * moka_stage_timing_read: ms[s-1] = mean duration of the stage-s launch over the *steps recorded steps. */
@@ -352,8 +359,10 @@ int moka_marks_read(moka_ctx *ctx, int64_t capacity, double *ms, int64_t *n);
  * gbs[1] = best read-only rate, gbs[2] = mean copy rate over the `iters` launches.  The buffer is kept for the next probe;
  * bytes = 0 frees it.  (MI355X_MICROARCH.md quotes 6.29 TB/s for such a copy; SURVEY.md 8d asks for both figures.) */
 int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[3]);
-/* which kernel the last moka_step_fe of this state used: 1 = the tuned stage kernel (+ vertex pass), 0 = the generic
- * one-launch kernel, -1 = no Forward-Euler step yet.  For tests and measurement; results are identical either way. */
+/* which kernel the last moka_step_fe of this state used: 1 = the tuned stage kernel (+ vertex pass), 2 = the same with the
+ * stale layerThicknessEdge formed from the previous level's layerThickness instead of gathered (every MOKA_FE_STALE_HEDGE
+ * step after the first of a run), 0 = the generic one-launch kernel, -1 = no Forward-Euler step yet.  For tests and
+ * measurement; results are identical either way. */
 int moka_last_fe_path(const moka_state *st);
 
 /* ---- optional nonlinear terms (extension; NOT in the reference, parity unpinned) ---------------------------------

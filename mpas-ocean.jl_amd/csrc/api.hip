@@ -102,6 +102,43 @@ int ensure_rk_bufs(moka_state *st)
     return MOKA_OK;
 }
 
+int ensure_spare(moka_state *st)
+{
+    if (st->spare.ssh) return MOKA_OK;
+    const Plan &p = st->mesh->plan;
+    LevelBufs tmp;
+    const size_t mark = st->allocs.size();
+    const size_t sb = st->f32 ? 4 : 8;
+    int rc = alloc_field(st, &tmp.u, (size_t)p.K * p.nE, sb);
+    if (rc == MOKA_OK) rc = alloc_field(st, &tmp.h, (size_t)p.K * p.nC, sb);
+    if (rc == MOKA_OK) rc = alloc_field(st, &tmp.ssh, (size_t)p.nC, sb);
+    if (rc != MOKA_OK) {
+        (void)hipStreamSynchronize(st->ctx->stream);
+        while (st->allocs.size() > mark) { (void)hipFree(st->allocs.back()); st->allocs.pop_back(); }
+        return rc;
+    }
+    st->spare = tmp;
+    st->phys[4] = tmp;
+    return MOKA_OK;
+}
+
+// Where a Forward-Euler step writes its new level: the spare set when it exists (the step may then read the previous level
+// while it runs), else the previous level's buffers (which the new level replaces anyway).
+LevelBufs &fe_new_level(moka_state *st) { return st->spare.ssh ? st->spare : st->lev[0]; }
+
+// prev <- cur <- new (<- old prev becomes the spare).  Without a spare set: the plain swap.
+void fe_rotate_levels(moka_state *st)
+{
+    if (st->spare.ssh) {
+        const LevelBufs oldPrev = st->lev[0];
+        st->lev[0] = st->lev[1];
+        st->lev[1] = st->spare;
+        st->spare = oldPrev;
+    } else {
+        std::swap(st->lev[0], st->lev[1]);
+    }
+}
+
 struct FieldRef {
     double *ptr;
     int kind;     // MOKA_CELL / EDGE / VERTEX
@@ -174,7 +211,8 @@ FeArgs fe_args(moka_state *st, int ops, int flags, double dt)
     a.hEdgeOld = st->hEdge[0]; a.hEdgeNew = st->hEdge[1];
     a.Fin = st->F; a.F = st->F; a.div = st->div; a.vort = st->vort;
     a.tendU = st->tendU; a.tendH = st->tendH;
-    a.u_new = st->lev[0].u; a.h_new = st->lev[0].h; a.ssh_new = st->lev[0].ssh;
+    const LevelBufs &nw = fe_new_level(st);
+    a.u_new = nw.u; a.h_new = nw.h; a.ssh_new = nw.ssh;
     return a;
 }
 
@@ -297,6 +335,22 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
     return launch_stage(dev, g, m->lpc, s);
 }
 
+// Argument block of the Forward-Euler step in the stage kernel (k_stage_rec2c* modes 4 / 5 / 6) from the generic kernel's.
+// MOKA_FE_STALE_HEDGE: the stored layerThicknessEdge is gathered (mode 4) unless it is known to be the interpolation of the
+// previous level's layerThickness and that level survives the step (a spare set takes the new level): then the cell loop
+// forms it from those rows (mode 6).
+StageArgs fe_stage_args(moka_state *st, const FeArgs &a, int flags)
+{
+    StageArgs s{};
+    s.pu = a.u; s.ph = a.h; s.ssh = a.ssh;
+    s.pu_out = a.u_new; s.ph_out = a.h_new; s.ssh_out = a.ssh_new;
+    s.tendU = a.tendU; s.tendH = a.tendH; s.a = a.dt;
+    s.hEdgeOld = (flags & MOKA_FE_STALE_HEDGE) ? a.hEdgeOld : nullptr;
+    s.hPrev = ((flags & MOKA_FE_STALE_HEDGE) && st->hEdgePrev && st->spare.ssh && a.h_new != st->lev[0].h) ? st->lev[0].h : nullptr;
+    s.hEdgeNew = a.hEdgeNew; s.F = a.F; s.div = a.div; s.areaCell = st->mesh->dev.areaCell;
+    return s;
+}
+
 int flush_lazy(moka_state *st, bool diag, bool tend)
 {
     if (diag && st->diagDirty && st->f32)   // no diagnostics-only kernel for float arrays: they come out of Forward-Euler steps
@@ -309,6 +363,7 @@ int flush_lazy(moka_state *st, bool diag, bool tend)
         HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
         std::swap(st->hEdge[0], st->hEdge[1]);
         st->diagDirty = false;
+        st->hEdgePrev = false;            // layerThicknessEdge now belongs to the CURRENT level
     }
     if (tend && st->tendDirty) {
         StageArgs g{};
@@ -514,6 +569,22 @@ int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[3])
         }
     gbs[0] = bestCopy; gbs[1] = bestRead; gbs[2] = sumCopy / iters;
     return MOKA_OK;
+}
+
+// Process-wide launch-shape switches for A/B measurements (results are identical for every setting):
+//   key 1: bit mask of the modes of the fp32-storage stage kernel that run as 512-thread workgroups bounded to 128 registers
+//          (default: modes 0 and 1; see kernels.hip, g_f32WideModes)
+int moka_set_tuning(int key, int value)
+{
+    if (key == 1) { moka::set_f32_wide_modes(value); return MOKA_OK; }
+    return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
+}
+
+int moka_get_tuning(int key, int *value)
+{
+    if (!value) return fail(nullptr, MOKA_ERR_ARG, "value is NULL");
+    if (key == 1) { *value = moka::f32_wide_modes(); return MOKA_OK; }
+    return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
 }
 
 int moka_kernel_variant_available(int variant)
@@ -773,6 +844,7 @@ int moka_state_upload(moka_state *st, int field, int time_level, const double *h
     if ((rc = flush_lazy(st, (prog1 && !st->f32) || is_diag_field(field), prog1 || is_tend_field(field)))) return rc;
     if ((rc = field_ref(st, field, time_level, &r))) return rc;   // flush may have swapped buffers
     if (time_level == 1 && (field == MOKA_F_SSH || field == MOKA_F_LAYER_THICKNESS)) st->sshConsistent = false;
+    if ((field == MOKA_F_LAYER_THICKNESS && time_level == 0) || field == MOKA_F_LAYER_THICKNESS_EDGE) st->hEdgePrev = false;
     return put_rows(st->mesh, r.ptr, host, r.kind, r.n, r.K, r.f32);
 }
 
@@ -794,6 +866,7 @@ int moka_advance_time_levels(moka_state *st, int flags)
     const Plan &p = st->mesh->plan;
     hipStream_t s = st->ctx->stream;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    st->hEdgePrev = false;                 // the previous level changes under the stored layerThicknessEdge
     // advance_2d_array / advance_3d_array (time_integration.jl:42-59): prev <- next.
     // Level-1-only copies (K > 1) go through the FE kernel's carry-over path instead.
     if ((flags & MOKA_FE_LEVEL1_ONLY) && p.K > 1)
@@ -820,6 +893,7 @@ int moka_diagnostic_compute(moka_state *st, int flags)
     FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE, flags, 0.0);
     HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
     std::swap(st->hEdge[0], st->hEdge[1]);
+    st->hEdgePrev = false;
     return MOKA_OK;
 }
 
@@ -891,22 +965,21 @@ int moka_step_fe(moka_state *st, double dt, int flags)
         const moka_mesh *mf = st->mesh;
         if ((flags & MOKA_FE_LEVEL1_ONLY) || mf->plan.nPatchesLaunch != mf->plan.nPatches)
             return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: Forward Euler steps all levels of a whole mesh (no MOKA_FE_LEVEL1_ONLY, no partitions)");
-        StageArgs g{};
-        g.pu = a.u; g.ph = a.h; g.ssh = a.ssh;
-        g.pu_out = a.u_new; g.ph_out = a.h_new; g.ssh_out = a.ssh_new;
-        g.tendU = a.tendU; g.tendH = a.tendH; g.a = dt;
-        g.hEdgeOld = (flags & MOKA_FE_STALE_HEDGE) ? a.hEdgeOld : nullptr;
-        g.hEdgeNew = a.hEdgeNew; g.F = a.F; g.div = a.div; g.areaCell = mf->dev.areaCell;
+        if (int rcs = ensure_spare(st)) return rcs;
+        a = fe_args(st, a.ops, flags, dt);                     // the new level goes to the spare set
+        StageArgs g = fe_stage_args(st, a, flags);
+        g.areaCell = mf->dev.areaCell;
         MeshDev dev = mf->dev;
         dev.tailPatch = -1;
         dev.maxOwnE = std::max(mf->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(mf->plan.maxOwnCLaunch, 1);
         HIPCHK(st->ctx, launch_stage_rec2c_f32(dev, g, st->ctx->stream));      // ssh as stored, like the Float64 step
         HIPCHK(st->ctx, launch_curl_f32(dev, reinterpret_cast<const float *>(a.u), reinterpret_cast<float *>(a.vort),
                                         flags & MOKA_FE_ACCUM_VORT, st->ctx->stream));
-        st->feFast = 1;
-        std::swap(st->lev[0], st->lev[1]);
+        st->feFast = g.hPrev ? 2 : 1;
+        fe_rotate_levels(st);
         std::swap(st->hEdge[0], st->hEdge[1]);
         st->sshConsistent = true;
+        st->hEdgePrev = true;
         return MOKA_OK;
     }
     // All levels on a whole mesh with the default kernel choice: the step runs in the tuned stage kernel (modes 4 / 5 of
@@ -914,17 +987,17 @@ int moka_step_fe(moka_state *st, double dt, int flags)
     // MOKA_FE_LEVEL1_ONLY, odd or large K, explicit kernel variants, partitioned meshes -- takes the generic one-launch kernel.
     bool fast = false;
     const moka_mesh *mm = st->mesh;
+    int fastMode = 0;
     if (!(flags & MOKA_FE_LEVEL1_ONLY) && (st->ctx->variant == 0 || st->ctx->variant == 11) && mm->lpc == 64 && mm->colOk &&
-        mm->plan.nPatchesLaunch == mm->plan.nPatches) {
-        StageArgs g{};
-        g.pu = a.u; g.ph = a.h; g.ssh = a.ssh;
-        g.pu_out = a.u_new; g.ph_out = a.h_new; g.ssh_out = a.ssh_new;
-        g.tendU = a.tendU; g.tendH = a.tendH; g.a = dt;
-        g.hEdgeOld = (flags & MOKA_FE_STALE_HEDGE) ? a.hEdgeOld : nullptr;
-        g.hEdgeNew = a.hEdgeNew; g.F = a.F; g.div = a.div; g.areaCell = mm->dev.areaCell;
+        mm->plan.nPatchesLaunch == mm->plan.nPatches && rec2c_supported(mm->dev)) {
+        if (int rcs = ensure_spare(st)) return rcs;
+        a = fe_args(st, a.ops, flags, dt);                     // the new level goes to the spare set
+        StageArgs g = fe_stage_args(st, a, flags);
+        g.areaCell = mm->dev.areaCell;
         const hipError_t e = launch_stage_rec2c(mm->dev, g, st->ctx->stream);
         if (e == hipSuccess) {
             fast = true;
+            fastMode = g.hPrev ? 2 : 1;
             const hipError_t ec = launch_curl2(mm->dev, a.u, a.vort, flags & MOKA_FE_ACCUM_VORT, st->ctx->stream);
             if (ec == hipErrorNotSupported) {
                 a.ops = FE_CURL;
@@ -937,10 +1010,12 @@ int moka_step_fe(moka_state *st, double dt, int flags)
         }
     }
     if (!fast) HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
-    st->feFast = fast ? 1 : 0;
-    std::swap(st->lev[0], st->lev[1]);
+    st->feFast = fast ? fastMode : 0;
+    fe_rotate_levels(st);
     std::swap(st->hEdge[0], st->hEdge[1]);
     st->sshConsistent = !(flags & MOKA_FE_LEVEL1_ONLY) || st->mesh->plan.K == 1;
+    st->hEdgePrev = fast;                  // the stage kernel interpolated every level of every computed edge from the level
+                                           // that is the previous one now
     return MOKA_OK;
 }
 
@@ -972,9 +1047,10 @@ StageArgs rk4_stage_args(moka_state *st, int s, double dt, const double *ssh0)
 }
 
 // buffers a stage writes that other ranks gather from next: stage 1,3 -> R1; 2 -> R2; 4 -> B; 0 -> current level
+// 5 = the new level of a distributed Forward-Euler step before its levels rotate
 LevelBufs &rk4_stage_output(moka_state *st, int s)
 {
-    return s == 0 ? st->lev[1] : s == 4 ? st->lev[0] : s == 2 ? st->rk[1] : st->rk[0];
+    return s == 0 ? st->lev[1] : s == 5 ? fe_new_level(st) : s == 4 ? st->lev[0] : s == 2 ? st->rk[1] : st->rk[0];
 }
 
 int rk4_begin(moka_state *st, const double **ssh0)
@@ -995,6 +1071,7 @@ void rk4_end(moka_state *st)
     st->sshConsistent = true;
     st->diagDirty = true;
     st->tendDirty = true;
+    st->hEdgePrev = false;
     st->lazyPu = st->lazyPh = nullptr; st->lazyOwner = nullptr;
 }
 }  // namespace mk

@@ -64,7 +64,7 @@ struct PushDst {              // where the rows for one neighbour go, for one ph
 
 struct PeerLink {
     bool connected = false, ipc = false;
-    void *mapped[12] = {};                // peer field bases as this process sees them: [set][u, h, ssh]
+    void *mapped[15] = {};                // peer field bases as this process sees them: [set][u, h, ssh]
     volatile uint64_t *flags = nullptr;   // the peer's flag block (host memory)
     size_t flagsBytes = 0;
     int32_t dstCell = 0, dstEdge = 0, slot = 0;
@@ -83,6 +83,7 @@ struct moka_halo {
     double dt = 0.0;
     const double *ssh0 = nullptr;
     int feFlags = 0;
+    bool feStageKernel = false, fePrev = false;   // the running distributed Forward-Euler step: stage kernel? mode 6?
     // direct transport
     bool directOk = false;
     std::string directWhy;
@@ -91,7 +92,7 @@ struct moka_halo {
     uint32_t *pushRows = nullptr;         // device: {source row (library numbering), row within the message part, nbr | kind << 16}
     int64_t nPushRows = 0;
     std::vector<PeerLink> peers;
-    PushDst *peerTab = nullptr;           // device: [4 sets][nNbr]
+    PushDst *peerTab = nullptr;           // device: [5 sets][nNbr]
     bool tabDirty = true;
     volatile uint64_t *flags = nullptr;   // my flag block: slot i = last exchange neighbour i has completed towards me
     size_t flagsBytes = 0;
@@ -145,11 +146,11 @@ int build_halo_map(moka_halo *hh, int nNbr, const int32_t *cells, const int64_t 
     return MOKA_OK;
 }
 
-// index (0..3) of the physical buffer set a LevelBufs currently names: 0/1 the two time levels as allocated, 2/3 the RK
-// provisional states.  Ranks that have applied the same sequence of steps agree on it.
+// index (0..4) of the physical buffer set a LevelBufs currently names: 0/1 the two time levels as allocated, 2/3 the RK
+// provisional states, 4 the Forward-Euler spare.  Ranks that have applied the same sequence of steps agree on it.
 int phys_index(const moka_state *st, const LevelBufs &b)
 {
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < moka_state::NPHYS; ++i)
         if (st->phys[i].u && st->phys[i].u == b.u) return i;
     return -1;
 }
@@ -209,8 +210,8 @@ int upload_peer_tab(moka_halo *h)
     const moka_state *st = h->st;
     const Plan &p = st->mesh->plan;
     const size_t sb = st->f32 ? 4 : 8, rowB = (size_t)p.K * sb;
-    std::vector<PushDst> tab((size_t)4 * std::max(h->nNbr, 1));
-    for (int t = 0; t < 4; ++t)
+    std::vector<PushDst> tab((size_t)moka_state::NPHYS * std::max(h->nNbr, 1));
+    for (int t = 0; t < moka_state::NPHYS; ++t)
         for (int i = 0; i < h->nNbr; ++i) {
             const PeerLink &pl = h->peers[i];
             PushDst d{};
@@ -317,7 +318,8 @@ int moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCell
             return fail(st->ctx, MOKA_ERR_ARG, "boundary / owned patch counts must be class boundaries of the mesh (moka_mesh_class_ranges)");
     }
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
-    if (int rc = ensure_rk_bufs(st)) return rc;     // the four physical buffer sets exist from here on
+    if (int rc = ensure_rk_bufs(st)) return rc;     // the five physical buffer sets exist from here on: a neighbour
+    if (int rc = ensure_spare(st)) return rc;       // addresses them by index when it pushes
     moka_halo *h = new (std::nothrow) moka_halo();
     if (!h) return fail(st->ctx, MOKA_ERR_ALLOC, "out of host memory");
     h->st = st;
@@ -427,11 +429,11 @@ int moka_halo_buffer_elems(const moka_halo *h, int64_t *sendElems, int64_t *recv
 }
 
 // what: 0 = the current time level, 1..4 = the output of RK4 stage `what` (valid between dist_begin and dist_end);
-// 4 is also the new time level of a distributed Forward-Euler step before its levels swap
+// 5 = the new time level of a distributed Forward-Euler step before its levels rotate
 int moka_halo_pack(moka_halo *h, int what, void *sendbuf)
 {
     if (!h || (!sendbuf && h->nSend)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
-    if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
+    if (what < 0 || what > 5) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..5");
     moka_state *st = h->st;
     moka_ctx *c = st->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -450,7 +452,7 @@ int moka_halo_pack(moka_halo *h, int what, void *sendbuf)
 int moka_halo_unpack(moka_halo *h, int what, const void *recvbuf)
 {
     if (!h || (!recvbuf && h->nRecv)) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
-    if (what < 0 || what > 4) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..4");
+    if (what < 0 || what > 5) return fail(h->st->ctx, MOKA_ERR_ARG, "what must be 0..5");
     moka_state *st = h->st;
     moka_ctx *c = st->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -545,7 +547,7 @@ int moka_halo_export(moka_halo *h, int32_t nbr, int32_t shared, moka_halo_peer_i
     if (int rc = ensure_flags(h, shared != 0)) return rc;
     if (shared && h->shmName.empty()) return hfail(h, MOKA_ERR_ARG, "the flag block of this halo was created process-local");
     std::memset(out, 0, sizeof *out);
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < moka_state::NPHYS; ++t) {
         void *ptrs[3] = {st->phys[t].u, st->phys[t].h, st->phys[t].ssh};
         for (int f = 0; f < 3; ++f) {
             out->ptr[3 * t + f] = (uint64_t)(uintptr_t)ptrs[f];
@@ -590,7 +592,7 @@ int moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer
     pl.dstCell = peer->dstCell; pl.dstEdge = peer->dstEdge; pl.slot = peer->slot;
     if (shared) {
         if (peer->pid == (int32_t)getpid()) return hfail(h, MOKA_ERR_ARG, "shared = 1 is for peers in ANOTHER process (use shared = 0 inside one process)");
-        for (int i = 0; i < 12; ++i) {
+        for (int i = 0; i < 3 * moka_state::NPHYS; ++i) {
             hipIpcMemHandle_t hd;
             std::memcpy(&hd, peer->ipc[i], sizeof hd);
             void *q = nullptr;
@@ -616,7 +618,7 @@ int moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer
         }
         pl.flags = static_cast<volatile uint64_t *>(q);
     } else {
-        for (int i = 0; i < 12; ++i) pl.mapped[i] = (void *)(uintptr_t)peer->ptr[i];
+        for (int i = 0; i < 3 * moka_state::NPHYS; ++i) pl.mapped[i] = (void *)(uintptr_t)peer->ptr[i];
         pl.flags = (volatile uint64_t *)(uintptr_t)peer->flagPtr;
         if (peer->device != st->ctx->device) {        // one process driving several devices: map the peer's memory
             const hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
@@ -641,7 +643,7 @@ int moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer
 int moka_halo_push_begin(moka_halo *h, int what)
 {
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
-    if (what < 0 || what > 4) return hfail(h, MOKA_ERR_ARG, "what must be 0..4");
+    if (what < 0 || what > 5) return hfail(h, MOKA_ERR_ARG, "what must be 0..5");
     if (!all_connected(h)) return hfail(h, MOKA_ERR_ARG, "direct halo transport: not every neighbour is connected");
     moka_state *st = h->st;
     moka_ctx *c = st->ctx;
@@ -796,19 +798,13 @@ int moka_rk4_dist_step(moka_halo *h, double dt, moka_transport_fn transport, voi
 // Everything a computed entity reads is local: an edge with an owned cell is computed here (its layerThicknessEdge
 // too, from the exchanged layerThickness of the halo cell -- so the stale-thickness flux of reference_compat needs no
 // exchange of its own), an edge without one arrives by exchange together with the new level's layerThickness / ssh.
-//   launch: boundary patches -> (push or pack of the NEW level, `what` = 4) -> interior patches -> relativeVorticity
+//   launch: relativeVorticity -> boundary patches -> (push or pack of the NEW level, `what` = 5) -> interior patches
 //   then the exchange completes (push_signal / push_wait, or transport + unpack), then moka_fe_dist_end swaps the levels.
 // ---------------------------------------------------------------------------------------------
-static int fe_stage_args(moka_state *st, double dt, int flags, StageArgs *g, FeArgs *a)
+static int fe_dist_args(moka_state *st, double dt, int flags, StageArgs *g, FeArgs *a)
 {
     *a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE | FE_TENDU | FE_TENDH | FE_UPDATE, flags, dt);
-    StageArgs s{};
-    s.pu = a->u; s.ph = a->h; s.ssh = a->ssh;
-    s.pu_out = a->u_new; s.ph_out = a->h_new; s.ssh_out = a->ssh_new;
-    s.tendU = a->tendU; s.tendH = a->tendH; s.a = dt;
-    s.hEdgeOld = (flags & MOKA_FE_STALE_HEDGE) ? a->hEdgeOld : nullptr;
-    s.hEdgeNew = a->hEdgeNew; s.F = a->F; s.div = a->div; s.areaCell = st->mesh->dev.areaCell;
-    *g = s;
+    *g = fe_stage_args(st, *a, flags);      // the new level goes to the spare set: the previous level stays readable (mode 6)
     return MOKA_OK;
 }
 
@@ -829,7 +825,7 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
     }
     StageArgs g;
     FeArgs a;
-    fe_stage_args(st, dt, flags, &g, &a);
+    fe_dist_args(st, dt, flags, &g, &a);
     h->feFlags = flags;
     const moka_mesh *mm = st->mesh;
     if (part == 2) {
@@ -864,11 +860,14 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
         dev.maxOwnE = mE; dev.maxOwnC = mC;
     }
     hipError_t e = hipErrorNotSupported;
+    h->fePrev = g.hPrev != nullptr;
     if (st->f32) {                         // the Forward-Euler modes of the fp32-storage kernel: no generic form behind them
         HIPCHK(c, launch_stage_rec2c_f32(dev, g, c->stream));
+        h->feStageKernel = true;
         return MOKA_OK;
     }
     if ((c->variant == 0 || c->variant == 11) && mm->lpc == 64 && mm->colOk) e = launch_stage_rec2c(dev, g, c->stream);
+    h->feStageKernel = e == hipSuccess;
     if (e == hipErrorNotSupported) {
         a.ops &= ~FE_CURL;                 // the generic one-launch kernel over the same patch range, vertices in part 2
         e = launch_fe(dev, a, mm->lpc, c->stream);
@@ -881,10 +880,13 @@ int moka_fe_dist_end(moka_halo *h)
 {
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
     moka_state *st = h->st;
-    std::swap(st->lev[0], st->lev[1]);
+    fe_rotate_levels(st);
     std::swap(st->hEdge[0], st->hEdge[1]);
     st->sshConsistent = true;
-    st->feFast = 1;
+    st->feFast = h->feStageKernel ? (h->fePrev ? 2 : 1) : 0;
+    // the stage kernel interpolated layerThicknessEdge of every edge with an owned cell from the level that is the previous one
+    // now (the generic one-launch kernel does the same, but a step of it is not what mode 6 was validated against)
+    st->hEdgePrev = h->feStageKernel;
     return MOKA_OK;
 }
 
@@ -901,18 +903,18 @@ int moka_fe_dist_step(moka_halo *h, double dt, int flags, moka_transport_fn tran
     if ((rc = moka_fe_dist_launch(h, dt, flags, 2))) return rc;
     if ((rc = moka_fe_dist_launch(h, dt, flags, 0))) return rc;
     if (direct) {
-        if ((rc = moka_halo_push_begin(h, 4))) return rc;
+        if ((rc = moka_halo_push_begin(h, 5))) return rc;
     } else if (h->nNbr > 0) {
-        if ((rc = moka_halo_pack(h, 4, sendbuf))) return rc;
+        if ((rc = moka_halo_pack(h, 5, sendbuf))) return rc;
     }
     if ((rc = moka_fe_dist_launch(h, dt, flags, 1))) return rc;
     if (direct) {
         if ((rc = moka_halo_push_signal(h))) return rc;
         if ((rc = moka_halo_push_wait(h, timeout_s))) return rc;
     } else if (h->nNbr > 0) {
-        if (int trc = transport(user, 4, sendbuf, recvbuf))
+        if (int trc = transport(user, 5, sendbuf, recvbuf))
             return hfail(h, MOKA_ERR_COMM, "the halo transport callback failed (code " + std::to_string(trc) + ")");
-        if ((rc = moka_halo_unpack(h, 4, recvbuf))) return rc;
+        if ((rc = moka_halo_unpack(h, 5, recvbuf))) return rc;
     }
     return moka_fe_dist_end(h);
 }

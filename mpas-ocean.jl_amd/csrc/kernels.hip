@@ -125,10 +125,14 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     // iteration's loads have arrived.  Issued at the end of their own iteration they force a vmcnt(0) at the loop top
     // (their data registers are reused at once), i.e. every iteration waited for its stores to be acknowledged before
     // the next gathers could start; now the acknowledgement overlaps the arithmetic and the next record reads.
-    // MODE 4 / 5: one Forward-Euler step (time_integration.jl:150-193) with the diagnostics of diagnostic_compute!
+    // MODE 4 / 5 / 6: one Forward-Euler step (time_integration.jl:150-193) with the diagnostics of diagnostic_compute!
     // (DiagnosticVars.jl:108-117) except relativeVorticity; 4 = thickness flux from the previous step's
-    // layerThicknessEdge (MOKA_FE_STALE_HEDGE, the reference's behaviour), 5 = from this step's.
-    constexpr bool FE = MODE >= 4, STALE = MODE == 4;
+    // layerThicknessEdge (MOKA_FE_STALE_HEDGE, the reference's behaviour), 5 = from this step's; 6 = the reference's
+    // behaviour again, with that stale layerThicknessEdge FORMED in the cell loop from the previous time level's
+    // layerThickness rows (a.hPrev) -- what the previous step interpolated it from, so the same bits (0.5 * (x + y) commutes)
+    // -- instead of six gathered rows of the stored array per cell: those were 9.35 GB of fetches for 4.2 GB of inputs
+    // (profiles/r02_variants.txt).  The host selects 6 only when the stored array IS that interpolation (moka_state.hEdgePrev).
+    constexpr bool FE = MODE >= 4, STALE = MODE == 4, PREV = MODE == 6;
     double2 pA = make_double2(0.0, 0.0), pB = pA, pD = pA, pE = pA;
     double pS = 0.0;
     // `pend` is false only in a group's first iteration; the loops carry `#pragma nounroll` so that the compiler does not peel
@@ -162,16 +166,17 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         const uint32_t mask = r[2 * ME], all = r[2 * ME + 1];
         const double invA = L.invA[ci];
         const uint32_t own = (uint32_t)c * rowB + voff;
-        double2 hc = make_double2(0.0, 0.0), uv[ME], hv[ME], cur = hc, nin = hc;
+        double2 hc = make_double2(0.0, 0.0), uv[ME], hv[ME], cur = hc, nin = hc, hpc = hc;
         if (act) {
             bool cached[ME];
             uint32_t ad[ME], goff[ME];
             v4u_t raw[ME];
             hc = gload2(a.ph, own);
+            if constexpr (PREV) hpc = gload2(a.hPrev, own);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
                 const uint32_t off = r[i];
-                hv[i] = STALE ? gload2(a.hEdgeOld, off + voff) : gload2(a.ph, r[ME + i] + voff);
+                hv[i] = STALE ? gload2(a.hEdgeOld, off + voff) : gload2(PREV ? a.hPrev : a.ph, r[ME + i] + voff);
                 ad[i] = urow_addr(off, cached[i]);
                 goff[i] = off + voff;
                 asm("" : "+v"(goff[i]));               // stays in a VGPR (see the edge loop)
@@ -194,7 +199,8 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME) - 1u && all)) == 0;
         double2 dv = make_double2(0.0, 0.0);                            // velocityDivCell (FE): Operators.jl:18,39
         // thickness at the edge: interpolated (Operators.jl:217) or, MODE 4, what the previous step stored
-        auto hE = [&](int i) { return STALE ? hv[i] : make_double2(0.5 * (hc.x + hv[i].x), 0.5 * (hc.y + hv[i].y)); };
+        const double2 hself = PREV ? hpc : hc;
+        auto hE = [&](int i) { return STALE ? hv[i] : make_double2(0.5 * (hself.x + hv[i].x), 0.5 * (hself.y + hv[i].y)); };
         if (plain) {
             if (act) {
 #pragma unroll
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (FE) {
                 hx = gload2(a.ph, r[ME2] * rowB + voff);               // layerThickness of cellsOnEdge[1], [2]
                 hy = gload2(a.ph, r[ME2 + 1] * rowB + voff);
-                if constexpr (STALE) hEo = gload2(a.hEdgeOld, own);
+                if constexpr (STALE || PREV) hEo = gload2(a.hEdgeOld, own);    // the own row: one contiguous stream per patch
             }
         }
         if (l < 2) sv = a.ssh[r[ME2 + l]];                             // ssh of cellsOnEdge[l]: after the gathers in the queue
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (FE) {
                 const double2 up = ubuf2[(size_t)ei * K2 + l];          // own row is in the cache
                 pE = make_double2(0.5 * (hx.x + hy.x), 0.5 * (hx.y + hy.y));              // layerThicknessEdge, Operators.jl:217
-                const double2 hF = STALE ? hEo : pE;
+                const double2 hF = (STALE || PREV) ? hEo : pE;
                 pD = make_double2(up.x * hF.x, up.y * hF.y);                              // thicknessFlux, DiagnosticVars.jl:165
                 pA = make_double2(up.x + a.a * t.x, up.y + a.a * t.y);                    // time_integration.jl:199
                 pB = t;
@@ -404,8 +410,10 @@ __device__ __forceinline__ d4 axpy4(d4 x, double a, d4 t)      // x + a*t, the r
 }
 __device__ __forceinline__ d4 round4(d4 v) { return widen4(narrow4(v)); }
 
-template <int ME, int ME2, int MODE>
-__global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
+// NT threads per patch, WPE waves per SIMD the register allocation is bounded for: (256, 3) is the whole-mesh default (three
+// workgroups per CU at P = 24); (512, 4) gives the modes that fit 128 registers two 8-wave workgroups per CU = 4 waves per SIMD.
+template <int ME, int ME2, int MODE, int NT = BLOCK, int WPE = 3>
+__global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int pl_ = patch_of_block(m.nPatches);
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
     // lanes beyond the last whole group idle.  Shuffles address lanes of the own group only.
     const int tid = threadIdx.x;
     const int K = m.K, K4 = K >> 2;
-    const int EPW = 64 / K4, NG = (BLOCK / 64) * EPW;
+    const int EPW = 64 / K4, NG = (NT / 64) * EPW;
     const int lane = tid & 63, sub = lane / K4;
     const int l = lane - sub * K4, gbase = sub * K4;
     const bool lane_on = sub < EPW;
@@ -446,48 +454,48 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         uint32_t vE[UE], vC[UC];
         double vW[UW], vF[UW], vG, vS, vA, vR;
 #pragma unroll
-        for (int j = 0; j < UU; ++j) vU[j] = (tid + j * BLOCK < nU) ? src[tid + j * BLOCK] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < UU; ++j) vU[j] = (tid + j * NT < nU) ? src[tid + j * NT] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < UE; ++j) vE[j] = (tid + j * BLOCK < nER) ? m.eRec[(size_t)e0 * m.EI + tid + j * BLOCK] : 0u;
+        for (int j = 0; j < UE; ++j) vE[j] = (tid + j * NT < nER) ? m.eRec[(size_t)e0 * m.EI + tid + j * NT] : 0u;
 #pragma unroll
         for (int j = 0; j < UW; ++j) {
-            vW[j] = (tid + j * BLOCK < nW) ? m.woe[(size_t)e0 * ME2 + tid + j * BLOCK] : 0.0;
-            vF[j] = (tid + j * BLOCK < nW) ? m.feoe[(size_t)e0 * ME2 + tid + j * BLOCK] : 0.0;
+            vW[j] = (tid + j * NT < nW) ? m.woe[(size_t)e0 * ME2 + tid + j * NT] : 0.0;
+            vF[j] = (tid + j * NT < nW) ? m.feoe[(size_t)e0 * ME2 + tid + j * NT] : 0.0;
         }
 #pragma unroll
-        for (int j = 0; j < UC; ++j) vC[j] = (tid + j * BLOCK < nCR) ? m.cRec[(size_t)c0 * m.CI + tid + j * BLOCK] : 0u;
+        for (int j = 0; j < UC; ++j) vC[j] = (tid + j * NT < nCR) ? m.cRec[(size_t)c0 * m.CI + tid + j * NT] : 0u;
         vG = tid < nOwnE ? m.gInvDc[e0 + tid] : 0.0;
         vS = tid < nS ? m.sdv[(size_t)c0 * ME + tid] : 0.0;
         vA = tid < nOwnC ? m.invArea[c0 + tid] : 0.0;
         vR = tid < nOwnC ? m.rsum[c0 + tid] : 0.0;
 #pragma unroll
-        for (int j = 0; j < UU; ++j) if (tid + j * BLOCK < nU) ubuf4[tid + j * BLOCK] = vU[j];
+        for (int j = 0; j < UU; ++j) if (tid + j * NT < nU) ubuf4[tid + j * NT] = vU[j];
 #pragma unroll
-        for (int j = 0; j < UE; ++j) if (tid + j * BLOCK < nER) L.eRec[tid + j * BLOCK] = vE[j];
+        for (int j = 0; j < UE; ++j) if (tid + j * NT < nER) L.eRec[tid + j * NT] = vE[j];
 #pragma unroll
         for (int j = 0; j < UW; ++j)
-            if (tid + j * BLOCK < nW) {
-                L.woe[tid + j * BLOCK] = vW[j];
-                L.feoe[tid + j * BLOCK] = vF[j];
+            if (tid + j * NT < nW) {
+                L.woe[tid + j * NT] = vW[j];
+                L.feoe[tid + j * NT] = vF[j];
             }
 #pragma unroll
-        for (int j = 0; j < UC; ++j) if (tid + j * BLOCK < nCR) L.cRec[tid + j * BLOCK] = vC[j];
+        for (int j = 0; j < UC; ++j) if (tid + j * NT < nCR) L.cRec[tid + j * NT] = vC[j];
         if (tid < nOwnE) L.g[tid] = vG;
         if (tid < nS) L.sdv[tid] = vS;
         if (tid < nOwnC) {
             L.invA[tid] = vA;
             L.rsum[tid] = vR;
         }
-        for (int i = tid + UU * BLOCK; i < nU; i += BLOCK) ubuf4[i] = src[i];
-        for (int i = tid + UE * BLOCK; i < nER; i += BLOCK) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
-        for (int i = tid + UW * BLOCK; i < nW; i += BLOCK) {
+        for (int i = tid + UU * NT; i < nU; i += NT) ubuf4[i] = src[i];
+        for (int i = tid + UE * NT; i < nER; i += NT) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
+        for (int i = tid + UW * NT; i < nW; i += NT) {
             L.woe[i] = m.woe[(size_t)e0 * ME2 + i];
             L.feoe[i] = m.feoe[(size_t)e0 * ME2 + i];
         }
-        for (int i = tid + UC * BLOCK; i < nCR; i += BLOCK) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
-        for (int i = tid + BLOCK; i < nOwnE; i += BLOCK) L.g[i] = m.gInvDc[e0 + i];
-        for (int i = tid + BLOCK; i < nS; i += BLOCK) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
-        for (int i = tid + BLOCK; i < nOwnC; i += BLOCK) {
+        for (int i = tid + UC * NT; i < nCR; i += NT) L.cRec[i] = m.cRec[(size_t)c0 * m.CI + i];
+        for (int i = tid + NT; i < nOwnE; i += NT) L.g[i] = m.gInvDc[e0 + i];
+        for (int i = tid + NT; i < nS; i += NT) L.sdv[i] = m.sdv[(size_t)c0 * ME + i];
+        for (int i = tid + NT; i < nOwnC; i += NT) {
             L.invA[i] = m.invArea[c0 + i];
             L.rsum[i] = m.rsum[c0 + i];
         }
@@ -505,9 +513,11 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         return ldsU + (cached ? loc : 0u);
     };
     const d4 zero{0.0, 0.0, 0.0, 0.0};
-    // MODE 4 / 5: one Forward-Euler step with the diagnostics of diagnostic_compute! except relativeVorticity, as in
-    // k_stage_rec2c; layerThicknessEdge, thicknessFlux, velocityDivCell and the tendencies are float arrays like the state
-    constexpr bool FE = MODE >= 4, STALE = MODE == 4;
+    // MODE 4 / 5 / 6: one Forward-Euler step with the diagnostics of diagnostic_compute! except relativeVorticity, as in
+    // k_stage_rec2c; layerThicknessEdge, thicknessFlux, velocityDivCell and the tendencies are float arrays like the state.
+    // (6: the stored layerThicknessEdge is the fp32-rounded interpolation; formed again from the previous level it has to be
+    // rounded the same way before it is used -- round4.)
+    constexpr bool FE = MODE >= 4, STALE = MODE == 4, PREV = MODE == 6;
 
     // ---------------- cells ----------------
     for (int ci = grp; ci < nOwnC; ci += NG) {
@@ -520,17 +530,18 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         // the cell loop keeps its 14 gathered rows packed as fp32 until the arithmetic needs them: widened at load they held
         // twice the registers through the whole latency window (mode 2 spilled)
         const float4 zf = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 hcf = zf, uf[ME], hf[ME], curf = zf, ninf = zf;
+        float4 hcf = zf, uf[ME], hf[ME], curf = zf, ninf = zf, hpcf = zf;
         if (act) {
             bool cached[ME];
             uint32_t ad[ME];
             v4u_t raw[ME];
             uint32_t goff[ME];
             hcf = gload4f(a.ph, own);
+            if constexpr (PREV) hpcf = gload4f(a.hPrev, own);
 #pragma unroll
             for (int i = 0; i < ME; ++i) {
                 const uint32_t off = r[i];
-                hf[i] = STALE ? gload4f(a.hEdgeOld, off + voff) : gload4f(a.ph, r[ME + i] + voff);
+                hf[i] = STALE ? gload4f(a.hEdgeOld, off + voff) : gload4f(PREV ? a.hPrev : a.ph, r[ME + i] + voff);
                 ad[i] = urow_addr(off, cached[i]);
                 goff[i] = off + voff;
                 asm("" : "+v"(goff[i]));               // stays in a VGPR (see k_stage_rec2c).  The deferred stores of that kernel
@@ -551,7 +562,13 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
         const d4 hc = widen4(hcf);
         d4 t = zero, dv = zero;                                         // dv: velocityDivCell (FE), Operators.jl:18,39
         // thickness at the edge: interpolated (Operators.jl:217) or, MODE 4, what the previous step stored
-        auto hE = [&](const d4 &hvi) { return STALE ? hvi : d4{0.5 * (hc.x + hvi.x), 0.5 * (hc.y + hvi.y), 0.5 * (hc.z + hvi.z), 0.5 * (hc.w + hvi.w)}; };
+        const d4 hself = PREV ? widen4(hpcf) : hc;
+        auto hE = [&](const d4 &hvi) {
+            if constexpr (STALE) return hvi;
+            const d4 m{0.5 * (hself.x + hvi.x), 0.5 * (hself.y + hvi.y), 0.5 * (hself.z + hvi.z), 0.5 * (hself.w + hvi.w)};
+            if constexpr (PREV) return round4(m);       // as the previous step stored it
+            else return m;
+        };
         const bool plain = __builtin_amdgcn_ballot_w64(!(mask == (1u << ME) - 1u && all)) == 0;   // see k_stage_rec2c
         if (plain) {
             if (act) {
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
             if constexpr (FE) {
                 hxf = gload4f(a.ph, r[ME2] * rowB + voff);             // layerThickness of cellsOnEdge[1], [2]
                 hyf = gload4f(a.ph, r[ME2 + 1] * rowB + voff);
-                if constexpr (STALE) hEof = gload4f(a.hEdgeOld, own);
+                if constexpr (STALE || PREV) hEof = gload4f(a.hEdgeOld, own);
             }
             if (l == 0) {                                              // behind the gathers in the queue: nothing waits for these two alone
                 sA = sshf[r[ME2]];
@@ -708,7 +725,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_rec2c_f32(const ColMesh m, c
                 const d4 up = widen4(ubuf4[(size_t)ei * K4 + l]);       // own row is in the cache
                 const d4 hx = widen4(hxf), hy = widen4(hyf);
                 const d4 pE{0.5 * (hx.x + hy.x), 0.5 * (hx.y + hy.y), 0.5 * (hx.z + hy.z), 0.5 * (hx.w + hy.w)};   // layerThicknessEdge, Operators.jl:217
-                const d4 hF = STALE ? widen4(hEof) : pE;
+                const d4 hF = (STALE || PREV) ? widen4(hEof) : pE;
                 gstore4(a.F, own, d4{up.x * hF.x, up.y * hF.y, up.z * hF.z, up.w * hF.w});                            // thicknessFlux, DiagnosticVars.jl:165
                 gstore4(a.hEdgeNew, own, pE);
                 gstore4(a.pu_out, own, axpy4(up, a.a, t));              // time_integration.jl:199
@@ -1198,6 +1215,7 @@ static bool launch_rec2c_nt(const ColMesh &m, const StageArgs &a, int mode, dim3
         case 3: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 3, NT>), g, b, lds, s, m, a, mE, mC); return true;
         case 4: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 4, NT>), g, b, lds, s, m, a, mE, mC); return true;
         case 5: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 5, NT>), g, b, lds, s, m, a, mE, mC); return true;
+        case 6: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 6, NT>), g, b, lds, s, m, a, mE, mC); return true;
     }
     return false;
 }
@@ -1217,6 +1235,13 @@ size_t rec2c_lds_bytes(const MeshDev &md)
     return ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 8 + 16;
 }
 
+// can launch_stage_rec2c serve whole-mesh launches of this mesh at all (even K <= 64, records + own rows within 64 KB of LDS)
+bool rec2c_supported(const MeshDev &md)
+{
+    const bool shape = (md.ME == 6 && md.ME2 == 10) || (md.ME == 8 && md.ME2 == 14) || (md.ME <= 6 && md.ME2 <= 14);
+    return md.cRec && md.eRec && md.K <= 64 && !(md.K & 1) && rec2c_lds_bytes(md) <= 64 * 1024 && md.maxOwnC >= 1 && md.maxOwnE >= 1 && shape;
+}
+
 hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t s)
 {
     const int nLaunch = md.nPatches + (md.tailPatch >= 0 ? 1 : 0);
@@ -1233,28 +1258,48 @@ hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t
     return ok ? hipGetLastError() : hipErrorNotSupported;
 }
 
-template <int ME, int ME2>
-static bool launch_rec2c_f32(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3 b, size_t lds, int mE, int mC, hipStream_t s)
+// Which modes of the fp32-storage kernel run as 512-thread workgroups bounded to 128 registers (two per CU = 4 waves per
+// SIMD instead of three 4-wave workgroups = 3): bit m = mode m.  Modes 0 and 1 (no Curr / New rows in flight) fit 128
+// registers without spills; the others do not (tools/kernel_regs.py) and stay at (256, 3).  moka_set_tuning(1, mask) changes
+// it for measurements.
+static std::atomic<int> g_f32WideModes{(1 << 0) | (1 << 1)};
+void set_f32_wide_modes(int mask) { g_f32WideModes.store(mask); }
+int f32_wide_modes() { return g_f32WideModes.load(); }
+
+template <int ME, int ME2, int NT, int WPE>
+static bool launch_rec2c_f32_nt(const ColMesh &m, const StageArgs &a, int mode, dim3 g, size_t lds, int mE, int mC, hipStream_t s)
 {
     // a launch that carries a halo-straddling patch of a partitioned mesh (up to 6 own edges per cell) may need more than
     // the default 64 KB of dynamic LDS; such launches are small (the boundary group), occupancy does not matter there
-    if (lds > 64 * 1024 && lds_attr_needed(ME == 6 ? (ME2 == 10 ? 0 : 1) : 2)) {
-        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 64 * 1024 && lds_attr_needed((ME == 6 ? (ME2 == 10 ? 0 : 1) : 2) * 2 + (NT == 512 ? 1 : 0))) {
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 0, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 1, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 2, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 3, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 4, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 5, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 6, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
+    const dim3 b(NT);
     switch (mode) {
-        case 0: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 0>), g, b, lds, s, m, a, mE, mC); return true;
-        case 1: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 1>), g, b, lds, s, m, a, mE, mC); return true;
-        case 2: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 2>), g, b, lds, s, m, a, mE, mC); return true;
-        case 3: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 3>), g, b, lds, s, m, a, mE, mC); return true;
-        case 4: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 4>), g, b, lds, s, m, a, mE, mC); return true;
-        case 5: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 5>), g, b, lds, s, m, a, mE, mC); return true;
+        case 0: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 0, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
+        case 1: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 1, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
+        case 2: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 2, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
+        case 3: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 3, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
+        case 4: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 4, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
+        case 5: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 5, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
+        case 6: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 6, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
     }
     return false;
+}
+
+template <int ME, int ME2>
+static bool launch_rec2c_f32(const ColMesh &m, const StageArgs &a, int mode, dim3 g, dim3, size_t lds, int mE, int mC, hipStream_t s)
+{
+    // two 512-thread workgroups must fit a CU's 160 KB of LDS for the wide form to mean 4 waves per SIMD
+    if (((f32_wide_modes() >> mode) & 1) && 2 * lds <= 160 * 1024)
+        return launch_rec2c_f32_nt<ME, ME2, 512, 4>(m, a, mode, g, lds, mE, mC, s);
+    return launch_rec2c_f32_nt<ME, ME2, BLOCK, 3>(m, a, mode, g, lds, mE, mC, s);
 }
 
 // fp32-state meshes: K % 4 == 0, K <= 128, byte-offset records, records + own u rows of the largest launched patch within

@@ -19,7 +19,8 @@ struct StageArgs {
     double a, b;
     // Forward-Euler step in the default stage kernel (k_stage_rec2c modes 4 / 5; every other kernel ignores these):
     // pu/ph/ssh = current level, pu_out/ph_out/ssh_out = new level, a = dt, tendU/tendH, and the diagnostics below
-    const double *hEdgeOld;       // previous step's layerThicknessEdge (mode 4: MOKA_FE_STALE_HEDGE) or NULL (mode 5)
+    const double *hEdgeOld;       // previous step's layerThicknessEdge (modes 4, 6: MOKA_FE_STALE_HEDGE) or NULL (mode 5)
+    const double *hPrev;          // mode 6: the previous time level's layerThickness, which hEdgeOld is the interpolation of
     double *hEdgeNew, *F, *div;   // layerThicknessEdge, thicknessFlux, velocityDivCell
     const double *areaCell;
 };
@@ -61,9 +62,12 @@ struct OpArgs {
 hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream_t s);          // generic index kernel
 hipError_t launch_stage_col(const MeshDev &m, const StageArgs &a, hipStream_t s);               // plain column kernel
 hipError_t launch_stage_rec2c(const MeshDev &m, const StageArgs &a, hipStream_t s);
+bool rec2c_supported(const MeshDev &m);
 // fp32-state form (state pointers of StageArgs are float arrays); stage_f32_supported: can this mesh carry one
 bool stage_f32_supported(const MeshDev &m);
 hipError_t launch_stage_rec2c_f32(const MeshDev &m, const StageArgs &a, hipStream_t s);
+void set_f32_wide_modes(int mask);      // measurement: which modes of the fp32-storage kernel run as (512 threads, 4 waves per SIMD)
+int f32_wide_modes();
 hipError_t launch_update_ssh_f32(const MeshDev &m, const float *h, float *ssh, int nlev, int lpc, hipStream_t s);
 hipError_t launch_permute_rows_f32(void *dst, const void *src, const int32_t *n2o, int64_t n, int K, int to_device,
                                    hipStream_t s);

@@ -231,7 +231,8 @@ inline int colp_mode(const StageArgs &a)
     if (a.hEdgeNew) {     // Forward-Euler step (k_stage_rec2c and k_stage_rec2c_f32)
         const bool ok = a.pu_out && a.ph_out && a.ssh_out && a.tendU && a.tendH && a.F && a.div && a.areaCell && !a.cu && !a.ch &&
                         !a.nu_in && !a.nh_in && !a.nu_out && !a.nh_out;
-        return ok ? (a.hEdgeOld ? 4 : 5) : -1;
+        if (a.hPrev && !a.hEdgeOld) return -1;
+        return ok ? (a.hPrev ? 6 : a.hEdgeOld ? 4 : 5) : -1;
     }
     const bool outs = a.pu_out || a.ph_out || a.nu_out || a.nh_out;
     if (a.tendU && a.tendH && !outs && !a.ssh_out) return 0;

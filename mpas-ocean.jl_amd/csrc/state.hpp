@@ -59,8 +59,17 @@ struct moka_state {
     double *hEdge[2] = {nullptr, nullptr};   // [0] is Diag.layerThicknessEdge, [1] the write target of the next step
     double *F = nullptr, *div = nullptr, *vort = nullptr, *tendU = nullptr, *tendH = nullptr;
     LevelBufs rk[2];                  // RK4 provisional states (lazily allocated)
-    LevelBufs phys[4];                // the same four buffer sets by allocation: [0],[1] the time levels as created (lev[] swaps),
-                                      // [2],[3] = rk[]: what a neighbour rank addresses when it pushes halo rows (halo.hip)
+    LevelBufs spare;                  // third time-level set of the tuned Forward-Euler step (lazily allocated): the step writes
+                                      // the new level here, so the PREVIOUS level's layerThickness stays readable while it runs
+                                      // (k_stage_rec2c mode 6), and the three sets rotate: prev <- cur <- new <- old prev
+    static constexpr int NPHYS = 5;
+    LevelBufs phys[NPHYS];            // the same buffer sets by allocation: [0],[1] the time levels as created (lev[] swaps /
+                                      // rotates), [2],[3] = rk[], [4] = the Forward-Euler spare: what a neighbour rank addresses
+                                      // when it pushes halo rows (halo.hip)
+    // Diag.layerThicknessEdge (hEdge[0]) is, bit for bit, the interpolation of lev[0].layerThickness on every edge a launch
+    // of this state computes: true after a Forward-Euler step of all levels through the stage kernel, false after anything
+    // else that writes either array (uploads, RK4 steps, the piecewise reference calls, lazily produced diagnostics)
+    bool hEdgePrev = false;
     double *scalar = nullptr;         // 1 double (sum_sq result)
     bool sshConsistent = false;       // lev[1].ssh == ksum(lev[1].h) - restingThicknessSum
     // moka_step_rk4 ends with diagnostic_compute! of the new state and leaves the stage-4 tendencies in
@@ -100,6 +109,10 @@ int fail(moka_ctx *ctx, int code, const std::string &msg);
 int h2d(moka_ctx *ctx, void *dst, const void *src, size_t bytes);
 int alloc_field(moka_state *st, double **out, size_t elems, size_t elemBytes = sizeof(double));
 int ensure_rk_bufs(moka_state *st);
+int ensure_spare(moka_state *st);
+// the set a Forward-Euler step writes its new level to / the rotation that makes it the current level
+LevelBufs &fe_new_level(moka_state *st);
+void fe_rotate_levels(moka_state *st);
 int flush_lazy(moka_state *st, bool diag, bool tend);
 // one fused tendency / RK-stage launch over patches [pBegin, pBegin + pCount) (default: all) on the compute stream (or `on`)
 hipError_t run_stage(moka_state *st, const StageArgs &g, int pBegin = 0, int pCount = -1, hipStream_t on = nullptr, int tail = -1);
@@ -108,5 +121,6 @@ LevelBufs &rk4_stage_output(moka_state *st, int s);
 int rk4_begin(moka_state *st, const double **ssh0);
 void rk4_end(moka_state *st);
 FeArgs fe_args(moka_state *st, int ops, int flags, double dt);
+StageArgs fe_stage_args(moka_state *st, const FeArgs &a, int flags);
 
 }  // namespace mk

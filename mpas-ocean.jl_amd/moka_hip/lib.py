@@ -84,7 +84,7 @@ EXPORTS = [
     "moka_rk4_dist_stage_launch", "moka_rk4_dist_step", "moka_fe_dist_launch", "moka_fe_dist_end", "moka_fe_dist_step",
     "moka_set_nonlinear", "moka_last_fe_path", "moka_set_viscosity_del2", "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
     "moka_adjoint_download",
-    "moka_mark", "moka_marks_reset", "moka_marks_read", "moka_bw_probe", "moka_ctx_pci_bus_id", "moka_halo_set_acquire",
+    "moka_mark", "moka_marks_reset", "moka_marks_read", "moka_bw_probe", "moka_ctx_pci_bus_id", "moka_halo_set_acquire", "moka_set_tuning", "moka_get_tuning",
 ]
 
 
@@ -210,6 +210,8 @@ def lib():
     L.moka_marks_read.argtypes = [vp, C.c_int64, _f64p, C.POINTER(C.c_int64)]
     L.moka_bw_probe.argtypes = [vp, C.c_int64, C.c_int, _f64p]
     L.moka_ctx_pci_bus_id.argtypes = [vp, C.c_char_p, C.c_int32]
+    L.moka_set_tuning.argtypes = [C.c_int, C.c_int]
+    L.moka_get_tuning.argtypes = [C.c_int, C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -282,7 +284,7 @@ PLAN_ARRAYS = {  # name -> (id, dtype)
 
 class HaloPeerInfo(C.Structure):
     """moka_halo_peer_info: what a rank tells a neighbour so that the neighbour can push halo rows to it (plain data)."""
-    _fields_ = [("ipc", (C.c_ubyte * 64) * 12), ("ptr", C.c_uint64 * 12), ("flagPtr", C.c_uint64),
+    _fields_ = [("ipc", (C.c_ubyte * 64) * 15), ("ptr", C.c_uint64 * 15), ("flagPtr", C.c_uint64),
                 ("shmName", C.c_char * 64), ("dstCell", C.c_int32), ("dstEdge", C.c_int32), ("nCells", C.c_int32),
                 ("nEdges", C.c_int32), ("slot", C.c_int32), ("nNeighbors", C.c_int32), ("pid", C.c_int32),
                 ("device", C.c_int32), ("stateBytes", C.c_int32), ("nVertLevels", C.c_int32)]

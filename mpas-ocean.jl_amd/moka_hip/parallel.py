@@ -1078,22 +1078,22 @@ class LocalCluster:
     def step_fe(self, flags=L.FE_REFERENCE_COMPAT & ~L.FE_LEVEL1_ONLY):
         """The reference's Forward-Euler step on the partition: relativeVorticity first (it reads old-level rows of halo edges,
         which the neighbours' next step overwrites once this rank's push is signalled: csrc/halo.hip), boundary patches,
-        exchange of the new level (what = 4), interior patches meanwhile."""
+        exchange of the new level (what = 5), interior patches meanwhile."""
         lib = L.lib()
         for m in self.models:
             L.check(lib.moka_fe_dist_launch(m._halo, m.dt, int(flags), 2), m.backend._h)
             L.check(lib.moka_fe_dist_launch(m._halo, m.dt, int(flags), 0), m.backend._h)
         for m in self.models:
             if self.direct:
-                L.check(lib.moka_halo_push_begin(m._halo, 4), m.backend._h)
+                L.check(lib.moka_halo_push_begin(m._halo, 5), m.backend._h)
             else:
-                L.check(lib.moka_halo_pack(m._halo, 4, m.sendbuf.data_ptr()), m.backend._h)
+                L.check(lib.moka_halo_pack(m._halo, 5, m.sendbuf.data_ptr()), m.backend._h)
         for m in self.models:
             L.check(lib.moka_fe_dist_launch(m._halo, m.dt, int(flags), 1), m.backend._h)
         if self.direct:
             self._finish_direct()
         else:
-            self._exchange(4, pack=False)
+            self._exchange(5, pack=False)
         for m in self.models:
             L.check(lib.moka_fe_dist_end(m._halo), m.backend._h)
 

@@ -40,3 +40,21 @@ def test_rccl_probe_rendezvous_in_child_processes():
                        capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "PROBE 0 True" in r.stdout and "PROBE 1 True" in r.stdout
+
+
+def test_sysfs_and_statistics_helpers(tmp_path):
+    """The plain-file readers of the calibration record (no GPU involved) and the per-step statistics."""
+    assert bench._dpm_current("0: 500Mhz\n1: 2394Mhz *\n2: 2400Mhz\n") == 2394.0
+    assert bench._dpm_current("S: 94Mhz *\n0: 500Mhz\n1: 2400Mhz") == 94.0
+    assert bench._dpm_current("0: 2000Mhz *") == 2000.0
+    assert bench._dpm_current(None) is None and bench._dpm_current("garbage") is None
+    hw = tmp_path / "hwmon" / "hwmon3"
+    hw.mkdir(parents=True)
+    (hw / "power1_input").write_text("554000000\n")
+    assert bench._power_watts(str(tmp_path)) == 554.0
+    assert bench._power_watts(str(tmp_path / "nothing")) is None
+    d = bench.device_sysfs("ffff:ff:1f.7")                # not a device of this machine: reported, not raised
+    assert d["pci_bus_id"] == "ffff:ff:1f.7" and "note" in d
+    st = bench.step_stats([7.0, 6.8, 6.9, 9.5, 6.85])
+    assert st["median"] == 6.9 and st["min"] == 6.8 and st["max"] == 9.5 and st["n"] == 5
+    assert abs(st["mean"] - 7.41) < 1e-12

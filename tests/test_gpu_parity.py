@@ -237,7 +237,9 @@ def test_forward_euler_tuned_path_bitwise(backend, meshname, K, flags, P):
     for step in range(4):
         mk.ocn_timestep(np.array([dtv]), Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=flags)
         st.step_fe(dtv, flags)
-        assert L.lib().moka_last_fe_path(Prog._state._h) == 1          # the tuned kernel, not the generic one
+        # the tuned kernel, not the generic one; with the stale-thickness flag every step after the first forms that thickness
+        # from the previous level's layerThickness (path 2, k_stage_rec2c mode 6) instead of gathering the stored array
+        assert L.lib().moka_last_fe_path(Prog._state._h) == (2 if (flags & 1) and step > 0 else 1)
         if step in (0, 3):
             got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
             for k in exp:
@@ -256,6 +258,63 @@ def test_forward_euler_tuned_path_bitwise(backend, meshname, K, flags, P):
     st.step_fe(dtv, flags)
     assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.layerThickness[-1].get(), st.h[1])
     assert np.array_equal(Prog.ssh[-1].get(), st.ssh[1])
+    Prog._state.close(); Setup.mesh.close()
+
+
+@pytest.mark.parametrize("sbytes,K", [(8, 60), (4, 80)])
+def test_forward_euler_stale_thickness_from_the_previous_level(backend, sbytes, K):
+    """Mode 6 of the stage kernels (round 3): with MOKA_FE_STALE_HEDGE the flux thickness of step n is the layerThicknessEdge
+    step n - 1 stored = the interpolation of the layerThickness that is the PREVIOUS time level at step n.  The kernel forms it
+    from those rows (a third level set keeps them readable while the step writes the new level) -- but only while the stored
+    array really is that interpolation.  Whatever writes either array in between (an upload of layerThicknessEdge or of the
+    previous level's layerThickness, an RK4 step, advanceTimeLevels!, diagnostic_compute!) must send the next step back to the
+    stored array (path 1); results equal the oracle bit for bit throughout, previous time level included."""
+    mesh = get_mesh("ico16")
+    ssh, u, h, rest = random_state(mesh, K, 77)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True, state_bytes=sbytes)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h, mixed=sbytes == 4)
+    lib, hS = L.lib(), Prog._state._h
+    rng = np.random.default_rng(3)
+
+    def step(expect_path, flags=3):
+        L.check(lib.moka_step_fe(hS, 20.0, flags), backend._h)
+        st.step_fe(20.0, flags)
+        assert lib.moka_last_fe_path(hS) == expect_path, (lib.moka_last_fe_path(hS), expect_path)
+
+    def check(tag):
+        got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+        for k in exp:
+            assert np.array_equal(got[k], exp[k]), (k, tag)
+
+    step(1); step(2); step(2)
+    check("three steps")                                   # includes the previous time level (three rotating sets)
+    # the caller overwrites Diag.layerThicknessEdge: it is no longer the interpolation of anything
+    he = (1000.0 / K + rng.uniform(-1, 1, (mesh.nEdges, K)))
+    if sbytes == 4:
+        he = he.astype(np.float32).astype(np.float64)
+    Diag.layerThicknessEdge.set(he); st.hEdge[:] = he
+    step(1); step(2)
+    check("after an upload of layerThicknessEdge")
+    # the caller overwrites the previous level's layerThickness: the stored array is still what the reference would use
+    h0 = Prog.layerThickness[0].get() + 0.25
+    Prog.layerThickness[0].set(h0); st.h[0][:] = Prog.layerThickness[0].get()
+    step(1); step(2)
+    check("after an upload of the previous level")
+    # a step without the flag in between (path 1, mode 5) keeps the relation: the next stale step may use the previous level
+    step(1, flags=2); step(2, flags=3)
+    check("fresh, then stale")
+    if sbytes == 8:
+        mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=20.0))
+        mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4); st.step_rk4(20.0)
+        step(1); step(2)
+        check("after an RK4 step")
+        # advanceTimeLevels! on its own (time_integration.jl:10-40): previous <- current, under the stored layerThicknessEdge
+        mk.advanceTimeLevels(Prog)
+        for a in (st.ssh, st.u, st.h):
+            a[0][...] = a[1]
+        step(1); step(2)
+        check("after advanceTimeLevels!")
     Prog._state.close(); Setup.mesh.close()
 
 
@@ -279,7 +338,7 @@ def test_forward_euler_tuned_path_level_masks(backend):
         st.hEdge[:] = Diag.layerThicknessEdge.get(); st.vort[:] = Diag.relativeVorticity.get()
         for _ in range(3):
             L.check(L.lib().moka_step_fe(Prog._state._h, 20.0, flags), backend._h)
-            assert L.lib().moka_last_fe_path(Prog._state._h) == 1
+            assert L.lib().moka_last_fe_path(Prog._state._h) in (1, 2)
             st.step_fe(20.0, flags)
         got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
         for k in exp:
