@@ -307,6 +307,7 @@ def calibrate(backend, tag):
     cal["sysfs"] = device_sysfs(backend.pci_bus_id())
     cal["probe_s"] = round(time.time() - t0, 2)
     log(f"[bench] calibration {tag}: copy {cal['copy_GBs']:.0f} GB/s (mean {cal['copy_GBs_mean']:.0f}), read {cal['read_GBs']:.0f} GB/s, "
+        f"row gather {cal['gather_GBs']:.0f} GB/s, "
         f"sclk {cal['sysfs'].get('sclk_mhz')} MHz, {cal['sysfs'].get('power_w')} W")
     return cal
 
@@ -435,6 +436,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg of the default single-GPU run")
     ap.add_argument("--tend-iters", type=int, default=20)
+    ap.add_argument("--f32-wide-modes", type=int, default=None,
+                    help="A/B measurement: bit mask of the fp32-storage kernel's modes launched as 512-thread / 4-waves-per-SIMD workgroups (moka_set_tuning key 1)")
     ap.add_argument("--transport", default="auto", choices=["auto", "ipc", "nccl", "nccl-a2a", "nccl-p2p", "nccl-default-stream", "gloo"],
                     help="halo transport for N > 1: auto = the fastest of those that qualify on this node -- ipc (direct stores "
                          "into the neighbours' IPC-mapped fields over xGMI) and the RCCL forms (nccl-a2a, nccl-p2p); nccl = the RCCL "
@@ -496,6 +499,9 @@ def main():
     backend = mk.MokaHIP(device_index)
     if args.variant:
         backend.set_kernel_variant(args.variant)
+    if args.f32_wide_modes is not None:
+        from moka_hip import lib as _L
+        _L.check(_L.lib().moka_set_tuning(1, int(args.f32_wide_modes)))
 
     # which physical devices do the ranks of this launch really use?  (host, PCI bus id) per rank
     my_dev = (socket.gethostname(), backend.pci_bus_id())
@@ -614,8 +620,11 @@ def main():
     calibration = {"copy_GBs_before": cal_before["copy_GBs"], "copy_GBs_after": cal_after["copy_GBs"],
                    "copy_GBs_mean_before": cal_before["copy_GBs_mean"], "copy_GBs_mean_after": cal_after["copy_GBs_mean"],
                    "read_GBs": cal_before["read_GBs"], "read_GBs_after": cal_after["read_GBs"],
+                   "gather_GBs_before": cal_before["gather_GBs"], "gather_GBs_after": cal_after["gather_GBs"],
                    "probe": f"{PROBE_BYTES >> 30} GiB footprint (half source, half destination), 16 bytes per lane, best of 5 launches, "
-                            "HIP events on the compute stream; before = in front of the warm-up, after = behind the timed region",
+                            "HIP events on the compute stream; before = in front of the warm-up, after = behind the timed region; "
+                            "copy = one word per thread (bytes read + written), read = read-only sweep with nontemporal loads, "
+                            "gather = 480-byte rows in a scattered order, a half-wave per row (the stage kernels' pattern)",
                    "guide_copy_ceiling_GBs": HBM_COPY_GBS,
                    "ms_per_step_at_guide_ceiling": ms_per_step * copy_this_run / HBM_COPY_GBS,
                    "clocks_power_before": cal_before["sysfs"], "clocks_power_after": cal_after["sysfs"]}

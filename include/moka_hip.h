@@ -356,9 +356,10 @@ int moka_marks_reset(moka_ctx *ctx);
 int moka_marks_read(moka_ctx *ctx, int64_t capacity, double *ms, int64_t *n);
 /* Same-run bandwidth calibration (measurement): a plain 16-byte-per-lane copy and a read-only sweep over a buffer of `bytes`
  * (two halves), each launch timed with HIP events on the compute stream; gbs[0] = best copy rate (bytes read + written, GB/s),
- * gbs[1] = best read-only rate, gbs[2] = mean copy rate over the `iters` launches.  The buffer is kept for the next probe;
- * bytes = 0 frees it.  (MI355X_MICROARCH.md quotes 6.29 TB/s for such a copy; SURVEY.md 8d asks for both figures.) */
-int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[3]);
+ * gbs[1] = best read-only rate, gbs[2] = mean copy rate over the `iters` launches, gbs[3] = best rate of a scattered gather of
+ * 480-byte rows, a half-wave per row (the stage kernels' access pattern).  The buffer is kept for the next probe;
+ * bytes = 0 frees it.  (MI355X_MICROARCH.md quotes 6.29 TB/s for such a copy; SURVEY.md 8d asks for the copy and read figures.) */
+int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[4]);
 /* which kernel the last moka_step_fe of this state used: 1 = the tuned stage kernel (+ vertex pass), 2 = the same with the
  * stale layerThicknessEdge formed from the previous level's layerThickness instead of gathered (every MOKA_FE_STALE_HEDGE
  * step after the first of a run), 0 = the generic one-launch kernel, -1 = no Forward-Euler step yet.  For tests and

@@ -529,8 +529,9 @@ int moka_marks_read(moka_ctx *ctx, int64_t capacity, double *ms, int64_t *n)
 // read-only sweep (MI355X_MICROARCH.md quotes 6.29 TB/s for the copy).  `bytes` = total footprint (two halves: source and
 // destination); every launch is timed on its own with HIP events on the compute stream, the best of `iters` is reported
 // (the first launch also faults the pages in).  gbs[0] = copy, bytes read + written per second; gbs[1] = read-only sweep of both
-// halves; gbs[2] = mean copy rate over the launches.  bytes = 0 releases the buffers.
-int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[3])
+// halves; gbs[2] = mean copy rate over the launches; gbs[3] = gather of 480-byte rows in a scattered order, a half-wave per
+// row (the access pattern of the stage kernels at 60 layers).  bytes = 0 releases the buffers.
+int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[4])
 {
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -553,21 +554,24 @@ int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[3])
     }
     unsigned char *a = static_cast<unsigned char *>(ctx->bwBuf), *b = a + half;
     uint32_t *sink = reinterpret_cast<uint32_t *>(a + 2 * half);
-    double bestCopy = 0.0, bestRead = 0.0, sumCopy = 0.0;
-    for (int pass = 0; pass < 2; ++pass)
+    double bestCopy = 0.0, bestRead = 0.0, sumCopy = 0.0, bestGather = 0.0;
+    const uint32_t rowB = 480;
+    for (int pass = 0; pass < 3; ++pass)
         for (int i = 0; i < iters; ++i) {
             HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
             if (pass == 0) HIPCHK(ctx, launch_bw_copy(b, a, (int64_t)half, ctx->nCUs, s));
-            else HIPCHK(ctx, launch_bw_read(a, (int64_t)(2 * half), sink, ctx->nCUs, s));
+            else if (pass == 1) HIPCHK(ctx, launch_bw_read(a, (int64_t)(2 * half), sink, ctx->nCUs, s));
+            else HIPCHK(ctx, launch_bw_gather(a, (int64_t)(2 * half), rowB, sink, ctx->nCUs, s));
             HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
             HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
             float ms = 0.f;
             HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
             const double r = (double)(2 * half) / ((double)ms * 1e-3) / 1e9;
             if (pass == 0) { bestCopy = std::max(bestCopy, r); sumCopy += r; }
-            else bestRead = std::max(bestRead, r);
+            else if (pass == 1) bestRead = std::max(bestRead, r);
+            else bestGather = std::max(bestGather, (double)((2 * half) / rowB * rowB) / ((double)ms * 1e-3) / 1e9);
         }
-    gbs[0] = bestCopy; gbs[1] = bestRead; gbs[2] = sumCopy / iters;
+    gbs[0] = bestCopy; gbs[1] = bestRead; gbs[2] = sumCopy / iters; gbs[3] = bestGather;
     return MOKA_OK;
 }
 
@@ -1142,12 +1146,22 @@ int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flag
     auto one = [&]() { return integrator == MOKA_FORWARD_EULER ? moka_step_fe(st, dt, flags) : moka_step_rk4(st, dt); };
     int64_t done = 0;
     int rc;
-    // Launch-bound regime (small meshes): capture TWO consecutive steps (the time-level buffers swap every step, so
-    // the pointer pattern has period 2) into a hipGraph and replay it.  The first step runs eagerly: it may have to
-    // make ssh consistent and allocate the RK buffers, neither of which may happen during capture.
+    // Launch-bound regime (small meshes): capture one PERIOD of consecutive steps into a hipGraph and replay it.  The
+    // pointer pattern of a step repeats after 2 steps when the two time-level sets swap (RK4; Forward Euler without a spare
+    // set) and after 6 when a Forward-Euler step rotates three level sets (period 3) while layerThicknessEdge's two buffers
+    // swap (period 2).  The first step runs eagerly: it may have to make ssh consistent and allocate the RK buffers or the
+    // spare set, none of which may happen during capture -- and it brings the state into the steady regime every later step
+    // is launched in (e.g. layerThicknessEdge formed from the previous level from the second step on).
     if (nsteps >= 6) {
         if ((rc = one())) return rc;
         ++done;
+        if (integrator == MOKA_FORWARD_EULER && st->spare.ssh && nsteps - done >= 2) {   // one more: the regime settles with step 2
+            if ((rc = one())) return rc;
+            ++done;
+        }
+    }
+    const int period = (integrator == MOKA_FORWARD_EULER && st->spare.ssh) ? 6 : 2;
+    if (done > 0 && nsteps - done >= period) {
         HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
         // nothing lazy may fire inside the capture (pending diagnostics of an fp32-storage state cannot be produced: they
         // stay pending -- an RK4 run leaves them pending anyway, a Forward-Euler step has none)
@@ -1157,20 +1171,21 @@ int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flag
         hipStream_t s = st->ctx->stream;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             const bool d0 = st->diagDirty, t0 = st->tendDirty;
-            st->diagDirty = st->tendDirty = false;             // keep flush_lazy inside the steps a no-op while capturing
-            int rc1 = one();
-            st->diagDirty = st->tendDirty = false;
-            int rc2 = rc1 ? rc1 : one();
+            int rc2 = MOKA_OK;
+            for (int i = 0; i < period && rc2 == MOKA_OK; ++i) {
+                st->diagDirty = st->tendDirty = false;         // keep flush_lazy inside the steps a no-op while capturing
+                rc2 = one();
+            }
             hipError_t ec = hipStreamEndCapture(s, &graph);
             if (rc2 || ec != hipSuccess || !graph) {
                 if (graph) (void)hipGraphDestroy(graph);
                 st->diagDirty = d0; st->tendDirty = t0;
                 return rc2 ? rc2 : fail(st->ctx, MOKA_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
             }
-            // the capture recorded the launches but executed nothing: the host-side level swaps of the two steps cancel
+            // the capture recorded the launches but executed nothing: the host-side swaps / rotations of one period cancel
             if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                 hipError_t el = hipSuccess;
-                while (nsteps - done >= 2 && (el = hipGraphLaunch(exec, s)) == hipSuccess) done += 2;
+                while (nsteps - done >= period && (el = hipGraphLaunch(exec, s)) == hipSuccess) done += period;
                 (void)hipGraphExecDestroy(exec);
                 if (el != hipSuccess) {
                     (void)hipGraphDestroy(graph);

@@ -1152,43 +1152,80 @@ __global__ __launch_bounds__(BLOCK) void k_copy(double *dst, const double *src, 
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = src[i];
 }
 
-// Bandwidth probes for bench.py's same-run calibration (moka_bw_probe): 16 bytes per lane, four loads in flight per lane,
-// grid-stride.  k_bw_copy moves n 16-byte words from src to dst (2*16*n bytes of traffic), k_bw_read only reads them (the
-// XOR of everything read decides a store that never happens, so no load can be dropped).
-__global__ __launch_bounds__(BLOCK) void k_bw_copy(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int64_t n)
+// Bandwidth probes for bench.py's same-run calibration (moka_bw_probe).  Shapes chosen by measurement
+// (tools/micro/bw_shapes.hip, profiles/r03_variants.txt): one 16-byte word per thread with the grid covering the buffer copies
+// at 6.2 TB/s (the guide's 6.29 TB/s "float4 copy"), grid-stride forms of the same copy stay at 4.7-5.8; a read-only sweep
+// reaches 6.4 TB/s with plain loads and 7.0-7.1 with nontemporal ones.
+//   k_bw_copy   : dst[i] = src[i], n 16-byte words                                  (2 * 16 * n bytes of traffic)
+//   k_bw_read   : every word read once, four nontemporal loads in flight per lane; the XOR of everything read decides a
+//                 store that never happens, so no load can be dropped
+//   k_bw_gather : the access pattern of the stage kernels -- rows of `rowB` bytes (a half-wave per row, 16 bytes per lane,
+//                 four rows in flight) fetched in a scattered order: row (i * 40503 + 977 * (i >> 7)) mod nRows, i.e.
+//                 consecutive half-waves touch rows far apart, every row about once
+typedef unsigned int bw_v4u __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(BLOCK) void k_bw_copy(bw_v4u *__restrict__ dst, const bw_v4u *__restrict__ src, int64_t n)
 {
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n; i += stride) dst[i] = src[i];
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
-__global__ __launch_bounds__(BLOCK) void k_bw_read(const uint4 *__restrict__ src, int64_t n, uint32_t *sink)
+__global__ __launch_bounds__(BLOCK) void k_bw_read(const bw_v4u *__restrict__ src, int64_t n, uint32_t *sink)
 {
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * (4 * BLOCK) + threadIdx.x;
     uint32_t acc = 0;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = b + j * BLOCK;
+        if (i < n) {
+            const bw_v4u a = __builtin_nontemporal_load(&src[i]);
+            acc ^= a.x ^ a.y ^ a.z ^ a.w;
+        }
     }
-    for (; i < n; i += stride) { const uint4 a = src[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
     if (acc == 0x9E3779B9u) *sink = acc;          // the buffers hold a byte pattern whose XOR never gives this
 }
 
-hipError_t launch_bw_copy(void *dst, const void *src, int64_t bytes, int nCUs, hipStream_t s)
+__global__ __launch_bounds__(BLOCK) void k_bw_gather(const unsigned char *__restrict__ src, int64_t nRows, uint32_t rowB, int64_t nFetch,
+                                                    uint32_t *sink)
 {
-    hipLaunchKernelGGL(k_bw_copy, dim3((unsigned)(nCUs * 8)), dim3(BLOCK), 0, s, static_cast<uint4 *>(dst),
-                       static_cast<const uint4 *>(src), bytes / 16);
+    const int l = threadIdx.x & 31;
+    const int64_t hw = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 5, nhw = ((int64_t)gridDim.x * BLOCK) >> 5;
+    const bool act = (uint32_t)l * 16u < rowB;
+    uint32_t acc = 0;
+    for (int64_t i = hw * 4; i < nFetch; i += nhw * 4) {
+        bw_v4u v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t f = i + j < nFetch ? i + j : i;
+            const int64_t r = (f * 40503 + 977 * (f >> 7)) % nRows;
+            v[j] = act ? *reinterpret_cast<const bw_v4u *>(src + r * rowB + (size_t)l * 16u) : bw_v4u{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+    }
+    if (acc == 0x9E3779B9u) *sink = acc;
+}
+
+hipError_t launch_bw_copy(void *dst, const void *src, int64_t bytes, int, hipStream_t s)
+{
+    const int64_t n = bytes / 16;
+    hipLaunchKernelGGL(k_bw_copy, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, static_cast<bw_v4u *>(dst),
+                       static_cast<const bw_v4u *>(src), n);
     return hipGetLastError();
 }
 
-hipError_t launch_bw_read(const void *src, int64_t bytes, uint32_t *sink, int nCUs, hipStream_t s)
+hipError_t launch_bw_read(const void *src, int64_t bytes, uint32_t *sink, int, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_bw_read, dim3((unsigned)(nCUs * 8)), dim3(BLOCK), 0, s, static_cast<const uint4 *>(src), bytes / 16, sink);
+    const int64_t n = bytes / 16;
+    hipLaunchKernelGGL(k_bw_read, dim3((unsigned)((n + 4 * BLOCK - 1) / (4 * BLOCK))), dim3(BLOCK), 0, s, static_cast<const bw_v4u *>(src), n, sink);
+    return hipGetLastError();
+}
+
+// every row of the buffer (bytes / rowB of them) fetched about once, in the scattered order above
+hipError_t launch_bw_gather(const void *src, int64_t bytes, uint32_t rowB, uint32_t *sink, int nCUs, hipStream_t s)
+{
+    const int64_t nRows = bytes / rowB;
+    hipLaunchKernelGGL(k_bw_gather, dim3((unsigned)(nCUs * 16)), dim3(BLOCK), 0, s, static_cast<const unsigned char *>(src), nRows, rowB, nRows, sink);
     return hipGetLastError();
 }
 

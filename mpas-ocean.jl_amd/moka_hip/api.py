@@ -91,9 +91,10 @@ class MokaHIP:
 
     def bw_probe(self, nbytes=4 << 30, iters=5):
         """Same-run bandwidth calibration (moka_bw_probe): {copy_GBs, read_GBs, copy_GBs_mean} of this device right now."""
-        g = (C.c_double * 3)()
+        g = (C.c_double * 4)()
         L.check(L.lib().moka_bw_probe(self._h, int(nbytes), int(iters), g), self._h)
-        return {"copy_GBs": float(g[0]), "read_GBs": float(g[1]), "copy_GBs_mean": float(g[2])} if nbytes > 0 else {}
+        return {"copy_GBs": float(g[0]), "read_GBs": float(g[1]), "copy_GBs_mean": float(g[2]),
+                "gather_GBs": float(g[3])} if nbytes > 0 else {}
 
     def pci_bus_id(self) -> str:
         buf = C.create_string_buffer(32)

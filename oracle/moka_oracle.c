@@ -82,6 +82,80 @@ void oracle_curl_on_vertex(const oracle_mesh *m, double *curl, const double *vec
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Reverse mode of the three stand-alone operators: what the reference obtains from Enzyme in
+ * test/enzyme/test_Enzyme_Operators.jl:42-63 (gradient) and :137-162 (divergence), written out by hand.
+ * Conventions are Enzyme's for in-place kernels with Duplicated arguments: the shadow of an input is
+ * ACCUMULATED into (d_in += J^T d_out); the shadow of an output the kernel overwrites is ZERO afterwards;
+ * the shadow of the curl output, which the kernel accumulates into (:142), stays as it is.
+ * Every sum has a fixed order (gather form where the transposed stencil is a per-entity list), so that the
+ * HIP twins (moka_*_vjp) can be compared bit for bit; the functions themselves are pinned the way the
+ * reference pins Enzyme: against central differences (eps = 1e-8 relative, atol = 1e-6; :102,127,196,221)
+ * and by the adjoint identity <J x, y> = <x, J^T y> (tests/test_oracle_operators.py).
+ * Forward mode needs no twin: the operators are linear, the tangent of the output is the operator applied
+ * to the tangent of the input (oracle_gradient_on_edge / _divergence_on_cell / _curl_on_vertex).
+ * ------------------------------------------------------------------------------------------ */
+/* Grad[k,e] = (S[k,c2] - S[k,c1]) / dcEdge[e]  =>  dS[k,c] += sum_i sign[i,c] * (dGrad[k,e_i] / dcEdge[e_i]),
+ * i in edgesOnCell order, sign = edgeSignOnCell (-1 where c is cellsOnEdge[1,e], HorzMesh.jl:302-306); then dGrad = 0 */
+void oracle_gradient_on_edge_vjp(const oracle_mesh *m, double *dScalar, double *dGrad)
+{
+    const int K = m->nVertLevels;
+    PFOR
+    for (int64_t c = 1; c <= m->nCells; ++c)
+        for (int k = 1; k <= K; ++k) {
+            double a = dScalar[IX(k, c, K)];
+            for (int i = 1; i <= m->nEdgesOnCell[c - 1]; ++i) {
+                int32_t e = m->edgesOnCell[IX(i, c, m->maxEdges)];
+                a += (double)m->edgeSignOnCell[IX(i, c, m->maxEdges)] * (dGrad[IX(k, e, K)] / m->dcEdge[e - 1]);
+            }
+            dScalar[IX(k, c, K)] = a;
+        }
+    memset(dGrad, 0, sizeof(double) * (size_t)K * (size_t)m->nEdges);
+}
+
+/* edgeSignOnCell of edge e in cell c (0 if c does not list e) */
+static double sign_of_edge_in_cell(const oracle_mesh *m, int32_t e, int32_t c)
+{
+    for (int i = 1; i <= m->nEdgesOnCell[c - 1]; ++i)
+        if (m->edgesOnCell[IX(i, c, m->maxEdges)] == e) return (double)m->edgeSignOnCell[IX(i, c, m->maxEdges)];
+    return 0.0;
+}
+
+/* P2^T: dTemp[k,e] -= sign(e in c1) * (dDiv[k,c1] / areaCell[c1]); the same for c2 (cellsOnEdge order); dDiv = 0
+ * P1^T: dVec[k,e] += dTemp[k,e] * dvEdge[e]; dTemp = 0                                  (Operators.jl:18,34-42) */
+void oracle_divergence_on_cell_vjp(const oracle_mesh *m, double *dVec, double *dTemp, double *dDiv)
+{
+    const int K = m->nVertLevels;
+    PFOR
+    for (int64_t e = 1; e <= m->nEdges; ++e) {
+        const int32_t c1 = m->cellsOnEdge[IX(1, e, 2)], c2 = m->cellsOnEdge[IX(2, e, 2)];
+        const double s1 = sign_of_edge_in_cell(m, (int32_t)e, c1), s2 = sign_of_edge_in_cell(m, (int32_t)e, c2);
+        for (int k = 1; k <= K; ++k) {
+            double t = dTemp[IX(k, e, K)];
+            t -= s1 * (dDiv[IX(k, c1, K)] / m->areaCell[c1 - 1]);
+            t -= s2 * (dDiv[IX(k, c2, K)] / m->areaCell[c2 - 1]);
+            dVec[IX(k, e, K)] += t * m->dvEdge[e - 1];
+            dTemp[IX(k, e, K)] = 0.0;
+        }
+    }
+    memset(dDiv, 0, sizeof(double) * (size_t)K * (size_t)m->nCells);
+}
+
+/* Curl[k,v] += dcEdge[e]*invA*Vec[k,e]*sign[j,v]  =>  dVec[k,e] += (dcEdge[e]*invA*sign[j,v]) * dCurl[k,v], in ascending
+ * (v, j) order (a serial scatter: the order the gather lists of the HIP twin are sorted in); dCurl stays (Operators.jl:142) */
+void oracle_curl_on_vertex_vjp(const oracle_mesh *m, double *dVec, const double *dCurl)
+{
+    const int K = m->nVertLevels;
+    for (int64_t v = 1; v <= m->nVertices; ++v) {
+        const double invA = 1.0 / m->areaTriangle[v - 1];
+        for (int j = 1; j <= m->vertexDegree; ++j) {
+            const int32_t e = m->edgesOnVertex[IX(j, v, m->vertexDegree)];
+            const double w = m->dcEdge[e - 1] * invA * (double)m->edgeSignOnVertex[IX(j, v, m->edgeSignOnVertexLD)];
+            for (int k = 1; k <= K; ++k) dVec[IX(k, e, K)] += w * dCurl[IX(k, v, K)];
+        }
+    }
+}
+
 /* K5  interpolateCell2Edge                                   src/ocn/Operators.jl:179-222
  *   edge[k,e] = 0.5 * (cell[k,c1] + cell[k,c2]), reference: k = 1 only (:207-208).
  * nlev = 1 reproduces the reference; nlev = K is the N3 extension. */

@@ -58,6 +58,11 @@ int    oracle_get_threads(void);
 void oracle_divergence_on_cell(const oracle_mesh *m, double *div, const double *vecEdge, double *temp);
 void oracle_gradient_on_edge(const oracle_mesh *m, double *grad, const double *scalarCell);
 void oracle_curl_on_vertex(const oracle_mesh *m, double *curl, const double *vecEdge);
+/* reverse mode of the three (test/enzyme/test_Enzyme_Operators.jl): input shadows accumulate, overwritten-output shadows are
+ * zeroed, the accumulated-into curl shadow stays; forward mode = the operators themselves applied to tangents (linear) */
+void oracle_gradient_on_edge_vjp(const oracle_mesh *m, double *dScalarCell, double *dGradEdge);
+void oracle_divergence_on_cell_vjp(const oracle_mesh *m, double *dVecEdge, double *dTempEdge, double *dDivCell);
+void oracle_curl_on_vertex_vjp(const oracle_mesh *m, double *dVecEdge, const double *dCurlVertex);
 void oracle_interpolate_cell2edge(const oracle_mesh *m, double *edgeValue, const double *cellValue, int nlev);
 void oracle_zero_out(double *a, int64_t n, int K, int nlev);
 

@@ -66,6 +66,9 @@ def lib():
         L.oracle_divergence_on_cell.argtypes = [mp, _f64p, _f64p, _f64p]
         L.oracle_gradient_on_edge.argtypes = [mp, _f64p, _f64p]
         L.oracle_curl_on_vertex.argtypes = [mp, _f64p, _f64p]
+        L.oracle_gradient_on_edge_vjp.argtypes = [mp, _f64p, _f64p]
+        L.oracle_divergence_on_cell_vjp.argtypes = [mp, _f64p, _f64p, _f64p]
+        L.oracle_curl_on_vertex_vjp.argtypes = [mp, _f64p, _f64p]
         L.oracle_interpolate_cell2edge.argtypes = [mp, _f64p, _f64p, C.c_int]
         L.oracle_thickness_flux.argtypes = [mp, _f64p, _f64p, _f64p, C.c_int]
         L.oracle_normal_velocity_tendency.argtypes = [mp, _f64p, _f64p, _f64p, C.c_int]
@@ -153,6 +156,16 @@ class OracleMesh:
         curl = np.zeros((self.mesh.nVertices, self.K)) if curl is None else curl
         lib().oracle_curl_on_vertex(self.ref, _p(curl), _p(vecEdge))
         return curl
+
+    # reverse mode of the operators (Enzyme's in-place conventions: see moka_oracle.c); arrays are modified in place
+    def gradient_on_edge_vjp(self, dScalar, dGrad):
+        lib().oracle_gradient_on_edge_vjp(self.ref, _p(dScalar), _p(dGrad))
+
+    def divergence_on_cell_vjp(self, dVec, dTemp, dDiv):
+        lib().oracle_divergence_on_cell_vjp(self.ref, _p(dVec), _p(dTemp), _p(dDiv))
+
+    def curl_on_vertex_vjp(self, dVec, dCurl):
+        lib().oracle_curl_on_vertex_vjp(self.ref, _p(dVec), _p(_c(dCurl, np.float64)))
 
     def interpolate_cell2edge(self, cellValue, nlev=None, out=None):
         cellValue = _c(cellValue, np.float64)

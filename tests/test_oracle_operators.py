@@ -106,3 +106,97 @@ def test_ksum_order_against_a_plain_serial_sum():
             assert abs(got - serial) <= 0.5 * K * ulp
             assert abs(got - serial) <= 1e-13 * abs(serial)
     assert worst >= 1.0                                      # they do differ in the last place: the order is a decision
+
+
+# ------------------------------------------------------------------------------------------------
+# Reverse and forward mode of the stand-alone operators: the reference's test/enzyme/test_Enzyme_Operators.jl restated for
+# the oracle twins.  Same mesh (48 x 48 planar periodic), same analytic fields, the same entries (input kBegin, output
+# kEnd, linear indices into (nVertLevels, n) arrays), the same check: AD against central differences with a relative
+# eps = 1e-8 and atol = 1e-6 (:102-127, :196-221).
+# ------------------------------------------------------------------------------------------------
+def _lin(a, idx1):
+    """Julia linear index (1-based) into a (nVertLevels, n) array == flat index into our (n, K) C-order array."""
+    return np.unravel_index(idx1 - 1, a.shape)
+
+
+def _fd(fun, x, k_in, k_out, eps=1e-8):
+    xp, xm = x.copy(), x.copy()
+    xp[k_in] += abs(xp[k_in]) * eps
+    xm[k_in] -= abs(xm[k_in]) * eps
+    return (fun(xp)[k_out] - fun(xm)[k_out]) / (xp[k_in] - xm[k_in])
+
+
+@pytest.mark.parametrize("K", [1, 10])
+def test_gradient_reverse_and_forward_mode_against_central_differences(K):
+    g = GOLD["mesh"]
+    mesh = meshgen.planar_hex_mesh(g["nx"], g["ny"], g["dc"])
+    om, ts = orc.OracleMesh(mesh, K), PlanarSetup(mesh, K)
+    scalar = ts.h()
+    for k_begin, k_end in ((1, 1), (K + 1, 3 * K + 1), (2 * K, 4 * K)):       # (1, 1) is the reference's pair (:58-59)
+        kin, kout = _lin(scalar, k_begin), _lin(np.zeros((mesh.nEdges, K)), k_end)
+        # reverse: d_grad[kEnd] = 1 -> d_scalar[kBegin]                                  (:58-68)
+        d_grad, d_scalar = np.zeros((mesh.nEdges, K)), np.zeros((mesh.nCells, K))
+        d_grad[kout] = 1.0
+        om.gradient_on_edge_vjp(d_scalar, d_grad)
+        rev = d_scalar[kin]
+        assert not d_grad.any()                                                          # overwritten output: shadow zeroed
+        # forward: d_scalar[kBegin] = 1 -> d_grad[kEnd] (the operator is linear: its tangent map is itself)   (:80-99)
+        t = np.zeros((mesh.nCells, K)); t[kin] = 1.0
+        fwd = om.gradient_on_edge(t)[kout]
+        fd = _fd(om.gradient_on_edge, scalar, kin, kout)
+        assert abs(rev - fd) < 1e-6 and abs(fwd - fd) < 1e-6, (k_begin, k_end, rev, fwd, fd)
+        if k_begin == 1:
+            assert rev != 0.0                                                            # cell 1 is a cell of edge 1 on this mesh
+
+
+@pytest.mark.parametrize("K", [1, 10])
+def test_divergence_reverse_and_forward_mode_against_central_differences(K):
+    g = GOLD["mesh"]
+    mesh = meshgen.planar_hex_mesh(g["nx"], g["ny"], g["dc"])
+    om, ts = orc.OracleMesh(mesh, K), PlanarSetup(mesh, K)
+    vec = ts.F_edge()
+    for k_begin, k_end in ((2, 1), (1, 1), (2 * K + 1, 1), (5 * K, K)):                  # (2, 1) is the reference's pair (:155-156)
+        kin, kout = _lin(vec, k_begin), _lin(np.zeros((mesh.nCells, K)), k_end)
+        d_div, d_vec, d_temp = np.zeros((mesh.nCells, K)), np.zeros((mesh.nEdges, K)), np.zeros((mesh.nEdges, K))
+        d_div[kout] = 1.0
+        om.divergence_on_cell_vjp(d_vec, d_temp, d_div)
+        rev = d_vec[kin]
+        assert not d_div.any() and not d_temp.any()
+        t = np.zeros((mesh.nEdges, K)); t[kin] = 1.0
+        fwd = om.divergence_on_cell(t)[kout]
+        fd = _fd(om.divergence_on_cell, vec, kin, kout)
+        assert abs(rev - fd) < 1e-6 and abs(fwd - fd) < 1e-6, (k_begin, k_end, rev, fwd, fd)
+        if (k_begin, k_end) == (2, 1) and K == 1:
+            assert rev != 0.0                                                            # edge 2 is an edge of cell 1 on this mesh
+
+
+def test_operator_transposes_satisfy_the_adjoint_identity():
+    """<J x, y> == <x, J^T y> for grad, div and curl on a sphere with pentagons (random x, y, K = 5): pins the three
+    transposes independently of finite differences; accumulation conventions included (shadows of inputs add up)."""
+    mesh = meshgen.icosahedral_mesh(6)
+    K = 5
+    om = orc.OracleMesh(mesh, K)
+    rng = np.random.default_rng(8)
+    xc, ye = rng.standard_normal((mesh.nCells, K)), rng.standard_normal((mesh.nEdges, K))
+    xe, yc, yv = rng.standard_normal((mesh.nEdges, K)), rng.standard_normal((mesh.nCells, K)), rng.standard_normal((mesh.nVertices, K))
+    rel = lambda a, b: abs(a - b) / max(abs(a), abs(b))
+    # gradient (accumulation: the shadow of the input adds up)
+    d_s, d_g = np.zeros((mesh.nCells, K)), ye.copy()
+    om.gradient_on_edge_vjp(d_s, d_g)
+    assert rel(np.vdot(om.gradient_on_edge(xc), ye), np.vdot(xc, d_s)) < 1e-12
+    twice, d_g = d_s.copy(), ye.copy()
+    om.gradient_on_edge_vjp(twice, d_g)
+    assert np.allclose(twice, 2 * d_s, rtol=1e-14, atol=0)
+    # divergence (through temp)
+    d_v, d_t, d_d = np.zeros((mesh.nEdges, K)), np.zeros((mesh.nEdges, K)), yc.copy()
+    om.divergence_on_cell_vjp(d_v, d_t, d_d)
+    assert rel(np.vdot(om.divergence_on_cell(xe), yc), np.vdot(xe, d_v)) < 1e-12
+    # a non-zero temp shadow is carried through P1^T as well: d_vec += d_temp * dvEdge
+    d_v2, d_t2, d_d2 = np.zeros((mesh.nEdges, K)), ye.copy(), np.zeros((mesh.nCells, K))
+    om.divergence_on_cell_vjp(d_v2, d_t2, d_d2)
+    assert np.array_equal(d_v2, ye * mesh.dvEdge[:, None]) and not d_t2.any()
+    # curl (accumulating primal: the output's shadow stays)
+    d_v, d_c = np.zeros((mesh.nEdges, K)), yv.copy()
+    om.curl_on_vertex_vjp(d_v, d_c)
+    assert np.array_equal(d_c, yv)
+    assert rel(np.vdot(om.curl_on_vertex(xe), yv), np.vdot(xe, d_v)) < 1e-12
