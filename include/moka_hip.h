@@ -189,6 +189,21 @@ int moka_curl_on_vertex(moka_mesh *mesh, const double *vecEdge, double *curlVert
 /* interpolateCell2Edge!(e, c, Mesh)         src/ocn/Operators.jl:179-222; nlev = 1 is the reference (level 1 only) */
 int moka_interpolate_cell2edge(moka_mesh *mesh, const double *cellValue, double *edgeValue, int nlev);
 
+/* Reverse (vjp) and forward (jvp) mode of the three operators -- what the reference obtains from Enzyme in
+ * test/enzyme/test_Enzyme_Operators.jl:42-131 (gradient) and :137-225 (divergence); the rules a maintainer registers are in
+ * julia/MokaHIPEnzymeExt.jl.  Host arrays of the primal's shapes.  Shadow conventions are Enzyme's for in-place kernels with
+ * Duplicated arguments: vjp ACCUMULATES into the shadow of the input and ZEROES the shadow of an output the primal overwrites
+ * (grad; div and temp); the shadow of the curl output, which the primal accumulates into, is left as it is.  The operators
+ * are linear, so jvp is the operator applied to the tangent of the input (curl: accumulated onto the tangent of the output).
+ * Transposes are gathers with a fixed summation order (oracle twins: oracle_*_vjp, bit-identical). */
+int moka_gradient_on_edge_vjp(moka_mesh *mesh, double *dGradEdge /* in, zeroed */, double *dScalarCell /* += */);
+int moka_gradient_on_edge_jvp(moka_mesh *mesh, const double *dScalarCell, double *dGradEdge);
+int moka_divergence_on_cell_vjp(moka_mesh *mesh, double *dDivCell /* in, zeroed */, double *dVecEdge /* += */,
+                                double *dTempEdge /* (opt) in, zeroed */);
+int moka_divergence_on_cell_jvp(moka_mesh *mesh, const double *dVecEdge, double *dTempEdge /* (opt) */, double *dDivCell);
+int moka_curl_on_vertex_vjp(moka_mesh *mesh, const double *dCurlVertex, double *dVecEdge /* += */);
+int moka_curl_on_vertex_jvp(moka_mesh *mesh, const double *dVecEdge, double *dCurlVertex /* += */);
+
 /* ---- state ----------------------------------------------------------------------------- */
 /* PrognosticVars/DiagnosticVars/TendencyVars constructors with KA.zeros on the backend
  * (PrognosticVars.jl:59-106, DiagnosticVars.jl:75-99, TendencyVars.jl:51-67); nTimeLevels = 2 */

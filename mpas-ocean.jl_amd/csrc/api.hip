@@ -772,6 +772,114 @@ int moka_curl_on_vertex(moka_mesh *mesh, const double *vecEdge, double *curlVert
     return run_operator(mesh, OP_CURL, 0, vecEdge, MOKA_EDGE, curlVertex, MOKA_VERTEX, true);
 }
 
+// ---------------------------------------------------------------------------------------------
+// reverse and forward mode of the stand-alone operators (test/enzyme/test_Enzyme_Operators.jl:42-131, 137-225).
+// The operators are linear: forward mode is the operator applied to the tangent, reverse mode its transpose applied to the
+// cotangent.  Shadow conventions are Enzyme's for in-place kernels with Duplicated arguments: the shadow of an input is
+// accumulated into, the shadow of an output the kernel overwrites is zero afterwards, the shadow of the (accumulated-into)
+// curl output stays.  Transposes are gathers with a fixed order (oracle twins: oracle_*_vjp).
+// ---------------------------------------------------------------------------------------------
+static int ensure_op_transposes(moka_mesh *m)
+{
+    if (m->opESign) return MOKA_OK;
+    const Plan &p = m->plan;
+    std::vector<std::vector<std::pair<std::pair<int32_t, int32_t>, int32_t>>> lists(p.nE);     // ((caller's vertex, slot), new vertex)
+    for (int v = 0; v < p.nV; ++v)
+        for (int j = 0; j < p.VD; ++j) {
+            const int e = p.eov[(size_t)v * p.VD + j];
+            if (e >= 0) lists[e].push_back({{p.vertN2O[v], j}, v});
+        }
+    int W = 1;
+    for (auto &l : lists) { std::sort(l.begin(), l.end()); W = std::max(W, (int)l.size()); }
+    std::vector<int32_t> tv((size_t)p.nE * W, -1);
+    std::vector<double> tc((size_t)p.nE * W, 0.0), es((size_t)p.nE * 2, 0.0);
+    for (int e = 0; e < p.nE; ++e) {
+        for (size_t q = 0; q < lists[e].size(); ++q) {
+            const int v = lists[e][q].second, j = lists[e][q].first.second;
+            tv[(size_t)e * W + q] = v;
+            tc[(size_t)e * W + q] = p.cv[(size_t)v * p.VD + j];
+        }
+        for (int q = 0; q < 2; ++q) {
+            const int c = p.ehdr[(size_t)e * 4 + q];
+            for (int i = 0; i < p.ME; ++i)
+                if (p.eoc[(size_t)c * p.ME + i] == e) { es[(size_t)e * 2 + q] = p.sdv[(size_t)c * p.ME + i] < 0.0 ? -1.0 : 1.0; break; }
+        }
+    }
+    int rc;
+    if ((rc = upload_vec(m, tv, &m->opTVert)) || (rc = upload_vec(m, tc, &m->opTCoef))) return rc;
+    if ((rc = upload_vec(m, es, &m->opESign))) return rc;
+    m->opTW = W;
+    return MOKA_OK;
+}
+
+int moka_gradient_on_edge_vjp(moka_mesh *m, double *dGradEdge, double *dScalarCell)
+{
+    if (!m || !dGradEdge || !dScalarCell) return fail(m ? m->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    const Plan &p = m->plan;
+    int rc = ensure_op_bufs(m);
+    if (rc) return rc;
+    HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
+    if ((rc = put_rows(m, m->opBuf[0], dGradEdge, MOKA_EDGE, p.nE, p.K))) return rc;
+    if ((rc = put_rows(m, m->opBuf[1], dScalarCell, MOKA_CELL, p.nC, p.K))) return rc;
+    OpArgs a{OP_GRAD_T, 0, m->opBuf[0], m->opBuf[1]};
+    HIPCHK(m->ctx, launch_operator(m->dev, a, m->lpc, m->ctx->stream));
+    if ((rc = get_rows(m, dScalarCell, m->opBuf[1], MOKA_CELL, p.nC, p.K))) return rc;
+    std::memset(dGradEdge, 0, sizeof(double) * (size_t)p.K * p.nE);       // the overwritten output's shadow
+    return MOKA_OK;
+}
+
+int moka_gradient_on_edge_jvp(moka_mesh *m, const double *dScalarCell, double *dGradEdge)
+{
+    return moka_gradient_on_edge(m, dScalarCell, dGradEdge);              // linear: the tangent map is the operator
+}
+
+int moka_divergence_on_cell_vjp(moka_mesh *m, double *dDivCell, double *dVecEdge, double *dTempEdge)
+{
+    if (!m || !dDivCell || !dVecEdge) return fail(m ? m->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    const Plan &p = m->plan;
+    int rc = ensure_op_bufs(m);
+    if (rc) return rc;
+    HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
+    if ((rc = ensure_op_transposes(m))) return rc;
+    if ((rc = put_rows(m, m->opBuf[0], dDivCell, MOKA_CELL, p.nC, p.K))) return rc;
+    if ((rc = put_rows(m, m->opBuf[1], dVecEdge, MOKA_EDGE, p.nE, p.K))) return rc;
+    if (dTempEdge && (rc = put_rows(m, m->opBuf[3], dTempEdge, MOKA_EDGE, p.nE, p.K))) return rc;
+    OpArgs a{OP_DIV_T, 0, m->opBuf[0], m->opBuf[1]};
+    a.in2 = dTempEdge ? m->opBuf[3] : nullptr;
+    a.auxD = m->opESign;
+    HIPCHK(m->ctx, launch_operator(m->dev, a, m->lpc, m->ctx->stream));
+    if ((rc = get_rows(m, dVecEdge, m->opBuf[1], MOKA_EDGE, p.nE, p.K))) return rc;
+    std::memset(dDivCell, 0, sizeof(double) * (size_t)p.K * p.nC);
+    if (dTempEdge) std::memset(dTempEdge, 0, sizeof(double) * (size_t)p.K * p.nE);
+    return MOKA_OK;
+}
+
+int moka_divergence_on_cell_jvp(moka_mesh *m, const double *dVecEdge, double *dTempEdge, double *dDivCell)
+{
+    return moka_divergence_on_cell(m, dVecEdge, dTempEdge, dDivCell);
+}
+
+int moka_curl_on_vertex_vjp(moka_mesh *m, const double *dCurlVertex, double *dVecEdge)
+{
+    if (!m || !dCurlVertex || !dVecEdge) return fail(m ? m->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    const Plan &p = m->plan;
+    int rc = ensure_op_bufs(m);
+    if (rc) return rc;
+    HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
+    if ((rc = ensure_op_transposes(m))) return rc;
+    if ((rc = put_rows(m, m->opBuf[0], dCurlVertex, MOKA_VERTEX, p.nV, p.K))) return rc;
+    if ((rc = put_rows(m, m->opBuf[1], dVecEdge, MOKA_EDGE, p.nE, p.K))) return rc;
+    OpArgs a{OP_CURL_T, 0, m->opBuf[0], m->opBuf[1]};
+    a.auxI = m->opTVert; a.auxD = m->opTCoef; a.auxW = m->opTW;
+    HIPCHK(m->ctx, launch_operator(m->dev, a, m->lpc, m->ctx->stream));
+    return get_rows(m, dVecEdge, m->opBuf[1], MOKA_EDGE, p.nE, p.K);       // the curl shadow stays: the primal accumulates
+}
+
+int moka_curl_on_vertex_jvp(moka_mesh *m, const double *dVecEdge, double *dCurlVertex)
+{
+    return moka_curl_on_vertex(m, dVecEdge, dCurlVertex);                 // accumulates, like the primal
+}
+
 int moka_divergence_on_cell(moka_mesh *m, const double *vecEdge, double *tempEdge, double *divCell)
 {
     if (!m || !vecEdge || !divCell) return fail(m ? m->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");

@@ -1035,6 +1035,48 @@ __global__ __launch_bounds__(BLOCK) void k_operator(const MeshDev m, const OpArg
                 a.out[off] = cacc;
             }
         }
+    } else if (a.op == OP_GRAD_T) {
+        // transpose of GradientOnEdge (Operators.jl:97): dS[k,c] += sum_i sign[i,c] * (dG[k,e_i] / dcEdge[e_i]), edgesOnCell order
+        const int c0 = m.patchCellStart[p], c1 = m.patchCellStart[p + 1];
+        for (int c = c0 + grp; c < c1; c += NG) {
+            for (int k = l; k < K; k += LPC) {
+                double acc = a.out[(size_t)c * K + k];
+                for (int i = 0; i < m.ME; ++i) {
+                    const int e = m.eoc[(size_t)c * m.ME + i];
+                    if (e >= 0) acc += (m.sdv[(size_t)c * m.ME + i] < 0.0 ? -1.0 : 1.0) * (a.in[(size_t)e * K + k] / m.dcEdge[e]);
+                }
+                a.out[(size_t)c * K + k] = acc;
+            }
+        }
+    } else if (a.op == OP_DIV_T) {
+        // transpose of DivergenceOnCell_P2, then _P1 (Operators.jl:34-42, :18): t = dTemp - s1 * (dD[c1] / area[c1]) - s2 * (...);
+        // dV += t * dvEdge
+        const int e0 = m.patchEdgeStart[p], e1 = m.patchEdgeStart[p + 1];
+        for (int e = e0 + grp; e < e1; e += NG) {
+            const int c1 = m.ehdr[(size_t)e * 4], c2 = m.ehdr[(size_t)e * 4 + 1];
+            const double s1 = a.auxD[(size_t)e * 2], s2 = a.auxD[(size_t)e * 2 + 1];
+            for (int k = l; k < K; k += LPC) {
+                const size_t off = (size_t)e * K + k;
+                double t = a.in2 ? a.in2[off] : 0.0;
+                t -= s1 * (a.in[(size_t)c1 * K + k] / m.areaCell[c1]);
+                t -= s2 * (a.in[(size_t)c2 * K + k] / m.areaCell[c2]);
+                a.out[off] += t * m.dvEdge[e];
+            }
+        }
+    } else if (a.op == OP_CURL_T) {
+        // transpose of CurlOnVertex (Operators.jl:137-146): dV[k,e] += sum over the (vertex, slot) pairs naming e, in ascending
+        // (caller's vertex id, slot) order, of coefficient * dC[k,v]
+        const int e0 = m.patchEdgeStart[p], e1 = m.patchEdgeStart[p + 1];
+        for (int e = e0 + grp; e < e1; e += NG) {
+            for (int k = l; k < K; k += LPC) {
+                double acc = a.out[(size_t)e * K + k];
+                for (int q = 0; q < a.auxW; ++q) {
+                    const int v = a.auxI[(size_t)e * a.auxW + q];
+                    if (v >= 0) acc += a.auxD[(size_t)e * a.auxW + q] * a.in[(size_t)v * K + k];
+                }
+                a.out[(size_t)e * K + k] = acc;
+            }
+        }
     }
 }
 
@@ -1297,9 +1339,10 @@ hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t
 
 // Which modes of the fp32-storage kernel run as 512-thread workgroups bounded to 128 registers (two per CU = 4 waves per
 // SIMD instead of three 4-wave workgroups = 3): bit m = mode m.  Modes 0 and 1 (no Curr / New rows in flight) fit 128
-// registers without spills; the others do not (tools/kernel_regs.py) and stay at (256, 3).  moka_set_tuning(1, mask) changes
-// it for measurements.
-static std::atomic<int> g_f32WideModes{(1 << 0) | (1 << 1)};
+// registers without spills, the others do not (tools/kernel_regs.py).  Measured on config 5 (profiles/r03_variants.txt):
+// mode 0, the tendency launch, 3.81 -> 3.71 ms; mode 1, RK stage 1, 4.81 -> 5.07 ms (its two result streams per entity
+// queue up behind twice as many waves) -- so mode 0 only.  moka_set_tuning(1, mask) changes it for measurements.
+static std::atomic<int> g_f32WideModes{1 << 0};
 void set_f32_wide_modes(int mask) { g_f32WideModes.store(mask); }
 int f32_wide_modes() { return g_f32WideModes.load(); }
 

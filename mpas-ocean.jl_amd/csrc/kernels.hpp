@@ -50,12 +50,18 @@ struct FeArgs {
     double *u_new, *h_new, *ssh_new;
 };
 
-enum : int { OP_GRADIENT = 0, OP_INTERP = 1, OP_DIV_P1 = 2, OP_DIV_P2 = 3, OP_CURL = 4 };
+// OP_*_T: the transposes (reverse mode of the stand-alone operators, moka_*_vjp), gather form, fixed summation order
+enum : int { OP_GRADIENT = 0, OP_INTERP = 1, OP_DIV_P1 = 2, OP_DIV_P2 = 3, OP_CURL = 4, OP_GRAD_T = 5, OP_DIV_T = 6, OP_CURL_T = 7 };
 
 struct OpArgs {
     int op, nlev;
     const double *in;
     double *out;
+    // transposes only
+    const double *in2 = nullptr;       // OP_DIV_T: the shadow of temp (added in before the multiplication by dvEdge)
+    const int32_t *auxI = nullptr;     // OP_CURL_T: (W, nE) vertices whose edgesOnVertex lists name the edge, by (caller's vertex id, slot); -1 = none
+    const double *auxD = nullptr;      // OP_CURL_T: (W, nE) their coefficients; OP_DIV_T: (2, nE) edgeSignOnCell of the edge in c1, c2
+    int auxW = 0;
 };
 
 // the product's stage kernels: default (kernels.hip) and the two fallbacks (stage_fallback.hip)

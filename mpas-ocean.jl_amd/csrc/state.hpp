@@ -41,8 +41,13 @@ struct moka_mesh {
     bool colOk = false;       // byte-offset records exist (every field < 4 GiB)
     bool tileOk = false;      // the tiled stage kernel (u rows + records in LDS) fits this mesh
     bool ptileOk = false;     // the persistent double-buffered tiled kernel fits this mesh
-    double *opBuf[3] = {nullptr, nullptr, nullptr};   // operator / transfer scratch, lazily sized
+    double *opBuf[4] = {nullptr, nullptr, nullptr, nullptr};   // operator scratch [0], [1], [3] / transfer staging [2], lazily sized
     size_t opBufElems = 0;
+    // transposed lists of the operator reverse mode (moka_*_vjp), built at first use
+    const int32_t *opTVert = nullptr;     // (opTW, nE) vertices naming the edge, sorted by (caller's vertex id, slot); -1 = none
+    const double *opTCoef = nullptr;      // (opTW, nE) their CurlOnVertex coefficients
+    const double *opESign = nullptr;      // (2, nE) edgeSignOnCell of the edge in cellsOnEdge[1], [2] (0: not listed there)
+    int opTW = 0;
     // (maxOwnE, maxOwnC) of a launched patch sub-range: a partition's halo-only patches own up to 6 edges per cell
     // and are never launched, so the LDS carve of a boundary / interior launch is sized by the patches it covers
     std::map<std::pair<int, int>, std::pair<int, int>> rangeMax;

@@ -81,6 +81,14 @@ mutable struct State                   # one moka_state behind Prog / Diag / Ten
     backend::Backend
     version::Int                       # bumped by every call that changes device fields
     bound::Vector{WeakRef}             # the MArrays bound to this state (to flush pending host writes)
+    tapes::Int                         # live tapes on this state: moka_tape_destroy dereferences the state (it may have to
+    dead::Bool                         # materialise lazily pending tendencies), and finalizers run in no particular order --
+end                                    # so the state is destroyed only when its own finalizer AND every tape's have run
+function destroy_state!(s::State)
+    s.handle == C_NULL && return
+    ccall((:moka_state_destroy, lib), Cvoid, (Ptr{Cvoid},), s.handle)
+    s.handle = C_NULL
+    release!(s.backend)
 end
 
 mutable struct MArray{T,N} <: AbstractArray{T,N}
@@ -161,14 +169,33 @@ mutable struct DeviceMesh
     handle::Ptr{Cvoid}
     backend::Backend
 end
-const MESHES = IdDict{Any,DeviceMesh}()          # reference Mesh object -> its device mesh (weak in spirit: cleared by close!)
+function destroy_mesh!(dm::DeviceMesh)
+    dm.handle == C_NULL && return
+    ccall((:moka_mesh_destroy, lib), Cvoid, (Ptr{Cvoid},), dm.handle)
+    dm.handle = C_NULL
+    release!(dm.backend)
+end
+# reference Mesh object -> its device mesh.  The key is held WEAKLY: when the caller drops its Mesh the entry goes, the
+# DeviceMesh becomes collectable (states that use it hold it themselves), its finalizer runs moka_mesh_destroy and the
+# context's count can reach zero.  `Mesh` is an immutable struct in the reference (MPASMesh.jl:19); a WeakKeyDict needs
+# mutable keys, so the key is one of its arrays -- the MArray of areaCell -- which is mutable and lives exactly as long as
+# the Mesh holds it.
+const MESHES = WeakKeyDict{Any,DeviceMesh}()
+mesh_key(m::Mesh) = m.HorzMesh.PrimaryCells.areaCell
+"release the device copy of `m` now (otherwise: when `m` is collected)"
+function close!(m::Mesh)
+    dm = pop!(MESHES, mesh_key(m), nothing)
+    dm === nothing || destroy_mesh!(dm)
+    nothing
+end
 
 hostof(a::MArray) = a.host
 hostof(a::Array) = a
 
 "moka_mesh_create from the arrays the reference's Mesh holds (Adapt.adapt_structure(backend, ::Mesh), MPASMesh.jl:26)"
 function device_mesh(m::Mesh, b::Backend)
-    haskey(MESHES, m) && return MESHES[m]
+    dm0 = get(MESHES, mesh_key(m), nothing)
+    dm0 === nothing || return dm0
     C, D, E, V = m.HorzMesh.PrimaryCells, m.HorzMesh.DualCells, m.HorzMesh.Edges, m.VertMesh
     rsum = vec(copy(hostof(V.restingThicknessSum)))               # (1,nC) or (nC): indexed linearly (SURVEY N5)
     arrs = map(hostof, (C.xᶜ, C.yᶜ, C.zᶜ, C.nEdgesOnCell, C.edgesOnCell, C.edgeSignOnCell, C.areaCell,
@@ -186,32 +213,67 @@ function device_mesh(m::Mesh, b::Backend)
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:moka_mesh_create, lib), Cint, (Ptr{Cvoid}, Ref{MeshDesc}, Ref{Ptr{Cvoid}}), b.ctx, d, ref), b.ctx)
         dm = DeviceMesh(ref[], retain!(b))
-        finalizer(dm) do x
-            ccall((:moka_mesh_destroy, lib), Cvoid, (Ptr{Cvoid},), x.handle)
-            release!(x.backend)
-        end
-        MESHES[m] = dm
+        finalizer(destroy_mesh!, dm)
+        MESHES[mesh_key(m)] = dm
         return dm
     end
 end
 
 # ---- operators (Operators.jl:46,102,151,179): arrays on the backend in/out, synchronous -----------------
-# called by test/ocn/test_Operators.jl:47,67,85 with arrays adapted to the backend: unbound MArrays, i.e. host data
+# called by test/ocn/test_Operators.jl:47,67,85 with arrays adapted to the backend: unbound MArrays, i.e. host data.
+# A BOUND array (a field of Prog / Diag / Tend) works too: inputs are read back first (sync_host!), outputs are written on
+# the host copy and marked dirty, so the next device call of the model uploads them (flush_host!).
+"host memory of an operator INPUT, up to date"
+input_host(a::MArray) = sync_host!(a).host
+"host memory of an operator OUTPUT: current contents first (read-modify-write operators), pending upload afterwards"
+function output_host(a::MArray)
+    sync_host!(a)
+    a.state === nothing || (a.host_dirty = true)
+    a.host
+end
 function MOKA.GradientOnEdge!(grad::MArray{Float64,2}, h::MArray{Float64,2}, m::Mesh; backend = grad.backend, workgroupsize = 64)
     dm = device_mesh(m, backend)
-    check(ccall((:moka_gradient_on_edge, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dm.handle, sync_host!(h).host, grad.host), backend.ctx)
+    check(ccall((:moka_gradient_on_edge, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dm.handle, input_host(h), output_host(grad)), backend.ctx)
 end
 function MOKA.DivergenceOnCell!(div::MArray{Float64,2}, V::MArray{Float64,2}, temp::MArray{Float64,2}, m::Mesh; backend = div.backend, nthreads = 50)
     dm = device_mesh(m, backend)
-    check(ccall((:moka_divergence_on_cell, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), dm.handle, sync_host!(V).host, temp.host, div.host), backend.ctx)
+    check(ccall((:moka_divergence_on_cell, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), dm.handle, input_host(V), output_host(temp), output_host(div)), backend.ctx)
 end
 function MOKA.CurlOnVertex!(curl::MArray{Float64,2}, V::MArray{Float64,2}, m::Mesh; backend = curl.backend)
     dm = device_mesh(m, backend)
-    check(ccall((:moka_curl_on_vertex, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dm.handle, sync_host!(V).host, sync_host!(curl).host), backend.ctx)
+    check(ccall((:moka_curl_on_vertex, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dm.handle, input_host(V), output_host(curl)), backend.ctx)
 end
 function MOKA.interpolateCell2Edge!(e::MArray{Float64,2}, c::MArray{Float64,2}, m::Mesh; backend = e.backend)
     dm = device_mesh(m, backend)
-    check(ccall((:moka_interpolate_cell2edge, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint), dm.handle, sync_host!(c).host, sync_host!(e).host, 1), backend.ctx)
+    check(ccall((:moka_interpolate_cell2edge, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint), dm.handle, input_host(c), output_host(e), 1), backend.ctx)
+end
+
+# reverse / forward mode of the three operators (include/moka_hip.h: moka_*_vjp / _jvp): what the EnzymeRules of
+# MokaHIPEnzymeExt.jl call.  Arguments are the SHADOW arrays; conventions are Enzyme's (input shadows accumulate, shadows of
+# overwritten outputs are zeroed, the curl shadow stays).
+function gradient_vjp!(d_grad::MArray{Float64,2}, d_h::MArray{Float64,2}, m::Mesh, backend)
+    dm = device_mesh(m, backend)
+    check(ccall((:moka_gradient_on_edge_vjp, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dm.handle, output_host(d_grad), output_host(d_h)), backend.ctx)
+end
+function gradient_jvp!(d_grad::MArray{Float64,2}, d_h::MArray{Float64,2}, m::Mesh, backend)
+    dm = device_mesh(m, backend)
+    check(ccall((:moka_gradient_on_edge_jvp, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dm.handle, input_host(d_h), output_host(d_grad)), backend.ctx)
+end
+function divergence_vjp!(d_div::MArray{Float64,2}, d_V::MArray{Float64,2}, d_temp::MArray{Float64,2}, m::Mesh, backend)
+    dm = device_mesh(m, backend)
+    check(ccall((:moka_divergence_on_cell_vjp, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), dm.handle, output_host(d_div), output_host(d_V), output_host(d_temp)), backend.ctx)
+end
+function divergence_jvp!(d_div::MArray{Float64,2}, d_V::MArray{Float64,2}, d_temp::MArray{Float64,2}, m::Mesh, backend)
+    dm = device_mesh(m, backend)
+    check(ccall((:moka_divergence_on_cell_jvp, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), dm.handle, input_host(d_V), output_host(d_temp), output_host(d_div)), backend.ctx)
+end
+function curl_vjp!(d_curl::MArray{Float64,2}, d_V::MArray{Float64,2}, m::Mesh, backend)
+    dm = device_mesh(m, backend)
+    check(ccall((:moka_curl_on_vertex_vjp, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dm.handle, input_host(d_curl), output_host(d_V)), backend.ctx)
+end
+function curl_jvp!(d_curl::MArray{Float64,2}, d_V::MArray{Float64,2}, m::Mesh, backend)
+    dm = device_mesh(m, backend)
+    check(ccall((:moka_curl_on_vertex_jvp, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dm.handle, input_host(d_V), output_host(d_curl)), backend.ctx)
 end
 
 # ---- binding Prog / Diag / Tend to one device state ---------------------------------------------------
@@ -237,10 +299,10 @@ function state_of(Prog::MProg, Diag, Tend, S::ModelSetup, b::Backend)
         dm = device_mesh(S.mesh, b)
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:moka_state_create, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), b.ctx, dm.handle, ref), b.ctx)
-        s = State(ref[], dm, retain!(b), 0, WeakRef[])
+        s = State(ref[], dm, retain!(b), 0, WeakRef[], 0, false)
         finalizer(s) do x
-            ccall((:moka_state_destroy, lib), Cvoid, (Ptr{Cvoid},), x.handle)
-            release!(x.backend)
+            x.dead = true
+            x.tapes == 0 && destroy_state!(x)
         end
         length(Prog.ssh) == 2 || error("nTimeLevels must be <= 2")           # time_integration.jl:23
         for t in 1:2                                                           # Julia index 1 = previous = level 0, end = current = 1
@@ -358,8 +420,11 @@ function Tape(s::State, capacity::Integer)
     check(ccall((:moka_tape_create, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), s.handle, capacity, ref), s.backend.ctx)
     t = Tape(ref[], s)                 # holds the state (hence mesh and context count) alive
     retain!(s.backend)
+    s.tapes += 1
     finalizer(t) do x
-        ccall((:moka_tape_destroy, lib), Cvoid, (Ptr{Cvoid},), x.handle)
+        ccall((:moka_tape_destroy, lib), Cvoid, (Ptr{Cvoid},), x.handle)      # the state is still there: it counts its tapes
+        x.state.tapes -= 1
+        x.state.dead && x.state.tapes == 0 && destroy_state!(x.state)
         release!(x.state.backend)
     end
     t

@@ -71,4 +71,76 @@ function EnzymeRules.reverse(config, func::Const{typeof(MOKA.ocn_run_loop)}, dre
     return ntuple(_ -> nothing, 11)
 end
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The stand-alone operators (test/enzyme/test_Enzyme_Operators.jl:42-131, 137-225).  The reference lets Enzyme differentiate
+#     gradient_test(grad, h, mesh, backend)       = GradientOnEdge!(grad, h, mesh; backend)
+#     divergence_test(div, F, temp, mesh, backend) = DivergenceOnCell!(div, F, temp, mesh; backend, nthreads = 64)
+# with Duplicated arrays and a Duplicated mesh (whose shadow stays zero: the mesh is not differentiated through here).
+# On this backend the operators are library calls, so they get rules.  They are LINEAR in their array argument:
+#   forward : the tangent of the output is the operator applied to the tangent of the input (moka_*_jvp);
+#   reverse : the augmented primal runs the operator and needs no tape; the reverse pass adds J^T (shadow of the output) to
+#             the shadow of the input and zeroes the shadow of the overwritten output (moka_*_vjp) -- curl accumulates into its
+#             output, so that shadow stays.
+# STATUS: NEVER EXECUTED (no Julia in this pipeline).  What they delegate to is tested through the C ABI with the reference's
+# own check (AD vs central differences, eps = 1e-8, atol = 1e-6): tests/test_gpu_parity.py::
+# test_operator_reverse_and_forward_mode_against_central_differences and ..._transposes_bitwise_against_the_oracle.
+# ---------------------------------------------------------------------------------------------------------------------
+using MokaHIP: gradient_vjp!, gradient_jvp!, divergence_vjp!, divergence_jvp!, curl_vjp!, curl_jvp!
+
+const DupArr = Union{Duplicated{<:MArray{Float64,2}},DuplicatedNoNeed{<:MArray{Float64,2}}}
+
+# ---- GradientOnEdge!(grad, h, mesh; backend, workgroupsize) ----
+function EnzymeRules.forward(config, func::Const{typeof(MOKA.GradientOnEdge!)}, ::Type{RT}, grad::DupArr, h::DupArr, mesh::Annotation;
+                             backend = grad.val.backend, workgroupsize = 64) where {RT}
+    MOKA.GradientOnEdge!(grad.val, h.val, mesh.val; backend, workgroupsize)
+    gradient_jvp!(grad.dval, h.dval, mesh.val, backend)
+    return nothing
+end
+function EnzymeRules.augmented_primal(config, func::Const{typeof(MOKA.GradientOnEdge!)}, ::Type{RT}, grad::DupArr, h::DupArr,
+                                      mesh::Annotation; backend = grad.val.backend, workgroupsize = 64) where {RT}
+    MOKA.GradientOnEdge!(grad.val, h.val, mesh.val; backend, workgroupsize)
+    return EnzymeRules.AugmentedReturn(nothing, nothing, nothing)             # linear: nothing to remember
+end
+function EnzymeRules.reverse(config, func::Const{typeof(MOKA.GradientOnEdge!)}, dret, tape, grad::DupArr, h::DupArr, mesh::Annotation;
+                             backend = grad.val.backend, workgroupsize = 64)
+    gradient_vjp!(grad.dval, h.dval, mesh.val, backend)                       # d_h += J^T d_grad; d_grad = 0
+    return (nothing, nothing, nothing)
+end
+
+# ---- DivergenceOnCell!(div, V, temp, mesh; backend, nthreads) ----
+function EnzymeRules.forward(config, func::Const{typeof(MOKA.DivergenceOnCell!)}, ::Type{RT}, div::DupArr, V::DupArr, temp::DupArr,
+                             mesh::Annotation; backend = div.val.backend, nthreads = 50) where {RT}
+    MOKA.DivergenceOnCell!(div.val, V.val, temp.val, mesh.val; backend, nthreads)
+    divergence_jvp!(div.dval, V.dval, temp.dval, mesh.val, backend)
+    return nothing
+end
+function EnzymeRules.augmented_primal(config, func::Const{typeof(MOKA.DivergenceOnCell!)}, ::Type{RT}, div::DupArr, V::DupArr,
+                                      temp::DupArr, mesh::Annotation; backend = div.val.backend, nthreads = 50) where {RT}
+    MOKA.DivergenceOnCell!(div.val, V.val, temp.val, mesh.val; backend, nthreads)
+    return EnzymeRules.AugmentedReturn(nothing, nothing, nothing)
+end
+function EnzymeRules.reverse(config, func::Const{typeof(MOKA.DivergenceOnCell!)}, dret, tape, div::DupArr, V::DupArr, temp::DupArr,
+                             mesh::Annotation; backend = div.val.backend, nthreads = 50)
+    divergence_vjp!(div.dval, V.dval, temp.dval, mesh.val, backend)           # d_V += P1^T (d_temp + P2^T d_div); d_div = d_temp = 0
+    return (nothing, nothing, nothing, nothing)
+end
+
+# ---- CurlOnVertex!(curl, V, mesh; backend): accumulates into curl (Operators.jl:142) ----
+function EnzymeRules.forward(config, func::Const{typeof(MOKA.CurlOnVertex!)}, ::Type{RT}, curl::DupArr, V::DupArr, mesh::Annotation;
+                             backend = curl.val.backend) where {RT}
+    MOKA.CurlOnVertex!(curl.val, V.val, mesh.val; backend)
+    curl_jvp!(curl.dval, V.dval, mesh.val, backend)                           # d_curl += J d_V
+    return nothing
+end
+function EnzymeRules.augmented_primal(config, func::Const{typeof(MOKA.CurlOnVertex!)}, ::Type{RT}, curl::DupArr, V::DupArr,
+                                      mesh::Annotation; backend = curl.val.backend) where {RT}
+    MOKA.CurlOnVertex!(curl.val, V.val, mesh.val; backend)
+    return EnzymeRules.AugmentedReturn(nothing, nothing, nothing)
+end
+function EnzymeRules.reverse(config, func::Const{typeof(MOKA.CurlOnVertex!)}, dret, tape, curl::DupArr, V::DupArr, mesh::Annotation;
+                             backend = curl.val.backend)
+    curl_vjp!(curl.dval, V.dval, mesh.val, backend)                           # d_V += J^T d_curl; d_curl stays
+    return (nothing, nothing, nothing)
+end
+
 end # module

@@ -24,6 +24,7 @@ __all__ = [
     "MokaHIP", "MokaError", "ForwardEuler", "RungeKutta4", "HorzMesh", "VerticalMesh", "Mesh", "ModelSetup",
     "PrognosticVars", "DiagnosticVars", "TendencyVars", "DeviceField",
     "GradientOnEdge", "DivergenceOnCell", "CurlOnVertex", "interpolateCell2Edge",
+    "GradientOnEdge_vjp", "GradientOnEdge_jvp", "DivergenceOnCell_vjp", "DivergenceOnCell_jvp", "CurlOnVertex_vjp", "CurlOnVertex_jvp",
     "advanceTimeLevels", "diagnostic_compute", "computeNormalVelocityTendency", "computeLayerThicknessTendency",
     "computeTendency", "ocn_timestep", "ocn_run_loop", "run_steps", "ocn_init_from_arrays", "ocn_init_alarms",
     "Clock", "OneTimeAlarm", "PeriodicAlarm", "Alarm", "advance", "isRinging", "reset", "stop", "changeTimeStep",
@@ -250,6 +251,58 @@ def interpolateCell2Edge(edgeValue, cellValue, mesh: Mesh, backend=None, nlev: i
     m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
     _chk_arr(edgeValue, (m.nEdges, K), "edgeValue"); _chk_arr(cellValue, (m.nCells, K), "cellValue")
     L.check(L.lib().moka_interpolate_cell2edge(mesh._h, L.f64(cellValue), L.f64(edgeValue), int(nlev)), mesh.backend._h)
+
+
+# ---- reverse (vjp) and forward (jvp) mode of the operators: what Enzyme gives the reference for
+# autodiff(Reverse / Forward, GradientOnEdge!, Duplicated(grad, d_grad), Duplicated(h, d_h), ...)
+# (test/enzyme/test_Enzyme_Operators.jl:61-66, 82-87, 160-166, 182-188).  Arrays are the shadows, modified in place with
+# Enzyme's conventions: input shadows accumulate, overwritten-output shadows are zeroed, the curl shadow stays. ----
+def GradientOnEdge_vjp(d_grad, d_h, mesh: Mesh):
+    mesh._need_device()
+    m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+    _chk_arr(d_grad, (m.nEdges, K), "d_grad"); _chk_arr(d_h, (m.nCells, K), "d_h")
+    L.check(L.lib().moka_gradient_on_edge_vjp(mesh._h, L.f64(d_grad), L.f64(d_h)), mesh.backend._h)
+
+
+def GradientOnEdge_jvp(d_grad, d_h, mesh: Mesh):
+    mesh._need_device()
+    m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+    _chk_arr(d_grad, (m.nEdges, K), "d_grad"); _chk_arr(d_h, (m.nCells, K), "d_h")
+    L.check(L.lib().moka_gradient_on_edge_jvp(mesh._h, L.f64(d_h), L.f64(d_grad)), mesh.backend._h)
+
+
+def DivergenceOnCell_vjp(d_div, d_vecEdge, d_temp, mesh: Mesh):
+    mesh._need_device()
+    m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+    _chk_arr(d_div, (m.nCells, K), "d_div"); _chk_arr(d_vecEdge, (m.nEdges, K), "d_VecEdge")
+    if d_temp is not None:
+        _chk_arr(d_temp, (m.nEdges, K), "d_temp")
+    L.check(L.lib().moka_divergence_on_cell_vjp(mesh._h, L.f64(d_div), L.f64(d_vecEdge), L.f64(d_temp) if d_temp is not None else None),
+            mesh.backend._h)
+
+
+def DivergenceOnCell_jvp(d_div, d_vecEdge, d_temp, mesh: Mesh):
+    mesh._need_device()
+    m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+    _chk_arr(d_div, (m.nCells, K), "d_div"); _chk_arr(d_vecEdge, (m.nEdges, K), "d_VecEdge")
+    if d_temp is not None:
+        _chk_arr(d_temp, (m.nEdges, K), "d_temp")
+    L.check(L.lib().moka_divergence_on_cell_jvp(mesh._h, L.f64(d_vecEdge), L.f64(d_temp) if d_temp is not None else None, L.f64(d_div)),
+            mesh.backend._h)
+
+
+def CurlOnVertex_vjp(d_curl, d_vecEdge, mesh: Mesh):
+    mesh._need_device()
+    m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+    _chk_arr(d_curl, (m.nVertices, K), "d_curl"); _chk_arr(d_vecEdge, (m.nEdges, K), "d_VecEdge")
+    L.check(L.lib().moka_curl_on_vertex_vjp(mesh._h, L.f64(d_curl), L.f64(d_vecEdge)), mesh.backend._h)
+
+
+def CurlOnVertex_jvp(d_curl, d_vecEdge, mesh: Mesh):
+    mesh._need_device()
+    m, K = mesh.HorzMesh.data, mesh.VertMesh.nVertLevels
+    _chk_arr(d_curl, (m.nVertices, K), "d_curl"); _chk_arr(d_vecEdge, (m.nEdges, K), "d_VecEdge")
+    L.check(L.lib().moka_curl_on_vertex_jvp(mesh._h, L.f64(d_vecEdge), L.f64(d_curl)), mesh.backend._h)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -85,6 +85,8 @@ EXPORTS = [
     "moka_set_nonlinear", "moka_last_fe_path", "moka_set_viscosity_del2", "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
     "moka_adjoint_download",
     "moka_mark", "moka_marks_reset", "moka_marks_read", "moka_bw_probe", "moka_ctx_pci_bus_id", "moka_halo_set_acquire", "moka_set_tuning", "moka_get_tuning",
+    "moka_gradient_on_edge_vjp", "moka_gradient_on_edge_jvp", "moka_divergence_on_cell_vjp", "moka_divergence_on_cell_jvp",
+    "moka_curl_on_vertex_vjp", "moka_curl_on_vertex_jvp",
 ]
 
 
@@ -138,6 +140,12 @@ def lib():
     L.moka_divergence_on_cell.argtypes = [vp, _f64p, _f64p, _f64p]
     L.moka_curl_on_vertex.argtypes = [vp, _f64p, _f64p]
     L.moka_interpolate_cell2edge.argtypes = [vp, _f64p, _f64p, C.c_int]
+    L.moka_gradient_on_edge_vjp.argtypes = [vp, _f64p, _f64p]
+    L.moka_gradient_on_edge_jvp.argtypes = [vp, _f64p, _f64p]
+    L.moka_divergence_on_cell_vjp.argtypes = [vp, _f64p, _f64p, _f64p]
+    L.moka_divergence_on_cell_jvp.argtypes = [vp, _f64p, _f64p, _f64p]
+    L.moka_curl_on_vertex_vjp.argtypes = [vp, _f64p, _f64p]
+    L.moka_curl_on_vertex_jvp.argtypes = [vp, _f64p, _f64p]
     L.moka_state_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.moka_state_destroy.argtypes = [vp]
     L.moka_state_destroy.restype = None

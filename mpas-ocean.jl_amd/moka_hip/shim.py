@@ -210,7 +210,7 @@ def ocn_setup_mesh(Config, backend: Backend) -> RefMesh:
 
 
 # ---- binding -----------------------------------------------------------------------------------------
-_MESHES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()      # const MESHES = IdDict{Any,DeviceMesh}()
+_MESHES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()      # const MESHES = WeakKeyDict{Any,DeviceMesh}() (+ close!)
 
 
 def _host(a):

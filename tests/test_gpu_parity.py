@@ -92,6 +92,114 @@ def test_operator_known_answers_and_bitwise(backend):
     M.close()
 
 
+def _lin(shape, idx1):
+    """Julia linear index (1-based) into a (nVertLevels, n) array == flat index into our (n, K) C-order array."""
+    return np.unravel_index(idx1 - 1, shape)
+
+
+@pytest.mark.parametrize("K", [1, 10])
+def test_operator_reverse_and_forward_mode_against_central_differences(backend, K):
+    """test/enzyme/test_Enzyme_Operators.jl restated through the C ABI: d grad[kEnd] / d h[kBegin] (:42-131) and
+    d div[kEnd] / d F[kBegin] (:137-225) in reverse AND forward mode on the 48 x 48 planar mesh with the reference's analytic
+    fields, against central differences of the HIP operators themselves with the reference's step (eps = 1e-8 relative) and
+    tolerance (atol = 1e-6).  The reference's own index pairs are (1, 1) and (2, 1) at nVertLevels = 1."""
+    mesh = get_mesh("planar48")
+    M = device_mesh(backend, mesh, K, multilayer=False)
+    ts = PlanarSetup(mesh, K)
+    eps = 1e-8
+
+    def fd(op, x, kin, kout):
+        xp, xm = x.copy(), x.copy()
+        xp[kin] += abs(xp[kin]) * eps
+        xm[kin] -= abs(xm[kin]) * eps
+        return (op(xp)[kout] - op(xm)[kout]) / (xp[kin] - xm[kin])
+
+    def grad_op(h):
+        g = np.zeros((mesh.nEdges, K)); mk.GradientOnEdge(g, h, M); return g
+
+    def div_op(v):
+        d, t = np.zeros((mesh.nCells, K)), np.zeros((mesh.nEdges, K)); mk.DivergenceOnCell(d, v, t, M); return d
+
+    scalar = ts.h()
+    for k_begin, k_end in ((1, 1), (K + 1, 3 * K + 1), (2 * K, 4 * K)):
+        kin, kout = _lin((mesh.nCells, K), k_begin), _lin((mesh.nEdges, K), k_end)
+        d_grad, d_h = np.zeros((mesh.nEdges, K)), np.zeros((mesh.nCells, K))
+        d_grad[kout] = 1.0
+        mk.GradientOnEdge_vjp(d_grad, d_h, M)                      # autodiff(Reverse, ...)   :61-67
+        rev = d_h[kin]
+        assert not d_grad.any()
+        d_grad, d_h = np.zeros((mesh.nEdges, K)), np.zeros((mesh.nCells, K))
+        d_h[kin] = 1.0
+        mk.GradientOnEdge_jvp(d_grad, d_h, M)                      # autodiff(Forward, ...)   :82-99
+        fwd = d_grad[kout]
+        ref = fd(grad_op, scalar, kin, kout)
+        assert abs(rev - ref) < 1e-6 and abs(fwd - ref) < 1e-6, ("grad", k_begin, k_end, rev, fwd, ref)
+        if k_begin == 1:
+            assert rev != 0.0
+    vec = ts.F_edge()
+    for k_begin, k_end in ((2, 1), (1, 1), (2 * K + 1, 1), (5 * K, K)):
+        kin, kout = _lin((mesh.nEdges, K), k_begin), _lin((mesh.nCells, K), k_end)
+        d_div, d_vec, d_temp = np.zeros((mesh.nCells, K)), np.zeros((mesh.nEdges, K)), np.zeros((mesh.nEdges, K))
+        d_div[kout] = 1.0
+        mk.DivergenceOnCell_vjp(d_div, d_vec, d_temp, M)           # :160-167
+        rev = d_vec[kin]
+        assert not d_div.any() and not d_temp.any()
+        d_div, d_vec, d_temp = np.zeros((mesh.nCells, K)), np.zeros((mesh.nEdges, K)), np.zeros((mesh.nEdges, K))
+        d_vec[kin] = 1.0
+        mk.DivergenceOnCell_jvp(d_div, d_vec, d_temp, M)           # :182-194
+        fwd = d_div[kout]
+        ref = fd(div_op, vec, kin, kout)
+        assert abs(rev - ref) < 1e-6 and abs(fwd - ref) < 1e-6, ("div", k_begin, k_end, rev, fwd, ref)
+        if (k_begin, k_end, K) == (2, 1, 1):
+            assert rev != 0.0
+    M.close()
+
+
+@pytest.mark.parametrize("meshname,K,ordering", [("planar48", 10, 0), ("ico16", 5, 0), ("ico12f", 60, 0), ("ico16", 3, 2), ("planar", 1, 1)])
+def test_operator_transposes_bitwise_against_the_oracle(backend, meshname, K, ordering):
+    """moka_*_vjp against the oracle's transposes, bit for bit, on random cotangents -- spheres with pentagons and flipped
+    edges, every ordering of the layout pass (the summation order is tied to the CALLER's numbering) -- with non-zero shadows
+    to accumulate into; and the forward mode against the oracle's operators applied to the tangents."""
+    mesh = get_mesh(meshname)
+    M = device_mesh(backend, mesh, K, multilayer=False, ordering=ordering)
+    om = orc.OracleMesh(mesh, K)
+    rng = np.random.default_rng(K + 100)
+    R = lambda n: rng.standard_normal((n, K))
+    # gradient
+    d_grad, d_h = R(mesh.nEdges), R(mesh.nCells)
+    o_grad, o_h = d_grad.copy(), d_h.copy()
+    mk.GradientOnEdge_vjp(d_grad, d_h, M); om.gradient_on_edge_vjp(o_h, o_grad)
+    assert np.array_equal(d_h, o_h) and not d_grad.any() and not o_grad.any()
+    t_h, t_grad = R(mesh.nCells), R(mesh.nEdges)
+    mk.GradientOnEdge_jvp(t_grad, t_h, M)
+    assert np.array_equal(t_grad, om.gradient_on_edge(t_h))
+    # divergence, with and without a temp shadow
+    for with_temp in (True, False):
+        d_div, d_vec, d_temp = R(mesh.nCells), R(mesh.nEdges), R(mesh.nEdges)
+        o_div, o_vec, o_temp = d_div.copy(), d_vec.copy(), (d_temp.copy() if with_temp else np.zeros((mesh.nEdges, K)))
+        mk.DivergenceOnCell_vjp(d_div, d_vec, d_temp if with_temp else None, M)
+        om.divergence_on_cell_vjp(o_vec, o_temp, o_div)
+        assert np.array_equal(d_vec, o_vec) and not d_div.any(), with_temp
+        if with_temp:
+            assert not d_temp.any()
+    t_vec, t_div, t_temp = R(mesh.nEdges), R(mesh.nCells), R(mesh.nEdges)
+    mk.DivergenceOnCell_jvp(t_div, t_vec, t_temp, M)
+    o_temp = np.zeros((mesh.nEdges, K))
+    assert np.array_equal(t_div, om.divergence_on_cell(t_vec, temp=o_temp)) and np.array_equal(t_temp, o_temp)
+    # curl: the primal accumulates, so the output's shadow stays and the forward mode accumulates
+    d_curl, d_vec = R(mesh.nVertices), R(mesh.nEdges)
+    o_vec, keep = d_vec.copy(), d_curl.copy()
+    mk.CurlOnVertex_vjp(d_curl, d_vec, M); om.curl_on_vertex_vjp(o_vec, keep)
+    assert np.array_equal(d_vec, o_vec) and np.array_equal(d_curl, keep)
+    t_vec, t_curl = R(mesh.nEdges), R(mesh.nVertices)
+    exp = om.curl_on_vertex(t_vec, curl=t_curl.copy())
+    mk.CurlOnVertex_jvp(t_curl, t_vec, M)
+    assert np.array_equal(t_curl, exp)
+    with pytest.raises(mk.MokaError):
+        mk.GradientOnEdge_vjp(np.zeros((mesh.nEdges, K + 1)), np.zeros((mesh.nCells, K)), M)
+    M.close()
+
+
 def test_operator_argument_errors(backend):
     mesh = get_mesh("planar")
     M = device_mesh(backend, mesh, 2)

@@ -186,7 +186,7 @@ def test_operator_transposes_satisfy_the_adjoint_identity():
     assert rel(np.vdot(om.gradient_on_edge(xc), ye), np.vdot(xc, d_s)) < 1e-12
     twice, d_g = d_s.copy(), ye.copy()
     om.gradient_on_edge_vjp(twice, d_g)
-    assert np.allclose(twice, 2 * d_s, rtol=1e-14, atol=0)
+    assert np.allclose(twice, 2 * d_s, rtol=1e-9, atol=1e-18)      # a second call adds the same sum onto the first
     # divergence (through temp)
     d_v, d_t, d_d = np.zeros((mesh.nEdges, K)), np.zeros((mesh.nEdges, K)), yc.copy()
     om.divergence_on_cell_vjp(d_v, d_t, d_d)

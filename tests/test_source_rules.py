@@ -49,3 +49,19 @@ def test_experiments_are_not_in_the_default_build():
     from moka_hip import lib as L
     avail = [v for v in range(12) if L.lib().moka_kernel_variant_available(v)]
     assert set(avail) >= {0, 3, 4, 11}
+
+
+def test_experimental_kernels_still_compile():
+    """csrc/experiments/ (the measured-and-lost execution shapes, kept as a record) includes kernels_common.hpp and StageArgs,
+    which keep changing: `make VARIANTS=1` into a build directory of its own must still compile them (hipcc cross-compiles
+    gfx950 without a GPU), and the resulting library must offer the variants the default build refuses."""
+    import ctypes
+    import subprocess
+    pkg = os.path.join(ROOT, "mpas-ocean.jl_amd")
+    r = subprocess.run(["make", "-C", pkg, "--no-print-directory", "-j4", "VARIANTS=1", "BUILD=build_variants",
+                        "SONAME=libmoka_hip_variants.so"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lib = ctypes.CDLL(os.path.join(pkg, "libmoka_hip_variants.so"))
+    assert all(lib.moka_kernel_variant_available(v) for v in range(0, 15))
+    from moka_hip import lib as L
+    assert not L.lib().moka_kernel_variant_available(12)          # the product library stays without them
