@@ -352,7 +352,8 @@ int moka_kernel_variant_available(int variant);
 int moka_set_kernel_variant(moka_ctx *ctx, int variant);
 /* Process-wide launch-shape switches for A/B measurements (every setting gives identical results).  key 1: bit mask of the
  * modes (0 tendency, 1..3 RK4 stages, 4..6 Forward Euler) of the fp32-storage stage kernel that run as 512-thread workgroups
- * bounded to 128 registers = 4 waves per SIMD instead of 3 (default: modes 0 and 1, the two that fit without spilling). */
+ * bounded to 128 registers = 4 waves per SIMD instead of 3 (default: mode 0, the tendency launch).  key 2: 0 = Forward-Euler
+ * steps always gather the stored layerThicknessEdge (mode 4); 1 (default) = formed from the previous level when valid (mode 6). */
 int moka_set_tuning(int key, int value);
 int moka_get_tuning(int key, int *value);
 /* Per-stage durations of moka_step_rk4 from HIP events on the compute stream (measurement: bench.py's per-mode roofline

@@ -346,8 +346,15 @@ StageArgs fe_stage_args(moka_state *st, const FeArgs &a, int flags)
     s.pu_out = a.u_new; s.ph_out = a.h_new; s.ssh_out = a.ssh_new;
     s.tendU = a.tendU; s.tendH = a.tendH; s.a = a.dt;
     s.hEdgeOld = (flags & MOKA_FE_STALE_HEDGE) ? a.hEdgeOld : nullptr;
-    s.hPrev = ((flags & MOKA_FE_STALE_HEDGE) && st->hEdgePrev && st->spare.ssh && a.h_new != st->lev[0].h) ? st->lev[0].h : nullptr;
+    s.hPrev = ((flags & MOKA_FE_STALE_HEDGE) && st->hEdgePrev && st->spare.ssh && a.h_new != st->lev[0].h && moka::fe_prev_mode())
+                  ? st->lev[0].h : nullptr;
     s.hEdgeNew = a.hEdgeNew; s.F = a.F; s.div = a.div; s.areaCell = st->mesh->dev.areaCell;
+    // relativeVorticity by the same launch (the vertices of the launched patches) where the stage kernels can carry it
+    {
+        MeshDev dev = st->mesh->dev;
+        dev.maxOwnE = std::max(st->mesh->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(st->mesh->plan.maxOwnCLaunch, 1);
+        if (moka::stage_curl_fits(dev, st->f32)) { s.vort = a.vort; s.accumVort = (flags & MOKA_FE_ACCUM_VORT) ? 1 : 0; }
+    }
     return s;
 }
 
@@ -577,10 +584,13 @@ int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[4])
 
 // Process-wide launch-shape switches for A/B measurements (results are identical for every setting):
 //   key 1: bit mask of the modes of the fp32-storage stage kernel that run as 512-thread workgroups bounded to 128 registers
-//          (default: modes 0 and 1; see kernels.hip, g_f32WideModes)
+//          (default: mode 0; see kernels.hip, g_f32WideModes)
+//   key 2: 0 = Forward-Euler steps always gather the stored layerThicknessEdge (stage-kernel mode 4), 1 (default) = they form
+//          it from the previous level's layerThickness whenever that is the same thing (mode 6)
 int moka_set_tuning(int key, int value)
 {
     if (key == 1) { moka::set_f32_wide_modes(value); return MOKA_OK; }
+    if (key == 2) { moka::set_fe_prev_mode(value); return MOKA_OK; }
     return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
 }
 
@@ -588,6 +598,7 @@ int moka_get_tuning(int key, int *value)
 {
     if (!value) return fail(nullptr, MOKA_ERR_ARG, "value is NULL");
     if (key == 1) { *value = moka::f32_wide_modes(); return MOKA_OK; }
+    if (key == 2) { *value = moka::fe_prev_mode(); return MOKA_OK; }
     return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
 }
 
@@ -649,7 +660,7 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     UP(eoc) UP(coc) UP(mltc) UP(sdv) UP(invArea) UP(areaCell) UP(rsum)
     UP(ehdr) UP(eoe) UP(woe) UP(gInvDc) UP(dcEdge) UP(dvEdge) UP(fEdge)
     UP(eov) UP(cv) UP(cellN2O) UP(edgeN2O) UP(vertN2O)
-    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(lcOff) UP(leOff) UP(patchRegular) UP(rowStart) UP(rowEdge) UP(cRecT) UP(eRecT)
+    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(vRec) UP(cRec3) UP(eRec3) UP(rowOff) UP(rowF) UP(lcOff) UP(leOff) UP(patchRegular) UP(rowStart) UP(rowEdge) UP(cRecT) UP(eRecT)
     if (p.nlOk) { UP(voe) UP(cov) UP(kite) UP(invAreaTri) UP(fVertex) UP(keCoef) UP(invDc) UP(keoc) UP(rowVoe) }
 #undef UP
     d.CI = p.CI; d.EI = p.EI;
@@ -668,6 +679,10 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
 #endif
 
     d.maxRows = p.maxRows; d.maxOwnE = p.maxOwnE; d.maxOwnC = p.maxOwnC;
+    d.maxOwnV = p.maxOwnV;
+    if (p.vRec.empty()) d.vRec = nullptr;       // (upload_vec hands out a dummy allocation for an empty vector)
+    d.CI3 = p.CI3; d.EI3 = p.EI3;
+    if (p.eRec3.empty()) d.cRec3 = d.eRec3 = d.rowOff = nullptr, d.rowF = nullptr;
 #ifdef MOKA_VARIANTS
     if (p.colOk && stage_tile_usable(d, p.ldsOk) && prepare_stage_tile(d) == hipSuccess) m->tileOk = true;
     if (p.colOk && stage_ptile_usable(d, p.ldsOk) && prepare_stage_ptile(d) == hipSuccess) m->ptileOk = true;
@@ -1084,9 +1099,15 @@ int moka_step_fe(moka_state *st, double dt, int flags)
         MeshDev dev = mf->dev;
         dev.tailPatch = -1;
         dev.maxOwnE = std::max(mf->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(mf->plan.maxOwnCLaunch, 1);
-        HIPCHK(st->ctx, launch_stage_rec2c_f32(dev, g, st->ctx->stream));      // ssh as stored, like the Float64 step
-        HIPCHK(st->ctx, launch_curl_f32(dev, reinterpret_cast<const float *>(a.u), reinterpret_cast<float *>(a.vort),
-                                        flags & MOKA_FE_ACCUM_VORT, st->ctx->stream));
+        hipError_t ef = launch_stage_rec2c_f32(dev, g, st->ctx->stream);      // ssh as stored, like the Float64 step
+        if (ef == hipErrorNotSupported && g.vort) {                            // vertex records do not fit beside the rows: own launch
+            g.vort = nullptr;
+            ef = launch_stage_rec2c_f32(dev, g, st->ctx->stream);
+        }
+        HIPCHK(st->ctx, ef);
+        if (!g.vort)
+            HIPCHK(st->ctx, launch_curl_f32(dev, reinterpret_cast<const float *>(a.u), reinterpret_cast<float *>(a.vort),
+                                            flags & MOKA_FE_ACCUM_VORT, st->ctx->stream));
         st->feFast = g.hPrev ? 2 : 1;
         fe_rotate_levels(st);
         std::swap(st->hEdge[0], st->hEdge[1]);
@@ -1106,16 +1127,22 @@ int moka_step_fe(moka_state *st, double dt, int flags)
         a = fe_args(st, a.ops, flags, dt);                     // the new level goes to the spare set
         StageArgs g = fe_stage_args(st, a, flags);
         g.areaCell = mm->dev.areaCell;
-        const hipError_t e = launch_stage_rec2c(mm->dev, g, st->ctx->stream);
+        hipError_t e = launch_stage_rec2c(mm->dev, g, st->ctx->stream);
+        if (e == hipErrorNotSupported && g.vort) {                             // vertex records do not fit beside the rows: own launch
+            g.vort = nullptr;
+            e = launch_stage_rec2c(mm->dev, g, st->ctx->stream);
+        }
         if (e == hipSuccess) {
             fast = true;
             fastMode = g.hPrev ? 2 : 1;
-            const hipError_t ec = launch_curl2(mm->dev, a.u, a.vort, flags & MOKA_FE_ACCUM_VORT, st->ctx->stream);
-            if (ec == hipErrorNotSupported) {
-                a.ops = FE_CURL;
-                HIPCHK(st->ctx, launch_fe(mm->dev, a, mm->lpc, st->ctx->stream));
-            } else {
-                HIPCHK(st->ctx, ec);
+            if (!g.vort) {
+                const hipError_t ec = launch_curl2(mm->dev, a.u, a.vort, flags & MOKA_FE_ACCUM_VORT, st->ctx->stream);
+                if (ec == hipErrorNotSupported) {
+                    a.ops = FE_CURL;
+                    HIPCHK(st->ctx, launch_fe(mm->dev, a, mm->lpc, st->ctx->stream));
+                } else {
+                    HIPCHK(st->ctx, ec);
+                }
             }
         } else if (e != hipErrorNotSupported) {
             HIPCHK(st->ctx, e);

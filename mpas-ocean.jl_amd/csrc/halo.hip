@@ -801,6 +801,18 @@ int moka_rk4_dist_step(moka_halo *h, double dt, moka_transport_fn transport, voi
 //   launch: relativeVorticity -> boundary patches -> (push or pack of the NEW level, `what` = 5) -> interior patches
 //   then the exchange completes (push_signal / push_wait, or transport + unpack), then moka_fe_dist_end swaps the levels.
 // ---------------------------------------------------------------------------------------------
+// Do the patch launches of a distributed Forward-Euler step carry the vertex pass themselves (StageArgs.vort)?  A pure function
+// of the mesh, the storage type and the kernel choice, so every part of a step -- in whatever order they are called -- agrees.
+static bool fe_vort_fused(const moka_halo *h)
+{
+    const moka_state *st = h->st;
+    const moka_mesh *mm = st->mesh;
+    MeshDev dev = mm->dev;
+    dev.maxOwnE = std::max(mm->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(mm->plan.maxOwnCLaunch, 1);   // bounds both ranges
+    if (st->f32) return stage_curl_fits(dev, true);
+    return (st->ctx->variant == 0 || st->ctx->variant == 11) && mm->lpc == 64 && mm->colOk && stage_curl_fits(dev, false);
+}
+
 static int fe_dist_args(moka_state *st, double dt, int flags, StageArgs *g, FeArgs *a)
 {
     *a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE | FE_TENDU | FE_TENDH | FE_UPDATE, flags, dt);
@@ -829,7 +841,12 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
     h->feFlags = flags;
     const moka_mesh *mm = st->mesh;
     if (part == 2) {
-        // relativeVorticity of the OLD state (DiagnosticVars.jl:108-117 runs before the update): every local vertex
+        // relativeVorticity of the OLD state (DiagnosticVars.jl:108-117 runs before the update): every local vertex -- unless
+        // the patch launches carry the vertices of their patches themselves (StageArgs.vort).  Then this part is empty: the
+        // vertices of the boundary patches are computed by the boundary launch, i.e. ahead of this rank's push, and no vertex of
+        // an interior patch has an edge whose row is received (its three cells are all interior: a cell next to a halo cell is
+        // a boundary cell, and a vertex with a boundary cell belongs to a boundary patch).
+        if (fe_vort_fused(h)) return MOKA_OK;
         if (int rc = launch_acquire(h, c->stream)) return rc;          // it reads received rows (old normalVelocity of halo edges)
         if (st->f32) {
             HIPCHK(c, launch_curl_f32(mm->dev, reinterpret_cast<const float *>(a.u), reinterpret_cast<float *>(a.vort),
@@ -861,6 +878,8 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
     }
     hipError_t e = hipErrorNotSupported;
     h->fePrev = g.hPrev != nullptr;
+    const bool vortFused = fe_vort_fused(h);
+    if (!vortFused) g.vort = nullptr;       // part 2 runs the vertex pass over every local vertex
     if (st->f32) {                         // the Forward-Euler modes of the fp32-storage kernel: no generic form behind them
         HIPCHK(c, launch_stage_rec2c_f32(dev, g, c->stream));
         h->feStageKernel = true;
@@ -869,6 +888,7 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
     if ((c->variant == 0 || c->variant == 11) && mm->lpc == 64 && mm->colOk) e = launch_stage_rec2c(dev, g, c->stream);
     h->feStageKernel = e == hipSuccess;
     if (e == hipErrorNotSupported) {
+        if (vortFused) return hfail(h, MOKA_ERR_UNSUPPORTED, "internal: the stage kernel refused a launch whose vertex pass it was to carry");
         a.ops &= ~FE_CURL;                 // the generic one-launch kernel over the same patch range, vertices in part 2
         e = launch_fe(dev, a, mm->lpc, c->stream);
     }

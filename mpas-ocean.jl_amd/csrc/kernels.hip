@@ -49,6 +49,16 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
     const int nOwnC = c1 - c0, nOwnE = e1 - e0;
     const uint32_t e0B = (uint32_t)e0 * rowB, nOwnB = (uint32_t)nOwnE * rowB;
+    // Forward-Euler modes with the vertex pass in the same launch (a.vort): the patch's vertex records sit behind the row cache
+    double *Lvw = reinterpret_cast<double *>(smem + recBytes + (size_t)maxOwnE * rowB);    // [maxOwnV][3] coefficients
+    uint32_t *Lvo = reinterpret_cast<uint32_t *>(Lvw + (size_t)m.maxOwnV * 3);              // [maxOwnV][4] u-row byte offsets
+    int v0 = 0, nOwnV = 0;
+    if constexpr (MODE >= 4) {
+        if (a.vort) {
+            v0 = cptr(m.patchVertStart)[p];
+            nOwnV = cptr(m.patchVertStart)[p + 1] - v0;
+        }
+    }
 
     {   // Staging: every global load of the patch's records and own u rows is issued before the first LDS write, so the workgroup
         // pays one memory latency here instead of one per array.  The unrolled part covers the default patch (P = 16: 48-51
@@ -73,6 +83,12 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         vS = tid < nS ? m.sdv[(size_t)c0 * ME + tid] : 0.0;
         vA = tid < nOwnC ? m.invArea[c0 + tid] : 0.0;
         vR = tid < nOwnC ? m.rsum[c0 + tid] : 0.0;
+        uint32_t vVo = 0u;
+        double vVw = 0.0;
+        if constexpr (MODE >= 4) {
+            if (tid < nOwnV * 4) vVo = m.vRec[(size_t)v0 * 4 + tid];
+            if (tid < nOwnV * 3) vVw = m.cv[(size_t)v0 * 3 + tid];
+        }
 #pragma unroll
         for (int j = 0; j < UU; ++j) if (tid + j * NT < nU) ubuf2[tid + j * NT] = vU[j];
 #pragma unroll
@@ -89,6 +105,12 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         if (tid < nOwnC) {
             L.invA[tid] = vA;
             L.rsum[tid] = vR;
+        }
+        if constexpr (MODE >= 4) {
+            if (tid < nOwnV * 4) Lvo[tid] = vVo;
+            if (tid < nOwnV * 3) Lvw[tid] = vVw;
+            for (int i = tid + NT; i < nOwnV * 4; i += NT) Lvo[i] = m.vRec[(size_t)v0 * 4 + i];
+            for (int i = tid + NT; i < nOwnV * 3; i += NT) Lvw[i] = m.cv[(size_t)v0 * 3 + i];
         }
         for (int i = tid + UU * NT; i < nU; i += NT) ubuf2[i] = src[i];
         for (int i = tid + UE * NT; i < nER; i += NT) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
@@ -319,7 +341,11 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (FE) {
                 hx = gload2(a.ph, r[ME2] * rowB + voff);               // layerThickness of cellsOnEdge[1], [2]
                 hy = gload2(a.ph, r[ME2 + 1] * rowB + voff);
-                if constexpr (STALE || PREV) hEo = gload2(a.hEdgeOld, own);    // the own row: one contiguous stream per patch
+                if constexpr (STALE) hEo = gload2(a.hEdgeOld, own);
+                if constexpr (PREV) {                                  // the same two cells one level back: rows the cell loop has
+                    const double2 px = gload2(a.hPrev, r[ME2] * rowB + voff), py = gload2(a.hPrev, r[ME2 + 1] * rowB + voff);   // just fetched
+                    hEo = make_double2(0.5 * (px.x + py.x), 0.5 * (px.y + py.y));          // what the previous step stored (Operators.jl:217)
+                }
             }
         }
         if (l < 2) sv = a.ssh[r[ME2 + l]];                             // ssh of cellsOnEdge[l]: after the gathers in the queue
@@ -373,6 +399,43 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         pend = true;
     }
     if (pend) flush_edge();
+
+    // ---------------- vertices: relativeVorticity of the OLD state (CurlOnVertex, Operators.jl:137-146) ----------------
+    // the summation of k_curl3 (edgesOnVertex order, on top of the stored value when it accumulates); normalVelocity rows of the
+    // patch's own edges come from the LDS row cache
+    if constexpr (FE) {
+#pragma nounroll
+        for (int vi = grp; vi < nOwnV; vi += NG) {
+            if (!act) continue;
+            const uint32_t *rv = Lvo + (size_t)vi * 4;
+            const double *wv = Lvw + (size_t)vi * 3;
+            const uint32_t own = (uint32_t)(v0 + vi) * rowB + voff;
+            bool cached[3];
+            uint32_t ad[3], goff[3];
+            v4u_t raw[3];
+            double2 uv[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint32_t off = rv[j];
+                ad[j] = urow_addr(off, cached[j]);
+                goff[j] = off + voff;
+                asm("" : "+v"(goff[j]));
+            }
+            double2 c = a.accumVort ? gload2(a.vort, own) : make_double2(0.0, 0.0);
+            lds_burst<3>(raw, ad);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                uv[j] = __builtin_bit_cast(double2, raw[j]);
+                if (!cached[j]) uv[j] = glb_row2(puG + goff[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                c.x += wv[j] * uv[j].x;
+                c.y += wv[j] * uv[j].y;
+            }
+            gstore2(a.vort, own, c);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -444,6 +507,16 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
     const int nOwnC = c1 - c0, nOwnE = e1 - e0;
     const uint32_t e0B = (uint32_t)e0 * rowB, nOwnB = (uint32_t)nOwnE * rowB;
     const float *sshf = reinterpret_cast<const float *>(a.ssh);
+    // Forward-Euler modes with the vertex pass in the same launch (a.vort): vertex records behind the row cache (see k_stage_rec2c)
+    double *Lvw = reinterpret_cast<double *>(smem + recBytes + (((size_t)maxOwnE * rowB + 15) & ~(size_t)15));
+    uint32_t *Lvo = reinterpret_cast<uint32_t *>(Lvw + (size_t)m.maxOwnV * 3);
+    int v0 = 0, nOwnV = 0;
+    if constexpr (MODE >= 4) {
+        if (a.vort) {
+            v0 = cptr(m.patchVertStart)[p];
+            nOwnV = cptr(m.patchVertStart)[p + 1] - v0;
+        }
+    }
 
     {   // staging in one phase (see k_stage_rec2c): every global load before the first LDS write; the unrolled part covers the
         // default patch (P = 24: 72-75 own edges at K = 80), the plain loops at the end whatever is larger
@@ -485,6 +558,10 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
         if (tid < nOwnC) {
             L.invA[tid] = vA;
             L.rsum[tid] = vR;
+        }
+        if constexpr (MODE >= 4) {
+            for (int i = tid; i < nOwnV * 4; i += NT) Lvo[i] = m.vRec[(size_t)v0 * 4 + i];
+            for (int i = tid; i < nOwnV * 3; i += NT) Lvw[i] = m.cv[(size_t)v0 * 3 + i];
         }
         for (int i = tid + UU * NT; i < nU; i += NT) ubuf4[i] = src[i];
         for (int i = tid + UE * NT; i < nER; i += NT) L.eRec[i] = m.eRec[(size_t)e0 * m.EI + i];
@@ -671,7 +748,11 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
             if constexpr (FE) {
                 hxf = gload4f(a.ph, r[ME2] * rowB + voff);             // layerThickness of cellsOnEdge[1], [2]
                 hyf = gload4f(a.ph, r[ME2 + 1] * rowB + voff);
-                if constexpr (STALE || PREV) hEof = gload4f(a.hEdgeOld, own);
+                if constexpr (STALE) hEof = gload4f(a.hEdgeOld, own);
+                if constexpr (PREV) {                                  // the same two cells one level back, rounded as it was stored
+                    const d4 px = gload4(a.hPrev, r[ME2] * rowB + voff), py = gload4(a.hPrev, r[ME2 + 1] * rowB + voff);
+                    hEof = narrow4(d4{0.5 * (px.x + py.x), 0.5 * (px.y + py.y), 0.5 * (px.z + py.z), 0.5 * (px.w + py.w)});
+                }
             }
             if (l == 0) {                                              // behind the gathers in the queue: nothing waits for these two alone
                 sA = sshf[r[ME2]];
@@ -731,6 +812,39 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
                 gstore4(a.pu_out, own, axpy4(up, a.a, t));              // time_integration.jl:199
                 gstore4(a.tendU, own, t);
             }
+        }
+    }
+    // ---------------- vertices: relativeVorticity of the OLD state (see k_stage_rec2c; the sums of k_curl3_f32) ----------------
+    if constexpr (FE) {
+        for (int vi = grp; vi < nOwnV; vi += NG) {
+            if (!act) continue;
+            const uint32_t *rv = Lvo + (size_t)vi * 4;
+            const double *wv = Lvw + (size_t)vi * 3;
+            const uint32_t own = (uint32_t)(v0 + vi) * rowB + voff;
+            bool cached[3];
+            uint32_t ad[3], goff[3];
+            v4u_t raw[3];
+            float4 uf[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint32_t off = rv[j];
+                ad[j] = urow_addr(off, cached[j]);
+                goff[j] = off + voff;
+                asm("" : "+v"(goff[j]));
+            }
+            d4 c = a.accumVort ? gload4(a.vort, own) : zero;
+            lds_burst<3>(raw, ad);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                uf[j] = __builtin_bit_cast(float4, raw[j]);
+                if (!cached[j]) uf[j] = glb_row4f(puG + goff[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const d4 uv = widen4(uf[j]);
+                c.x += wv[j] * uv.x; c.y += wv[j] * uv.y; c.z += wv[j] * uv.z; c.w += wv[j] * uv.w;
+            }
+            gstore4(a.vort, own, c);
         }
     }
 }
@@ -1314,6 +1428,27 @@ size_t rec2c_lds_bytes(const MeshDev &md)
     return ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 8 + 16;
 }
 
+// the vertex records a Forward-Euler launch with the vertex pass stages behind the row cache: 3 coefficients + 4 offsets per vertex
+static inline size_t vert_lds_bytes(const MeshDev &md) { return (size_t)md.maxOwnV * (3 * 8 + 4 * 4) + 16; }
+
+bool stage_curl_fused(const MeshDev &md) { return md.vRec != nullptr && md.VD == 3 && md.patchVertStart != nullptr && md.maxOwnV > 0; }
+
+// ... and do its vertex records fit beside the records and own rows of patches as large as md.maxOwnE / md.maxOwnC
+bool stage_curl_fits(const MeshDev &md, bool f32)
+{
+    if (!stage_curl_fused(md)) return false;
+    const size_t rows = (size_t)md.maxOwnE * md.K * (f32 ? 4 : 8);
+    const size_t lds = ((rec_lds_bytes(md) + 15) & ~(size_t)15) + rows + 16 + vert_lds_bytes(md) + 16;
+    return f32 ? (stage_f32_supported(md) && lds <= 160 * 1024) : (rec2c_supported(md) && lds <= 64 * 1024);
+}
+
+static inline ColMesh col_mesh(const MeshDev &md, int nLaunch)
+{
+    return ColMesh{md.nC, md.nE, md.K, nLaunch, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
+                   md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc, md.tailPatch >= 0 ? md.tailPatch + 1 : 0,
+                   md.patchVertStart, md.vRec, md.cv, md.maxOwnV};
+}
+
 // can launch_stage_rec2c serve whole-mesh launches of this mesh at all (even K <= 64, records + own rows within 64 KB of LDS)
 bool rec2c_supported(const MeshDev &md)
 {
@@ -1325,10 +1460,10 @@ hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t
 {
     const int nLaunch = md.nPatches + (md.tailPatch >= 0 ? 1 : 0);
     const dim3 g(8 * ((nLaunch + 7) / 8)), b(BLOCK);
-    const ColMesh m{md.nC, md.nE, md.K, nLaunch, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
-                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc, md.tailPatch >= 0 ? md.tailPatch + 1 : 0};
+    const ColMesh m = col_mesh(md, nLaunch);
     const int mode = colp_mode(a);
-    const size_t lds = rec2c_lds_bytes(md);
+    if (a.vort && (mode < 4 || !stage_curl_fused(md))) return hipErrorNotSupported;
+    const size_t lds = rec2c_lds_bytes(md) + (a.vort ? vert_lds_bytes(md) : 0);
     if (mode < 0 || md.K > 64 || (md.K & 1) || lds > 64 * 1024 || md.maxOwnC < 1 || md.maxOwnE < 1) return hipErrorNotSupported;
     bool ok = false;
     if (md.ME == 6 && md.ME2 == 10) ok = launch_rec2c<6, 10>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
@@ -1345,6 +1480,10 @@ hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t
 static std::atomic<int> g_f32WideModes{1 << 0};
 void set_f32_wide_modes(int mask) { g_f32WideModes.store(mask); }
 int f32_wide_modes() { return g_f32WideModes.load(); }
+// measurement: 0 keeps Forward-Euler steps on the gathered layerThicknessEdge (mode 4) even when mode 6 applies
+static std::atomic<int> g_fePrevMode{1};
+void set_fe_prev_mode(int on) { g_fePrevMode.store(on); }
+int fe_prev_mode() { return g_fePrevMode.load(); }
 
 template <int ME, int ME2, int NT, int WPE>
 static bool launch_rec2c_f32_nt(const ColMesh &m, const StageArgs &a, int mode, dim3 g, size_t lds, int mE, int mC, hipStream_t s)
@@ -1396,11 +1535,12 @@ hipError_t launch_stage_rec2c_f32(const MeshDev &md, const StageArgs &a, hipStre
 {
     const int nLaunch = md.nPatches + (md.tailPatch >= 0 ? 1 : 0);
     const dim3 g(8 * ((nLaunch + 7) / 8)), b(BLOCK);
-    const ColMesh m{md.nC, md.nE, md.K, nLaunch, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
-                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc, md.tailPatch >= 0 ? md.tailPatch + 1 : 0};
+    const ColMesh m = col_mesh(md, nLaunch);
     const int mode = colp_mode(a);
     if (mode < 0 || !stage_f32_supported(md)) return hipErrorNotSupported;
-    const size_t lds = ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 4 + 16;
+    if (a.vort && (mode < 4 || !stage_curl_fused(md))) return hipErrorNotSupported;
+    const size_t lds = ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 4 + 16 + (a.vort ? vert_lds_bytes(md) + 16 : 0);
+    if (lds > 160 * 1024) return hipErrorNotSupported;
     bool ok = false;
     if (md.ME == 6 && md.ME2 == 10) ok = launch_rec2c_f32<6, 10>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
     else if (md.ME == 8 && md.ME2 == 14) ok = launch_rec2c_f32<8, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);

@@ -23,6 +23,11 @@ struct StageArgs {
     const double *hPrev;          // mode 6: the previous time level's layerThickness, which hEdgeOld is the interpolation of
     double *hEdgeNew, *F, *div;   // layerThicknessEdge, thicknessFlux, velocityDivCell
     const double *areaCell;
+    // relativeVorticity of the OLD state (CurlOnVertex, Operators.jl:137-146) by the same launch: the vertices of the launched
+    // patches, normalVelocity rows from the patch's LDS row cache where it has them.  NULL: the caller launches the vertex
+    // pass itself (k_curl3 / k_fe).  vertexDegree 3 meshes with byte-offset records only (stage_curl_fused()).
+    double *vort;
+    int accumVort;                // MOKA_FE_ACCUM_VORT: on top of what the array holds (Operators.jl:135,142)
 };
 
 // the slice of MeshDev the column kernel reads (kept small: kernel arguments live in SGPRs)
@@ -33,6 +38,11 @@ struct ColMesh {
     const int32_t *mltc;
     const double *sdv, *invArea, *rsum, *woe, *feoe, *gInvDc;
     int32_t tailPlus1;   // != 0: the launch's last workgroup takes patch tailPlus1 - 1 instead of patchBegin + nPatches - 1
+    // vertex pass of the Forward-Euler modes (StageArgs.vort): the patches' vertex ranges, u-row offsets and coefficients
+    const int32_t *patchVertStart;
+    const uint32_t *vRec;
+    const double *cv;
+    int32_t maxOwnV;
 };
 
 enum : int {
@@ -69,11 +79,16 @@ hipError_t launch_stage(const MeshDev &m, const StageArgs &a, int lpc, hipStream
 hipError_t launch_stage_col(const MeshDev &m, const StageArgs &a, hipStream_t s);               // plain column kernel
 hipError_t launch_stage_rec2c(const MeshDev &m, const StageArgs &a, hipStream_t s);
 bool rec2c_supported(const MeshDev &m);
+// can the Forward-Euler modes of the stage kernels carry the relativeVorticity pass of this mesh (StageArgs.vort)
+bool stage_curl_fused(const MeshDev &m);
+bool stage_curl_fits(const MeshDev &m, bool f32);      // ... with patches of m.maxOwnE / m.maxOwnC own edges / cells
 // fp32-state form (state pointers of StageArgs are float arrays); stage_f32_supported: can this mesh carry one
 bool stage_f32_supported(const MeshDev &m);
 hipError_t launch_stage_rec2c_f32(const MeshDev &m, const StageArgs &a, hipStream_t s);
 void set_f32_wide_modes(int mask);      // measurement: which modes of the fp32-storage kernel run as (512 threads, 4 waves per SIMD)
 int f32_wide_modes();
+void set_fe_prev_mode(int on);          // measurement: 0 = never form the stale layerThicknessEdge from the previous level (mode 6)
+int fe_prev_mode();
 hipError_t launch_update_ssh_f32(const MeshDev &m, const float *h, float *ssh, int nlev, int lpc, hipStream_t s);
 hipError_t launch_permute_rows_f32(void *dst, const void *src, const int32_t *n2o, int64_t n, int K, int to_device,
                                    hipStream_t s);

@@ -104,6 +104,17 @@ typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
 template <int N>
 __device__ __forceinline__ void lds_burst(v4u_t (&v)[N], const uint32_t (&ad)[N]);
 template <>
+__device__ __forceinline__ void lds_burst<3>(v4u_t (&v)[3], const uint32_t (&ad)[3])
+{
+    asm volatile("ds_read_b128 %[o0], %[a0]\n\t"
+                 "ds_read_b128 %[o1], %[a1]\n\t"
+                 "ds_read_b128 %[o2], %[a2]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [o0] "=&v"(v[0]), [o1] "=&v"(v[1]), [o2] "=&v"(v[2])
+                 : [a0] "v"(ad[0]), [a1] "v"(ad[1]), [a2] "v"(ad[2])
+                 : "memory");
+}
+template <>
 __device__ __forceinline__ void lds_burst<6>(v4u_t (&v)[6], const uint32_t (&ad)[6])
 {
     asm volatile("ds_read_b128 %[o0], %[a0]\n\t"

@@ -55,6 +55,22 @@ struct Plan {
     std::vector<uint32_t> cRec, eRec;
     std::vector<uint32_t> cRecT, eRecT;   // the same with patch-local LDS row-image offsets in the u-row slots (tiled kernels)
     std::vector<double>   feoe;       // nE*ME2
+    // COMPACT records of the default stage kernels (round 3; built when ldsOk && colOk): a patch touches ~110 distinct
+    // normalVelocity rows, so a slot names its row by a patch-local id of one byte instead of a 32-bit offset, and what
+    // belongs to the ROW (its byte offset, fEdge of its edge) is stored once per patch row instead of once per slot:
+    //   rowOff[rowStart[q] + id], rowF[rowStart[q] + id] : byte offset / fEdge of patch q's row `id` (own edges first: id < nOwnE)
+    //   cRec3[c][CI3]: [0,2) the ME row ids, one byte each (invalid slots: the id of slot 0) | [2,2+ME) h-row offsets of the cells
+    //                  across | [2+ME] valid-slot mask | all-levels flag << 8
+    //   eRec3[e][EI3]: [0,NID) the ME2 row ids, one byte each (invalid slots: the edge's own id) | [NID] maxLevelEdgeTop |
+    //                  valid-slot mask << 16 | [NID+1] c1 | [NID+2] c2            NID = (ME2 + 3) / 4
+    // 139 bytes per edge instead of 224 (weightsOnEdge stay per slot): -0.26 GB per launch at config 4, -0.94 GB at config 5.
+    std::vector<uint32_t> cRec3, eRec3, rowOff;
+    std::vector<double>   rowF;
+    int32_t CI3 = 0, EI3 = 0;
+    // vRec[v][4] (vertexDegree 3 only): u-row byte offsets of the vertex's three edges | 0 -- the relativeVorticity pass of the
+    // Forward-Euler modes of the stage kernels (weights: cv)
+    std::vector<uint32_t> vRec;
+    int32_t maxOwnV = 0;              // most vertices any patch owns
     int32_t CI = 0, EI = 0;
     bool colOk = false;               // K*stateBytes*nE < 4 GiB: offsets fit 32 bits
     // patch-local view for the LDS-tiled kernel: the u-rows a patch needs are its own edges
@@ -110,6 +126,11 @@ struct MeshDev {
     const uint32_t *cRec, *eRec;
     const uint32_t *cRecT, *eRecT;
     const double *feoe;
+    const uint32_t *vRec;
+    int32_t maxOwnV;
+    const uint32_t *cRec3, *eRec3, *rowOff;
+    const double *rowF;
+    int32_t CI3, EI3;
     int32_t CI, EI;
     // LDS-tiled kernel
     const int32_t *haloStart, *haloEdge, *rowStart, *rowEdge;

@@ -531,6 +531,14 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
                 r[ME2 + 3] = (uint32_t)p.ehdr[4 * (size_t)e + 3];
             }
         }
+        p.vRec.clear();
+        if (p.colOk && p.VD == 3) {
+            p.vRec.assign((size_t)nV * 4, 0u);
+            for (int v = 0; v < nV; ++v)
+                for (int j = 0; j < 3; ++j) p.vRec[(size_t)v * 4 + j] = (uint32_t)((uint64_t)p.eov[(size_t)v * 3 + j] * rowB);
+        }
+        p.maxOwnV = 0;
+        for (int q = 0; q < p.nPatches; ++q) p.maxOwnV = std::max(p.maxOwnV, p.patchVertStart[q + 1] - p.patchVertStart[q]);
     }
 
     // ---- patch-local row lists for the LDS-tiled kernel ----
@@ -603,6 +611,56 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
             for (int i = 0; i < ME; ++i)
                 if (p.eoc[IX(i, c, ME)] >= 0) p.keoc[IX(i, c, ME)] = p.keCoef[p.eoc[IX(i, c, ME)]];
     }
+    // ---- compact records of the default stage kernels (see moka_internal.hpp) ----
+    p.cRec3.clear(); p.eRec3.clear(); p.rowOff.clear(); p.rowF.clear();
+    p.CI3 = 2 + ME + 1;
+    p.EI3 = (ME2 + 3) / 4 + 3;
+    if (p.ldsOk && p.colOk && ME <= 8 && ME2 <= 16 && p.K < 65536) {
+        const uint64_t rowB = (uint64_t)p.K * p.stateBytes;
+        const int NID = (ME2 + 3) / 4;
+        p.rowOff.resize(p.rowEdge.size());
+        p.rowF.resize(p.rowEdge.size());
+        for (size_t r = 0; r < p.rowEdge.size(); ++r) {
+            p.rowOff[r] = (uint32_t)((uint64_t)p.rowEdge[r] * rowB);
+            p.rowF[r] = p.fEdge[p.rowEdge[r]];
+        }
+        p.cRec3.assign((size_t)nC * p.CI3, 0u);
+        p.eRec3.assign((size_t)nE * p.EI3, 0u);
+        for (int c = 0; c < nC; ++c) {
+            uint32_t *r = &p.cRec3[(size_t)c * p.CI3];
+            uint32_t mask = 0, all = 1;
+            const uint32_t id0 = p.leoc[(size_t)c * 8 + 0];          // slot 0 always exists (nEdgesOnCell >= 1)
+            for (int i = 0; i < ME; ++i) {
+                const bool on = p.eoc[IX(i, c, ME)] >= 0;
+                const uint32_t id = on ? p.leoc[(size_t)c * 8 + i] : id0;
+                r[i >> 2] |= id << (8 * (i & 3));
+                r[2 + i] = on ? (uint32_t)((uint64_t)p.coc[IX(i, c, ME)] * rowB) : (uint32_t)((uint64_t)c * rowB);
+                if (on) {
+                    mask |= 1u << i;
+                    if (p.mltc[IX(i, c, ME)] < p.K) all = 0;
+                }
+            }
+            r[2 + ME] = mask | (all << 8);
+        }
+        std::vector<int32_t> patchOfEdge(nE, 0);
+        for (int q = 0; q < p.nPatches; ++q)
+            for (int e = p.patchEdgeStart[q]; e < p.patchEdgeStart[q + 1]; ++e) patchOfEdge[e] = q;
+        for (int e = 0; e < nE; ++e) {
+            uint32_t *r = &p.eRec3[(size_t)e * p.EI3];
+            uint32_t mask = 0;
+            const uint32_t own = (uint32_t)(e - p.patchEdgeStart[patchOfEdge[e]]);
+            for (int i = 0; i < ME2; ++i) {
+                const bool on = p.eoe[IX(i, e, ME2)] >= 0;
+                const uint32_t id = on ? p.leoe[(size_t)e * 16 + i] : own;
+                r[i >> 2] |= id << (8 * (i & 3));
+                if (on) mask |= 1u << i;
+            }
+            r[NID] = (uint32_t)std::min(p.ehdr[4 * (size_t)e + 3], 65535) | (mask << 16);
+            r[NID + 1] = (uint32_t)p.ehdr[4 * (size_t)e];
+            r[NID + 2] = (uint32_t)p.ehdr[4 * (size_t)e + 1];
+        }
+    }
+
     // records of the LDS-DMA tiled kernels: eRec / cRec with the u-row slots replaced by the byte offset of the row inside a
     // patch's LDS row image (pieces of 1 KiB holding 1024 / rowBytes whole rows; csrc/experiments/stage_tile.hip)
     p.eRecT.clear(); p.cRecT.clear();
