@@ -381,6 +381,14 @@ int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[4]);
  * step after the first of a run), 0 = the generic one-launch kernel, -1 = no Forward-Euler step yet.  For tests and
  * measurement; results are identical either way. */
 int moka_last_fe_path(const moka_state *st);
+/* 1 while the TendencyVars / DiagnosticVars of the last Forward-Euler step are pending.  With the default kernel choice a
+ * Forward-Euler step of all levels is LEAN: it stores the new time level and relativeVorticity; tendNormalVelocity,
+ * tendLayerThickness, thicknessFlux, velocityDivCell and layerThicknessEdge of the step are produced on the first read
+ * (download, sum_sq, upload, the piecewise reference calls, a taped step ...), from the level the step started from -- same
+ * arithmetic, same bits -- and superseded by the next step otherwise, like the DiagnosticVars an RK4 step leaves pending.
+ * The first step of a run with MOKA_FE_STALE_HEDGE, steps on a tape, MOKA_FE_LEVEL1_ONLY steps and moka_set_tuning(4, 0)
+ * store everything at once. */
+int moka_fe_lazy_pending(const moka_state *st);
 
 /* ---- optional nonlinear terms (extension; NOT in the reference, parity unpinned) ---------------------------------
  * north_star names potential-vorticity Coriolis over edgesOnEdge, the KE + ssh gradient over cellsOnEdge and vertex

@@ -335,20 +335,73 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
     return launch_stage(dev, g, m->lpc, s);
 }
 
-// Argument block of the Forward-Euler step in the stage kernel (k_stage_rec2c* modes 4 / 5 / 6) from the generic kernel's.
-// MOKA_FE_STALE_HEDGE: the stored layerThicknessEdge is gathered (mode 4) unless it is known to be the interpolation of the
-// previous level's layerThickness and that level survives the step (a spare set takes the new level): then the cell loop
-// forms it from those rows (mode 6).
+// Forward-Euler step in the stage kernels (k_stage_rec2c* modes 4 / 5 / 6): all levels, the default kernel choice, a mesh the
+// kernels can carry.  (MOKA_FE_LEVEL1_ONLY, odd or large K, explicit kernel variants take the generic one-launch kernel k_fe.)
+bool fe_stage_path(const moka_state *st, int flags)
+{
+    const moka_mesh *mm = st->mesh;
+    if (flags & MOKA_FE_LEVEL1_ONLY) return false;
+    if (st->f32) return true;                                  // checked when the state was created
+    MeshDev dev = mm->dev;
+    dev.maxOwnE = std::max(mm->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(mm->plan.maxOwnCLaunch, 1);
+    return (st->ctx->variant == 0 || st->ctx->variant == 11) && mm->lpc == 64 && mm->colOk && rec2c_supported(dev);
+}
+
+// A LEAN step stores the new level and relativeVorticity only (moka_state.feLazy).  It needs the stage-kernel path, the spare
+// level set, and -- with the reference's stale flux thickness -- that thickness to be derivable from the previous level.
+bool fe_lean(const moka_state *st, int flags)
+{
+    return moka::fe_lean_enabled() && !st->feForceEager && fe_stage_path(st, flags) && st->spare.ssh &&
+           (!(flags & MOKA_FE_STALE_HEDGE) || (st->hEdgePrev && moka::fe_prev_mode()));
+}
+
+// What a Forward-Euler step does about lazily pending arrays before its first launch.  A lean step reads none of them and
+// supersedes them -- except relativeVorticity when it accumulates onto a value an RK4 step left pending; anything else needs
+// them in memory.  Idempotent: the parts of a distributed step all call it.
+int fe_begin(moka_state *st, int flags)
+{
+    // an fp32-storage state after an RK4 step has no current DiagnosticVars: a step that carries none over (flags 0) may follow
+    if (st->f32 && st->diagDirty && !(flags & (MOKA_FE_STALE_HEDGE | MOKA_FE_ACCUM_VORT))) st->diagDirty = false;
+    if (fe_lean(st, flags) && !(st->diagDirty && (flags & MOKA_FE_ACCUM_VORT))) {
+        st->diagDirty = st->tendDirty = false;
+        st->lazyPu = st->lazyPh = nullptr; st->lazyOwner = nullptr;
+        return MOKA_OK;
+    }
+    return flush_lazy(st, true, true);
+}
+
+void fe_end(moka_state *st, int flags, bool stageKernel, bool lean, bool prevMode)
+{
+    fe_rotate_levels(st);
+    if (!lean) std::swap(st->hEdge[0], st->hEdge[1]);          // a lean step has not written layerThicknessEdge
+    st->feFast = stageKernel ? (prevMode ? 2 : 1) : 0;
+    st->feLazy = lean;
+    st->feLazyStale = lean && (flags & MOKA_FE_STALE_HEDGE);
+    // the stage kernel interpolated (or, lean, will interpolate) layerThicknessEdge of every computed edge from the level that is
+    // the previous one now: the next step may form the reference's stale flux thickness from that level (mode 6)
+    st->hEdgePrev = stageKernel;
+}
+
+// Argument block of a Forward-Euler launch of the stage kernels from the generic kernel's.  MOKA_FE_STALE_HEDGE: the stored
+// layerThicknessEdge is gathered (mode 4) unless it is known to be the interpolation of the previous level's layerThickness and
+// that level survives the step (the spare set takes the new level): then it is formed from those rows (mode 6).  A lean step
+// passes no TendencyVars / DiagnosticVars outputs.
 StageArgs fe_stage_args(moka_state *st, const FeArgs &a, int flags)
 {
     StageArgs s{};
     s.pu = a.u; s.ph = a.h; s.ssh = a.ssh;
     s.pu_out = a.u_new; s.ph_out = a.h_new; s.ssh_out = a.ssh_new;
-    s.tendU = a.tendU; s.tendH = a.tendH; s.a = a.dt;
-    s.hEdgeOld = (flags & MOKA_FE_STALE_HEDGE) ? a.hEdgeOld : nullptr;
-    s.hPrev = ((flags & MOKA_FE_STALE_HEDGE) && st->hEdgePrev && st->spare.ssh && a.h_new != st->lev[0].h && moka::fe_prev_mode())
-                  ? st->lev[0].h : nullptr;
-    s.hEdgeNew = a.hEdgeNew; s.F = a.F; s.div = a.div; s.areaCell = st->mesh->dev.areaCell;
+    s.a = a.dt;
+    const bool stale = flags & MOKA_FE_STALE_HEDGE;
+    const bool prev = stale && st->hEdgePrev && st->spare.ssh && a.h_new != st->lev[0].h && moka::fe_prev_mode();
+    s.hEdgeOld = stale && !prev ? a.hEdgeOld : nullptr;
+    s.hPrev = prev ? st->lev[0].h : nullptr;
+    s.feMode = prev ? 6 : stale ? 4 : 5;
+    s.areaCell = st->mesh->dev.areaCell;
+    if (!fe_lean(st, flags)) {
+        s.tendU = a.tendU; s.tendH = a.tendH;
+        s.hEdgeNew = a.hEdgeNew; s.F = a.F; s.div = a.div;
+    }
     // relativeVorticity by the same launch (the vertices of the launched patches) where the stage kernels can carry it
     {
         MeshDev dev = st->mesh->dev;
@@ -358,8 +411,32 @@ StageArgs fe_stage_args(moka_state *st, const FeArgs &a, int flags)
     return s;
 }
 
+// The arrays a lean Forward-Euler step left pending (moka_state.feLazy), produced now: the same launch over the same patches
+// with the new-level outputs switched off and the diagnostic outputs on, from the level the step started from (the previous
+// one now) and, for the stale flux thickness, the level before it (`spare`).
+static int materialize_fe(moka_state *st)
+{
+    const moka_mesh *mm = st->mesh;
+    StageArgs g{};
+    g.pu = st->lev[0].u; g.ph = st->lev[0].h; g.ssh = st->lev[0].ssh;
+    g.feMode = st->feLazyStale ? 6 : 5;
+    g.hPrev = st->feLazyStale ? st->spare.h : nullptr;
+    g.tendU = st->tendU; g.tendH = st->tendH; g.F = st->F; g.div = st->div;
+    g.hEdgeNew = st->hEdge[0];                                  // mode 6 reads no stored layerThicknessEdge: written in place
+    g.areaCell = mm->dev.areaCell;
+    MeshDev dev = mm->dev;
+    dev.tailPatch = -1;
+    dev.patchBegin = 0; dev.nPatches = mm->plan.nPatchesLaunch;
+    dev.maxOwnE = std::max(mm->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(mm->plan.maxOwnCLaunch, 1);
+    HIPCHK(st->ctx, st->f32 ? launch_stage_rec2c_f32(dev, g, st->ctx->stream) : launch_stage_rec2c(dev, g, st->ctx->stream));
+    st->feLazy = false;
+    return MOKA_OK;
+}
+
 int flush_lazy(moka_state *st, bool diag, bool tend)
 {
+    if ((diag || tend) && st->feLazy)
+        if (int rc = materialize_fe(st)) return rc;
     if (diag && st->diagDirty && st->f32)   // no diagnostics-only kernel for float arrays: they come out of Forward-Euler steps
         return fail(st->ctx, MOKA_ERR_UNSUPPORTED,
                     "fp32-storage state: DiagnosticVars exist after Forward-Euler steps only (not after RK4 steps or uploads)");
@@ -587,10 +664,16 @@ int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[4])
 //          (default: mode 0; see kernels.hip, g_f32WideModes)
 //   key 2: 0 = Forward-Euler steps always gather the stored layerThicknessEdge (stage-kernel mode 4), 1 (default) = they form
 //          it from the previous level's layerThickness whenever that is the same thing (mode 6)
+//   key 4: 0 = every Forward-Euler step stores all of its DiagnosticVars / TendencyVars; 1 (default) = lean steps where possible
+//          (new level and relativeVorticity stored, the rest produced on first read: moka_state.feLazy)
+//   key 3: 0 = the relativeVorticity pass of a Forward-Euler step always gets a launch of its own, 1 (default) = it rides in the
+//          stage-kernel launches where they can carry it
 int moka_set_tuning(int key, int value)
 {
     if (key == 1) { moka::set_f32_wide_modes(value); return MOKA_OK; }
     if (key == 2) { moka::set_fe_prev_mode(value); return MOKA_OK; }
+    if (key == 3) { moka::set_curl_fused(value); return MOKA_OK; }
+    if (key == 4) { moka::set_fe_lean(value); return MOKA_OK; }
     return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
 }
 
@@ -599,6 +682,8 @@ int moka_get_tuning(int key, int *value)
     if (!value) return fail(nullptr, MOKA_ERR_ARG, "value is NULL");
     if (key == 1) { *value = moka::f32_wide_modes(); return MOKA_OK; }
     if (key == 2) { *value = moka::fe_prev_mode(); return MOKA_OK; }
+    if (key == 3) { *value = moka::curl_fused(); return MOKA_OK; }
+    if (key == 4) { *value = moka::fe_lean_enabled(); return MOKA_OK; }
     return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
 }
 
@@ -650,6 +735,9 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     MeshDev &d = m->dev;
     d.nC = p.nC; d.nE = p.nE; d.nV = p.nV; d.K = p.K; d.ME = p.ME; d.ME2 = p.ME2; d.VD = p.VD; d.nPatches = p.nPatches;
+    d.tailPatch = -1;      // no extra patch rides in a launch of this view (0, the zero-initialised value, would name patch 0: a
+                           // whole-mesh Forward-Euler launch then ran patch 0 twice -- harmless while every result was a pure
+                           // function of the inputs, wrong once relativeVorticity accumulates in the same launch)
     m->lpc = lanes_per_column(p.K);
 #define UP(field)                                                \
     if ((rc = upload_vec(m, p.field, &d.field)) != MOKA_OK) {    \
@@ -660,7 +748,7 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     UP(eoc) UP(coc) UP(mltc) UP(sdv) UP(invArea) UP(areaCell) UP(rsum)
     UP(ehdr) UP(eoe) UP(woe) UP(gInvDc) UP(dcEdge) UP(dvEdge) UP(fEdge)
     UP(eov) UP(cv) UP(cellN2O) UP(edgeN2O) UP(vertN2O)
-    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(vRec) UP(cRec3) UP(eRec3) UP(rowOff) UP(rowF) UP(lcOff) UP(leOff) UP(patchRegular) UP(rowStart) UP(rowEdge) UP(cRecT) UP(eRecT)
+    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(vRec) UP(lcOff) UP(leOff) UP(patchRegular) UP(rowStart) UP(rowEdge) UP(cRecT) UP(eRecT)
     if (p.nlOk) { UP(voe) UP(cov) UP(kite) UP(invAreaTri) UP(fVertex) UP(keCoef) UP(invDc) UP(keoc) UP(rowVoe) }
 #undef UP
     d.CI = p.CI; d.EI = p.EI;
@@ -681,8 +769,6 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     d.maxRows = p.maxRows; d.maxOwnE = p.maxOwnE; d.maxOwnC = p.maxOwnC;
     d.maxOwnV = p.maxOwnV;
     if (p.vRec.empty()) d.vRec = nullptr;       // (upload_vec hands out a dummy allocation for an empty vector)
-    d.CI3 = p.CI3; d.EI3 = p.EI3;
-    if (p.eRec3.empty()) d.cRec3 = d.eRec3 = d.rowOff = nullptr, d.rowF = nullptr;
 #ifdef MOKA_VARIANTS
     if (p.colOk && stage_tile_usable(d, p.ldsOk) && prepare_stage_tile(d) == hipSuccess) m->tileOk = true;
     if (p.colOk && stage_ptile_usable(d, p.ldsOk) && prepare_stage_ptile(d) == hipSuccess) m->ptileOk = true;
@@ -966,6 +1052,10 @@ int moka_state_upload(moka_state *st, int field, int time_level, const double *h
     int rc = field_ref(st, field, time_level, &r);
     if (rc) return rc;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    // the arrays of a lean Forward-Euler step are derived from the previous level (and the one before): whatever the caller
+    // overwrites, they are produced from the values the step saw
+    if (st->feLazy && !(field <= MOKA_F_LAYER_THICKNESS && time_level == 1))
+        if ((rc = flush_lazy(st, true, true))) return rc;
     const bool prog1 = field <= MOKA_F_LAYER_THICKNESS && time_level == 1;   // pending lazy results refer to the old state
     // (an fp32-storage state cannot materialise pending diagnostics: they stay pending, i.e. unavailable)
     if ((rc = flush_lazy(st, (prog1 && !st->f32) || is_diag_field(field), prog1 || is_tend_field(field)))) return rc;
@@ -993,6 +1083,7 @@ int moka_advance_time_levels(moka_state *st, int flags)
     const Plan &p = st->mesh->plan;
     hipStream_t s = st->ctx->stream;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (int rcl = flush_lazy(st, st->feLazy, st->feLazy)) return rcl;      // a lean step's arrays derive from the level overwritten now
     st->hEdgePrev = false;                 // the previous level changes under the stored layerThicknessEdge
     // advance_2d_array / advance_3d_array (time_integration.jl:42-59): prev <- next.
     // Level-1-only copies (K > 1) go through the FE kernel's carry-over path instead.
@@ -1068,6 +1159,7 @@ int moka_tendencies(moka_state *st)
         if ((rc = make_ssh_consistent(st, st->lev[1].ssh))) return rc;
         st->sshConsistent = true;
     }
+    if (st->feLazy && (rc = flush_lazy(st, true, true))) return rc;        // (it would overwrite the tendencies written here later)
     StageArgs a{};
     a.pu = st->lev[1].u; a.ph = st->lev[1].h; a.ssh = st->lev[1].ssh;
     a.tendU = st->tendU; a.tendH = st->tendH;
@@ -1081,82 +1173,62 @@ int moka_step_fe(moka_state *st, double dt, int flags)
     if (!st) return fail(nullptr, MOKA_ERR_ARG, "state is NULL");
     if (st->nonlinear) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "nonlinear terms: moka_tendencies / RK4 only");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
-    // an fp32-storage state after an RK4 step has no current DiagnosticVars: a step that carries none over (flags 0) may follow
-    if (st->f32 && st->diagDirty && !(flags & (MOKA_FE_STALE_HEDGE | MOKA_FE_ACCUM_VORT))) st->diagDirty = false;
-    if (int rcl = flush_lazy(st, true, true)) return rcl;
-    // advanceTimeLevels! + diagnostic_compute! + both tendencies + updates (time_integration.jl:163-189)
-    // in one launch: new values are written into the previous level's buffers, then the levels swap.
-    FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE | FE_TENDU | FE_TENDH | FE_UPDATE, flags, dt);
-    if (st->f32) {
-        // fp32-storage state: the step exists in the stage kernel's Forward-Euler modes only (all levels, whole mesh)
-        const moka_mesh *mf = st->mesh;
-        if ((flags & MOKA_FE_LEVEL1_ONLY) || mf->plan.nPatchesLaunch != mf->plan.nPatches)
-            return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: Forward Euler steps all levels of a whole mesh (no MOKA_FE_LEVEL1_ONLY, no partitions)");
-        if (int rcs = ensure_spare(st)) return rcs;
-        a = fe_args(st, a.ops, flags, dt);                     // the new level goes to the spare set
-        StageArgs g = fe_stage_args(st, a, flags);
-        g.areaCell = mf->dev.areaCell;
-        MeshDev dev = mf->dev;
-        dev.tailPatch = -1;
-        dev.maxOwnE = std::max(mf->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(mf->plan.maxOwnCLaunch, 1);
-        hipError_t ef = launch_stage_rec2c_f32(dev, g, st->ctx->stream);      // ssh as stored, like the Float64 step
-        if (ef == hipErrorNotSupported && g.vort) {                            // vertex records do not fit beside the rows: own launch
-            g.vort = nullptr;
-            ef = launch_stage_rec2c_f32(dev, g, st->ctx->stream);
-        }
-        HIPCHK(st->ctx, ef);
-        if (!g.vort)
-            HIPCHK(st->ctx, launch_curl_f32(dev, reinterpret_cast<const float *>(a.u), reinterpret_cast<float *>(a.vort),
-                                            flags & MOKA_FE_ACCUM_VORT, st->ctx->stream));
-        st->feFast = g.hPrev ? 2 : 1;
-        fe_rotate_levels(st);
-        std::swap(st->hEdge[0], st->hEdge[1]);
-        st->sshConsistent = true;
-        st->hEdgePrev = true;
-        return MOKA_OK;
-    }
-    // All levels on a whole mesh with the default kernel choice: the step runs in the tuned stage kernel (modes 4 / 5 of
-    // k_stage_rec2c: everything but relativeVorticity) plus the vertex pass of the generic kernel.  Anything else --
-    // MOKA_FE_LEVEL1_ONLY, odd or large K, explicit kernel variants, partitioned meshes -- takes the generic one-launch kernel.
-    bool fast = false;
     const moka_mesh *mm = st->mesh;
-    int fastMode = 0;
-    if (!(flags & MOKA_FE_LEVEL1_ONLY) && (st->ctx->variant == 0 || st->ctx->variant == 11) && mm->lpc == 64 && mm->colOk &&
-        mm->plan.nPatchesLaunch == mm->plan.nPatches && rec2c_supported(mm->dev)) {
-        if (int rcs = ensure_spare(st)) return rcs;
-        a = fe_args(st, a.ops, flags, dt);                     // the new level goes to the spare set
+    const bool whole = mm->plan.nPatchesLaunch == mm->plan.nPatches;
+    if (st->f32 && ((flags & MOKA_FE_LEVEL1_ONLY) || !whole))
+        return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "fp32-storage state: Forward Euler steps all levels of a whole mesh (no MOKA_FE_LEVEL1_ONLY, no partitions)");
+    // All levels on a whole mesh with the default kernel choice: the step runs in the stage kernels (modes 4 / 5 / 6 of
+    // k_stage_rec2c*), relativeVorticity in the same launch where the vertex records fit.  Anything else -- MOKA_FE_LEVEL1_ONLY, odd
+    // or large K, explicit kernel variants, local meshes of a partition outside the halo API -- takes the generic one-launch kernel.
+    const bool stagePath = whole && fe_stage_path(st, flags);
+    if (stagePath)
+        if (int rcs = ensure_spare(st)) return rcs;            // the new level goes to the spare set; the previous one stays readable
+    const bool lean = stagePath && fe_lean(st, flags);
+    if (int rcl = fe_begin(st, flags)) return rcl;
+    // advanceTimeLevels! + diagnostic_compute! + both tendencies + updates (time_integration.jl:163-189) in one launch: the new
+    // level is written into the spare set (or, without one, over the previous level), then the levels rotate.
+    FeArgs a = fe_args(st, FE_FLUX | FE_DIV | FE_CURL | FE_HEDGE | FE_TENDU | FE_TENDH | FE_UPDATE, flags, dt);
+    bool fast = false, prevMode = false;
+    if (stagePath) {
         StageArgs g = fe_stage_args(st, a, flags);
-        g.areaCell = mm->dev.areaCell;
-        hipError_t e = launch_stage_rec2c(mm->dev, g, st->ctx->stream);
-        if (e == hipErrorNotSupported && g.vort) {                             // vertex records do not fit beside the rows: own launch
+        MeshDev dev = mm->dev;
+        dev.tailPatch = -1;
+        dev.maxOwnE = std::max(mm->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(mm->plan.maxOwnCLaunch, 1);
+        auto launch = [&]() { return st->f32 ? launch_stage_rec2c_f32(dev, g, st->ctx->stream) : launch_stage_rec2c(dev, g, st->ctx->stream); };
+        hipError_t e = launch();
+        if (e == hipErrorNotSupported && g.vort) {             // vertex records do not fit beside the rows after all: own launch
             g.vort = nullptr;
-            e = launch_stage_rec2c(mm->dev, g, st->ctx->stream);
+            e = launch();
         }
         if (e == hipSuccess) {
             fast = true;
-            fastMode = g.hPrev ? 2 : 1;
-            if (!g.vort) {
-                const hipError_t ec = launch_curl2(mm->dev, a.u, a.vort, flags & MOKA_FE_ACCUM_VORT, st->ctx->stream);
-                if (ec == hipErrorNotSupported) {
-                    a.ops = FE_CURL;
-                    HIPCHK(st->ctx, launch_fe(mm->dev, a, mm->lpc, st->ctx->stream));
+            prevMode = g.hPrev != nullptr;
+            if (!g.vort) {                                     // ssh as stored, relativeVorticity of the OLD state
+                if (st->f32) {
+                    HIPCHK(st->ctx, launch_curl_f32(dev, reinterpret_cast<const float *>(a.u), reinterpret_cast<float *>(a.vort),
+                                                    flags & MOKA_FE_ACCUM_VORT, st->ctx->stream));
                 } else {
-                    HIPCHK(st->ctx, ec);
+                    const hipError_t ec = launch_curl2(mm->dev, a.u, a.vort, flags & MOKA_FE_ACCUM_VORT, st->ctx->stream);
+                    if (ec == hipErrorNotSupported) {
+                        a.ops = FE_CURL;
+                        HIPCHK(st->ctx, launch_fe(mm->dev, a, mm->lpc, st->ctx->stream));
+                    } else {
+                        HIPCHK(st->ctx, ec);
+                    }
                 }
             }
-        } else if (e != hipErrorNotSupported) {
-            HIPCHK(st->ctx, e);
+        } else if (e != hipErrorNotSupported || st->f32 || lean) {
+            HIPCHK(st->ctx, e);                                // (fp32 storage and lean steps have no generic form behind them)
+            return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "internal: the stage kernel refused a Forward-Euler launch it was selected for");
         }
     }
-    if (!fast) HIPCHK(st->ctx, launch_fe(st->mesh->dev, a, st->mesh->lpc, st->ctx->stream));
-    st->feFast = fast ? fastMode : 0;
-    fe_rotate_levels(st);
-    std::swap(st->hEdge[0], st->hEdge[1]);
-    st->sshConsistent = !(flags & MOKA_FE_LEVEL1_ONLY) || st->mesh->plan.K == 1;
-    st->hEdgePrev = fast;                  // the stage kernel interpolated every level of every computed edge from the level
-                                           // that is the previous one now
+    if (!fast) HIPCHK(st->ctx, launch_fe(mm->dev, a, mm->lpc, st->ctx->stream));
+    fe_end(st, flags, fast, fast && lean, prevMode);
+    st->sshConsistent = !(flags & MOKA_FE_LEVEL1_ONLY) || mm->plan.K == 1;
     return MOKA_OK;
 }
+
+int moka_fe_lazy_pending(const moka_state *st) { return st && st->feLazy ? 1 : 0; }
 
 // Argument block of RK4 stage s (1..4).  A = Curr (current level), B = New accumulator (the previous
 // level's buffers, becomes the current level at the end), R1/R2 = provisional states.
@@ -1196,6 +1268,7 @@ int rk4_begin(moka_state *st, const double **ssh0)
 {
     int rc = ensure_rk_bufs(st);
     if (rc) return rc;
+    st->feLazy = false;              // the arrays a lean Forward-Euler step left pending are superseded by this step's (rk4_end)
     *ssh0 = st->lev[1].ssh;
     if (!st->sshConsistent) {    // the tendency of stage 1 uses ssh computed from layerThickness
         if ((rc = make_ssh_consistent(st, st->rk[1].ssh))) return rc;
@@ -1343,6 +1416,8 @@ int moka_sum_sq(moka_state *st, int field, int time_level, double *out)
     int rc = field_ref(st, field, time_level, &r);
     if (rc) return rc;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if ((rc = flush_lazy(st, is_diag_field(field), is_tend_field(field)))) return rc;     // lazily pending arrays are produced on a read
+    if ((rc = field_ref(st, field, time_level, &r))) return rc;                            // (the flush may have swapped buffers)
     if ((rc = ensure_op_bufs(st->mesh))) return rc;
     hipStream_t s = st->ctx->stream;
     // caller's numbering, then the strictly serial order of sumArray (run_loop.jl:47-51)
@@ -1554,7 +1629,10 @@ int moka_step_fe_taped(moka_tape *t, double dt, int flags)
     HIPCHK(st->ctx, hipMemcpyAsync(t->uTape + nEK * t->n, st->lev[1].u, bytes, hipMemcpyDeviceToDevice, s));
     const bool stale = flags & MOKA_FE_STALE_HEDGE;
     if (stale) HIPCHK(st->ctx, hipMemcpyAsync(t->hTape + nEK * t->n, st->hEdge[0], bytes, hipMemcpyDeviceToDevice, s));
-    if ((rc = moka_step_fe(st, dt, flags))) return rc;
+    st->feForceEager = true;            // the tape copies DiagnosticVars around the step: it stores all of its arrays
+    rc = moka_step_fe(st, dt, flags);
+    st->feForceEager = false;
+    if (rc) return rc;
     // a refreshed layerThicknessEdge (= interp of the pre-step thickness) is what the flux used: it is Diag's after the step
     if (!stale) HIPCHK(st->ctx, hipMemcpyAsync(t->hTape + nEK * t->n, st->hEdge[0], bytes, hipMemcpyDeviceToDevice, s));
     t->dts.push_back(dt);
@@ -1659,6 +1737,7 @@ int moka_tape_record_fe(moka_tape *t, int flags, int after)
     HIPCHK(st->ctx, hipStreamWaitEvent(s, st->ctx->evHalo, 0));
     if (!after) {
         if (int rc = flush_lazy(st, true, true)) return rc;
+        st->feForceEager = true;        // until moka_tape_commit_fe: the recorded step stores all of its arrays
         HIPCHK(st->ctx, hipMemcpyAsync(t->uTape + nEK * t->n, st->lev[1].u, bytes, hipMemcpyDeviceToDevice, s));
         if (stale) HIPCHK(st->ctx, hipMemcpyAsync(t->hTape + nEK * t->n, st->hEdge[0], bytes, hipMemcpyDeviceToDevice, s));
         t->recMask = 1;
@@ -1674,6 +1753,7 @@ int moka_tape_commit_fe(moka_tape *t, double dt, int flags)
 {
     if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
     if (t->recMask != 3) return fail(t->st->ctx, MOKA_ERR_ARG, "moka_tape_commit_fe: record before and after the step first");
+    t->st->feForceEager = false;
     t->recMask = 0;
     t->kind = 0;
     t->dts.push_back(dt);

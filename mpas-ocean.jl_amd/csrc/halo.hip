@@ -830,11 +830,8 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
     if (flags & MOKA_FE_LEVEL1_ONLY && st->mesh->plan.K > 1)
         return hfail(h, MOKA_ERR_UNSUPPORTED, "distributed Forward Euler steps all levels (MOKA_FE_LEVEL1_ONLY is for nVertLevels = 1)");
     HIPCHK(c, hipSetDevice(c->device));
-    {   // whichever part of a step is launched first finds pending lazy results (after it: nothing is pending, a no-op)
-        // an fp32-storage state after an RK4 step has no current DiagnosticVars: a step that carries none over may follow
-        if (st->f32 && st->diagDirty && !(flags & (MOKA_FE_STALE_HEDGE | MOKA_FE_ACCUM_VORT))) st->diagDirty = false;
-        if (int rc = flush_lazy(st, true, true)) return rc;
-    }
+    // whichever part of a step is launched first deals with lazily pending arrays (idempotent: the other parts find nothing)
+    if (int rc = fe_begin(st, flags)) return rc;
     StageArgs g;
     FeArgs a;
     fe_dist_args(st, dt, flags, &g, &a);
@@ -900,13 +897,10 @@ int moka_fe_dist_end(moka_halo *h)
 {
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
     moka_state *st = h->st;
-    fe_rotate_levels(st);
-    std::swap(st->hEdge[0], st->hEdge[1]);
+    // (lean: decided by the same pure function the launches used; the stage kernel interpolates layerThicknessEdge of every edge
+    //  with an owned cell from the level that becomes the previous one now)
+    fe_end(st, h->feFlags, h->feStageKernel, h->feStageKernel && fe_lean(st, h->feFlags), h->fePrev);
     st->sshConsistent = true;
-    st->feFast = h->feStageKernel ? (h->fePrev ? 2 : 1) : 0;
-    // the stage kernel interpolated layerThicknessEdge of every edge with an owned cell from the level that is the previous one
-    // now (the generic one-launch kernel does the same, but a step of it is not what mode 6 was validated against)
-    st->hEdgePrev = h->feStageKernel;
     return MOKA_OK;
 }
 

@@ -170,14 +170,14 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 gstore2o(a.nh_out, pOff, pB);
             }
             if constexpr (MODE == 3) gstore2o(a.nh_out, pOff, pB);
-            if constexpr (FE) {
-                gstore2o(a.ph_out, pOff, pA);
-                gstore2o(a.tendH, pOff, pB);
-                gstore2o(a.div, pOff, pD);
+            if constexpr (FE) {                          // every output group of a Forward-Euler launch is optional (wave-uniform):
+                if (a.ph_out) gstore2o(a.ph_out, pOff, pA);   // a lean step stores the new level only, the launch that materialises the
+                if (a.tendH) gstore2o(a.tendH, pOff, pB);     // step's DiagnosticVars / TendencyVars on demand stores only those
+                if (a.div) gstore2o(a.div, pOff, pD);
             }
         }
         if constexpr (MODE != 0)
-            if (l == 0) a.ssh_out[pC] = pS;
+            if (l == 0 && (!FE || a.ssh_out)) a.ssh_out[pC] = pS;
     };
     // ---------------- cells ----------------
 #pragma nounroll
@@ -212,8 +212,8 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (MODE == 2) cur = gload2(a.ch, own);
             if constexpr (MODE == 2 || MODE == 3) nin = gload2(a.nh_in, own);
         }
-        double area = 0.0;
-        if constexpr (FE) area = a.areaCell[c];
+        double area = 1.0;
+        if constexpr (FE) if (a.div) area = a.areaCell[c];
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this iteration's loads (needed next anyway) ...
         if (pend) flush_cell();                                        // ... so that the stores queue up behind them, not ahead
         double2 t = make_double2(0.0, 0.0);
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 hs = make_double2(hc.x + a.a * t.x, hc.y + a.a * t.y);                        // time_integration.jl:199
                 pA = hs;
                 pB = t;
-                pD = make_double2(dv.x / area, dv.y / area);                                  // Operators.jl:41
+                if (a.div) pD = make_double2(dv.x / area, dv.y / area);                       // Operators.jl:41
             }
         }
         if constexpr (MODE != 0) {
@@ -298,10 +298,10 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             }
             if constexpr (MODE == 3) gstore2o(a.nu_out, pOff, pB);
             if constexpr (FE) {
-                gstore2o(a.pu_out, pOff, pA);
-                gstore2o(a.tendU, pOff, pB);
-                gstore2o(a.F, pOff, pD);
-                gstore2o(a.hEdgeNew, pOff, pE);
+                if (a.pu_out) gstore2o(a.pu_out, pOff, pA);
+                if (a.tendU) gstore2o(a.tendU, pOff, pB);
+                if (a.F) gstore2o(a.F, pOff, pD);
+                if (a.hEdgeNew) gstore2o(a.hEdgeNew, pOff, pE);
             }
         }
     };
@@ -339,12 +339,17 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (MODE == 2) cur = gload2(a.cu, own);
             if constexpr (MODE == 2 || MODE == 3) nin = gload2(a.nu_in, own);
             if constexpr (FE) {
-                hx = gload2(a.ph, r[ME2] * rowB + voff);               // layerThickness of cellsOnEdge[1], [2]
-                hy = gload2(a.ph, r[ME2 + 1] * rowB + voff);
-                if constexpr (STALE) hEo = gload2(a.hEdgeOld, own);
-                if constexpr (PREV) {                                  // the same two cells one level back: rows the cell loop has
-                    const double2 px = gload2(a.hPrev, r[ME2] * rowB + voff), py = gload2(a.hPrev, r[ME2 + 1] * rowB + voff);   // just fetched
-                    hEo = make_double2(0.5 * (px.x + py.x), 0.5 * (px.y + py.y));          // what the previous step stored (Operators.jl:217)
+                // the edge's own diagnostics: loaded for only when they are stored (a lean step stores neither)
+                if (a.hEdgeNew || (MODE == 5 && a.F)) {
+                    hx = gload2(a.ph, r[ME2] * rowB + voff);           // layerThickness of cellsOnEdge[1], [2]
+                    hy = gload2(a.ph, r[ME2 + 1] * rowB + voff);
+                }
+                if (a.F) {
+                    if constexpr (STALE) hEo = gload2(a.hEdgeOld, own);
+                    if constexpr (PREV) {                              // the same two cells one level back: rows the cell loop has
+                        const double2 px = gload2(a.hPrev, r[ME2] * rowB + voff), py = gload2(a.hPrev, r[ME2 + 1] * rowB + voff);   // just fetched
+                        hEo = make_double2(0.5 * (px.x + py.x), 0.5 * (px.y + py.y));      // what the previous step stored (Operators.jl:217)
+                    }
                 }
             }
         }
@@ -634,8 +639,8 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
             if constexpr (MODE == 2) curf = gload4f(a.ch, own);
             if constexpr (MODE == 2 || MODE == 3) ninf = gload4f(a.nh_in, own);
         }
-        double area = 0.0;
-        if constexpr (FE) area = a.areaCell[c];
+        double area = 1.0;
+        if constexpr (FE) if (a.div) area = a.areaCell[c];
         const d4 hc = widen4(hcf);
         d4 t = zero, dv = zero;                                         // dv: velocityDivCell (FE), Operators.jl:18,39
         // thickness at the edge: interpolated (Operators.jl:217) or, MODE 4, what the previous step stored
@@ -694,11 +699,11 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
                 hs = round4(axpy4(widen4(ninf), a.b, t));
                 gstore4(a.nh_out, own, hs);
             }
-            if constexpr (FE) {
+            if constexpr (FE) {                          // every output group is optional (see k_stage_rec2c)
                 hs = round4(axpy4(hc, a.a, t));                                               // time_integration.jl:199
-                gstore4(a.ph_out, own, hs);
-                gstore4(a.tendH, own, t);
-                gstore4(a.div, own, d4{dv.x / area, dv.y / area, dv.z / area, dv.w / area});  // Operators.jl:41
+                if (a.ph_out) gstore4(a.ph_out, own, hs);
+                if (a.tendH) gstore4(a.tendH, own, t);
+                if (a.div) gstore4(a.div, own, d4{dv.x / area, dv.y / area, dv.z / area, dv.w / area});  // Operators.jl:41
             }
         }
         if constexpr (MODE != 0) {
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
             for (int sft = 16; sft >= 1; sft >>= 1) {
                 hs = d4{hs.x + gxor(hs.x, sft), hs.y + gxor(hs.y, sft), hs.z + gxor(hs.z, sft), hs.w + gxor(hs.w, sft)};
             }
-            if (l == 0)                                                                       // :209 (+N3), stored fp32
+            if (l == 0 && (!FE || a.ssh_out))                                                 // :209 (+N3), stored fp32
                 reinterpret_cast<float *>(a.ssh_out)[c] = (float)(((hs.x + hs.z) + (hs.y + hs.w)) - L.rsum[ci]);
         }
     }
@@ -746,12 +751,16 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
             if constexpr (MODE == 2) cur = gload4(a.cu, own);
             if constexpr (MODE == 2 || MODE == 3) nin = gload4(a.nu_in, own);
             if constexpr (FE) {
-                hxf = gload4f(a.ph, r[ME2] * rowB + voff);             // layerThickness of cellsOnEdge[1], [2]
-                hyf = gload4f(a.ph, r[ME2 + 1] * rowB + voff);
-                if constexpr (STALE) hEof = gload4f(a.hEdgeOld, own);
-                if constexpr (PREV) {                                  // the same two cells one level back, rounded as it was stored
-                    const d4 px = gload4(a.hPrev, r[ME2] * rowB + voff), py = gload4(a.hPrev, r[ME2 + 1] * rowB + voff);
-                    hEof = narrow4(d4{0.5 * (px.x + py.x), 0.5 * (px.y + py.y), 0.5 * (px.z + py.z), 0.5 * (px.w + py.w)});
+                if (a.hEdgeNew || (MODE == 5 && a.F)) {
+                    hxf = gload4f(a.ph, r[ME2] * rowB + voff);         // layerThickness of cellsOnEdge[1], [2]
+                    hyf = gload4f(a.ph, r[ME2 + 1] * rowB + voff);
+                }
+                if (a.F) {
+                    if constexpr (STALE) hEof = gload4f(a.hEdgeOld, own);
+                    if constexpr (PREV) {                              // the same two cells one level back, rounded as it was stored
+                        const d4 px = gload4(a.hPrev, r[ME2] * rowB + voff), py = gload4(a.hPrev, r[ME2 + 1] * rowB + voff);
+                        hEof = narrow4(d4{0.5 * (px.x + py.x), 0.5 * (px.y + py.y), 0.5 * (px.z + py.z), 0.5 * (px.w + py.w)});
+                    }
                 }
             }
             if (l == 0) {                                              // behind the gathers in the queue: nothing waits for these two alone
@@ -807,10 +816,10 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
                 const d4 hx = widen4(hxf), hy = widen4(hyf);
                 const d4 pE{0.5 * (hx.x + hy.x), 0.5 * (hx.y + hy.y), 0.5 * (hx.z + hy.z), 0.5 * (hx.w + hy.w)};   // layerThicknessEdge, Operators.jl:217
                 const d4 hF = (STALE || PREV) ? widen4(hEof) : pE;
-                gstore4(a.F, own, d4{up.x * hF.x, up.y * hF.y, up.z * hF.z, up.w * hF.w});                            // thicknessFlux, DiagnosticVars.jl:165
-                gstore4(a.hEdgeNew, own, pE);
-                gstore4(a.pu_out, own, axpy4(up, a.a, t));              // time_integration.jl:199
-                gstore4(a.tendU, own, t);
+                if (a.F) gstore4(a.F, own, d4{up.x * hF.x, up.y * hF.y, up.z * hF.z, up.w * hF.w});                  // thicknessFlux, DiagnosticVars.jl:165
+                if (a.hEdgeNew) gstore4(a.hEdgeNew, own, pE);
+                if (a.pu_out) gstore4(a.pu_out, own, axpy4(up, a.a, t));   // time_integration.jl:199
+                if (a.tendU) gstore4(a.tendU, own, t);
             }
         }
     }
@@ -1431,7 +1440,15 @@ size_t rec2c_lds_bytes(const MeshDev &md)
 // the vertex records a Forward-Euler launch with the vertex pass stages behind the row cache: 3 coefficients + 4 offsets per vertex
 static inline size_t vert_lds_bytes(const MeshDev &md) { return (size_t)md.maxOwnV * (3 * 8 + 4 * 4) + 16; }
 
-bool stage_curl_fused(const MeshDev &md) { return md.vRec != nullptr && md.VD == 3 && md.patchVertStart != nullptr && md.maxOwnV > 0; }
+// measurement: 0 = the vertex pass always gets a launch of its own (k_curl3)
+static std::atomic<int> g_curlFused{1};
+void set_curl_fused(int on) { g_curlFused.store(on); }
+int curl_fused() { return g_curlFused.load(); }
+
+bool stage_curl_fused(const MeshDev &md)
+{
+    return g_curlFused.load() && md.vRec != nullptr && md.VD == 3 && md.patchVertStart != nullptr && md.maxOwnV > 0;
+}
 
 // ... and do its vertex records fit beside the records and own rows of patches as large as md.maxOwnE / md.maxOwnC
 bool stage_curl_fits(const MeshDev &md, bool f32)
@@ -1480,6 +1497,10 @@ hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t
 static std::atomic<int> g_f32WideModes{1 << 0};
 void set_f32_wide_modes(int mask) { g_f32WideModes.store(mask); }
 int f32_wide_modes() { return g_f32WideModes.load(); }
+// measurement: 0 = every Forward-Euler step stores all of its DiagnosticVars / TendencyVars (no lean steps)
+static std::atomic<int> g_feLean{1};
+void set_fe_lean(int on) { g_feLean.store(on); }
+int fe_lean_enabled() { return g_feLean.load(); }
 // measurement: 0 keeps Forward-Euler steps on the gathered layerThicknessEdge (mode 4) even when mode 6 applies
 static std::atomic<int> g_fePrevMode{1};
 void set_fe_prev_mode(int on) { g_fePrevMode.store(on); }

@@ -19,7 +19,12 @@ struct StageArgs {
     double a, b;
     // Forward-Euler step in the default stage kernel (k_stage_rec2c modes 4 / 5; every other kernel ignores these):
     // pu/ph/ssh = current level, pu_out/ph_out/ssh_out = new level, a = dt, tendU/tendH, and the diagnostics below
-    const double *hEdgeOld;       // previous step's layerThicknessEdge (modes 4, 6: MOKA_FE_STALE_HEDGE) or NULL (mode 5)
+    // feMode != 0 marks a Forward-Euler launch and names its kernel mode (4 / 5 / 6).  Every OUTPUT group of such a launch is
+    // optional: {pu_out, ph_out, ssh_out} = the new level; {tendU, tendH, F, div, hEdgeNew} = the step's TendencyVars /
+    // DiagnosticVars; vort.  A lean step passes the first (and vort), the launch that materialises a lean step's arrays on
+    // demand passes the second.
+    int feMode;
+    const double *hEdgeOld;       // previous step's layerThicknessEdge (mode 4: MOKA_FE_STALE_HEDGE) or NULL (modes 5, 6)
     const double *hPrev;          // mode 6: the previous time level's layerThickness, which hEdgeOld is the interpolation of
     double *hEdgeNew, *F, *div;   // layerThicknessEdge, thicknessFlux, velocityDivCell
     const double *areaCell;
@@ -87,6 +92,10 @@ bool stage_f32_supported(const MeshDev &m);
 hipError_t launch_stage_rec2c_f32(const MeshDev &m, const StageArgs &a, hipStream_t s);
 void set_f32_wide_modes(int mask);      // measurement: which modes of the fp32-storage kernel run as (512 threads, 4 waves per SIMD)
 int f32_wide_modes();
+void set_curl_fused(int on);            // measurement: 0 = the Forward-Euler vertex pass always gets a launch of its own
+int curl_fused();
+void set_fe_lean(int on);               // measurement: 0 = Forward-Euler steps always store every array (no lean steps)
+int fe_lean_enabled();
 void set_fe_prev_mode(int on);          // measurement: 0 = never form the stale layerThicknessEdge from the previous level (mode 6)
 int fe_prev_mode();
 hipError_t launch_update_ssh_f32(const MeshDev &m, const float *h, float *ssh, int nlev, int lpc, hipStream_t s);

@@ -239,11 +239,12 @@ static inline int patch_grid(const MeshDev &m) { return 8 * ((m.nPatches + 7) / 
 // which pipelined specialisation serves this argument block (-1: none, use the plain column kernel)
 inline int colp_mode(const StageArgs &a)
 {
-    if (a.hEdgeNew) {     // Forward-Euler step (k_stage_rec2c and k_stage_rec2c_f32)
-        const bool ok = a.pu_out && a.ph_out && a.ssh_out && a.tendU && a.tendH && a.F && a.div && a.areaCell && !a.cu && !a.ch &&
-                        !a.nu_in && !a.nh_in && !a.nu_out && !a.nh_out;
-        if (a.hPrev && !a.hEdgeOld) return -1;
-        return ok ? (a.hPrev ? 6 : a.hEdgeOld ? 4 : 5) : -1;
+    if (a.feMode) {       // Forward-Euler launch (k_stage_rec2c and k_stage_rec2c_f32): output groups are optional, as groups
+        const bool lvl = a.pu_out && a.ph_out && a.ssh_out, noLvl = !a.pu_out && !a.ph_out && !a.ssh_out;
+        const bool dia = a.tendU && a.tendH && a.F && a.div && a.hEdgeNew && a.areaCell, noDia = !a.tendU && !a.tendH && !a.F && !a.div && !a.hEdgeNew;
+        const bool ok = (lvl || noLvl) && (dia || noDia) && (lvl || dia) && !a.cu && !a.ch && !a.nu_in && !a.nh_in && !a.nu_out && !a.nh_out &&
+                        (a.feMode == 4 ? a.hEdgeOld != nullptr : a.feMode == 6 ? a.hPrev != nullptr : a.feMode == 5);
+        return ok ? a.feMode : -1;
     }
     const bool outs = a.pu_out || a.ph_out || a.nu_out || a.nh_out;
     if (a.tendU && a.tendH && !outs && !a.ssh_out) return 0;

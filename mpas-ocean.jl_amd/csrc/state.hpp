@@ -75,6 +75,14 @@ struct moka_state {
     // of this state computes: true after a Forward-Euler step of all levels through the stage kernel, false after anything
     // else that writes either array (uploads, RK4 steps, the piecewise reference calls, lazily produced diagnostics)
     bool hEdgePrev = false;
+    // The last Forward-Euler step was LEAN: it stored the new time level (and relativeVorticity) only.  Its TendencyVars and
+    // DiagnosticVars (tendNormalVelocity, tendLayerThickness, thicknessFlux, velocityDivCell, layerThicknessEdge) are pending:
+    // produced on the first read (flush_lazy) from the level the step started from -- the previous level now -- and, for the
+    // reference's stale flux thickness, the level before it, which the rotation of three level sets has kept in `spare`.
+    // Same arithmetic, same bits as a step that stores everything; the next lean step reads none of those arrays and
+    // supersedes them, exactly as an RK4 step supersedes its lazily produced diagnostics.
+    bool feLazy = false, feLazyStale = false;
+    bool feForceEager = false;        // a tape is recording: every step stores all of its arrays
     double *scalar = nullptr;         // 1 double (sum_sq result)
     bool sshConsistent = false;       // lev[1].ssh == ksum(lev[1].h) - restingThicknessSum
     // moka_step_rk4 ends with diagnostic_compute! of the new state and leaves the stage-4 tendencies in
@@ -127,5 +135,11 @@ int rk4_begin(moka_state *st, const double **ssh0);
 void rk4_end(moka_state *st);
 FeArgs fe_args(moka_state *st, int ops, int flags, double dt);
 StageArgs fe_stage_args(moka_state *st, const FeArgs &a, int flags);
+// Forward-Euler step in the stage kernels: is that path open to this state / these flags; will the step be lean (see
+// moka_state.feLazy); what a step has to do about lazily pending arrays before its launches (idempotent within a step)
+bool fe_stage_path(const moka_state *st, int flags);
+bool fe_lean(const moka_state *st, int flags);
+int fe_begin(moka_state *st, int flags);
+void fe_end(moka_state *st, int flags, bool stageKernel, bool lean, bool prevMode);
 
 }  // namespace mk

@@ -86,7 +86,7 @@ EXPORTS = [
     "moka_adjoint_download",
     "moka_mark", "moka_marks_reset", "moka_marks_read", "moka_bw_probe", "moka_ctx_pci_bus_id", "moka_halo_set_acquire", "moka_set_tuning", "moka_get_tuning",
     "moka_gradient_on_edge_vjp", "moka_gradient_on_edge_jvp", "moka_divergence_on_cell_vjp", "moka_divergence_on_cell_jvp",
-    "moka_curl_on_vertex_vjp", "moka_curl_on_vertex_jvp",
+    "moka_curl_on_vertex_vjp", "moka_curl_on_vertex_jvp", "moka_fe_lazy_pending",
 ]
 
 
@@ -204,6 +204,7 @@ def lib():
     L.moka_fe_dist_step.argtypes = [vp, C.c_double, C.c_int, TRANSPORT_FN, vp, vp, vp, C.c_double]
     L.moka_set_nonlinear.argtypes = [vp, C.c_int]
     L.moka_last_fe_path.argtypes = [vp]
+    L.moka_fe_lazy_pending.argtypes = [vp]
     L.moka_set_viscosity_del2.argtypes = [vp, C.c_double]
     L.moka_tape_create.argtypes = [vp, C.c_int64, C.POINTER(vp)]
     L.moka_tape_destroy.argtypes = [vp]

@@ -2,6 +2,7 @@
 same seeded inputs.  fp64 throughout; the bar is BIT-EXACT equality (np.array_equal), which is
 stricter than the 1e-12 relative tolerance BASELINE.md states -- the kernels evaluate every
 expression in the reference's operand order with FMA contraction off."""
+import ctypes as C
 import datetime as dt
 import json
 import math
@@ -424,6 +425,82 @@ def test_forward_euler_stale_thickness_from_the_previous_level(backend, sbytes, 
         step(1); step(2)
         check("after advanceTimeLevels!")
     Prog._state.close(); Setup.mesh.close()
+
+
+@pytest.mark.parametrize("sbytes,K,flags", [(8, 60, 3), (8, 60, 0), (4, 80, 3), (8, 34, 1), (4, 40, 2)])
+def test_forward_euler_lean_steps_produce_every_array_on_demand(backend, sbytes, K, flags):
+    """A Forward-Euler step of all levels is LEAN by default: it stores the new time level and relativeVorticity; the step's
+    tendNormalVelocity, tendLayerThickness, thicknessFlux, velocityDivCell and layerThicknessEdge are produced on the first read,
+    from the level the step started from (moka_fe_lazy_pending).  Whatever reads them -- a download, sumArray, an upload that
+    overwrites one of their inputs, the piecewise reference calls, an RK4 step in between -- sees the bits a step that stores
+    everything (moka_set_tuning(4, 0)) and the oracle produce."""
+    mesh = get_mesh("ico16")
+    ssh, u, h, rest = random_state(mesh, K, 90 + K + flags)
+    lib = L.lib()
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    dtv = 20.0
+
+    def fresh():
+        Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True, state_bytes=sbytes)
+        return Setup, Diag, Tend, Prog, orc.OracleState(om, ssh, u, h, mixed=sbytes == 4)
+
+    def step(Prog, st, n=1, fl=flags):
+        for _ in range(n):
+            L.check(lib.moka_step_fe(Prog._state._h, dtv, fl), backend._h)
+            st.step_fe(dtv, fl)
+
+    def check(Prog, Diag, Tend, st, tag):
+        got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+        for k in exp:
+            assert np.array_equal(got[k], exp[k]), (k, tag)
+
+    # (a) every step stores everything: the reference point
+    L.check(lib.moka_set_tuning(4, 0))
+    try:
+        Setup, Diag, Tend, Prog, st = fresh()
+        step(Prog, st, 4)
+        assert lib.moka_fe_lazy_pending(Prog._state._h) == 0
+        check(Prog, Diag, Tend, st, "eager")
+        Prog._state.close(); Setup.mesh.close()
+    finally:
+        L.check(lib.moka_set_tuning(4, 1))
+    # (b) lean steps
+    Setup, Diag, Tend, Prog, st = fresh()
+    hS = Prog._state._h
+    step(Prog, st, 1)
+    assert lib.moka_fe_lazy_pending(hS) == (0 if flags & 1 else 1)     # the first stale-thickness step has a stored array to read
+    step(Prog, st, 3)
+    assert lib.moka_fe_lazy_pending(hS) == 1
+    # one read produces all of them
+    assert np.array_equal(Tend.tendNormalVelocity.get(), st.tendU)
+    assert lib.moka_fe_lazy_pending(hS) == 0
+    check(Prog, Diag, Tend, st, "after four lean steps")
+    step(Prog, st, 2)
+    assert lib.moka_fe_lazy_pending(hS) == 1
+    # sumArray of a pending array (run_loop.jl:47-51 on Diag.thicknessFlux)
+    out = C.c_double()
+    L.check(lib.moka_sum_sq(hS, L.F_THICKNESS_FLUX, 1, C.byref(out)), backend._h)
+    F = np.ascontiguousarray(st.F)
+    assert out.value == orc.lib().oracle_sum_sq(orc._p(F), F.size) and lib.moka_fe_lazy_pending(hS) == 0
+    step(Prog, st, 1)
+    # the caller overwrites an INPUT of the pending arrays (the previous level): they are produced from what the step saw
+    u0 = Prog.normalVelocity[0].get() * 0.5
+    Prog.normalVelocity[0].set(u0); st.u[0][:] = Prog.normalVelocity[0].get()
+    assert lib.moka_fe_lazy_pending(hS) == 0
+    check(Prog, Diag, Tend, st, "upload of the previous level while arrays were pending")
+    step(Prog, st, 2)
+    check(Prog, Diag, Tend, st, "two more lean steps")
+    Prog._state.close(); Setup.mesh.close()
+    # (c) an RK4 step supersedes pending arrays; the Forward-Euler step after it starts from the RK4 diagnostics
+    if sbytes == 8:
+        Setup, Diag, Tend, Prog, st = fresh()
+        step(Prog, st, 3)
+        mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dtv))
+        mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4); st.step_rk4(dtv)
+        assert lib.moka_fe_lazy_pending(Prog._state._h) == 0
+        step(Prog, st, 3)
+        check(Prog, Diag, Tend, st, "RK4 in between")
+        Prog._state.close(); Setup.mesh.close()
 
 
 def test_forward_euler_tuned_path_level_masks(backend):

@@ -28,8 +28,18 @@ b = mk.MokaHIP(0)
 Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, cfg, b, multilayer=True, state_bytes=sbytes)
 out = {"workload": wl, "nCells": mesh.nCells, "K": K}
 n = 20
-for name, key2, flags in (("mode4_gathered_hEdge", 0, 3), ("mode6_from_previous_level", 1, 3), ("mode5_fresh", 1, 2)):
+# (name, key 2: stale thickness from the previous level, flags, key 3: vertex pass inside the launches, key 4: lean steps)
+for name, key2, flags, key3, key4 in (("all_arrays_stored_mode4_gathered_hEdge", 0, 3, 1, 0),
+                                      ("all_arrays_stored_mode4_vertex_pass_as_its_own_launch", 0, 3, 0, 0),
+                                      ("all_arrays_stored_mode6_from_previous_level", 1, 3, 1, 0),
+                                      ("all_arrays_stored_mode5_fresh", 1, 2, 1, 0),
+                                      ("lean_mode6_reference_compat", 1, 3, 1, 1),
+                                      ("lean_mode6_vertex_pass_as_its_own_launch", 1, 3, 0, 1),
+                                      ("lean_mode5_fresh_accumulating_vorticity", 1, 2, 1, 1),
+                                      ("lean_mode5_flags0", 1, 0, 1, 1)):
     L.check(L.lib().moka_set_tuning(2, key2))
+    L.check(L.lib().moka_set_tuning(3, key3))
+    L.check(L.lib().moka_set_tuning(4, key4))
     for _ in range(3):
         mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=flags)
     b.synchronize()
@@ -38,6 +48,9 @@ for name, key2, flags in (("mode4_gathered_hEdge", 0, 3), ("mode6_from_previous_
         mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=flags)
         b.mark()
     ms = sorted(b.marks_read())
-    out[name] = {"median_ms": ms[len(ms) // 2], "min_ms": ms[0], "max_ms": ms[-1], "path": L.lib().moka_last_fe_path(Prog._state._h)}
+    out[name] = {"median_ms": ms[len(ms) // 2], "min_ms": ms[0], "max_ms": ms[-1], "path": L.lib().moka_last_fe_path(Prog._state._h),
+                 "arrays_pending": L.lib().moka_fe_lazy_pending(Prog._state._h)}
 L.check(L.lib().moka_set_tuning(2, 1))
+L.check(L.lib().moka_set_tuning(3, 1))
+L.check(L.lib().moka_set_tuning(4, 1))
 print(json.dumps(out))
