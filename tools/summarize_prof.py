@@ -28,8 +28,11 @@ if os.path.exists(bj):
             bench = json.loads(line)
     if bench:
         print("== bench.py line of the traced run ==")
-        print(json.dumps({k: bench[k] for k in ("value", "ms_per_step", "steps", "warmup", "config", "roofline", "tendency_kernel")
-                          if k in bench}))
+        print(json.dumps({k: bench[k] for k in ("value", "ms_per_step", "step_ms", "steps", "warmup", "config", "roofline", "calibration",
+                                                "tendency_kernel", "forward_euler_compat") if k in bench}))
+        if isinstance(bench.get("config5"), dict) and "ms_per_step" in bench["config5"]:
+            print("== its config-5 leg ==")
+            print(json.dumps(bench["config5"]))
 if os.path.exists(os.path.join(out, "command.txt")):
     print(open(os.path.join(out, "command.txt")).read())
 
@@ -42,11 +45,21 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
         seq.append((int(r["Start_Timestamp"]), short(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     # reproducibility check against the bench line: the LAST steps*4 RK-stage launches (modes 1,2,2,3) before the tendency
     # launches are the timed region + the per-stage pass; take the timed region = launches [warmup*4, (warmup+steps)*4)
+    legs = []
     if bench:
         seq.sort()
-        stage = [(n, d) for _, n, d in seq if re.match(r"k_stage_rec2c(_f32)?<\d+, \d+, [123]", n)]
-        w, k = bench["warmup"], bench["steps"]
+        f32_main = "f32" in bench["config"]["workload"]
+        legs.append(("headline workload " + bench["config"]["workload"], bench, r"k_stage_rec2c_f32<\d+, \d+, [123]" if f32_main else r"k_stage_rec2c<\d+, \d+, [123]"))
+        c5 = bench.get("config5")
+        if isinstance(c5, dict) and "ms_per_step" in c5:
+            legs.append(("config-5 leg", {"warmup": c5["warmup"], "steps": c5["steps"], "ms_per_step": c5["ms_per_step"],
+                                          "roofline": {"algorithmic_bytes_per_launch": c5["roofline"]["achieved"] * 1e9 * c5["ms_per_step"] * 1e-3 / 4,
+                                                       "frac": c5["roofline"]["frac"]}}, r"k_stage_rec2c_f32<\d+, \d+, [123]"))
+    for leg_name, bl, pat in legs:
+        stage = [(n, d) for _, n, d in seq if re.match(pat, n)]
+        w, k = bl["warmup"], bl["steps"]
         timed = stage[4 * w:4 * (w + k)]
+        print(f"== {leg_name} ==")
         if len(timed) == 4 * k:
             per_mode = defaultdict(list)
             for n, d in timed:
@@ -55,12 +68,12 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
             print("== timed region of the traced run: stage kernels per RK4 step ==")
             for n, v in per_mode.items():
                 print(f"{n:70s} launches/step={len(v) / k:.0f} avg_us={sum(v) / len(v) / 1e3:10.1f}")
-            ok = tot <= bench["ms_per_step"] * 1.001
-            print(f"sum of the stage kernels per step = {tot:.3f} ms; bench ms_per_step of the same run = {bench['ms_per_step']:.3f} ms "
+            ok = tot <= bl["ms_per_step"] * 1.001
+            print(f"sum of the stage kernels per step = {tot:.3f} ms; bench ms_per_step of the same run = {bl['ms_per_step']:.3f} ms "
                   f"-> {'CONSISTENT' if ok else 'INCONSISTENT (kernel time exceeds wall time)'}")
-            b_contract = bench["roofline"]["algorithmic_bytes_per_launch"] * 4
+            b_contract = bl["roofline"]["algorithmic_bytes_per_launch"] * 4
             print(f"roofline frac recomputed from this trace (contract bytes / kernel time / 8 TB/s) = {b_contract / (tot * 1e-3) / 8e12:.4f}; "
-                  f"bench.py printed {bench['roofline']['frac']:.4f}")
+                  f"bench.py printed {bl['roofline']['frac']:.4f}")
     print("== kernel trace (ns) ==")
     print(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>10s}")
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
