@@ -434,6 +434,14 @@ def config5_leg(mk, backend, args, copy_gbs):
                         "formula": "contract: 18 state streams per step + 4 B_mesh, S = 4",
                         "per_stage": per_stage, "per_stage_steps": nst, "per_stage_sum_ms": ssum},
            "cpu_baseline": None, "cpu_baseline_note": "skipped for this leg: the CPU baseline belongs to the headline (config 4) line"}
+    try:     # PMC traffic of this workload's stage launches, taken by tools/profile.sh in separate passes (as for the headline line)
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(name, {})
+        if rec.get("config", {}).get("patch_cells") == info.get("patch_cells") and rec.get("stage_bytes_per_launch"):
+            out["roofline"]["traffic"] = rec["stage_bytes_per_launch"]
+            out["roofline"]["algorithmic_bytes_per_launch"] = b_step / 4
+            out["roofline"]["traffic_source"] = {"file": "profiles/pmc_traffic.json", "profiled_at_commit": rec.get("commit")}
+    except Exception:
+        pass
     out.update(single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, max(5, min(args.tend_iters, 10))))
     out["tendency"] = out["tendency_kernel"]
     backend.synchronize()
