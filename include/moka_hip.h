@@ -170,7 +170,7 @@ enum {
     MOKA_PA_EOC = 0, MOKA_PA_COC, MOKA_PA_MLTC, MOKA_PA_SDV, MOKA_PA_INVAREA, MOKA_PA_AREACELL, MOKA_PA_RSUM,
     MOKA_PA_EHDR, MOKA_PA_EOE, MOKA_PA_WOE, MOKA_PA_GINVDC, MOKA_PA_DCEDGE, MOKA_PA_DVEDGE, MOKA_PA_FEDGE,
     MOKA_PA_EOV, MOKA_PA_CV, MOKA_PA_HALO_START, MOKA_PA_HALO_EDGE, MOKA_PA_LEOC, MOKA_PA_LEOE,
-    MOKA_PA_CREC, MOKA_PA_EREC, MOKA_PA_FEOE
+    MOKA_PA_CREC, MOKA_PA_EREC, MOKA_PA_FEOE, MOKA_PA_PVSTART, MOKA_PA_PVLIST, MOKA_PA_LVOE
 };
 int  moka_plan_array(const moka_plan *plan, int which, const void **data, int64_t *count);
 
@@ -353,7 +353,12 @@ int moka_set_kernel_variant(moka_ctx *ctx, int variant);
 /* Process-wide launch-shape switches for A/B measurements (every setting gives identical results).  key 1: bit mask of the
  * modes (0 tendency, 1..3 RK4 stages, 4..6 Forward Euler) of the fp32-storage stage kernel that run as 512-thread workgroups
  * bounded to 128 registers = 4 waves per SIMD instead of 3 (default: mode 0, the tendency launch).  key 2: 0 = Forward-Euler
- * steps always gather the stored layerThicknessEdge (mode 4); 1 (default) = formed from the previous level when valid (mode 6). */
+ * steps always gather the stored layerThicknessEdge (mode 4); 1 (default) = formed from the previous level when valid (mode 6).
+ * key 3: relativeVorticity of a Forward-Euler step inside the stage launches (1, default) or as a launch of its own (0).
+ * key 4: lean Forward-Euler steps (1, default) or every array stored every step (0).  key 5: launch shape of the nonlinear
+ * stage kernel's patch form (0 default: potential vorticity of the patch's vertices in LDS, three workgroups per CU; 1: q_e of
+ * its edge rows in LDS, two workgroups; 2 / 3: other shapes of the default).  key 6 (test hook): upper limit of the vertex rows
+ * that form keeps resident (0 = what the LDS budget holds). */
 int moka_set_tuning(int key, int value);
 int moka_get_tuning(int key, int *value);
 /* Per-stage durations of moka_step_rk4 from HIP events on the compute stream (measurement: bench.py's per-mode roofline

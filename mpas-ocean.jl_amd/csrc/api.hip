@@ -666,6 +666,9 @@ int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[4])
 //          it from the previous level's layerThickness whenever that is the same thing (mode 6)
 //   key 4: 0 = every Forward-Euler step stores all of its DiagnosticVars / TendencyVars; 1 (default) = lean steps where possible
 //          (new level and relativeVorticity stored, the rest produced on first read: moka_state.feLazy)
+//   key 5: launch shape of the nonlinear stage kernel's patch form (nonlinear.hip, g_nlShape): 0 (default) vertex rows in LDS, three
+//          512-thread workgroups per CU; 1 = round 2's edge rows in LDS, two workgroups; 2 / 3 = other shapes of the vertex-row form
+//   key 6: test hook, upper limit of the vertex rows that form keeps in LDS (0 = none)
 //   key 3: 0 = the relativeVorticity pass of a Forward-Euler step always gets a launch of its own, 1 (default) = it rides in the
 //          stage-kernel launches where they can carry it
 int moka_set_tuning(int key, int value)
@@ -674,6 +677,8 @@ int moka_set_tuning(int key, int value)
     if (key == 2) { moka::set_fe_prev_mode(value); return MOKA_OK; }
     if (key == 3) { moka::set_curl_fused(value); return MOKA_OK; }
     if (key == 4) { moka::set_fe_lean(value); return MOKA_OK; }
+    if (key == 5) { moka::set_nl_shape(value); return MOKA_OK; }
+    if (key == 6) { moka::set_nl_cap_limit(value); return MOKA_OK; }
     return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
 }
 
@@ -684,6 +689,8 @@ int moka_get_tuning(int key, int *value)
     if (key == 2) { *value = moka::fe_prev_mode(); return MOKA_OK; }
     if (key == 3) { *value = moka::curl_fused(); return MOKA_OK; }
     if (key == 4) { *value = moka::fe_lean_enabled(); return MOKA_OK; }
+    if (key == 5) { *value = moka::nl_shape(); return MOKA_OK; }
+    if (key == 6) { *value = moka::nl_cap_limit(); return MOKA_OK; }
     return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
 }
 
@@ -750,7 +757,9 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     UP(eov) UP(cv) UP(cellN2O) UP(edgeN2O) UP(vertN2O)
     UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(vRec) UP(lcOff) UP(leOff) UP(patchRegular) UP(rowStart) UP(rowEdge) UP(cRecT) UP(eRecT)
     if (p.nlOk) { UP(voe) UP(cov) UP(kite) UP(invAreaTri) UP(fVertex) UP(keCoef) UP(invDc) UP(keoc) UP(rowVoe) }
+    if (p.nl5Ok) { UP(pvStart) UP(pvList) UP(lvoe) }
 #undef UP
+    d.maxPV = p.nl5Ok ? p.maxPV : 0;
     d.CI = p.CI; d.EI = p.EI;
     m->colOk = p.colOk;
     d.tileRecOk = 0;

@@ -152,9 +152,16 @@ struct NlArgs {
     double *zv;     // (K, nV) relativeVorticity
     double *divc;   // (K, nC) velocityDivCell
     double visc;
+#ifdef MOKA_EXP_NL_ABL
+    int abl;        // ablation experiments only (make exp EXP=-DMOKA_EXP_NL_ABL): which part of k_stage_nl5 to leave out
+#endif
 };
 // form: 0 = best available, 1 = patch kernels without the LDS q_e rows, 2 = 16-byte-lane entity kernels, 3 = generic lane-group kernels
 // (prepare and stage must be called with the same form: forms 0 / 1 keep F alone in NlArgs.fq, forms 2 / 3 {F, q_e} pairs)
+void set_nl_shape(int v);
+int nl_shape();
+void set_nl_cap_limit(int v);
+int nl_cap_limit();
 hipError_t launch_nl_prepare(const MeshDev &m, const double *u, const double *h, const NlArgs &nl, int lpc, int form, hipStream_t s);
 // rowsOk: the plan built the patch row lists (rowStart / rowEdge / leoe; Plan.ldsOk)
 hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &nl, int lpc, bool rowsOk, int form, hipStream_t s);

@@ -55,18 +55,6 @@ struct Plan {
     std::vector<uint32_t> cRec, eRec;
     std::vector<uint32_t> cRecT, eRecT;   // the same with patch-local LDS row-image offsets in the u-row slots (tiled kernels)
     std::vector<double>   feoe;       // nE*ME2
-    // COMPACT records of the default stage kernels (round 3; built when ldsOk && colOk): a patch touches ~110 distinct
-    // normalVelocity rows, so a slot names its row by a patch-local id of one byte instead of a 32-bit offset, and what
-    // belongs to the ROW (its byte offset, fEdge of its edge) is stored once per patch row instead of once per slot:
-    //   rowOff[rowStart[q] + id], rowF[rowStart[q] + id] : byte offset / fEdge of patch q's row `id` (own edges first: id < nOwnE)
-    //   cRec3[c][CI3]: [0,2) the ME row ids, one byte each (invalid slots: the id of slot 0) | [2,2+ME) h-row offsets of the cells
-    //                  across | [2+ME] valid-slot mask | all-levels flag << 8
-    //   eRec3[e][EI3]: [0,NID) the ME2 row ids, one byte each (invalid slots: the edge's own id) | [NID] maxLevelEdgeTop |
-    //                  valid-slot mask << 16 | [NID+1] c1 | [NID+2] c2            NID = (ME2 + 3) / 4
-    // 139 bytes per edge instead of 224 (weightsOnEdge stay per slot): -0.26 GB per launch at config 4, -0.94 GB at config 5.
-    std::vector<uint32_t> cRec3, eRec3, rowOff;
-    std::vector<double>   rowF;
-    int32_t CI3 = 0, EI3 = 0;
     // vRec[v][4] (vertexDegree 3 only): u-row byte offsets of the vertex's three edges | 0 -- the relativeVorticity pass of the
     // Forward-Euler modes of the stage kernels (weights: cv)
     std::vector<uint32_t> vRec;
@@ -104,6 +92,12 @@ struct Plan {
     std::vector<double>  keCoef, invDc;         // nE  0.25*dcEdge*dvEdge ; 1/dcEdge
     std::vector<double>  keoc;     // nC*ME  keCoef of the cell's edge in slot i (0 for padding): no dependent load in the kernels
     std::vector<int32_t> rowVoe;   // 2 per entry of rowEdge: verticesOnEdge of that row's edge (patch row lists only)
+    // k_stage_nl5: pvList[pvStart[q] .. pvStart[q+1]) = the distinct vertices of patch q's own edges and of their edgesOnEdge;
+    // lvoe[e][32] = patch-local ids (one byte each) of the two vertices of every edgesOnEdge slot and of e itself (layout: plan.cpp)
+    std::vector<int32_t> pvStart, pvList;
+    std::vector<uint8_t> lvoe;
+    int32_t maxPV = 0;
+    bool nl5Ok = false;
 };
 
 int build_plan(const moka_mesh_desc *d, Plan &out);   // returns moka_status
@@ -128,9 +122,6 @@ struct MeshDev {
     const double *feoe;
     const uint32_t *vRec;
     int32_t maxOwnV;
-    const uint32_t *cRec3, *eRec3, *rowOff;
-    const double *rowF;
-    int32_t CI3, EI3;
     int32_t CI, EI;
     // LDS-tiled kernel
     const int32_t *haloStart, *haloEdge, *rowStart, *rowEdge;
@@ -142,6 +133,9 @@ struct MeshDev {
     const int32_t *voe, *cov;
     const double *kite, *invAreaTri, *fVertex, *keCoef, *invDc, *keoc;
     const int32_t *rowVoe;
+    const int32_t *pvStart, *pvList;   // k_stage_nl5 (nullptr when the plan could not build them)
+    const uint8_t *lvoe;
+    int32_t maxPV, pvCap;              // most vertices any patch lists; rows k_stage_nl5 keeps in LDS (set per launch)
     int32_t tileRecOk;    // eRecT / cRecT exist and every patch fits the loader budget of the persistent tiled kernel
     int32_t tailPatch;    // >= 0: one extra, non-adjacent patch rides in this launch (default stage kernels only)
 };

@@ -611,55 +611,40 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
             for (int i = 0; i < ME; ++i)
                 if (p.eoc[IX(i, c, ME)] >= 0) p.keoc[IX(i, c, ME)] = p.keCoef[p.eoc[IX(i, c, ME)]];
     }
-    // ---- compact records of the default stage kernels (see moka_internal.hpp) ----
-    p.cRec3.clear(); p.eRec3.clear(); p.rowOff.clear(); p.rowF.clear();
-    p.CI3 = 2 + ME + 1;
-    p.EI3 = (ME2 + 3) / 4 + 3;
-    if (p.ldsOk && p.colOk && ME <= 8 && ME2 <= 16 && p.K < 65536) {
-        const uint64_t rowB = (uint64_t)p.K * p.stateBytes;
-        const int NID = (ME2 + 3) / 4;
-        p.rowOff.resize(p.rowEdge.size());
-        p.rowF.resize(p.rowEdge.size());
-        for (size_t r = 0; r < p.rowEdge.size(); ++r) {
-            p.rowOff[r] = (uint32_t)((uint64_t)p.rowEdge[r] * rowB);
-            p.rowF[r] = p.fEdge[p.rowEdge[r]];
-        }
-        p.cRec3.assign((size_t)nC * p.CI3, 0u);
-        p.eRec3.assign((size_t)nE * p.EI3, 0u);
-        for (int c = 0; c < nC; ++c) {
-            uint32_t *r = &p.cRec3[(size_t)c * p.CI3];
-            uint32_t mask = 0, all = 1;
-            const uint32_t id0 = p.leoc[(size_t)c * 8 + 0];          // slot 0 always exists (nEdgesOnCell >= 1)
-            for (int i = 0; i < ME; ++i) {
-                const bool on = p.eoc[IX(i, c, ME)] >= 0;
-                const uint32_t id = on ? p.leoc[(size_t)c * 8 + i] : id0;
-                r[i >> 2] |= id << (8 * (i & 3));
-                r[2 + i] = on ? (uint32_t)((uint64_t)p.coc[IX(i, c, ME)] * rowB) : (uint32_t)((uint64_t)c * rowB);
-                if (on) {
-                    mask |= 1u << i;
-                    if (p.mltc[IX(i, c, ME)] < p.K) all = 0;
+    // ---- patch vertex lists of k_stage_nl5: the distinct vertices of a patch's own edges and of their edgesOnEdge, and per
+    // own edge a 32-byte record of patch-local vertex ids (one byte each): slots 0-4 in bytes 0-9, slots 5-9 in bytes 12-21 (the
+    // two vertices of edgesOnEdge slot i: bytes 12 (i / 5) + 2 (i % 5), + 1), the edge's own two vertices in bytes 24, 25 ----
+    p.pvStart.assign(p.nPatches + 1, 0);
+    p.pvList.clear(); p.lvoe.clear();
+    p.maxPV = 0; p.nl5Ok = false;
+    if (p.nlOk && p.ldsOk && ME2 <= 10) {
+        p.nl5Ok = true;
+        p.lvoe.assign((size_t)nE * 32, 0);
+        std::vector<int32_t> lv(p.nV, -1);
+        for (int q = 0; q < p.nPatches; ++q) {
+            const size_t base = p.pvList.size();
+            auto lid = [&](int v) {
+                if (lv[v] < 0) { lv[v] = (int32_t)(p.pvList.size() - base); p.pvList.push_back(v); }
+                return (uint8_t)std::min(lv[v], 255);
+            };
+            for (int e = p.patchEdgeStart[q]; e < p.patchEdgeStart[q + 1]; ++e) {
+                uint8_t *r = &p.lvoe[(size_t)e * 32];
+                r[24] = lid(p.voe[2 * (size_t)e]); r[25] = lid(p.voe[2 * (size_t)e + 1]);
+                for (int i = 0; i < 10; ++i) {
+                    const int x = i < ME2 ? p.eoe[IX(i, e, ME2)] : -1;
+                    const int b = 12 * (i / 5) + 2 * (i % 5);
+                    r[b] = x >= 0 ? lid(p.voe[2 * (size_t)x]) : r[24];
+                    r[b + 1] = x >= 0 ? lid(p.voe[2 * (size_t)x + 1]) : r[25];
                 }
             }
-            r[2 + ME] = mask | (all << 8);
-        }
-        std::vector<int32_t> patchOfEdge(nE, 0);
-        for (int q = 0; q < p.nPatches; ++q)
-            for (int e = p.patchEdgeStart[q]; e < p.patchEdgeStart[q + 1]; ++e) patchOfEdge[e] = q;
-        for (int e = 0; e < nE; ++e) {
-            uint32_t *r = &p.eRec3[(size_t)e * p.EI3];
-            uint32_t mask = 0;
-            const uint32_t own = (uint32_t)(e - p.patchEdgeStart[patchOfEdge[e]]);
-            for (int i = 0; i < ME2; ++i) {
-                const bool on = p.eoe[IX(i, e, ME2)] >= 0;
-                const uint32_t id = on ? p.leoe[(size_t)e * 16 + i] : own;
-                r[i >> 2] |= id << (8 * (i & 3));
-                if (on) mask |= 1u << i;
-            }
-            r[NID] = (uint32_t)std::min(p.ehdr[4 * (size_t)e + 3], 65535) | (mask << 16);
-            r[NID + 1] = (uint32_t)p.ehdr[4 * (size_t)e];
-            r[NID + 2] = (uint32_t)p.ehdr[4 * (size_t)e + 1];
+            const int n = (int)(p.pvList.size() - base);
+            if (n > 255) p.nl5Ok = false;
+            p.maxPV = std::max(p.maxPV, n);
+            for (size_t j = base; j < p.pvList.size(); ++j) lv[p.pvList[j]] = -1;
+            p.pvStart[q + 1] = (int32_t)p.pvList.size();
         }
     }
+    p.pvList.push_back(0);
 
     // records of the LDS-DMA tiled kernels: eRec / cRec with the u-row slots replaced by the byte offset of the row inside a
     // patch's LDS row image (pieces of 1 KiB holding 1024 / rowBytes whole rows; csrc/experiments/stage_tile.hip)
@@ -812,6 +797,7 @@ int moka_plan_array(const moka_plan *plan, int which, const void **data, int64_t
         VEC(MOKA_PA_EOV, eov) VEC(MOKA_PA_CV, cv)
         VEC(MOKA_PA_HALO_START, haloStart) VEC(MOKA_PA_HALO_EDGE, haloEdge) VEC(MOKA_PA_LEOC, leoc) VEC(MOKA_PA_LEOE, leoe)
         VEC(MOKA_PA_CREC, cRec) VEC(MOKA_PA_EREC, eRec) VEC(MOKA_PA_FEOE, feoe)
+        VEC(MOKA_PA_PVSTART, pvStart) VEC(MOKA_PA_PVLIST, pvList) VEC(MOKA_PA_LVOE, lvoe)
         default: moka::set_error("unknown plan array id"); return MOKA_ERR_ARG;
     }
 #undef VEC

@@ -288,6 +288,7 @@ PLAN_ARRAYS = {  # name -> (id, dtype)
     "eov": (14, np.int32), "cv": (15, np.float64),
     "haloStart": (16, np.int32), "haloEdge": (17, np.int32), "leoc": (18, np.uint8), "leoe": (19, np.uint8),
     "cRec": (20, np.uint32), "eRec": (21, np.uint32), "feoe": (22, np.float64),
+    "pvStart": (23, np.int32), "pvList": (24, np.int32), "lvoe": (25, np.uint8),
 }
 
 

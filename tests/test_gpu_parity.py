@@ -1176,12 +1176,16 @@ def test_nonlinear_tendency_and_rk4_bitwise(backend, meshname, K, nsteps):
     Prog._state.close(); Setup.mesh.close()
 
 
-@pytest.mark.parametrize("variant", [0, 4, 3])
+@pytest.mark.parametrize("variant,shape", [(0, 0), (0, 1), (0, 2), (0, 3), (0, 10), (4, 0), (3, 0)])
 @pytest.mark.parametrize("meshname,K,visc", [("ico16", 60, 0.0), ("planar", 64, 1.0), ("ico32", 34, 0.0)])
-def test_nonlinear_kernel_forms_with_partial_edge_masks(backend, meshname, K, visc, variant):
-    """The three forms of the nonlinear kernels (variant 0: patch kernels with q_e rows in LDS; 4: patch kernels gathering
-    the vertex potential vorticity; 3: generic lane-group kernels) against the oracle, with maxLevelEdgeTop < K on a third of
-    the edges (the masks of horizontal_advection.jl:63 and the edge loop) and, on one mesh, Del2 mixing on top."""
+def test_nonlinear_kernel_forms_with_partial_edge_masks(backend, meshname, K, visc, variant, shape):
+    """The forms of the nonlinear kernels (variant 0: patch kernels -- launch shape 0 / 2 / 3: potential vorticity of the patch's
+    vertices in LDS, 1: q_e of its edge rows in LDS (moka_set_tuning key 5); variant 4: patch kernels gathering the vertex potential
+    vorticity; 3: generic lane-group kernels) against the oracle, with maxLevelEdgeTop < K on a third of the edges (the masks of
+    horizontal_advection.jl:63 and the edge loop) and, on one mesh, Del2 mixing on top.  Shape 10 = shape 0 with only 40 vertex rows
+    resident, so that every patch takes the path of the few patches of a large mesh that list more vertices than the LDS holds."""
+    L.check(L.lib().moka_set_tuning(5, shape % 10))
+    L.check(L.lib().moka_set_tuning(6, 40 if shape == 10 else 0))
     mesh = get_mesh(meshname)
     ssh, u, h, rest = random_state(mesh, K, 91 + K)
     dtv = 2.0 if meshname == "planar" else 20.0
@@ -1214,6 +1218,8 @@ def test_nonlinear_kernel_forms_with_partial_edge_masks(backend, meshname, K, vi
         Prog._state.close(); M.close()
     finally:
         backend.set_kernel_variant(0)
+        L.check(L.lib().moka_set_tuning(5, 0))
+        L.check(L.lib().moka_set_tuning(6, 0))
 
 
 @pytest.mark.parametrize("meshname,K,nsteps", [("ico16", 1, 3), ("ico16", 60, 2), ("planar", 4, 3), ("ico12f", 5, 2), ("ico16", 70, 2),

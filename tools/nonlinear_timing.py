@@ -16,11 +16,18 @@ ssh, u, h, rest, dts = mg.sphere_synthetic_state(mesh, K)
 cfg = {"time_management": {"config_start_time": dt.datetime(1, 1, 1), "config_run_duration": dt.timedelta(hours=1)},
        "time_integration": {"config_dt": dt.timedelta(seconds=dts), "config_number_of_time_levels": 2}}
 b = mk.MokaHIP(0)
-Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, cfg, b, multilayer=True)
-for nl in (False, True):
+pc = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # patch_cells (0 = the plan's default)
+Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, cfg, b, multilayer=True, patch_cells=pc)
+print('patch_cells', Setup.mesh.info().get('patch_cells'), flush=True)
+from moka_hip import lib as L              # noqa: E402
+shapes = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 0, 2, 3]
+abls = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]      # ablations of an exp build (-DMOKA_EXP_NL_ABL)
+for nl, shape, abl in [(False, 0, 0)] + [(True, sh, ab) for sh in shapes for ab in abls]:
+    L.check(L.lib().moka_set_tuning(5, shape))
+    L.check(L.lib().moka_set_tuning(6, 1000 + abl if abl else 0))      # launch shape of the nonlinear stage kernel (include/moka_hip.h)
     mk.set_nonlinear(Prog, nl)
     mk.run_steps(Prog, mk.RungeKutta4, dts, 3)
     b.synchronize(); t0 = time.perf_counter()
     mk.run_steps(Prog, mk.RungeKutta4, dts, 10)
     b.synchronize(); t1 = time.perf_counter()
-    print(f"{'nonlinear' if nl else 'linear   '}: {mesh.nCells} cells x {K}: {1e3 * (t1 - t0) / 10:.2f} ms per RK4 step")
+    print(f"{'nonlinear shape ' + str(shape) + (' ablation ' + str(abl) if abl else '') if nl else 'linear           '}: {mesh.nCells} cells x {K}: {1e3 * (t1 - t0) / 10:.2f} ms per RK4 step", flush=True)
