@@ -317,10 +317,16 @@ int  moka_halo_push_wait(moka_halo *h, double timeout_s); /* host: wait for ever
 /* distributed form of moka_step_rk4, piecewise: begin; for stage 1..4 { stage(s,0) boundary patches; pack(s) or
  * push_begin(s); stage(s,1) interior patches (overlaps the exchange); transport + unpack(s), or push_signal + push_wait };
  * end.  moka_rk4_dist_stage_launch(s) = stage(s,0) + push_begin(s) + stage(s,1).
- * part = 2: the whole local mesh in one launch, halo entities included (redundantly), exchange behind it -- the form the
- * optional nonlinear terms run in on a partitioned mesh (their stencil needs a halo two cells deep: build_local(rings = 2)). */
+ * part = 2: the whole local mesh in one launch, halo entities included (redundantly), exchange behind it.
+ * States with the optional nonlinear terms (their stencil needs a halo two cells deep: build_local(rings = 2)) split a stage
+ * into its preparation pass and its stage kernel: part 3 = preparation over the boundary and halo patches (after the previous
+ * stage's exchange has arrived), part 4 = preparation over the interior patches (owned rows only: may be queued as soon as the
+ * previous stage's launches are, and then overlaps that stage's exchange), parts 0 / 1 = the stage kernel over the boundary /
+ * interior patches.  moka_rk4_dist_step orders them so; part 2 remains for the kernel variants without per-patch kernels
+ * (moka_rk4_dist_parts_available == 0). */
 int  moka_rk4_dist_begin(moka_halo *h, double dt);
 int  moka_rk4_dist_stage(moka_halo *h, int stage, int part);
+int  moka_rk4_dist_parts_available(const moka_halo *h);
 int  moka_rk4_dist_stage_launch(moka_halo *h, int stage);
 int  moka_rk4_dist_end(moka_halo *h);
 /* ... and as ONE call per step.  transport == NULL: the direct exchange (every neighbour must be connected, MOKA_ERR_ARG

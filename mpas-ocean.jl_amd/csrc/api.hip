@@ -267,13 +267,17 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
     if (st->nonlinear) {
         // vector-invariant form: potential vorticity at vertices -> edges, kinetic energy at cells, thickness flux at edges
         // (whole mesh: the stencil of the edge pass reaches two cells deep), then the generic stage kernel's nonlinear twin
-        if (pCount >= 0) return hipErrorNotSupported;
         const bool del2 = st->viscDel2 != 0.0;
         const NlArgs nl{st->nlQv, st->nlQe, st->nlKe, del2 ? st->nlZv : nullptr, del2 ? st->nlDiv : nullptr, st->viscDel2};
         // kernel variants 4 / 3 select the plainer forms of the nonlinear kernels too (tests run every form against the oracle)
         const int form = st->ctx->variant == 4 ? 1 : st->ctx->variant == 3 ? 3 : 0;
-        hipError_t e = launch_nl_prepare(dev, g.pu, g.ph, nl, m->lpc, form, s);
-        if (e != hipSuccess) return e;
+        // a patch range (partitioned meshes: moka_rk4_dist_stage) is served by the patch forms only
+        if (pCount >= 0 && !nl_patch_forms(dev, m->lpc, form)) return hipErrorNotSupported;
+        if (st->nlPhase != 2) {
+            hipError_t e = launch_nl_prepare(dev, g.pu, g.ph, nl, m->lpc, form, s);
+            if (e != hipSuccess) return e;
+        }
+        if (st->nlPhase == 1) return hipSuccess;
         return launch_stage_nl(dev, g, nl, m->lpc, m->plan.ldsOk, form, s);
     }
     if (st->f32) {   // the one fp32-storage kernel (checked at state creation against the patches that are ever launched)
@@ -760,6 +764,7 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     if (p.nl5Ok) { UP(pvStart) UP(pvList) UP(lvoe) }
 #undef UP
     d.maxPV = p.nl5Ok ? p.maxPV : 0;
+    if (!p.nl5Ok) { d.pvStart = nullptr; d.pvList = nullptr; d.lvoe = nullptr; }
     d.CI = p.CI; d.EI = p.EI;
     m->colOk = p.colOk;
     d.tileRecOk = 0;

@@ -712,33 +712,73 @@ int moka_rk4_dist_begin(moka_halo *h, double dt)
     // like moka_step_rk4: lazily pending diagnostics / stage-4 tendencies of the previous step are superseded, not computed
     h->dt = dt;
     if (int rc = rk4_begin(st, &h->ssh0)) return rc;
-    h->overlapNow = h->overlapB;              // fixed for the step: the two forms order their launches by different events
+    h->overlapNow = h->overlapB && !st->nonlinear;   // fixed for the step: the two forms order their launches by different events
     if (h->overlapNow) HIPCHK(st->ctx, hipEventRecord(st->ctx->evInterior, st->ctx->stream));
     return MOKA_OK;
 }
 
 // part 0: patches [0, first) = the boundary patches (their rows are what other ranks need); part 1: [first, owned).
 // Halo patches [owned, nPatches) are never computed: their rows arrive through the exchange.
+// part 2: the whole local mesh in one launch, halo entities included (redundantly: the exchange behind the stage overwrites them).
+// States with the optional nonlinear terms (two-ring halo: every owned stencil is local) split a stage into its two kernels:
+//   part 3: the preparation pass (potential vorticity, kinetic energy, thickness flux of the stage's provisional state) over the
+//           boundary and the halo patches -- it reads halo rows, so the exchange of the previous stage must have arrived;
+//   part 4: the same over the interior patches, which read owned rows only: it can be queued behind the PREVIOUS stage's
+//           interior launch and then runs while that stage's exchange is still under way;
+//   parts 0 / 1: the stage kernel over the boundary / interior patches (after parts 3 and 4 of the same stage).
+// moka_rk4_dist_step orders them; part 2 stays the plain form (and the only one for the kernel variants without patch kernels).
 int moka_rk4_dist_stage(moka_halo *h, int stage, int part)
 {
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
-    if (stage < 1 || stage > 4 || part < 0 || part > 2) return hfail(h, MOKA_ERR_ARG, "stage must be 1..4, part 0, 1 or 2");
+    if (stage < 1 || stage > 4 || part < 0 || part > 4) return hfail(h, MOKA_ERR_ARG, "stage must be 1..4, part 0..4");
     moka_state *st = h->st;
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (part == 2) {
-        // the whole local mesh in one launch, halo entities included (redundantly: the exchange behind the stage overwrites
-        // them): the form the optional nonlinear terms run in -- their two-ring halo makes every owned stencil local
         const StageArgs g = rk4_stage_args(st, stage, h->dt, h->ssh0);
         HIPCHK(st->ctx, run_stage(st, g));
         return MOKA_OK;
     }
-    if (st->nonlinear) return hfail(h, MOKA_ERR_UNSUPPORTED, "nonlinear terms on a partitioned mesh: whole-mesh stages only (part = 2)");
+    if (part >= 3 && !st->nonlinear) return hfail(h, MOKA_ERR_ARG, "parts 3 and 4 are the preparation passes of the nonlinear terms");
+    if (st->nonlinear) {
+        if (h->overlapNow) return hfail(h, MOKA_ERR_ARG, "nonlinear terms: moka_rk4_dist_begin first");
+        const StageArgs g = rk4_stage_args(st, stage, h->dt, h->ssh0);
+        const int nP = st->mesh->plan.nPatches;
+        hipError_t e = hipSuccess;
+        st->nlPhase = part >= 3 ? 1 : 2;
+        if (part == 0) {
+            if (int rc = launch_acquire(h, st->ctx->stream)) { st->nlPhase = 0; return rc; }
+            e = run_stage(st, g, 0, h->pFirst);
+        } else if (part == 1) {
+            e = run_stage(st, g, h->pFirst, h->pOwned - h->pFirst);
+        } else if (part == 4) {
+            e = run_stage(st, g, h->pFirst, h->pOwned - h->pFirst);
+        } else {
+            if (int rc = launch_acquire(h, st->ctx->stream)) { st->nlPhase = 0; return rc; }
+            e = run_stage(st, g, 0, h->pFirst);
+            if (e == hipSuccess) e = run_stage(st, g, h->pOwned, nP - h->pOwned);
+        }
+        st->nlPhase = 0;
+        if (e == hipErrorNotSupported)
+            return hfail(h, MOKA_ERR_UNSUPPORTED, "nonlinear terms on patch ranges need the patch kernels (kernel variant 0 or 4, even K <= 64): use part 2");
+        HIPCHK(st->ctx, e);
+        return MOKA_OK;
+    }
     // Boundary group first, interior right behind it on the same (compute) stream: in-order, no cross-queue wait in the
     // compute chain.  Launched concurrently the two kernels share the CUs and the ~130 boundary workgroups finish no
     // earlier than the thousands of interior ones (measured 290 us instead of 35 us), which would push the exchange
     // behind the interior compute it is meant to hide under.  The comm stream waits for the boundary group only (its
     // event is recorded before the interior launch is queued).
     return dist_stage_part(h, stage, part);
+}
+
+// can this state's stages run part by part (linear terms: always; nonlinear terms: with the patch kernels)
+int moka_rk4_dist_parts_available(const moka_halo *h)
+{
+    if (!h) return 0;
+    const moka_state *st = h->st;
+    if (!st->nonlinear) return 1;
+    const int form = st->ctx->variant == 4 ? 1 : st->ctx->variant == 3 ? 3 : 0;
+    return nl_patch_forms(st->mesh->dev, st->mesh->lpc, form) ? 1 : 0;
 }
 
 // direct transport, the device-queue half of a stage: boundary patches, push (comm stream), interior patches
@@ -773,21 +813,31 @@ int moka_rk4_dist_step(moka_halo *h, double dt, moka_transport_fn transport, voi
     const bool direct = h->nNbr > 0 && !transport;
     if (direct && !all_connected(h)) return hfail(h, MOKA_ERR_ARG, "no transport callback and not every neighbour is connected");
     if ((rc = moka_rk4_dist_begin(h, dt))) return rc;
+    const bool nl = h->st->nonlinear;
+    if (nl && !moka_rk4_dist_parts_available(h))
+        return hfail(h, MOKA_ERR_UNSUPPORTED, "nonlinear terms: this kernel variant has whole-mesh stages only (moka_rk4_dist_stage part 2)");
+    // nonlinear terms: the preparation pass of the interior patches of stage s + 1 is queued right behind the interior launch of
+    // stage s (it reads owned rows only) and so overlaps exchange s as well; that of the boundary and halo patches follows the wait
+    if (nl && (rc = moka_rk4_dist_stage(h, 1, 4))) return rc;
     for (int s = 1; s <= 4; ++s) {
+        if (nl && (rc = moka_rk4_dist_stage(h, s, 3))) return rc;
         if ((rc = moka_rk4_dist_stage(h, s, 0))) return rc;
         if (direct) {
             if ((rc = moka_halo_push_begin(h, s))) return rc;
             if ((rc = moka_rk4_dist_stage(h, s, 1))) return rc;
+            if (nl && s < 4 && (rc = moka_rk4_dist_stage(h, s + 1, 4))) return rc;
             if ((rc = moka_halo_push_signal(h))) return rc;
             if ((rc = moka_halo_push_wait(h, timeout_s))) return rc;
         } else if (h->nNbr > 0) {
             if ((rc = moka_halo_pack(h, s, sendbuf))) return rc;
             if ((rc = moka_rk4_dist_stage(h, s, 1))) return rc;
+            if (nl && s < 4 && (rc = moka_rk4_dist_stage(h, s + 1, 4))) return rc;
             if (int trc = transport(user, s, sendbuf, recvbuf))
                 return hfail(h, MOKA_ERR_COMM, "the halo transport callback failed at stage " + std::to_string(s) + " (code " + std::to_string(trc) + ")");
             if ((rc = moka_halo_unpack(h, s, recvbuf))) return rc;
         } else {
             if ((rc = moka_rk4_dist_stage(h, s, 1))) return rc;
+            if (nl && s < 4 && (rc = moka_rk4_dist_stage(h, s + 1, 4))) return rc;
         }
     }
     return moka_rk4_dist_end(h);

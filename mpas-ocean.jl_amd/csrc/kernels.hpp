@@ -160,6 +160,7 @@ struct NlArgs {
 // (prepare and stage must be called with the same form: forms 0 / 1 keep F alone in NlArgs.fq, forms 2 / 3 {F, q_e} pairs)
 void set_nl_shape(int v);
 int nl_shape();
+bool nl_patch_forms(const MeshDev &m, int lpc, int form);   // do the nonlinear launches of this mesh go through the per-patch kernels (which serve patch ranges)
 void set_nl_cap_limit(int v);
 int nl_cap_limit();
 hipError_t launch_nl_prepare(const MeshDev &m, const double *u, const double *h, const NlArgs &nl, int lpc, int form, hipStream_t s);

@@ -93,9 +93,9 @@ struct Plan {
     std::vector<double>  keoc;     // nC*ME  keCoef of the cell's edge in slot i (0 for padding): no dependent load in the kernels
     std::vector<int32_t> rowVoe;   // 2 per entry of rowEdge: verticesOnEdge of that row's edge (patch row lists only)
     // k_stage_nl5: pvList[pvStart[q] .. pvStart[q+1]) = the distinct vertices of patch q's own edges and of their edgesOnEdge;
-    // lvoe[e][32] = patch-local ids (one byte each) of the two vertices of every edgesOnEdge slot and of e itself (layout: plan.cpp)
+    // lvoe[e][24] = patch-local ids (16 bits each) of the two vertices of every edgesOnEdge slot and of e itself (layout: plan.cpp)
     std::vector<int32_t> pvStart, pvList;
-    std::vector<uint8_t> lvoe;
+    std::vector<uint16_t> lvoe;
     int32_t maxPV = 0;
     bool nl5Ok = false;
 };
@@ -134,7 +134,7 @@ struct MeshDev {
     const double *kite, *invAreaTri, *fVertex, *keCoef, *invDc, *keoc;
     const int32_t *rowVoe;
     const int32_t *pvStart, *pvList;   // k_stage_nl5 (nullptr when the plan could not build them)
-    const uint8_t *lvoe;
+    const uint16_t *lvoe;
     int32_t maxPV, pvCap;              // most vertices any patch lists; rows k_stage_nl5 keeps in LDS (set per launch)
     int32_t tileRecOk;    // eRecT / cRecT exist and every patch fits the loader budget of the persistent tiled kernel
     int32_t tailPatch;    // >= 0: one extra, non-adjacent patch rides in this launch (default stage kernels only)

@@ -343,8 +343,9 @@ __global__ __launch_bounds__(BLOCK) void k_nl_prep4(const MeshDev m, const doubl
     __shared__ int2 sEc[NL4_ECH];
     const int grp = threadIdx.x >> 5, l = threadIdx.x & 31, K = m.K;
     const bool act = 2 * l < K;
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;       // (a launch may cover a patch range of a partitioned mesh)
     const int v0 = m.patchVertStart[p], v1 = m.patchVertStart[p + 1], c0 = m.patchCellStart[p], c1 = m.patchCellStart[p + 1];
     const int e0 = m.patchEdgeStart[p], e1 = m.patchEdgeStart[p + 1];
     const int nChunks = max(max((v1 - v0 + NL4_VCH - 1) / NL4_VCH, (c1 - c0 + NL4_CCH - 1) / NL4_CCH), (e1 - e0 + NL4_ECH - 1) / NL4_ECH);
@@ -657,8 +658,9 @@ __global__ __launch_bounds__(BLOCK, 3) void k_stage_nl3(const MeshDev m, const S
     __shared__ double sW[NL3_MAXE * ME2_];
     const int grp = threadIdx.x >> 5, l = threadIdx.x & 31, K = m.K, k0 = 2 * l;
     const bool act = k0 < K;
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;       // (a launch may cover a patch range of a partitioned mesh)
     const double *__restrict__ F = nl.fq;
     const int e0 = m.patchEdgeStart[p], e1 = m.patchEdgeStart[p + 1];
     for (int i = threadIdx.x; i < (e1 - e0) * ME2_; i += BLOCK) {
@@ -791,8 +793,9 @@ __global__ __launch_bounds__(NT, 4) void k_stage_nl4(const MeshDev m, const Stag
     int *sX = reinterpret_cast<int *>(sV + m.maxRows);                     // [maxOwnE][ME2]  edgesOnEdge (global ids, -1 = none)
     int *sCe = sX + (size_t)m.maxOwnE * ME2_;                              // [maxOwnC][2 ME] edgesOnCell | maxLevelEdgeTop of the edge
     unsigned char *sL = reinterpret_cast<unsigned char *>(sCe + (size_t)m.maxOwnC * 2 * ME_);   // [maxOwnE][16]  patch-local row of each slot
-    const int p = patch_of_block(m.nPatches);
-    if (p >= m.nPatches) return;
+    const int pl_ = patch_of_block(m.nPatches);
+    if (pl_ >= m.nPatches) return;
+    const int p = pl_ + m.patchBegin;       // (a launch may cover a patch range of a partitioned mesh)
     const double *__restrict__ F = nl.fq;
     const int e0 = m.patchEdgeStart[p], e1 = m.patchEdgeStart[p + 1], nOwn = e1 - e0;
     const int r0 = m.rowStart[p], nRows = m.rowStart[p + 1] - r0;
@@ -936,7 +939,7 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
     constexpr int NG = NT / 32;
     constexpr int RB = (80 + NG - 1) / NG;           // vertex rows in flight per half-wave: one round serves 80 vertices
     constexpr int FB = (48 + NG - 1) / NG;           // own F rows in flight per half-wave: one round serves 48 edges
-    static_assert(ME2_ == 10, "lvoe's layout: two groups of five edgesOnEdge slots");
+    static_assert(ME2_ == 10, "lvoe's layout: ten edgesOnEdge slots, then the edge itself");
     extern __shared__ __align__(16) unsigned char nl5_smem[];
     const int grp = threadIdx.x >> 5, l = threadIdx.x & 31, K = m.K, k0 = 2 * l;
     const bool act = k0 < K;
@@ -950,7 +953,7 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
     int *sX = reinterpret_cast<int *>(sCs + (size_t)m.maxOwnC * (ME_ + 1));   // [maxOwnE][ME2]  edgesOnEdge (global ids, -1 = none)
     int *sCe = sX + (size_t)m.maxOwnE * ME2_;                              // [maxOwnC][2 ME] edgesOnCell | maxLevelEdgeTop of the edge
     int *sPv = sCe + (size_t)m.maxOwnC * 2 * ME_;                          // [maxPV]         the patch's vertices
-    unsigned *sLv = reinterpret_cast<unsigned *>(sPv + m.maxPV);           // [maxOwnE][8]    patch-local vertex ids, one byte each (plan.cpp: lvoe)
+    unsigned *sLv = reinterpret_cast<unsigned *>(sPv + m.maxPV);           // [maxOwnE][12]   patch-local vertex ids, 16 bits each (plan.cpp: lvoe)
     const int pl_ = patch_of_block(m.nPatches);
     if (pl_ >= m.nPatches) return;
     const int p = pl_ + m.patchBegin;
@@ -961,7 +964,7 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
     const int nLds = min(nPV, m.pvCap);       // the few patches with more vertices than the LDS budget holds gather the rest on use
     for (int i = threadIdx.x; i < nPV; i += NT) sPv[i] = m.pvList[pv0 + i];
     for (int i = threadIdx.x; i < nOwn * ME2_; i += NT) { sX[i] = m.eoe[(size_t)e0 * ME2_ + i]; sW[i] = m.woe[(size_t)e0 * ME2_ + i]; }
-    for (int i = threadIdx.x; i < nOwn * 8; i += NT) sLv[i] = reinterpret_cast<const unsigned *>(m.lvoe)[(size_t)e0 * 8 + i];
+    for (int i = threadIdx.x; i < nOwn * 12; i += NT) sLv[i] = reinterpret_cast<const unsigned *>(m.lvoe)[(size_t)e0 * 12 + i];
     const int c0 = m.patchCellStart[p], nC = m.patchCellStart[p + 1] - c0;
     for (int i = threadIdx.x; i < nOwn; i += NT) {
         sH[i] = reinterpret_cast<const int4 *>(m.ehdr)[e0 + i];
@@ -1087,8 +1090,8 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
         double2 t = make_double2(0.0, 0.0);
         double2 qo;
         {
-            const unsigned w = sLv[le * 8 + 6];
-            const double2 qa = over ? qany(w & 0xFFu) : qrow(w & 0xFFu), qb = over ? qany((w >> 8) & 0xFFu) : qrow((w >> 8) & 0xFFu);
+            const unsigned w = sLv[le * 12 + 10];
+            const double2 qa = over ? qany(w & 0xFFFFu) : qrow(w & 0xFFFFu), qb = over ? qany(w >> 16) : qrow(w >> 16);
             qo = make_double2(0.5 * (qa.x + qb.x), 0.5 * (qa.y + qb.y));   // q_e of this edge
         }
         double2 ucur, nbu;
@@ -1098,13 +1101,12 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
             if (ay) t.y -= g * ds;
             if (ax) t.x -= invDc * (k2.x - k1.x);
             if (ay) t.y -= invDc * (k2.y - k1.y);
-            const unsigned char *lb = reinterpret_cast<const unsigned char *>(sLv + le * 8);
+            const unsigned short *lb = reinterpret_cast<const unsigned short *>(sLv + le * 12);
 #pragma unroll 1
             for (int i = 0; i < ME2_; ++i) {
                 const int x = sX[le * ME2_ + i];
                 const double2 Fi = ldo(F, (unsigned)(x < 0 ? e : x) * rowB + lo);
-                const int bb = 12 * (i / 5) + 2 * (i % 5);
-                const double2 qa = qany(lb[bb]), qb = qany(lb[bb + 1]);
+                const double2 qa = qany(lb[2 * i]), qb = qany(lb[2 * i + 1]);
                 const double w = sW[le * ME2_ + i];
                 const double qnx = 0.5 * (qa.x + qb.x), qny = 0.5 * (qa.y + qb.y);
                 const double tx = t.x + w * Fi.x * (0.5 * (qo.x + qnx)), ty = t.y + w * Fi.y * (0.5 * (qo.y + qny));
@@ -1151,17 +1153,15 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
             if (ay) t.y -= g * ds;
             if (ax) t.x -= invDc * (k2.x - k1.x);
             if (ay) t.y -= invDc * (k2.y - k1.y);
-            unsigned lv[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) lv[i] = sLv[le * 8 + i];
+
             if (NL_ABL(1)) {
 #pragma unroll
                 for (int i = 0; i < ME2_; ++i) { t.x += Fx[i].x; t.y += Fx[i].y; }
             } else
 #pragma unroll
             for (int i = 0; i < ME2_; ++i) {
-                const int bb = 12 * (i / 5) + 2 * (i % 5);                // byte of the slot's first vertex in the record
-                const unsigned ia = (lv[bb >> 2] >> (8 * (bb & 3))) & 0xFFu, ib = (lv[(bb + 1) >> 2] >> (8 * ((bb + 1) & 3))) & 0xFFu;
+                const unsigned lvi = sLv[le * 12 + i];
+                const unsigned ia = lvi & 0xFFFFu, ib = lvi >> 16;
                 const bool ok = sX[le * ME2_ + i] >= 0;
                 const double w = sW[le * ME2_ + i];
                 const double2 qa = qrow(ia), qb = qrow(ib);
@@ -1193,7 +1193,7 @@ static inline size_t nl5_lds_bytes(const MeshDev &m, int cap, bool cf)
 {
     return (size_t)cap * m.K * 8 + (cf ? (size_t)m.maxOwnE * m.K * 8 : 0) + (size_t)m.maxOwnE * m.ME2 * 8 + (size_t)m.maxOwnE * 32 +
            (size_t)m.maxOwnC * (m.ME + 1) * 8 + (size_t)m.maxOwnE * m.ME2 * 4 + (size_t)m.maxOwnC * 2 * m.ME * 4 + (size_t)m.maxPV * 4 +
-           (size_t)m.maxOwnE * 32;
+           (size_t)m.maxOwnE * 48;
 }
 
 // vertex rows kept resident: all of the largest patch's when two workgroups per CU still fit, otherwise what that budget holds -- the
@@ -1215,6 +1215,8 @@ static inline size_t nl4_lds_bytes(const MeshDev &m)
 
 // 1 = the patch form serves this mesh (even K <= 64, hexagon-dominated widths); NlArgs.fq then holds F alone
 static inline bool nl3_ok(const MeshDev &m) { return m.K <= 64 && !(m.K & 1) && m.ME == 6 && m.ME2 == 10 && m.VD == 3 && m.patchVertStart && m.maxOwnE <= NL3_MAXE; }
+
+bool nl_patch_forms(const MeshDev &m, int lpc, int form) { return lpc == 64 && nl3_ok(m) && form <= 1; }
 
 static inline dim3 grid2(int n) { return dim3((unsigned)std::min(std::max((n + 7) / 8, 1), 65536)); }
 

@@ -612,33 +612,33 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
                 if (p.eoc[IX(i, c, ME)] >= 0) p.keoc[IX(i, c, ME)] = p.keCoef[p.eoc[IX(i, c, ME)]];
     }
     // ---- patch vertex lists of k_stage_nl5: the distinct vertices of a patch's own edges and of their edgesOnEdge, and per
-    // own edge a 32-byte record of patch-local vertex ids (one byte each): slots 0-4 in bytes 0-9, slots 5-9 in bytes 12-21 (the
-    // two vertices of edgesOnEdge slot i: bytes 12 (i / 5) + 2 (i % 5), + 1), the edge's own two vertices in bytes 24, 25 ----
+    // own edge a record of 24 patch-local vertex ids (16 bits each: the boundary patches of a partitioned mesh can be scattered
+    // cells with ~300 vertices): entries 2 i, 2 i + 1 = the two vertices of edgesOnEdge slot i (i < 10), entries 20, 21 = the
+    // edge's own two vertices, 22, 23 unused ----
     p.pvStart.assign(p.nPatches + 1, 0);
     p.pvList.clear(); p.lvoe.clear();
     p.maxPV = 0; p.nl5Ok = false;
-    if (p.nlOk && p.ldsOk && ME2 <= 10) {
+    if (p.nlOk && ME2 <= 10) {
         p.nl5Ok = true;
-        p.lvoe.assign((size_t)nE * 32, 0);
+        p.lvoe.assign((size_t)nE * 24, 0);
         std::vector<int32_t> lv(p.nV, -1);
         for (int q = 0; q < p.nPatches; ++q) {
             const size_t base = p.pvList.size();
             auto lid = [&](int v) {
                 if (lv[v] < 0) { lv[v] = (int32_t)(p.pvList.size() - base); p.pvList.push_back(v); }
-                return (uint8_t)std::min(lv[v], 255);
+                return (uint16_t)std::min(lv[v], 65535);
             };
             for (int e = p.patchEdgeStart[q]; e < p.patchEdgeStart[q + 1]; ++e) {
-                uint8_t *r = &p.lvoe[(size_t)e * 32];
-                r[24] = lid(p.voe[2 * (size_t)e]); r[25] = lid(p.voe[2 * (size_t)e + 1]);
+                uint16_t *r = &p.lvoe[(size_t)e * 24];
+                r[20] = lid(p.voe[2 * (size_t)e]); r[21] = lid(p.voe[2 * (size_t)e + 1]);
                 for (int i = 0; i < 10; ++i) {
                     const int x = i < ME2 ? p.eoe[IX(i, e, ME2)] : -1;
-                    const int b = 12 * (i / 5) + 2 * (i % 5);
-                    r[b] = x >= 0 ? lid(p.voe[2 * (size_t)x]) : r[24];
-                    r[b + 1] = x >= 0 ? lid(p.voe[2 * (size_t)x + 1]) : r[25];
+                    r[2 * i] = x >= 0 ? lid(p.voe[2 * (size_t)x]) : r[20];
+                    r[2 * i + 1] = x >= 0 ? lid(p.voe[2 * (size_t)x + 1]) : r[21];
                 }
             }
             const int n = (int)(p.pvList.size() - base);
-            if (n > 255) p.nl5Ok = false;
+            if (n > 65535) p.nl5Ok = false;
             p.maxPV = std::max(p.maxPV, n);
             for (size_t j = base; j < p.pvList.size(); ++j) lv[p.pvList[j]] = -1;
             p.pvStart[q + 1] = (int32_t)p.pvList.size();

@@ -98,6 +98,7 @@ struct moka_state {
     bool f32 = false;
     // optional nonlinear terms (moka_set_nonlinear): scratch of the three preparation passes
     bool nonlinear = false;
+    int nlPhase = 0;                  // what run_stage launches for a nonlinear state: 0 preparation + stage, 1 preparation only, 2 stage only
     double *nlQv = nullptr, *nlQe = nullptr, *nlKe = nullptr;
     int feFast = -1;                            // moka_last_fe_path
     double *nlZv = nullptr, *nlDiv = nullptr;   // Del2 mixing (moka_set_viscosity_del2)

@@ -509,6 +509,7 @@ def set_nonlinear(Prog: "PrognosticVars", on: bool = True, visc_del2: float = 0.
     tendencies / RK4 steps on or off.  An extension: the reference has only the linear terms; default off.
     `visc_del2` != 0 adds Del2 momentum mixing (the reference's uncalled sketch, horizontal_momentum_mixing.jl:53-80)."""
     L.check(L.lib().moka_set_nonlinear(Prog._state._h, 1 if on else 0), Prog._state.mesh.backend._h)
+    Prog._state.nonlinear = bool(on)
     if on:
         L.check(L.lib().moka_set_viscosity_del2(Prog._state._h, float(visc_del2)), Prog._state.mesh.backend._h)
 

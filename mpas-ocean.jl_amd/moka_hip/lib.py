@@ -84,7 +84,7 @@ EXPORTS = [
     "moka_rk4_dist_stage_launch", "moka_rk4_dist_step", "moka_fe_dist_launch", "moka_fe_dist_end", "moka_fe_dist_step",
     "moka_set_nonlinear", "moka_last_fe_path", "moka_set_viscosity_del2", "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
     "moka_adjoint_download",
-    "moka_mark", "moka_marks_reset", "moka_marks_read", "moka_bw_probe", "moka_ctx_pci_bus_id", "moka_halo_set_acquire", "moka_set_tuning", "moka_get_tuning",
+    "moka_mark", "moka_marks_reset", "moka_marks_read", "moka_bw_probe", "moka_ctx_pci_bus_id", "moka_halo_set_acquire", "moka_set_tuning", "moka_get_tuning", "moka_rk4_dist_parts_available",
     "moka_gradient_on_edge_vjp", "moka_gradient_on_edge_jvp", "moka_divergence_on_cell_vjp", "moka_divergence_on_cell_jvp",
     "moka_curl_on_vertex_vjp", "moka_curl_on_vertex_jvp", "moka_fe_lazy_pending",
 ]
@@ -175,6 +175,7 @@ def lib():
     L.moka_halo_unpack.argtypes = [vp, C.c_int, vp]
     L.moka_rk4_dist_begin.argtypes = [vp, C.c_double]
     L.moka_rk4_dist_stage.argtypes = [vp, C.c_int, C.c_int]
+    L.moka_rk4_dist_parts_available.argtypes = [vp]
     L.moka_rk4_dist_end.argtypes = [vp]
     L.moka_plan_class_ranges.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), _i32p, _i32p, _i32p]
     L.moka_mesh_class_ranges.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), _i32p, _i32p, _i32p]
@@ -288,7 +289,7 @@ PLAN_ARRAYS = {  # name -> (id, dtype)
     "eov": (14, np.int32), "cv": (15, np.float64),
     "haloStart": (16, np.int32), "haloEdge": (17, np.int32), "leoc": (18, np.uint8), "leoe": (19, np.uint8),
     "cRec": (20, np.uint32), "eRec": (21, np.uint32), "feoe": (22, np.float64),
-    "pvStart": (23, np.int32), "pvList": (24, np.int32), "lvoe": (25, np.uint8),
+    "pvStart": (23, np.int32), "pvList": (24, np.int32), "lvoe": (25, np.uint16),
 }
 
 

@@ -958,21 +958,41 @@ class LocalCluster:
         self._finish_direct()
 
     def step_rk4(self):
+        """One RK4 step on every rank.  With the optional nonlinear terms a stage is two kernels: the preparation pass over the
+        boundary and halo patches waits for the previous stage's exchange, the one over the interior patches is queued behind the
+        previous stage's interior launch and overlaps that exchange (moka_rk4_dist_stage parts 3 / 4; the order of
+        moka_rk4_dist_step)."""
         lib = L.lib()
+        nl = bool(getattr(self.models[0].Prog._state, "nonlinear", False))
+
+        def each(fn, *a):
+            for m in self.models:
+                L.check(fn(m._halo, *a), m.backend._h)
         for m in self.models:
             L.check(lib.moka_rk4_dist_begin(m._halo, m.dt), m.backend._h)
+        if nl:
+            each(lib.moka_rk4_dist_stage, 1, 4)
         for s in (1, 2, 3, 4):
+            if nl:
+                each(lib.moka_rk4_dist_stage, s, 3)
             if self.direct:
-                for m in self.models:
-                    L.check(lib.moka_rk4_dist_stage_launch(m._halo, s), m.backend._h)   # boundary, push, interior
+                if nl:
+                    for m in self.models:
+                        L.check(lib.moka_rk4_dist_stage(m._halo, s, 0), m.backend._h)
+                        L.check(lib.moka_halo_push_begin(m._halo, s), m.backend._h)
+                        L.check(lib.moka_rk4_dist_stage(m._halo, s, 1), m.backend._h)
+                        if s < 4:
+                            L.check(lib.moka_rk4_dist_stage(m._halo, s + 1, 4), m.backend._h)
+                else:
+                    each(lib.moka_rk4_dist_stage_launch, s)             # boundary, push, interior
                 self._finish_direct()
                 continue
-            for m in self.models:
-                L.check(lib.moka_rk4_dist_stage(m._halo, s, 0), m.backend._h)     # boundary patches
+            each(lib.moka_rk4_dist_stage, s, 0)                          # boundary patches
             for m in self.models:
                 L.check(lib.moka_halo_pack(m._halo, s, m.sendbuf.data_ptr()), m.backend._h)
-            for m in self.models:
-                L.check(lib.moka_rk4_dist_stage(m._halo, s, 1), m.backend._h)     # interior overlaps the exchange
+            each(lib.moka_rk4_dist_stage, s, 1)                          # interior overlaps the exchange
+            if nl and s < 4:
+                each(lib.moka_rk4_dist_stage, s + 1, 4)
             self._exchange(s, pack=False)
         for m in self.models:
             L.check(lib.moka_rk4_dist_end(m._halo), m.backend._h)

@@ -19,6 +19,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import oracle as orc  # noqa: E402
+from moka_hip import lib as L  # noqa: E402
 from moka_hip import meshgen as mg  # noqa: E402
 from moka_hip import parallel as par  # noqa: E402
 
@@ -227,8 +228,11 @@ def main():
             nlm = par.DistributedModel(mesh, ssh, u, h, rest, dt, backend, rank, world, transport="gloo", part=part, nonlinear=True)
             nlm.exchange_state()
             onl, stn = orc.OracleNonlinear(om), orc.OracleState(om, ssh, u, h)
-            for _ in range(2):
-                nlm.step_rk4_whole()
+            for i in range(3):
+                # one library call per step (stage kernel over boundary / interior patches, the interior's preparation pass under the
+                # exchange) and the plain form (every stage one launch over the whole local mesh, exchange behind it), alternately
+                parts = bool(L.lib().moka_rk4_dist_parts_available(nlm._halo))       # per-patch kernels: even 34 <= K <= 64
+                (nlm.step_rk4 if parts and i != 1 else nlm.step_rk4_whole)()
                 onl.step_rk4(stn, dt)
             (cg, s_, hh), (eg, uu) = nlm.owned_state()
             assert np.array_equal(hh, stn.h[1][cg]) and np.array_equal(uu, stn.u[1][eg]) and np.array_equal(s_, stn.ssh[1][cg]), "nonlinear"

@@ -391,13 +391,27 @@ def test_nonlinear_terms_on_a_partitioned_mesh(world, K, visc, nsteps):
     cl = par.LocalCluster(mesh, ssh, u, h, rest, dt, world, direct=False, nonlinear=True, visc_del2=v)
     assert all(m.lm.rings == 2 for m in cl.models)
     cl.exchange_state()
-    for _ in range(nsteps):
-        cl.step_rk4_whole()
+    parts = all(L.lib().moka_rk4_dist_parts_available(m._halo) for m in cl.models)
+    assert parts == (K % 2 == 0 and K <= 64)             # the per-patch kernels serve even K <= 64; K = 3: whole-mesh stages only
+    for i in range(nsteps):
+        # alternately: every stage as one launch over the whole local mesh with the exchange behind it, and the overlapped form
+        # (stage kernel over boundary / interior patches, preparation passes split so that the interior's overlaps the exchange)
+        (cl.step_rk4 if parts and i % 2 == 0 else cl.step_rk4_whole)()
         nl.step_rk4(st, dt)
     gs, gu, gh = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
     assert np.array_equal(gu, st.u[1])
     assert np.array_equal(gh, st.h[1])
     assert np.array_equal(gs, st.ssh[1])
+    if parts and world <= 4:                               # the same over the direct transport (stores into the neighbours' fields)
+        cd = par.LocalCluster(mesh, st.ssh[1], st.u[1], st.h[1], rest, dt, world, direct=True, nonlinear=True, visc_del2=v)
+        cd.exchange_state()
+        ref = orc.OracleState(om, st.ssh[1], st.u[1], st.h[1])
+        for _ in range(2):
+            cd.step_rk4()
+            nl.step_rk4(ref, dt)
+        ds, du, dh = cd.gather_owned(mesh.nCells, mesh.nEdges, K)
+        assert np.array_equal(du, ref.u[1]) and np.array_equal(dh, ref.h[1]) and np.array_equal(ds, ref.ssh[1])
+        cd.close()
     # back to the reference's terms on the same (two-ring) local meshes: the ordinary distributed step
     from moka_hip import api as mk
     for m in cl.models:

@@ -202,13 +202,13 @@ def test_edge_ownership_is_levelled_to_the_mean(P, groups):
 
 def test_patch_vertex_lists_of_the_nonlinear_stage_kernel():
     """k_stage_nl5 keeps the potential vorticity of a patch's vertices in LDS: pvList names them, lvoe[e] holds, per edgesOnEdge slot
-    and for the edge itself, the patch-local ids of the slot edge's two vertices.  Check both against verticesOnEdge."""
+    and for the edge itself, the patch-local ids (16 bits each) of the slot edge's two vertices.  Check both against verticesOnEdge."""
     mesh = mg.icosahedral_mesh(8)
     K = 60
     plan = L.Plan(mesh, K)
     nE = mesh.nEdges
     pc, pe, pv = plan.patch_ranges()
-    pvStart, pvList, lvoe = plan.array("pvStart"), plan.array("pvList"), plan.array("lvoe").reshape(nE, 32)
+    pvStart, pvList, lvoe = plan.array("pvStart"), plan.array("pvList"), plan.array("lvoe").reshape(nE, 24)
     eoe = plan.array("eoe").reshape(nE, -1)
     assert eoe.shape[1] == 10 and len(pvStart) == len(pe)
     eperm, vperm = plan.permutation(L.EDGE), plan.permutation(L.VERTEX)
@@ -217,13 +217,12 @@ def test_patch_vertex_lists_of_the_nonlinear_stage_kernel():
     most = 0
     for q in range(len(pe) - 1):
         verts = pvList[pvStart[q]:pvStart[q + 1]]
-        assert len(set(verts.tolist())) == len(verts) <= 255
+        assert len(set(verts.tolist())) == len(verts) <= 65535
         most = max(most, len(verts))
         for e in range(pe[q], pe[q + 1]):
-            assert np.array_equal(verts[lvoe[e, 24:26]], voe[e])
+            assert np.array_equal(verts[lvoe[e, 20:22]], voe[e])
             for i in range(10):
-                b = 12 * (i // 5) + 2 * (i % 5)
                 x = eoe[e, i]
-                assert np.array_equal(verts[lvoe[e, b:b + 2]], voe[x] if x >= 0 else voe[e])
+                assert np.array_equal(verts[lvoe[e, 2 * i:2 * i + 2]], voe[x] if x >= 0 else voe[e])
     assert most <= 96          # a 16-cell patch: ~75 vertices (its own edges' and those of the ring of cells around it)
     plan.close()
