@@ -464,6 +464,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg of the default single-GPU run")
     ap.add_argument("--tend-iters", type=int, default=20)
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
+                    help="A/B measurement: moka_set_tuning(KEY, VALUE) before anything runs (include/moka_hip.h lists the keys); repeatable")
     ap.add_argument("--f32-wide-modes", type=int, default=None,
                     help="A/B measurement: bit mask of the fp32-storage kernel's modes launched as 512-thread / 4-waves-per-SIMD workgroups (moka_set_tuning key 1)")
     ap.add_argument("--transport", default="auto", choices=["auto", "ipc", "nccl", "nccl-a2a", "nccl-p2p", "nccl-default-stream", "gloo"],
@@ -530,6 +532,10 @@ def main():
     if args.f32_wide_modes is not None:
         from moka_hip import lib as _L
         _L.check(_L.lib().moka_set_tuning(1, int(args.f32_wide_modes)))
+    for kv in args.tuning:
+        from moka_hip import lib as _L
+        k_, v_ = kv.split("=")
+        _L.check(_L.lib().moka_set_tuning(int(k_), int(v_)))
 
     # which physical devices do the ranks of this launch really use?  (host, PCI bus id) per rank
     my_dev = (socket.gethostname(), backend.pci_bus_id())
