@@ -444,6 +444,13 @@ int  moka_tape_record_rk4(moka_tape *t, int slot, int what);
 int  moka_tape_commit_rk4(moka_tape *t, double dt);
 int  moka_adjoint_rk4_stage_fields(moka_tape *t, int stage, void **fieldU, void **fieldH, void **scratchS);
 int  moka_adjoint_rk4_stage(moka_tape *t, int stage);
+/* ... and with the exchange overlapped: moka_adjoint_rk4_stage_part(t, sg, 0) transposes the entities of the boundary cell class
+ * (what other ranks gather from), the caller starts the exchange of the rows that produced (moka_adjoint_rk4_stage_out_fields names
+ * the arrays stage sg writes for the next transposed stage; after sg = 1: the adjoint state itself), part 1 = the interior class
+ * runs meanwhile (owned rows only), then the exchange completes.  Halo entities are not computed.  Chunk kernels only
+ * (even 34 <= nVertLevels <= 64), MOKA_ERR_UNSUPPORTED otherwise. */
+int  moka_adjoint_rk4_stage_part(moka_tape *t, int stage, int part);
+int  moka_adjoint_rk4_stage_out_fields(moka_tape *t, int stage, void **fieldU, void **fieldH, void **scratchS);
 /* Forward-Euler runs on a partitioned mesh: record before (after = 0) and behind (after = 1) the distributed step, commit;
  * reversal per recorded step: exchange the halo rows of the three fields moka_adjoint_fe_step_fields names (the adjoints of
  * normalVelocity, layerThickness and ssh; that of the carried layerThicknessEdge needs none), then moka_adjoint_fe_step. */

@@ -239,9 +239,9 @@ __global__ __launch_bounds__(BLOCK, TT ? 3 : 4) void k_adj_edge3(const AdjMesh m
     const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
     const int K = m.K, k0 = 2 * l;
     const bool act = k0 < K;
-    const int nCh = (m.nE + ADJ_CH - 1) / ADJ_CH, ch = patch_of_block(nCh);
+    const int nCh = (m.eCount + ADJ_CH - 1) / ADJ_CH, ch = patch_of_block(nCh);
     if (ch >= nCh) return;
-    const int e0 = ch * ADJ_CH, ne = min(ADJ_CH, m.nE - e0);
+    const int e0 = m.eBegin + ch * ADJ_CH, ne = min(ADJ_CH, m.eBegin + m.eCount - e0);
     for (int i = threadIdx.x; i < ne * WU; i += BLOCK) { sSrc[i] = m.teoe[(size_t)e0 * WU + i]; sW[i] = m.tw[(size_t)e0 * WU + i]; }
     for (int i = threadIdx.x; i < ne; i += BLOCK) {
         sHd[i] = reinterpret_cast<const int4 *>(m.ehdr)[e0 + i];
@@ -356,9 +356,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_adj_cell3(const AdjMesh m, const A
     const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
     const int K = m.K, k0 = 2 * l;
     const bool act = k0 < K;
-    const int nCh = (m.nC + ADJ_CCH - 1) / ADJ_CCH, ch = patch_of_block(nCh);
+    const int nCh = (m.cCount + ADJ_CCH - 1) / ADJ_CCH, ch = patch_of_block(nCh);
     if (ch >= nCh) return;
-    const int c0 = ch * ADJ_CCH, nc = min(ADJ_CCH, m.nC - c0);
+    const int c0 = m.cBegin + ch * ADJ_CCH, nc = min(ADJ_CCH, m.cBegin + m.cCount - c0);
     for (int i = threadIdx.x; i < nc * ME_; i += BLOCK) {
         const int c = c0 + i / ME_;
         const int e = m.eoc[(size_t)c0 * ME_ + i];
@@ -502,13 +502,16 @@ static hipError_t launch_adj_cell_lpc(const AdjMesh &m, const AdjArgs &a, hipStr
 static int grid2(int n) { return std::min(std::max((n + 7) / 8, 1), 65536); }
 
 bool adj_fused_available(const AdjMesh &m, int lpc) { return lpc == 64 && m.K <= 64 && !(m.K & 1) && m.W == 10 && m.ME == 6; }
+static inline bool adj_whole(const AdjMesh &m) { return m.eBegin == 0 && m.eCount == m.nE && m.cBegin == 0 && m.cCount == m.nC; }
 
 hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s)
 {
     if (a.tt && (a.fuseE || a.lamScale != 1.0) && !adj_fused_available(m, lpc)) return hipErrorNotSupported;
+    if (!adj_whole(m) && !(adj_fused_available(m, lpc) && a.tt && a.fuseE)) return hipErrorNotSupported;   // entity ranges: chunk kernels only
     if (lpc == 64 && m.K <= 64 && !(m.K & 1)) {   // even 34 <= K <= 64: 16-byte lanes
         if (m.W == 10) {
-            const unsigned g = 8u * (unsigned)(((m.nE + ADJ_CH - 1) / ADJ_CH + 7) / 8);
+            if (m.eCount <= 0) return hipSuccess;
+            const unsigned g = 8u * (unsigned)(((m.eCount + ADJ_CH - 1) / ADJ_CH + 7) / 8);
             if (a.tt) hipLaunchKernelGGL((k_adj_edge3<true>), dim3(g), dim3(BLOCK), 0, s, m, a);
             else hipLaunchKernelGGL((k_adj_edge3<false>), dim3(g), dim3(BLOCK), 0, s, m, a);
         } else {
@@ -524,9 +527,11 @@ hipError_t launch_adj_edge(const AdjMesh &m, const AdjArgs &a, int lpc, hipStrea
 
 hipError_t launch_adj_cell(const AdjMesh &m, const AdjArgs &a, int lpc, hipStream_t s)
 {
+    if (!adj_whole(m) && !(adj_fused_available(m, lpc) && a.tt && a.fuseE)) return hipErrorNotSupported;
     if (a.tt && a.fuseE) {
         if (!adj_fused_available(m, lpc)) return hipErrorNotSupported;
-        const unsigned g = 8u * (unsigned)(((m.nC + ADJ_CCH - 1) / ADJ_CCH + 7) / 8);
+        if (m.cCount <= 0) return hipSuccess;
+        const unsigned g = 8u * (unsigned)(((m.cCount + ADJ_CCH - 1) / ADJ_CCH + 7) / 8);
         hipLaunchKernelGGL((k_adj_cell3<6>), dim3(g), dim3(BLOCK), 0, s, m, a);
         return hipGetLastError();
     }

@@ -1504,6 +1504,7 @@ struct moka_tape {
     int kind = -1;                                   // -1 empty, 0 Forward Euler, 1 RK4 (one integrator per tape)
     int cur = 0;                                     // index of the adjoint state that is current
     int revNext = 4;                                 // stage-wise reverse RK4 step (moka_adjoint_rk4_stage): the stage that comes next
+    int revPart = 0;                                 // ... and, part by part (moka_adjoint_rk4_stage_part), which part of it
     int recMask = 0;                                 // piecewise taping (moka_tape_record_rk4): slots of the open step already filled
     bool seeded = false;
     moka::AdjMesh am{};
@@ -1589,6 +1590,7 @@ int moka_tape_create(moka_state *st, int64_t capacity_steps, moka_tape **out)
     A(&t->Enew, nEK); A(&t->csum, nE);
     moka::AdjMesh &am = t->am;
     am.nC = nC; am.nE = nE; am.K = p.K; am.ME = ME; am.W = W;
+    am.eBegin = 0; am.eCount = nE; am.cBegin = 0; am.cCount = nC;
     am.eoc = st->mesh->dev.eoc; am.ehdr = st->mesh->dev.ehdr; am.fEdge = st->mesh->dev.fEdge; am.gInvDc = st->mesh->dev.gInvDc;
     if (rc == MOKA_OK) rc = tape_upload(t, teoe, &am.teoe);
     if (rc == MOKA_OK) rc = tape_upload(t, tw, &am.tw);
@@ -1828,7 +1830,8 @@ static void rk4_reverse_fields(moka_tape *t, int sg, double **fU, double **fH)
     *fH = sg == 4 ? t->lamH[t->cur] : kH[kc];
 }
 
-static int rk4_reverse_stage(moka_tape *t, int sg)
+// part < 0: every local entity; 0 / 1: the edges and cells of cell class 0 (boundary: what other ranks gather from) / 1 (interior)
+static int rk4_reverse_stage(moka_tape *t, int sg, int part = -1)
 {
     moka_state *st = t->st;
     const Plan &p = st->mesh->plan;
@@ -1847,6 +1850,13 @@ static int rk4_reverse_stage(moka_tape *t, int sg)
     // chunk kernels (even K <= 64, hexagon-width lists): stage 4 reads X scaled on the fly (kb4 is never stored) and
     // u*Fbar is recomputed by the cell kernel instead of travelling through memory
     const bool fused = moka::adj_fused_available(t->am, st->mesh->lpc);
+    moka::AdjMesh am = t->am;
+    if (part >= 0) {
+        if (!fused) return fail(st->ctx, MOKA_ERR_UNSUPPORTED, "reverse RK4 stages part by part need the chunk kernels (even 34 <= K <= 64, hexagon-width lists)");
+        if ((int)p.classCellStart.size() < 3) return fail(st->ctx, MOKA_ERR_ARG, "the mesh has no cell classes (moka_mesh_desc.cellClass)");
+        am.cBegin = p.classCellStart[part]; am.cCount = p.classCellStart[part + 1] - am.cBegin;
+        am.eBegin = p.classEdgeStart[part]; am.eCount = p.classEdgeStart[part + 1] - am.eBegin;
+    }
     if (sg == 4 && !fused) {
         HIPCHK(st->ctx, launch_scale_copy(kU[0], XU, cb[3], (int64_t)nEK, s));
         HIPCHK(st->ctx, launch_scale_copy(kH[0], XH, cb[3], (int64_t)nCK, s));
@@ -1866,8 +1876,9 @@ static int rk4_reverse_stage(moka_tape *t, int sg)
         a.kNextU = kU[1 - kc]; a.kNextH = kH[1 - kc];
         a.cbNext = cb[sg - 2]; a.caNext = ca[sg - 2];
     }
-    HIPCHK(st->ctx, launch_adj_edge(t->am, a, st->mesh->lpc, s));
-    HIPCHK(st->ctx, launch_adj_cell(t->am, a, st->mesh->lpc, s));
+    HIPCHK(st->ctx, launch_adj_edge(am, a, st->mesh->lpc, s));     // the cell kernel reads csum of the cells' edges: written by the edge
+    HIPCHK(st->ctx, launch_adj_cell(am, a, st->mesh->lpc, s));     // kernel of the same part or (interior cells) of the boundary part
+    if (part == 0) return MOKA_OK;                                 // the step's bookkeeping moves with the last part
     if (sg == 1) {
         t->cur = o;
         t->dts.pop_back(); t->flags.pop_back();
@@ -1937,10 +1948,43 @@ int moka_adjoint_rk4_stage(moka_tape *t, int sg)
     moka_state *st = t->st;
     if (!t->seeded) return fail(st->ctx, MOKA_ERR_ARG, "seed the adjoint first (moka_adjoint_seed_sum_sq_ssh)");
     if (sg < 1 || sg > 4 || t->kind != 1 || t->n <= 0) return fail(st->ctx, MOKA_ERR_ARG, "no recorded RK4 step / stage must be 4..1");
-    if (sg != t->revNext) return fail(st->ctx, MOKA_ERR_ARG, "reverse RK4 stages run 4, 3, 2, 1");
+    if (sg != t->revNext || t->revPart != 0) return fail(st->ctx, MOKA_ERR_ARG, "reverse RK4 stages run 4, 3, 2, 1");
     HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
     if (int rc = rk4_reverse_stage(t, sg)) return rc;
     t->revNext = sg == 1 ? 4 : sg - 1;
+    return MOKA_OK;
+}
+
+// The same stage in two launches on a partitioned mesh: part 0 = the entities of the boundary class (whose rows other ranks
+// gather from in the next transposed stage), part 1 = the interior class.  Between the two the caller starts the exchange of
+// the rows part 0 produced (moka_adjoint_rk4_stage_out_fields + moka_halo_pack_fields); it then overlaps part 1, which reads and
+// writes owned rows only.  Halo entities are not computed at all (moka_adjoint_rk4_stage computes them redundantly).
+int moka_adjoint_rk4_stage_part(moka_tape *t, int sg, int part)
+{
+    if (!t) return fail(nullptr, MOKA_ERR_ARG, "tape is NULL");
+    moka_state *st = t->st;
+    if (!t->seeded) return fail(st->ctx, MOKA_ERR_ARG, "seed the adjoint first (moka_adjoint_seed_sum_sq_ssh)");
+    if (sg < 1 || sg > 4 || t->kind != 1 || t->n <= 0) return fail(st->ctx, MOKA_ERR_ARG, "no recorded RK4 step / stage must be 4..1");
+    if (part < 0 || part > 1) return fail(st->ctx, MOKA_ERR_ARG, "part must be 0 (boundary class) or 1 (interior class)");
+    if (sg != t->revNext || part != t->revPart) return fail(st->ctx, MOKA_ERR_ARG, "reverse RK4 stages run 4, 3, 2, 1, each as part 0 then part 1");
+    HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
+    if (int rc = rk4_reverse_stage(t, sg, part)) return rc;
+    t->revPart = 1 - part;
+    if (part == 1) t->revNext = sg == 1 ? 4 : sg - 1;
+    return MOKA_OK;
+}
+
+// The arrays stage `sg` of the reverse step in progress WRITES and the next transposed stage gathers from (stage sg - 1's k-bar;
+// after stage 1: the adjoint state handed to the previous recorded step): what has to be exchanged behind part 0 of the stage.
+int moka_adjoint_rk4_stage_out_fields(moka_tape *t, int sg, void **fieldU, void **fieldH, void **scratchS)
+{
+    if (!t || !fieldU || !fieldH) return fail(t ? t->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (sg < 1 || sg > 4 || t->kind != 1 || t->n <= 0) return fail(t->st->ctx, MOKA_ERR_ARG, "no recorded RK4 step / stage must be 4..1");
+    double *kU[2] = {t->kbU, t->pbU}, *kH[2] = {t->kbH, t->pbH};
+    const int kc = (4 - sg) & 1, o = 1 - t->cur;
+    *fieldU = sg == 1 ? t->lamU[o] : kU[1 - kc];
+    *fieldH = sg == 1 ? t->lamH[o] : kH[1 - kc];
+    if (scratchS) *scratchS = t->lamS[o];              // an (nCells) array nothing reads here: stands in for ssh in the exchange maps
     return MOKA_OK;
 }
 

@@ -178,6 +178,9 @@ struct AdjMesh {
     const double *sd;                  // (2, nE) dvEdge*edgeSign*invArea for c1, c2
     const double *fEdge, *gInvDc;      // (nE)
     const int32_t *efull;              // (nE) 1: all W sources exist and the edge and every source are active on all levels
+    // the entities a launch of the chunk kernels (k_adj_edge3 / k_adj_cell3) covers: edges [eBegin, eBegin + eCount), cells
+    // [cBegin, cBegin + cCount) -- everything by default, one cell class of a partitioned mesh in moka_adjoint_rk4_stage_part
+    int32_t eBegin, eCount, cBegin, cCount;
 };
 struct AdjArgs {
     double dt;

@@ -677,16 +677,52 @@ class DistributedModel:
         L.check(L.lib().moka_halo_unpack_fields(self._halo, fu, fh, fs, self.recvbuf.data_ptr()), self.backend._h)
         L.check(L.lib().moka_adjoint_rk4_stage(self._tape._h, sg), self.backend._h)
 
-    def adjoint_gradient(self, nsteps: int):
-        """Seeds with d sum(ssh^2) at the current state and reverses the `nsteps` recorded steps, exchanging the halo rows of
-        the adjoint fields before every transposed stage; returns owned_gradient()."""
+    def adjoint_gradient(self, nsteps: int, overlap: bool = True):
+        """Seeds with d sum(ssh^2) at the current state and reverses the `nsteps` recorded steps; returns owned_gradient().
+        overlap=False: the halo rows of the adjoint fields are exchanged in front of every transposed stage, which then runs over
+        the whole local mesh.  overlap=True (where the chunk kernels serve the mesh): a stage transposes the boundary class first,
+        the rows that produced travel while the interior class is transposed (moka_adjoint_rk4_stage_part)."""
         self.adjoint_seed()
+        if overlap and self.adjoint_parts_available():
+            self.adjoint_pack(4)                              # the seed's halo rows, once
+            self._transport_buffered()
+            self._adjoint_unpack(*self._adjoint_fields(4))
+            for step in range(nsteps):
+                for sg in (4, 3, 2, 1):
+                    last = step == nsteps - 1 and sg == 1     # nothing gathers from the final gradient
+                    out = self.adjoint_stage_boundary_and_pack(sg, pack=not last)
+                    self.adjoint_stage_interior(sg)
+                    if not last:
+                        self._transport_buffered()
+                        self._adjoint_unpack(*out)
+            return self.owned_gradient()
         for _ in range(nsteps):
             for sg in (4, 3, 2, 1):
                 self.adjoint_pack(sg)
                 self._transport_buffered()
                 self.adjoint_unpack_and_stage(sg)
         return self.owned_gradient()
+
+    def adjoint_parts_available(self):
+        """Can the transposed RK4 stages of this model run class by class (the chunk kernels: even 34 <= K <= 64)?"""
+        return self.K % 2 == 0 and 34 <= self.K <= 64 and self.state_bytes == 8
+
+    def _adjoint_unpack(self, fu, fh, fs):
+        L.check(L.lib().moka_halo_unpack_fields(self._halo, fu, fh, fs, self.recvbuf.data_ptr()), self.backend._h)
+
+    def adjoint_stage_boundary_and_pack(self, sg, pack=True):
+        """Part 0 of the transposed stage `sg` (the boundary class) and, behind it, the pack of the rows it wrote for the next
+        transposed stage; returns those arrays (for the unpack once the exchange has arrived)."""
+        lib, t = L.lib(), self._tape._h
+        L.check(lib.moka_adjoint_rk4_stage_part(t, sg, 0), self.backend._h)
+        fu, fh, fs = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.check(lib.moka_adjoint_rk4_stage_out_fields(t, sg, C.byref(fu), C.byref(fh), C.byref(fs)), self.backend._h)
+        if pack:
+            L.check(lib.moka_halo_pack_fields(self._halo, fu, fh, fs, self.sendbuf.data_ptr()), self.backend._h)
+        return fu, fh, fs
+
+    def adjoint_stage_interior(self, sg):
+        L.check(L.lib().moka_adjoint_rk4_stage_part(self._tape._h, sg, 1), self.backend._h)
 
     def owned_gradient(self):
         """(global cell ids, d/d layerThickness), (global edge ids, d/d normalVelocity) of the entities this rank owns."""
@@ -1050,18 +1086,35 @@ class LocalCluster:
             L.check(lib.moka_rk4_dist_end(m._halo), m.backend._h)
             L.check(lib.moka_tape_commit_rk4(m._tape._h, m.dt), m.backend._h)
 
-    def adjoint_gradient(self, nsteps: int, nCells: int, nEdges: int, K: int):
+    def adjoint_gradient(self, nsteps: int, nCells: int, nEdges: int, K: int, overlap: bool = True):
         """d sum(ssh^2 over the whole mesh) / d (normalVelocity, layerThickness) at the state the tapes started from,
-        assembled from the ranks' owned rows."""
+        assembled from the ranks' owned rows.  overlap: see DistributedModel.adjoint_gradient."""
         for m in self.models:
             m.adjoint_seed()
-        for _ in range(nsteps):
-            for sg in (4, 3, 2, 1):
-                for m in self.models:
-                    m.adjoint_pack(sg)
-                self._move()
-                for m in self.models:
-                    m.adjoint_unpack_and_stage(sg)
+        if overlap and all(m.adjoint_parts_available() for m in self.models):
+            for m in self.models:
+                m.adjoint_pack(4)
+            self._move()
+            for m in self.models:
+                m._adjoint_unpack(*m._adjoint_fields(4))
+            for step in range(nsteps):
+                for sg in (4, 3, 2, 1):
+                    last = step == nsteps - 1 and sg == 1
+                    outs = [m.adjoint_stage_boundary_and_pack(sg, pack=not last) for m in self.models]
+                    for m in self.models:
+                        m.adjoint_stage_interior(sg)
+                    if not last:
+                        self._move()
+                        for m, out in zip(self.models, outs):
+                            m._adjoint_unpack(*out)
+        else:
+            for _ in range(nsteps):
+                for sg in (4, 3, 2, 1):
+                    for m in self.models:
+                        m.adjoint_pack(sg)
+                    self._move()
+                    for m in self.models:
+                        m.adjoint_unpack_and_stage(sg)
         gu, gh = np.full((nEdges, K), np.nan), np.full((nCells, K), np.nan)
         for m in self.models:
             (cg, hh), (eg, uu) = m.owned_gradient()

@@ -300,11 +300,15 @@ def test_metis_workflow_files(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("world,K,nsteps", [(2, 60, 2), (4, 60, 2), (3, 34, 3), (8, 60, 1), (5, 1, 3)])
-def test_reverse_mode_on_a_partitioned_mesh(world, K, nsteps):
+def test_reverse_mode_on_a_partitioned_mesh(world, K, nsteps, overlap):
     """d sum(ssh^2) / d initial state of an RK4 run on 2-8 ranks (tests/ on one GPU): every rank tapes its part of the
-    distributed steps (halo rows included) and reverses it with the halo rows of the adjoint fields exchanged before every
-    transposed stage; the assembled gradient equals the single-domain oracle's (OracleAdjointRK4) bit for bit."""
+    distributed steps (halo rows included) and reverses it; the assembled gradient equals the single-domain oracle's
+    (OracleAdjointRK4) bit for bit.  overlap=False: the halo rows of the adjoint fields are exchanged before every transposed
+    stage, which runs over the whole local mesh; overlap=True: a stage transposes the boundary class, starts the exchange of what
+    that produced and transposes the interior class meanwhile (moka_adjoint_rk4_stage_part; K = 1 has no chunk kernels and falls
+    back to the first form)."""
     import oracle as orc
     mesh = mg.icosahedral_mesh(20)
     rng = np.random.default_rng(37 + world)
@@ -325,7 +329,8 @@ def test_reverse_mode_on_a_partitioned_mesh(world, K, nsteps):
     gs, gu_, gh_ = cl.gather_owned(mesh.nCells, mesh.nEdges, K)
     assert np.array_equal(gu_, st.u[1]) and np.array_equal(gh_, st.h[1]) and np.array_equal(gs, st.ssh[1])
     gU, gH = adj.gradient_sum_sq_ssh()
-    gu, gh = cl.adjoint_gradient(nsteps, mesh.nCells, mesh.nEdges, K)
+    assert all(m.adjoint_parts_available() == (K >= 34) for m in cl.models)
+    gu, gh = cl.adjoint_gradient(nsteps, mesh.nCells, mesh.nEdges, K, overlap=overlap)
     assert np.array_equal(gu, gU)
     assert np.array_equal(gh, gH)
     assert np.abs(gU).max() > 0 and np.abs(gH).max() > 0
