@@ -73,7 +73,7 @@ while time.time() - t0 < budget:
                 cl.step_rk4_taped()
                 adj.step_rk4(20.0)
             gU, gH = adj.gradient_sum_sq_ssh()
-            gu, gh = cl.adjoint_gradient(2, mesh.nCells, mesh.nEdges, K)
+            gu, gh = cl.adjoint_gradient(2, mesh.nCells, mesh.nEdges, K, overlap=bool(rng.integers(0, 2)))   # stages by cell class or whole
             assert np.array_equal(gu, gU) and np.array_equal(gh, gH), tag + " reverse RK4"
             n_rev["rk4"] += 1
         else:
@@ -91,11 +91,15 @@ while time.time() - t0 < budget:
     if not f32 and n % 5 == 4:
         # the optional nonlinear terms on the same partition (two-ring halo, whole-mesh stages), random Del2 viscosity
         visc = float(rng.choice([0.0, 0.01 * float(mesh.dcEdge.min()) ** 2 / 20.0]))
-        cn = par.LocalCluster(mesh, ssh, u, h, rest, 20.0, world, patch_cells=P, direct=False, nonlinear=True, visc_del2=visc)
+        cn = par.LocalCluster(mesh, ssh, u, h, rest, 20.0, world, patch_cells=P, direct=bool(rng.integers(0, 2)) and K % 2 == 0 and 34 <= K <= 64,
+                              nonlinear=True, visc_del2=visc)
         onl, stn = (orc.OracleNonlinear(om, visc_del2=visc) if visc else orc.OracleNonlinear(om)), orc.OracleState(om, ssh, u, h)
         cn.exchange_state()
-        for _ in range(2):
-            cn.step_rk4_whole()
+        from moka_hip import lib as L_
+        parts = all(L_.lib().moka_rk4_dist_parts_available(m._halo) for m in cn.models)
+        for i in range(2):
+            # stage kernel over boundary / interior patches with the interior's preparation pass under the exchange, or whole-mesh stages
+            (cn.step_rk4 if parts and (cn.direct or i or rng.integers(0, 2)) else cn.step_rk4_whole)()
             onl.step_rk4(stn, 20.0)
         gs, gu, gh = cn.gather_owned(mesh.nCells, mesh.nEdges, K)
         assert np.array_equal(gu, stn.u[1]) and np.array_equal(gh, stn.h[1]) and np.array_equal(gs, stn.ssh[1]), tag + f" nonlinear visc {visc}"

@@ -117,17 +117,22 @@ while time.time() - t0 < budget:
             stats["adjoint_rk4"] += 1
         if n % 4 == 3 and mesh.kiteAreasOnVertex is not None:      # nonlinear terms + Del2, one RK4 step, any of the three kernel forms
             visc = float(rng.choice([0.0, 0.01 * float(mesh.dcEdge.min()) ** 2 / dtv]))
-            form = int(rng.choice([0, 0, 4, 3]))
+            form = int(rng.choice([0, 0, 0, 4, 3]))
             b.set_kernel_variant(form)
+            # launch shape of the patch form (moka_set_tuning key 5) and, at random, few resident vertex rows (key 6: the path of the
+            # patches that list more vertices than the LDS holds)
+            shape, cap = int(rng.choice([0, 0, 1, 2, 3])), int(rng.choice([0, 0, 24, 48]))
+            L.check(L.lib().moka_set_tuning(5, shape)); L.check(L.lib().moka_set_tuning(6, cap))
             Prog3 = mk.PrognosticVars(st.ssh[1], st.u[1], st.h[1], 2, M)
             mk.set_nonlinear(Prog3, True, visc_del2=visc)
             nl = orc.OracleNonlinear(om, visc_del2=visc)
             st3 = orc.OracleState(om, st.ssh[1], st.u[1], st.h[1])
             L.check(L.lib().moka_step_rk4(Prog3._state._h, dtv), b._h)
             b.set_kernel_variant(0)
+            L.check(L.lib().moka_set_tuning(5, 0)); L.check(L.lib().moka_set_tuning(6, 0))
             nl.step_rk4(st3, dtv)
             assert np.array_equal(Prog3.normalVelocity[-1].get(), st3.u[1]) and np.array_equal(Prog3.layerThickness[-1].get(), st3.h[1]), \
-                tag + f" nonlinear visc {visc} form {form}"
+                tag + f" nonlinear visc {visc} form {form} shape {shape} cap {cap}"
             Prog3._state.close()
             stats["nonlinear"] += 1
     stats["f32"] += int(f32); stats["masked"] += int((mlt < K).any()); stats["cells_max"] = max(stats["cells_max"], mesh.nCells)
