@@ -307,7 +307,7 @@ def calibrate(backend, tag):
     cal["sysfs"] = device_sysfs(backend.pci_bus_id())
     cal["probe_s"] = round(time.time() - t0, 2)
     log(f"[bench] calibration {tag}: copy {cal['copy_GBs']:.0f} GB/s (mean {cal['copy_GBs_mean']:.0f}), read {cal['read_GBs']:.0f} GB/s, "
-        f"row gather {cal['gather_GBs']:.0f} GB/s, "
+        f"row gather {cal['gather_GBs']:.0f} GB/s, 3 reads + 2 writes {cal.get('streams5_GBs', float('nan')):.0f} GB/s, "
         f"sclk {cal['sysfs'].get('sclk_mhz')} MHz, {cal['sysfs'].get('power_w')} W")
     return cal
 
@@ -655,10 +655,12 @@ def main():
                    "copy_GBs_mean_before": cal_before["copy_GBs_mean"], "copy_GBs_mean_after": cal_after["copy_GBs_mean"],
                    "read_GBs": cal_before["read_GBs"], "read_GBs_after": cal_after["read_GBs"],
                    "gather_GBs_before": cal_before["gather_GBs"], "gather_GBs_after": cal_after["gather_GBs"],
+                   "streams5_GBs_before": cal_before.get("streams5_GBs"), "streams5_GBs_after": cal_after.get("streams5_GBs"),
                    "probe": f"{PROBE_BYTES >> 30} GiB footprint (half source, half destination), 16 bytes per lane, best of 5 launches, "
                             "HIP events on the compute stream; before = in front of the warm-up, after = behind the timed region; "
                             "copy = one word per thread (bytes read + written), read = read-only sweep with nontemporal loads, "
-                            "gather = 480-byte rows in a scattered order, a half-wave per row (the stage kernels' pattern)",
+                            "gather = 480-byte rows in a scattered order, a half-wave per row (the stage kernels' pattern), "
+                            "streams5 = three streams read and two written at once (the mix of the RK stage launches)",
                    "guide_copy_ceiling_GBs": HBM_COPY_GBS,
                    "ms_per_step_at_guide_ceiling": ms_per_step * copy_this_run / HBM_COPY_GBS,
                    "clocks_power_before": cal_before["sysfs"], "clocks_power_after": cal_after["sysfs"]}

@@ -387,6 +387,9 @@ int moka_marks_read(moka_ctx *ctx, int64_t capacity, double *ms, int64_t *n);
  * 480-byte rows, a half-wave per row (the stage kernels' access pattern).  The buffer is kept for the next probe;
  * bytes = 0 frees it.  (MI355X_MICROARCH.md quotes 6.29 TB/s for such a copy; SURVEY.md 8d asks for the copy and read figures.) */
 int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[4]);
+/* ... and a fifth figure: three streams read and two written at once (the mix of the RK stage launches), over the buffer
+ * moka_bw_probe allocated: GB/s of all five streams, best of `iters` launches */
+int moka_bw_probe_streams(moka_ctx *ctx, int iters, double *gbs);
 /* which kernel the last moka_step_fe of this state used: 1 = the tuned stage kernel (+ vertex pass), 2 = the same with the
  * stale layerThicknessEdge formed from the previous level's layerThickness instead of gathered (every MOKA_FE_STALE_HEDGE
  * step after the first of a run), 0 = the generic one-launch kernel, -1 = no Forward-Euler step yet.  For tests and

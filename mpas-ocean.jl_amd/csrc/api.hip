@@ -663,6 +663,31 @@ int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[4])
     return MOKA_OK;
 }
 
+// A fifth figure for the same calibration: three streams read and two written at once (k_bw_streams) over the buffer moka_bw_probe
+// allocated (call that first); GB/s of all five, best of `iters` launches.
+int moka_bw_probe_streams(moka_ctx *ctx, int iters, double *gbs)
+{
+    if (!ctx || !gbs || iters < 1) return fail(ctx, MOKA_ERR_ARG, "NULL argument or iters < 1");
+    if (!ctx->bwBuf || ctx->bwBytes < ((size_t)5 << 20)) return fail(ctx, MOKA_ERR_ARG, "moka_bw_probe first: it owns the buffer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int64_t n = (int64_t)(ctx->bwBytes / 5 / 16);
+    double best = 0.0;
+    for (int i = 0; i < iters; ++i) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+        HIPCHK(ctx, launch_bw_streams(ctx->bwBuf, (int64_t)ctx->bwBytes, s));
+        HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        best = std::max(best, (double)(5 * 16 * n) / ((double)ms * 1e-3) / 1e9);
+    }
+    // the probes XOR the pattern away: restore it, the read probe's sentinel test relies on it
+    HIPCHK(ctx, hipMemsetAsync(ctx->bwBuf, 0x5A, ctx->bwBytes + 64, s));
+    *gbs = best;
+    return MOKA_OK;
+}
+
 // Process-wide launch-shape switches for A/B measurements (results are identical for every setting):
 //   key 1: bit mask of the modes of the fp32-storage stage kernel that run as 512-thread workgroups bounded to 128 registers
 //          (default: mode 0; see kernels.hip, g_f32WideModes)

@@ -1371,6 +1371,29 @@ __global__ __launch_bounds__(BLOCK) void k_bw_gather(const unsigned char *__rest
     if (acc == 0x9E3779B9u) *sink = acc;
 }
 
+// k_bw_streams: five streams at once, three read and two written, one 16-byte word per thread and stream -- the traffic mix of the RK
+// stage launches of modes 2 / 3 (Provis and Curr and New in, Provis' and New out), which the boxes that run this library 10 % slower
+// slow down most, while their copy, read and gather rates are those of the fast boxes (profiles/r03_variants.txt)
+__global__ __launch_bounds__(BLOCK) void k_bw_streams(bw_v4u *__restrict__ o1, bw_v4u *__restrict__ o2, const bw_v4u *__restrict__ a,
+                                                     const bw_v4u *__restrict__ b, const bw_v4u *__restrict__ c, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) {
+        const bw_v4u x = a[i], y = b[i], z = c[i];
+        o1[i] = x ^ y;
+        o2[i] = x ^ z;
+    }
+}
+
+// `bytes` = the whole buffer: split into five equal parts (a, b, c read; two written)
+hipError_t launch_bw_streams(void *buf, int64_t bytes, hipStream_t s)
+{
+    const int64_t n = bytes / 5 / 16;
+    bw_v4u *p = static_cast<bw_v4u *>(buf);
+    hipLaunchKernelGGL(k_bw_streams, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, p + 3 * n, p + 4 * n, p, p + n, p + 2 * n, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_bw_copy(void *dst, const void *src, int64_t bytes, int, hipStream_t s)
 {
     const int64_t n = bytes / 16;

@@ -94,8 +94,12 @@ class MokaHIP:
         """Same-run bandwidth calibration (moka_bw_probe): {copy_GBs, read_GBs, copy_GBs_mean} of this device right now."""
         g = (C.c_double * 4)()
         L.check(L.lib().moka_bw_probe(self._h, int(nbytes), int(iters), g), self._h)
+        if nbytes <= 0:
+            return {}
+        s5 = C.c_double()
+        L.check(L.lib().moka_bw_probe_streams(self._h, int(iters), C.byref(s5)), self._h)
         return {"copy_GBs": float(g[0]), "read_GBs": float(g[1]), "copy_GBs_mean": float(g[2]),
-                "gather_GBs": float(g[3])} if nbytes > 0 else {}
+                "gather_GBs": float(g[3]), "streams5_GBs": float(s5.value)}
 
     def pci_bus_id(self) -> str:
         buf = C.create_string_buffer(32)
