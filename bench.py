@@ -152,6 +152,18 @@ def device_sysfs(pci_bus_id):
     busy = _read(os.path.join(dev, "gpu_busy_percent"))
     if busy and busy.strip().isdigit():
         out["busy_percent"] = int(busy.strip())
+    mbusy = _read(os.path.join(dev, "mem_busy_percent"))
+    if mbusy and mbusy.strip().isdigit():
+        out["mem_busy_percent"] = int(mbusy.strip())
+    # temperatures (hwmon: edge / junction / mem, millidegrees): HBM refreshes twice as often when hot
+    temps = {}
+    for t in glob.glob(os.path.join(dev, "hwmon", "hwmon*", "temp*_input")):
+        label = (_read(t.replace("_input", "_label")) or os.path.basename(t)).strip()
+        v = _read(t)
+        if v and v.strip().lstrip("-").isdigit():
+            temps[label] = round(int(v.strip()) / 1000.0, 1)
+    if temps:
+        out["temp_c"] = temps
     others = []
     for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
         if "-" in os.path.basename(card):
