@@ -71,7 +71,9 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
             per_step = sorted(sum(d for _, d in timed[4 * i:4 * i + 4]) / 1e6 for i in range(k))
             med = (per_step[(k - 1) // 2] + per_step[k // 2]) / 2
             wall = bl.get("ms_per_step_wall_mean", bl["ms_per_step"])
-            ok = tot <= wall * 1.001 and med <= bl["ms_per_step"] * 1.002
+            # 0.3 %: the trace's kernel intervals and the HIP events around the region come from two clocks' worth of rounding, and the
+            # profiler's begin / end stamps of back-to-back kernels overlap by a few microseconds
+            ok = tot <= wall * 1.003 and med <= bl["ms_per_step"] * 1.003
             print(f"stage kernels per step: mean {tot:.3f} ms, median {med:.3f} ms; bench line of the same run: wall mean {wall:.3f} ms, "
                   f"ms_per_step (median of per-step event times) {bl['ms_per_step']:.3f} ms "
                   f"-> {'CONSISTENT' if ok else 'INCONSISTENT (kernel time exceeds the timed region)'}")
