@@ -153,9 +153,6 @@ struct NlArgs {
     double *zv;     // (K, nV) relativeVorticity
     double *divc;   // (K, nC) velocityDivCell
     double visc;
-#ifdef MOKA_EXP_NL_ABL
-    int abl;        // ablation experiments only (make exp EXP=-DMOKA_EXP_NL_ABL): which part of k_stage_nl5 to leave out
-#endif
 };
 // form: 0 = best available, 1 = patch kernels without the LDS q_e rows, 2 = 16-byte-lane entity kernels, 3 = generic lane-group kernels
 // (prepare and stage must be called with the same form: forms 0 / 1 keep F alone in NlArgs.fq, forms 2 / 3 {F, q_e} pairs)

@@ -928,11 +928,6 @@ __global__ __launch_bounds__(NT, 4) void k_stage_nl4(const MeshDev m, const Stag
 // Measured (profiles/r03_variants.txt): every kernel of this library delivers ~20 G gathered rows per second, so the rows gathered
 // from global memory per patch are what a launch costs: 880 -> 660 here.  Three workgroups per CU (512 threads bounded to 80
 // registers, the F gathers in two batches) were built and measured, too: no faster than two with all ten gathers in one batch.
-#ifdef MOKA_EXP_NL_ABL
-#define NL_ABL(n) (nl.abl == (n))
-#else
-#define NL_ABL(n) false
-#endif
 template <int ME_, int ME2_, int NT, int MINW, bool CF>
 __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const StageArgs a, const NlArgs nl)
 {
@@ -992,7 +987,7 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
             if (act && rr < nOwn) fr[j] = ldo(F, (unsigned)(e0 + rr) * rowB + lo);
         }
     }
-    for (int c = c0 + grp; c < c0 + nC && !NL_ABL(3); c += NG) {
+    for (int c = c0 + grp; c < c0 + nC; c += NG) {
         double2 hs = make_double2(0.0, 0.0);
         if (act) {
             double2 Fe[ME_];
@@ -1118,10 +1113,7 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
             if (a.nu_out && a.nu_in) nbu = ldo(a.nu_in, (unsigned)(e) * rowB + lo);
         } else {
             double2 Fx[ME2_];
-            if (NL_ABL(2)) {
-#pragma unroll
-                for (int i = 0; i < ME2_; ++i) Fx[i] = qo;
-            } else if (CF) {           // rows of the own patch from LDS in one burst, the others overwritten by exec-masked global loads
+            if (CF) {           // rows of the own patch from LDS in one burst, the others overwritten by exec-masked global loads
                 bool cached[ME2_];
                 uint32_t ad[ME2_], goff[ME2_];
                 v4u_t raw[ME2_];
@@ -1154,10 +1146,6 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
             if (ax) t.x -= invDc * (k2.x - k1.x);
             if (ay) t.y -= invDc * (k2.y - k1.y);
 
-            if (NL_ABL(1)) {
-#pragma unroll
-                for (int i = 0; i < ME2_; ++i) { t.x += Fx[i].x; t.y += Fx[i].y; }
-            } else
 #pragma unroll
             for (int i = 0; i < ME2_; ++i) {
                 const unsigned lvi = sLv[le * 12 + i];
@@ -1178,7 +1166,6 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
             if (ax) t.x += ((d2.x - d1.x) * invDc - (z2.x - z1.x) * invDv) * nl.visc;
             if (ay) t.y += ((d2.y - d1.y) * invDc - (z2.y - z1.y) * invDv) * nl.visc;
         }
-        if (NL_ABL(4) && t.x != 12345.678) { pend = false; continue; }
         pOff = (unsigned)(e) * rowB + lo;
         pT = t;
         pA = make_double2(ucur.x + a.a * t.x, ucur.y + a.a * t.y);
@@ -1203,7 +1190,7 @@ static inline int nl5_cap(const MeshDev &m, bool cf)
     const size_t budget = 80 * 1024, rec = nl5_lds_bytes(m, 0, cf);
     if (rec >= budget) return 0;
     int cap = (int)std::min<size_t>((size_t)m.maxPV, (budget - rec) / ((size_t)m.K * 8));
-    if (const int lim = g_nlCapLimit.load(); lim > 0 && lim < 1000) cap = std::min(cap, lim);
+    if (const int lim = g_nlCapLimit.load(); lim > 0) cap = std::min(cap, lim);
     return cap;
 }
 
@@ -1262,12 +1249,8 @@ hipError_t launch_nl_prepare(const MeshDev &m, const double *u, const double *h,
 #undef CALL
 }
 
-hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &nl_in, int lpc, bool rowsOk, int form, hipStream_t s)
+hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &nl, int lpc, bool rowsOk, int form, hipStream_t s)
 {
-    NlArgs nl = nl_in;
-#ifdef MOKA_EXP_NL_ABL
-    nl.abl = g_nlCapLimit.load() >= 1000 ? g_nlCapLimit.load() - 1000 : 0;      // ablation code rides on tuning key 6 (1000 + n)
-#endif
     const int shape = g_nlShape.load();
     if (lpc == 64 && nl3_ok(m) && form == 0 && shape != 1 && m.pvStart && m.maxPV > 0 &&
         (uint64_t)std::max(m.nE, std::max(m.nV, m.nC)) * m.K * 8 < (1ull << 32)) {

@@ -21,13 +21,11 @@ Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, cfg, b,
 print('patch_cells', Setup.mesh.info().get('patch_cells'), flush=True)
 from moka_hip import lib as L              # noqa: E402
 shapes = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 0, 2, 3]
-abls = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]      # ablations of an exp build (-DMOKA_EXP_NL_ABL)
-for nl, shape, abl in [(False, 0, 0)] + [(True, sh, ab) for sh in shapes for ab in abls]:
-    L.check(L.lib().moka_set_tuning(5, shape))
-    L.check(L.lib().moka_set_tuning(6, 1000 + abl if abl else 0))      # launch shape of the nonlinear stage kernel (include/moka_hip.h)
+for nl, shape in [(False, 0)] + [(True, sh) for sh in shapes]:
+    L.check(L.lib().moka_set_tuning(5, shape))      # launch shape of the nonlinear stage kernel (include/moka_hip.h)
     mk.set_nonlinear(Prog, nl)
     mk.run_steps(Prog, mk.RungeKutta4, dts, 3)
     b.synchronize(); t0 = time.perf_counter()
     mk.run_steps(Prog, mk.RungeKutta4, dts, 10)
     b.synchronize(); t1 = time.perf_counter()
-    print(f"{'nonlinear shape ' + str(shape) + (' ablation ' + str(abl) if abl else '') if nl else 'linear           '}: {mesh.nCells} cells x {K}: {1e3 * (t1 - t0) / 10:.2f} ms per RK4 step", flush=True)
+    print(f"{'nonlinear shape ' + str(shape) if nl else 'linear           '}: {mesh.nCells} cells x {K}: {1e3 * (t1 - t0) / 10:.2f} ms per RK4 step", flush=True)
