@@ -1,6 +1,9 @@
 """bench.py host-side contract: the algorithmic-bytes formula is SURVEY.md section 8(d)'s, sizes are BASELINE's."""
 import importlib.util
 import os
+import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
@@ -58,3 +61,53 @@ def test_sysfs_and_statistics_helpers(tmp_path):
     st = bench.step_stats([7.0, 6.8, 6.9, 9.5, 6.85])
     assert st["median"] == 6.9 and st["min"] == 6.8 and st["max"] == 9.5 and st["n"] == 5
     assert abs(st["mean"] - 7.41) < 1e-12
+
+
+def _run_bench(args, nproc=1, timeout=420):
+    """bench.py as the driver launches it (a child process; torch.distributed.run for N > 1): the JSON line it prints."""
+    import json
+    import socket
+    import subprocess
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_on_one_gpu_small_workload():
+    """The driver's contract on a small workload: one JSON line with the metric, the roofline (with its calibration) and the
+    CPU baseline; value = cells x layers / median step time."""
+    b = _run_bench(["--workload", "small_10k_x60", "--steps", "6", "--warmup", "2", "--no-config5", "--tend-iters", "3"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "calibration", "step_ms"):
+        assert k in b, k
+    assert b["n_gpus"] == 1 and b["ranks"] == 1 and b["rehearsal"] is False and b["steps"] == 6 and b["dtype"] == "f64"
+    assert b["config"]["workload"] == "small_10k_x60" and b["vs_baseline"] is None and b["higher_is_better"] is True
+    nC, K = b["config"]["nCells"], b["config"]["nVertLevels"]
+    assert abs(b["value"] - nC * K / (b["step_ms"]["median"] * 1e-3)) <= 1e-6 * b["value"]
+    r = b["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert b["calibration"]["copy_GBs_before"] > 1000 and b["calibration"]["streams5_GBs_before"] > 1000
+    assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["cores"] >= 1 and b["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_is_labelled_a_rehearsal():
+    """bench.py --gpus 2 the way the driver starts it, with both ranks on the one GPU of this box: the transport selection must
+    qualify a transport (bitwise against the host-staged exchange), and the line must say what it is -- one distinct device, two
+    ranks, a rehearsal -- instead of claiming two GPUs."""
+    b = _run_bench(["--workload", "small_10k_x60", "--steps", "4", "--warmup", "2"], nproc=2)
+    assert b["ranks"] == 2 and b["n_gpus"] == 1 and b["n_devices_visible"] == 1 and b["ranks_per_device"] == 2 and b["rehearsal"] is True
+    assert b["scaling"] == "strong" and b["config"]["halo_transport"] in ("ipc", "ipc-acq", "gloo", "nccl-a2a", "nccl-p2p")
+    assert b["config"]["halo_transport"] in b["config"]["halo_transport_trials_ms_per_step"]
+    assert b["value"] > 0 and "REHEARSAL" in b["config"]["parallelism"]
