@@ -925,9 +925,10 @@ __global__ __launch_bounds__(NT, 4) void k_stage_nl4(const MeshDev m, const Stag
 //     edge gathers are rows of its own patch;
 //   * the qv / F row loads are issued in front of the cell loop and land in LDS behind it: the two phases share one round trip;
 //   * 32-bit byte offsets from uniform bases (one address register per gather).
-// Measured (profiles/r03_variants.txt): every kernel of this library delivers ~20 G gathered rows per second, so the rows gathered
-// from global memory per patch are what a launch costs: 880 -> 660 here.  Three workgroups per CU (512 threads bounded to 80
-// registers, the F gathers in two batches) were built and measured, too: no faster than two with all ten gathers in one batch.
+// Measured (profiles/r03_variants.txt, config 4): 3.2-3.3 ms per launch for k_stage_nl4 -> 2.9-3.1 here; the vertex rows bring
+// 7 %, the F row cache another 1.4 % (a gather that hits the L2 is cheap: rows gathered from memory per patch, 880 -> 660, do not
+// predict the time).  Three workgroups per CU (512 threads bounded to 80 registers, the F gathers in two batches) were built and
+// measured, too: no faster than two with all ten gathers in one batch.
 template <int ME_, int ME2_, int NT, int MINW, bool CF>
 __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const StageArgs a, const NlArgs nl)
 {
