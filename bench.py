@@ -320,6 +320,7 @@ def calibrate(backend, tag):
     cal["probe_s"] = round(time.time() - t0, 2)
     log(f"[bench] calibration {tag}: copy {cal['copy_GBs']:.0f} GB/s (mean {cal['copy_GBs_mean']:.0f}), read {cal['read_GBs']:.0f} GB/s, "
         f"row gather {cal['gather_GBs']:.0f} GB/s, 3 reads + 2 writes {cal.get('streams5_GBs', float('nan')):.0f} GB/s, "
+        f"128 MiB re-read {cal.get('reread128_GBs', float('nan')):.0f} GB/s, row gather over 32 GiB {cal.get('gather32G_GBs', float('nan')):.0f} GB/s, "
         f"sclk {cal['sysfs'].get('sclk_mhz')} MHz, {cal['sysfs'].get('power_w')} W")
     return cal
 
@@ -668,11 +669,16 @@ def main():
                    "read_GBs": cal_before["read_GBs"], "read_GBs_after": cal_after["read_GBs"],
                    "gather_GBs_before": cal_before["gather_GBs"], "gather_GBs_after": cal_after["gather_GBs"],
                    "streams5_GBs_before": cal_before.get("streams5_GBs"), "streams5_GBs_after": cal_after.get("streams5_GBs"),
+                   "reread128_GBs_before": cal_before.get("reread128_GBs"), "reread128_GBs_after": cal_after.get("reread128_GBs"),
+                   "gather32G_GBs_before": cal_before.get("gather32G_GBs"), "gather32G_GBs_after": cal_after.get("gather32G_GBs"),
                    "probe": f"{PROBE_BYTES >> 30} GiB footprint (half source, half destination), 16 bytes per lane, best of 5 launches, "
                             "HIP events on the compute stream; before = in front of the warm-up, after = behind the timed region; "
                             "copy = one word per thread (bytes read + written), read = read-only sweep with nontemporal loads, "
                             "gather = 480-byte rows in a scattered order, a half-wave per row (the stage kernels' pattern), "
-                            "streams5 = three streams read and two written at once (the mix of the RK stage launches)",
+                            "streams5 = three streams read and two written at once (the mix of the RK stage launches), "
+                            "reread128 = a 128 MiB region read 16 times back to back (what comes back from the Infinity Cache: the stage "
+                            "kernels fetch a fifth of their bytes a second time), gather32G = the row gather over a 32 GiB footprint of its "
+                            "own, a quarter of the rows (address translation for a state-sized span)",
                    "guide_copy_ceiling_GBs": HBM_COPY_GBS,
                    "ms_per_step_at_guide_ceiling": ms_per_step * copy_this_run / HBM_COPY_GBS,
                    "clocks_power_before": cal_before["sysfs"], "clocks_power_after": cal_after["sysfs"]}

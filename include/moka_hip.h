@@ -390,6 +390,12 @@ int moka_bw_probe(moka_ctx *ctx, int64_t bytes, int iters, double gbs[4]);
 /* ... and a fifth figure: three streams read and two written at once (the mix of the RK stage launches), over the buffer
  * moka_bw_probe allocated: GB/s of all five streams, best of `iters` launches */
 int moka_bw_probe_streams(moka_ctx *ctx, int iters, double *gbs);
+/* ... and a sixth: `region` bytes of that buffer (between the L2s' 32 MB and the Infinity Cache's 256 MB) read `reps` times back to
+ * back -- the rate at which re-read data returns; GB/s over all passes, best of `iters` */
+int moka_bw_probe_reread(moka_ctx *ctx, int64_t region, int reps, int iters, double *gbs);
+/* ... and a seventh: the scattered row gather over a footprint of its own of `bytes` (allocated and freed here; e.g. 32 GiB, the span
+ * of a state with all its arrays), a quarter of the rows once each: nearly every fetch needs an address translation the TLBs do not hold */
+int moka_bw_probe_gather_big(moka_ctx *ctx, int64_t bytes, int iters, double *gbs);
 /* which kernel the last moka_step_fe of this state used: 1 = the tuned stage kernel (+ vertex pass), 2 = the same with the
  * stale layerThicknessEdge formed from the previous level's layerThickness instead of gathered (every MOKA_FE_STALE_HEDGE
  * step after the first of a run), 0 = the generic one-launch kernel, -1 = no Forward-Euler step yet.  For tests and

@@ -688,6 +688,66 @@ int moka_bw_probe_streams(moka_ctx *ctx, int iters, double *gbs)
     return MOKA_OK;
 }
 
+// A sixth figure: `region` bytes (more than the 32 MB of L2s, less than the 256 MB Infinity Cache: 128 MiB) read `reps` times back
+// to back, GB/s over all passes, best of `iters` -- the rate at which re-read data comes back.  The stage kernels fetch a fifth
+// to a quarter of their bytes a second time (rows of neighbouring patches, profiles/r03_traffic_attribution.txt); the streaming
+// probes above never read anything twice.
+int moka_bw_probe_reread(moka_ctx *ctx, int64_t region, int reps, int iters, double *gbs)
+{
+    if (!ctx || !gbs || iters < 1 || reps < 1) return fail(ctx, MOKA_ERR_ARG, "NULL argument or iters / reps < 1");
+    if (!ctx->bwBuf || region < ((int64_t)1 << 20) || (size_t)region > ctx->bwBytes) return fail(ctx, MOKA_ERR_ARG, "moka_bw_probe first: it owns the buffer (region must fit it)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    unsigned char *a = static_cast<unsigned char *>(ctx->bwBuf);
+    uint32_t *sink = reinterpret_cast<uint32_t *>(a + ctx->bwBytes);
+    region &= ~(int64_t)4095;
+    double best = 0.0;
+    HIPCHK(ctx, launch_bw_read(a, region, sink, ctx->nCUs, s));          // first touch: from HBM
+    for (int i = 0; i < iters; ++i) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+        for (int r = 0; r < reps; ++r) HIPCHK(ctx, launch_bw_read(a, region, sink, ctx->nCUs, s));
+        HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        best = std::max(best, (double)region * reps / ((double)ms * 1e-3) / 1e9);
+    }
+    *gbs = best;
+    return MOKA_OK;
+}
+
+// A seventh: the scattered row gather over a LARGE footprint of its own (`bytes`, e.g. 32 GiB: what a state with all its arrays
+// spans), a quarter of the rows fetched once each -- consecutive half-waves land ~19 MB apart, so nearly every fetch needs an
+// address translation the TLBs do not hold.  The 4 GiB gather of moka_bw_probe fits them.
+int moka_bw_probe_gather_big(moka_ctx *ctx, int64_t bytes, int iters, double *gbs)
+{
+    if (!ctx || !gbs || iters < 1 || bytes < ((int64_t)1 << 24)) return fail(ctx, MOKA_ERR_ARG, "NULL argument, iters < 1 or less than 16 MiB");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    void *buf = nullptr;
+    hipError_t e = hipMalloc(&buf, (size_t)bytes + 64);
+    if (e != hipSuccess) return fail(ctx, MOKA_ERR_ALLOC, std::string("big gather probe: hipMalloc: ") + hipGetErrorString(e));
+    const uint32_t rowB = 480;
+    const int64_t nRows = bytes / rowB, nFetch = nRows / 4;
+    uint32_t *sink = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(buf) + bytes);
+    double best = 0.0;
+    hipError_t rc = hipMemsetAsync(buf, 0x5A, (size_t)bytes + 64, s);
+    for (int i = 0; i < iters && rc == hipSuccess; ++i) {
+        if ((rc = hipEventRecord(ctx->ev0, s)) != hipSuccess) break;
+        if ((rc = launch_bw_gather_n(buf, nRows, rowB, nFetch, sink, ctx->nCUs, s)) != hipSuccess) break;
+        if ((rc = hipEventRecord(ctx->ev1, s)) != hipSuccess) break;
+        if ((rc = hipEventSynchronize(ctx->ev1)) != hipSuccess) break;
+        float ms = 0.f;
+        if ((rc = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1)) != hipSuccess) break;
+        best = std::max(best, (double)nFetch * rowB / ((double)ms * 1e-3) / 1e9);
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(buf);
+    HIPCHK(ctx, rc);
+    *gbs = best;
+    return MOKA_OK;
+}
+
 // Process-wide launch-shape switches for A/B measurements (results are identical for every setting):
 //   key 1: bit mask of the modes of the fp32-storage stage kernel that run as 512-thread workgroups bounded to 128 registers
 //          (default: mode 0; see kernels.hip, g_f32WideModes)

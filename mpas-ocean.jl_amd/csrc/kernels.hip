@@ -1417,6 +1417,13 @@ hipError_t launch_bw_gather(const void *src, int64_t bytes, uint32_t rowB, uint3
     return hipGetLastError();
 }
 
+// the same gather with the footprint (nRows) and the number of fetches given separately
+hipError_t launch_bw_gather_n(const void *src, int64_t nRows, uint32_t rowB, int64_t nFetch, uint32_t *sink, int nCUs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bw_gather, dim3((unsigned)(nCUs * 16)), dim3(BLOCK), 0, s, static_cast<const unsigned char *>(src), nRows, rowB, nFetch, sink);
+    return hipGetLastError();
+}
+
 template <int LPC>
 static hipError_t launch_fe_lpc(const MeshDev &m, const FeArgs &a, hipStream_t s)
 {

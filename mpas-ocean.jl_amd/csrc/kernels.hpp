@@ -137,6 +137,7 @@ hipError_t launch_copy(double *dst, const double *src, int64_t n, hipStream_t s)
 // bandwidth probes of the same-run calibration (moka_bw_probe): 16-byte-per-lane copy / read-only sweep of `bytes`
 hipError_t launch_bw_copy(void *dst, const void *src, int64_t bytes, int nCUs, hipStream_t s);
 hipError_t launch_bw_streams(void *buf, int64_t bytes, hipStream_t s);
+hipError_t launch_bw_gather_n(const void *src, int64_t nRows, uint32_t rowB, int64_t nFetch, uint32_t *sink, int nCUs, hipStream_t s);
 hipError_t launch_bw_read(const void *src, int64_t bytes, uint32_t *sink, int nCUs, hipStream_t s);
 hipError_t launch_bw_gather(const void *src, int64_t bytes, uint32_t rowB, uint32_t *sink, int nCUs, hipStream_t s);
 // halo pack / unpack: rows of (K doubles) gathered into / scattered from a contiguous buffer

@@ -98,8 +98,12 @@ class MokaHIP:
             return {}
         s5 = C.c_double()
         L.check(L.lib().moka_bw_probe_streams(self._h, int(iters), C.byref(s5)), self._h)
+        rr, gb = C.c_double(), C.c_double()
+        L.check(L.lib().moka_bw_probe_reread(self._h, 128 << 20, 16, int(iters), C.byref(rr)), self._h)
+        L.check(L.lib().moka_bw_probe_gather_big(self._h, 32 << 30, 3, C.byref(gb)), self._h)
         return {"copy_GBs": float(g[0]), "read_GBs": float(g[1]), "copy_GBs_mean": float(g[2]),
-                "gather_GBs": float(g[3]), "streams5_GBs": float(s5.value)}
+                "gather_GBs": float(g[3]), "streams5_GBs": float(s5.value), "reread128_GBs": float(rr.value),
+                "gather32G_GBs": float(gb.value)}
 
     def pci_bus_id(self) -> str:
         buf = C.create_string_buffer(32)
