@@ -426,9 +426,10 @@ def config5_leg(mk, backend, args, copy_gbs):
     cfg = {"time_management": {"config_start_time": dt.datetime(1, 1, 1), "config_run_duration": dt.timedelta(hours=1)},
            "time_integration": {"config_dt": dt.timedelta(seconds=dts), "config_number_of_time_levels": 2}}
     t0 = time.time()
+    placement = {}
     Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, cfg, backend, multilayer=True,
-                                                       state_bytes=sbytes)
-    log(f"[bench] config 5 plan + upload: {time.time() - t0:.1f}s")
+                                                       state_bytes=sbytes, placement_tries=args.placement_tries, placement_report=placement)
+    log(f"[bench] config 5 plan + upload: {time.time() - t0:.1f}s; placements tried: {placement}")
     info = Setup.mesh.info()
     step = lambda: mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)  # noqa: E731
     steps, warmup = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
@@ -446,6 +447,7 @@ def config5_leg(mk, backend, args, copy_gbs):
                         "frac_of_copy_this_run": b_step / (st["median"] * 1e-3) / 1e9 / copy_gbs if copy_gbs else None,
                         "formula": "contract: 18 state streams per step + 4 B_mesh, S = 4",
                         "per_stage": per_stage, "per_stage_steps": nst, "per_stage_sum_ms": ssum},
+           "placement": placement,
            "cpu_baseline": None, "cpu_baseline_note": "skipped for this leg: the CPU baseline belongs to the headline (config 4) line"}
     try:     # PMC traffic of this workload's stage launches, taken by tools/profile.sh in separate passes (as for the headline line)
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(name, {})
@@ -477,6 +479,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg of the default single-GPU run")
     ap.add_argument("--tend-iters", type=int, default=20)
+    ap.add_argument("--placement-tries", type=int, default=6,
+                    help="placements of the state's arrays tried at set-up, the fastest kept (mk.prognostic_vars_best_placement: where the "
+                         "allocator puts the arrays decides 5-14 %% of every launch; DESIGN section 5); 1 = take what comes")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B measurement: moka_set_tuning(KEY, VALUE) before anything runs (include/moka_hip.h lists the keys); repeatable")
     ap.add_argument("--f32-wide-modes", type=int, default=None,
@@ -569,7 +574,8 @@ def main():
         t0 = time.time()
         model = mp.DistributedModel(mesh, ssh, u, h, rest, dts, backend, rank, world, ordering=args.ordering,
                                     patch_cells=args.patch_cells, transport="gloo", group=gloo_group,
-                                    state_bytes=sbytes)
+                                    state_bytes=sbytes, placement_tries=args.placement_tries)
+        placement = model.placement
         log(f"[bench] rank {rank}: partition + local plan + upload: {time.time() - t0:.1f}s  {model.info()}")
         # Choose the halo transport on this node.  Every candidate must, on every rank, (1) set up, (2) deliver exactly the
         # bytes the host-staged gloo exchange delivers for the same state, (3) run steps whose owned state equals the same
@@ -591,10 +597,12 @@ def main():
         info = model.info()
     else:
         t0 = time.time()
+        placement = {}
         Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, cfg, backend, multilayer=True,
                                                            ordering=args.ordering, patch_cells=args.patch_cells,
-                                                           state_bytes=sbytes)
-        log(f"[bench] plan + upload: {time.time() - t0:.1f}s")
+                                                           state_bytes=sbytes, placement_tries=args.placement_tries,
+                                                           placement_report=placement)
+        log(f"[bench] plan + upload: {time.time() - t0:.1f}s; placements tried: {placement}")
         info = Setup.mesh.info()
         step = lambda: mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)  # noqa: E731
 
@@ -707,7 +715,9 @@ def main():
                       + (" -- REHEARSAL: ranks share a device" if rehearsal else ""),
                       **({"halo_transport": args.transport, "halo_transport_trials_ms_per_step": transport_trials,
                           "rccl_usable": rccl_ok} if world > 1 else {})},
-           "roofline": roofline, "calibration": calibration}
+           "roofline": roofline, "calibration": calibration,
+           "placement": dict(placement, note="placements of the state's arrays tried at set-up (rank 0's; three dt = 0 steps each), the fastest kept: "
+                                             "where the allocator puts the arrays decides 5-14 % of every launch (DESIGN section 5)")}
 
     if world == 1:
         out.update(single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, args.tend_iters))

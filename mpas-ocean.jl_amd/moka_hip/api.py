@@ -29,7 +29,7 @@ __all__ = [
     "computeTendency", "ocn_timestep", "ocn_run_loop", "run_steps", "ocn_init_from_arrays", "ocn_init_alarms",
     "Clock", "OneTimeAlarm", "PeriodicAlarm", "Alarm", "advance", "isRinging", "reset", "stop", "changeTimeStep",
     "attachAlarm", "setCurrentTime", "ocn_setup_clock", "ocn_setup_mesh", "ocn_init", "write_netcdf",
-    "ConfigRead", "ConfigGet", "GlobalConfig", "AdjointTape", "set_nonlinear", "REFERENCE_COMPAT",
+    "ConfigRead", "ConfigGet", "GlobalConfig", "AdjointTape", "set_nonlinear", "REFERENCE_COMPAT", "prognostic_vars_best_placement",
 ]
 
 MokaError = L.MokaError
@@ -494,19 +494,59 @@ def ocn_run_loop(*args, backend=None, flags: int | None = None):
     return None
 
 
+def prognostic_vars_best_placement(ssh, normalVelocity, layerThickness, nTimeLevels, mesh: "Mesh", tries: int = 5, report: dict | None = None):
+    """PrognosticVars(...) with the state's arrays in the fastest of `tries` placements.
+
+    Why: where the allocator puts a state's arrays decides whether every stage launch runs at full speed or 5-14 % slower -- a stable
+    property of the memory (profiles/r03_variants.txt: six states alive together in one process: 6.74 6.84 6.75 7.19 6.87 6.77 ms per
+    RK4 step, each reproducible), invisible to copy / read / gather probes and not steerable through the addresses this side of the
+    allocator sees.  So: allocate a candidate, time three RK4 steps with dt = 0 on it (they leave the state as it is), keep it
+    alive, allocate the next elsewhere; keep the fastest, release the others.  Costs tries x (one upload + ~40 ms) at set-up."""
+    import time as _time
+    backend = mesh.backend
+    cands, times = [], []
+    for _ in range(max(1, int(tries))):
+        P = PrognosticVars(ssh, normalVelocity, layerThickness, nTimeLevels, mesh)
+        h = P._state._h
+        if tries > 1:
+            L.check(L.lib().moka_step_rk4(h, 0.0), backend._h)                  # allocates the RK buffers too; warm-up
+            backend.marks_reset(); backend.mark()
+            for _k in range(3):
+                L.check(L.lib().moka_step_rk4(h, 0.0), backend._h)
+                backend.mark()
+            ms = sorted(backend.marks_read())
+            times.append(ms[len(ms) // 2])
+        cands.append(P)
+        # stop early only when the best two agree within 1 % AND a clearly slower one (3 % or more) has been seen: then the best are
+        # the fast kind.  (Two that merely agree can both be the slow kind: in some sessions most placements are.)
+        if len(times) >= 3 and sorted(times)[1] <= 1.01 * min(times) and max(times) >= 1.03 * min(times):
+            break
+    best = int(np.argmin(times)) if times else 0
+    for i, P in enumerate(cands):
+        if i != best:
+            P._state.close()
+    P = cands[best]
+    if tries > 1:      # dt = 0 steps leave normalVelocity / layerThickness as uploaded; ssh was recomputed from layerThickness: restore the caller's
+        P.ssh[-1].set(np.asarray(ssh, dtype=np.float64))
+    if report is not None:
+        report.update({"tries": len(cands), "ms_per_step_of_each": [float(t) for t in times], "chosen": best})
+    return P
+
+
 def ocn_init_from_arrays(mesh_data, ssh, normalVelocity, layerThickness, restingThickness, config: dict,
                          backend: MokaHIP, multilayer: bool = False, ordering: int = L.ORDER_DEFAULT,
-                         patch_cells: int = 0, state_bytes: int = 8):
+                         patch_cells: int = 0, state_bytes: int = 8, placement_tries: int = 1, placement_report: dict | None = None):
     """ocn_init(config_fp; backend) (init.jl:3-30) with the NetCDF/YAML reads replaced by arrays:
-    returns (Setup, Diag, Tend, Prog) like the reference."""
+    returns (Setup, Diag, Tend, Prog) like the reference.  placement_tries > 1: see prognostic_vars_best_placement."""
     K = np.asarray(normalVelocity).reshape(mesh_data.nEdges, -1).shape[1]
     h_mesh = HorzMesh(mesh_data)
     v_mesh = VerticalMesh(h_mesh, nVertLevels=K, restingThickness=restingThickness, multilayer=multilayer)
     mesh = Mesh(h_mesh, v_mesh, backend=backend, ordering=ordering, patch_cells=patch_cells, state_bytes=state_bytes)
     clock = ocn_setup_clock(config)
     Setup = ModelSetup(config, mesh, clock)
-    Prog = PrognosticVars(ssh, normalVelocity, layerThickness,
-                          config.get("time_integration", {}).get("config_number_of_time_levels", 2), mesh)
+    Prog = prognostic_vars_best_placement(ssh, normalVelocity, layerThickness,
+                                          config.get("time_integration", {}).get("config_number_of_time_levels", 2), mesh,
+                                          tries=placement_tries, report=placement_report)
     Diag = DiagnosticVars(config, mesh, Prog._state)
     Tend = TendencyVars(config, mesh, Prog._state)
     return Setup, Diag, Tend, Prog

@@ -280,6 +280,7 @@ class DistributedModel:
 
     def __init__(self, mesh, ssh, u, h, rest, dt, backend, rank, world, ordering=0, patch_cells=0,
                  transport="nccl", part=None, group=None, state_bytes=8, exchange_lists=None, timeout_s=30.0, nonlinear=False,
+                 placement_tries=1,
                  visc_del2=0.0):
         """exchange_lists(wants: {rank: obj}) -> {rank: obj}: all-to-all of small Python objects between the ranks
         (default: torch.distributed.all_gather_object on `group`); LocalCluster passes None and calls finish() itself."""
@@ -310,8 +311,12 @@ class DistributedModel:
             desc.verticesOnEdge = None
         L.check(L.lib().moka_mesh_create(backend._h, C.byref(desc), C.byref(self.mesh._h)), backend._h)
         api._own(self.mesh, L.lib().moka_mesh_destroy, self.mesh._h, backend)
-        self.Prog = api.PrognosticVars(np.asarray(ssh)[lm.cells_g], np.asarray(u).reshape(mesh.nEdges, K)[lm.edges_g],
-                                       np.asarray(h).reshape(mesh.nCells, K)[lm.cells_g], 2, self.mesh)
+        # placement_tries > 1: the rank's arrays in the fastest of a few placements (api.prognostic_vars_best_placement; before the
+        # halo exists: its peers address the buffers chosen here)
+        self.placement = {}
+        self.Prog = api.prognostic_vars_best_placement(np.asarray(ssh)[lm.cells_g], np.asarray(u).reshape(mesh.nEdges, K)[lm.edges_g],
+                                                       np.asarray(h).reshape(mesh.nCells, K)[lm.cells_g], 2, self.mesh,
+                                                       tries=placement_tries, report=self.placement)
         self.Diag = api.DiagnosticVars(None, self.mesh, self.Prog._state)
         self.Tend = api.TendencyVars(None, self.mesh, self.Prog._state)
         if self.nonlinear:

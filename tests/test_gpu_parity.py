@@ -1289,3 +1289,29 @@ def test_nonlinear_keeps_williamson_tc2_steady_on_the_gpu(backend):
         drift[nonlinear] = np.abs(Prog.layerThickness[-1].get() - h).max()
         Prog._state.close(); Setup.mesh.close()
     assert np.isfinite(drift[True]) and drift[True] < 0.25 * drift[False], drift
+
+
+def test_best_placement_leaves_the_state_as_uploaded(backend):
+    """mk.prognostic_vars_best_placement: several candidate placements of the state's arrays, three dt = 0 RK4 steps timed on each, the fastest
+    kept -- the state it returns holds exactly what was uploaded (an ssh that is NOT the column sum of layerThickness included), and steps from
+    it equal the oracle's bit for bit."""
+    mesh = get_mesh("ico16")
+    K = 60
+    ssh, u, h, rest = random_state(mesh, K, 5)
+    ssh = ssh + 0.125                                   # inconsistent with layerThickness on purpose: the caller's array must survive
+    hm = mk.HorzMesh(mesh)
+    vm = mk.VerticalMesh(hm, nVertLevels=K, restingThickness=rest, multilayer=True)
+    M = mk.Mesh(hm, vm, backend=backend)
+    rep = {}
+    Prog = mk.prognostic_vars_best_placement(ssh, u, h, 2, M, tries=4, report=rep)
+    assert 3 <= rep["tries"] <= 4 and len(rep["ms_per_step_of_each"]) == rep["tries"] and 0 <= rep["chosen"] < rep["tries"]
+    assert np.array_equal(Prog.ssh[-1].get(), ssh) and np.array_equal(Prog.normalVelocity[-1].get(), u)
+    assert np.array_equal(Prog.layerThickness[-1].get(), h)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    mk.run_steps(Prog, mk.RungeKutta4, 20.0, 2)
+    for _ in range(2):
+        st.step_rk4(20.0)
+    assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.layerThickness[-1].get(), st.h[1])
+    assert np.array_equal(Prog.ssh[-1].get(), st.ssh[1])
+    Prog._state.close(); M.close()
