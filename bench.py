@@ -479,7 +479,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg of the default single-GPU run")
     ap.add_argument("--tend-iters", type=int, default=20)
-    ap.add_argument("--placement-tries", type=int, default=6,
+    ap.add_argument("--placement-tries", type=int, default=8,
                     help="placements of the state's arrays tried at set-up, the fastest kept (mk.prognostic_vars_best_placement: where the "
                          "allocator puts the arrays decides 5-14 %% of every launch; DESIGN section 5); 1 = take what comes")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",

@@ -502,10 +502,20 @@ def prognostic_vars_best_placement(ssh, normalVelocity, layerThickness, nTimeLev
     RK4 step, each reproducible), invisible to copy / read / gather probes and not steerable through the addresses this side of the
     allocator sees.  So: allocate a candidate, time three RK4 steps with dt = 0 on it (they leave the state as it is), keep it
     alive, allocate the next elsewhere; keep the fastest, release the others.  Costs tries x (one upload + ~40 ms) at set-up."""
-    import time as _time
     backend = mesh.backend
     cands, times = [], []
-    for _ in range(max(1, int(tries))):
+    tries = max(1, int(tries))
+    if tries > 1:       # all candidates are alive at once: keep them within half of the device memory that is free now
+        try:
+            import torch
+            free_b = torch.cuda.mem_get_info(backend.device)[0]
+            nE, nC = mesh.HorzMesh.data.nEdges, mesh.HorzMesh.data.nCells
+            K = mesh.VertMesh.nVertLevels
+            state_b = 4 * (K * (nE + nC) + nC) * int(getattr(mesh, "state_bytes", 8))       # two time levels + two RK provisional states
+            tries = max(1, min(tries, int(0.5 * free_b // max(state_b, 1))))
+        except Exception:
+            pass
+    for _ in range(tries):
         P = PrognosticVars(ssh, normalVelocity, layerThickness, nTimeLevels, mesh)
         h = P._state._h
         if tries > 1:
