@@ -53,12 +53,16 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
         c5 = bench.get("config5")
         if isinstance(c5, dict) and "ms_per_step" in c5:
             legs.append(("config-5 leg", {"warmup": c5["warmup"], "steps": c5["steps"], "ms_per_step": c5["ms_per_step"],
+                                          "ms_per_step_wall_mean": c5.get("ms_per_step_wall_mean", c5["ms_per_step"]),
+                                          "placement": c5.get("placement", {}),
                                           "roofline": {"algorithmic_bytes_per_launch": c5["roofline"]["achieved"] * 1e9 * c5["ms_per_step"] * 1e-3 / 4,
                                                        "frac": c5["roofline"]["frac"]}}, r"k_stage_rec2c_f32<\d+, \d+, [123]"))
     for leg_name, bl, pat in legs:
         stage = [(n, d) for _, n, d in seq if re.match(pat, n)]
         w, k = bl["warmup"], bl["steps"]
-        timed = stage[4 * w:4 * (w + k)]
+        # in front of the warm-up: the placement trials of the set-up (one warm-up + three timed dt = 0 steps per candidate: 16 launches each)
+        skip = 16 * len(bl.get("placement", {}).get("ms_per_step_of_each", []))
+        timed = stage[skip + 4 * w:skip + 4 * (w + k)]
         print(f"== {leg_name} ==")
         if len(timed) == 4 * k:
             per_mode = defaultdict(list)
