@@ -505,14 +505,16 @@ def prognostic_vars_best_placement(ssh, normalVelocity, layerThickness, nTimeLev
     backend = mesh.backend
     cands, times = [], []
     tries = max(1, int(tries))
-    if tries > 1:       # all candidates are alive at once: keep them within half of the device memory that is free now
+    if tries > 1:       # all candidates are alive at once: keep them within 60 % of the device memory that is free now
         try:
             import torch
             free_b = torch.cuda.mem_get_info(backend.device)[0]
-            nE, nC = mesh.HorzMesh.data.nEdges, mesh.HorzMesh.data.nCells
+            d = mesh.HorzMesh.data
             K = mesh.VertMesh.nVertLevels
-            state_b = 4 * (K * (nE + nC) + nC) * int(getattr(mesh, "state_bytes", 8))       # two time levels + two RK provisional states
-            tries = max(1, min(tries, int(0.5 * free_b // max(state_b, 1))))
+            # two time levels, two RK provisional states, DiagnosticVars (layerThicknessEdge x 2, thicknessFlux, velocityDivCell,
+            # relativeVorticity) and TendencyVars: what moka_state_create + the first RK4 step allocate
+            state_b = int(getattr(mesh, "state_bytes", 8)) * K * (8 * d.nEdges + 6 * d.nCells + d.nVertices)
+            tries = max(1, min(tries, int(0.6 * free_b // max(state_b, 1))))
         except Exception:
             pass
     for _ in range(tries):
