@@ -459,6 +459,7 @@ int  moka_adjoint_rk4_stage(moka_tape *t, int stage);
  * runs meanwhile (owned rows only), then the exchange completes.  Halo entities are not computed.  Chunk kernels only
  * (even 34 <= nVertLevels <= 64), MOKA_ERR_UNSUPPORTED otherwise. */
 int  moka_adjoint_rk4_stage_part(moka_tape *t, int stage, int part);
+int  moka_adjoint_rk4_parts_available(const moka_tape *t);   /* 1: moka_adjoint_rk4_stage_part serves this tape's mesh */
 int  moka_adjoint_rk4_stage_out_fields(moka_tape *t, int stage, void **fieldU, void **fieldH, void **scratchS);
 /* Forward-Euler runs on a partitioned mesh: record before (after = 0) and behind (after = 1) the distributed step, commit;
  * reversal per recorded step: exchange the halo rows of the three fields moka_adjoint_fe_step_fields names (the adjoints of

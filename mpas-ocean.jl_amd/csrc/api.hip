@@ -2059,6 +2059,14 @@ int moka_adjoint_rk4_stage_part(moka_tape *t, int sg, int part)
     return MOKA_OK;
 }
 
+// 1: this tape's transposed RK4 stages can run class by class (the chunk kernels serve the mesh and the mesh has cell classes)
+int moka_adjoint_rk4_parts_available(const moka_tape *t)
+{
+    if (!t) return 0;
+    const moka_state *st = t->st;
+    return moka::adj_fused_available(t->am, st->mesh->lpc) && (int)st->mesh->plan.classCellStart.size() >= 3 ? 1 : 0;
+}
+
 // The arrays stage `sg` of the reverse step in progress WRITES and the next transposed stage gathers from (stage sg - 1's k-bar;
 // after stage 1: the adjoint state handed to the previous recorded step): what has to be exchanged behind part 0 of the stage.
 int moka_adjoint_rk4_stage_out_fields(moka_tape *t, int sg, void **fieldU, void **fieldH, void **scratchS)

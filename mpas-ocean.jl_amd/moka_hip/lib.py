@@ -84,7 +84,7 @@ EXPORTS = [
     "moka_rk4_dist_stage_launch", "moka_rk4_dist_step", "moka_fe_dist_launch", "moka_fe_dist_end", "moka_fe_dist_step",
     "moka_set_nonlinear", "moka_last_fe_path", "moka_set_viscosity_del2", "moka_tape_create", "moka_tape_destroy", "moka_step_fe_taped", "moka_step_rk4_taped", "moka_adjoint_seed_sum_sq_ssh", "moka_adjoint_sweep",
     "moka_adjoint_download",
-    "moka_mark", "moka_marks_reset", "moka_marks_read", "moka_bw_probe", "moka_bw_probe_streams", "moka_bw_probe_reread", "moka_bw_probe_gather_big", "moka_ctx_pci_bus_id", "moka_halo_set_acquire", "moka_set_tuning", "moka_get_tuning", "moka_rk4_dist_parts_available", "moka_adjoint_rk4_stage_part", "moka_adjoint_rk4_stage_out_fields",
+    "moka_mark", "moka_marks_reset", "moka_marks_read", "moka_bw_probe", "moka_bw_probe_streams", "moka_bw_probe_reread", "moka_bw_probe_gather_big", "moka_ctx_pci_bus_id", "moka_halo_set_acquire", "moka_set_tuning", "moka_get_tuning", "moka_rk4_dist_parts_available", "moka_adjoint_rk4_stage_part", "moka_adjoint_rk4_parts_available", "moka_adjoint_rk4_stage_out_fields",
     "moka_gradient_on_edge_vjp", "moka_gradient_on_edge_jvp", "moka_divergence_on_cell_vjp", "moka_divergence_on_cell_jvp",
     "moka_curl_on_vertex_vjp", "moka_curl_on_vertex_jvp", "moka_fe_lazy_pending",
 ]
@@ -190,6 +190,7 @@ def lib():
     L.moka_adjoint_rk4_stage_fields.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.moka_adjoint_rk4_stage.argtypes = [vp, C.c_int]
     L.moka_adjoint_rk4_stage_part.argtypes = [vp, C.c_int, C.c_int]
+    L.moka_adjoint_rk4_parts_available.argtypes = [vp]
     L.moka_adjoint_rk4_stage_out_fields.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.moka_tape_record_fe.argtypes = [vp, C.c_int, C.c_int]
     L.moka_tape_commit_fe.argtypes = [vp, C.c_double, C.c_int]

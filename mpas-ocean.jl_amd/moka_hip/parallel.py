@@ -709,8 +709,10 @@ class DistributedModel:
         return self.owned_gradient()
 
     def adjoint_parts_available(self):
-        """Can the transposed RK4 stages of this model run class by class (the chunk kernels: even 34 <= K <= 64)?"""
-        return self.K % 2 == 0 and 34 <= self.K <= 64 and self.state_bytes == 8
+        """Can the transposed RK4 stages of this model's tape run class by class (the chunk kernels: even 34 <= K <= 64, hexagon-width
+        lists)?  The library says (moka_adjoint_rk4_parts_available)."""
+        t = getattr(self, "_tape", None)
+        return bool(t is not None and L.lib().moka_adjoint_rk4_parts_available(t._h))
 
     def _adjoint_unpack(self, fu, fh, fs):
         L.check(L.lib().moka_halo_unpack_fields(self._halo, fu, fh, fs, self.recvbuf.data_ptr()), self.backend._h)
