@@ -236,6 +236,17 @@ def main():
                 onl.step_rk4(stn, dt)
             (cg, s_, hh), (eg, uu) = nlm.owned_state()
             assert np.array_equal(hh, stn.h[1][cg]) and np.array_equal(uu, stn.u[1][eg]) and np.array_equal(s_, stn.ssh[1][cg]), "nonlinear"
+            if transport == "ipc" and parts:
+                # ... and over the direct transport: the neighbours' push kernels store into this rank's IPC-mapped fields while its
+                # interior stage kernel and the next stage's interior preparation pass run
+                nlm.connect_ipc()
+                nlm.set_transport("ipc")
+                dist.barrier()
+                for _ in range(2):
+                    nlm.step_rk4()
+                    onl.step_rk4(stn, dt)
+                (cg, s_, hh), (eg, uu) = nlm.owned_state()
+                assert np.array_equal(hh, stn.h[1][cg]) and np.array_equal(uu, stn.u[1][eg]) and np.array_equal(s_, stn.ssh[1][cg]), "nonlinear over ipc"
             dist.barrier()
             nlm.close()
         dist.barrier()               # nobody pushes into fields that are about to be freed
