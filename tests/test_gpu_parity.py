@@ -1304,7 +1304,7 @@ def test_best_placement_leaves_the_state_as_uploaded(backend):
     M = mk.Mesh(hm, vm, backend=backend)
     rep = {}
     Prog = mk.prognostic_vars_best_placement(ssh, u, h, 2, M, tries=4, report=rep)
-    assert 3 <= rep["tries"] <= 4 and len(rep["ms_per_step_of_each"]) == rep["tries"] and 0 <= rep["chosen"] < rep["tries"]
+    assert rep["tries"] == 4 and len(rep["ms_per_step_of_each"]) == rep["tries"] and 0 <= rep["chosen"] < rep["tries"]
     assert np.array_equal(Prog.ssh[-1].get(), ssh) and np.array_equal(Prog.normalVelocity[-1].get(), u)
     assert np.array_equal(Prog.layerThickness[-1].get(), h)
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
