@@ -325,6 +325,40 @@ def calibrate(backend, tag):
     return cal
 
 
+def under_load(backend, fn, seconds=1.0, batch=10):
+    """Clock and power WHILE launches run: `fn` called back to back for ~`seconds` while a thread samples sysfs every 4 ms (the
+    reads in calibrate() happen between timed regions, when the device idles at 2.4 GHz and < 400 W).  Every stage launch of this
+    library runs the package at its power limit and the shader clock gives way (profiles/r04_variants.txt section 4): these figures
+    say how far, on this box, in this run.  Outside every timed region."""
+    import threading
+    pci = backend.pci_bus_id()
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            d = device_sysfs(pci)
+            samples.append((d.get("sclk_mhz"), d.get("power_w"), d.get("fclk_mhz"), d.get("mclk_mhz")))
+            time.sleep(0.004)
+    th = threading.Thread(target=sampler, daemon=True)
+    backend.synchronize()
+    th.start()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(batch):
+            fn()
+        backend.synchronize()
+        n += batch
+    el = time.perf_counter() - t0
+    stop.set()
+    th.join()
+    tail = samples[len(samples) // 4:]                    # the sensors average over tens of ms: drop the ramp
+    col = lambda i: [x[i] for x in tail if x[i] is not None]  # noqa: E731
+    mean = lambda v: (sum(v) / len(v)) if v else None         # noqa: E731
+    return {"ms_per_call_sustained": el / max(n, 1) * 1e3, "calls": n, "sclk_mhz_mean": mean(col(0)), "sclk_mhz_min": min(col(0), default=None),
+            "power_w_mean": mean(col(1)), "power_w_max": max(col(1), default=None), "fclk_mhz": mean(col(2)), "mclk_mhz": mean(col(3)),
+            "samples": len(tail)}
+
+
 def timed_steps(backend, step, steps, warmup, sync_all):
     """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides, with one HIP event per step on
     the compute stream.  Returns (wall seconds, [ms per step])."""
@@ -415,6 +449,20 @@ def single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_te
     return out
 
 
+def placement_summary(rep):
+    """What moka_state_optimize_placement did at set-up (rank 0's state): first_placement_ms = the four stage launches of an RK4
+    step as moka_state_create placed the arrays (what a caller gets without the search), ms_after = with the kept layout, the
+    per-array trials, and how close the kept layout is to the best timing any trial saw."""
+    out = dict(rep)
+    if rep.get("ms_before"):
+        out["first_placement_ms"] = rep["ms_before"]
+        out["kept_vs_first"] = rep["ms_after"] / rep["ms_before"]
+    out["note"] = ("moka_state_optimize_placement (C ABI; what julia/MokaHIP.jl calls at binding): dt = 0 stage launches timed with the "
+                   "library's events, one array re-allocated per trial, kept when the launches it takes part in got faster; "
+                   "ms_* = sum of the four stage launches' medians (DESIGN section 5)")
+    return out
+
+
 def config5_leg(mk, backend, args, copy_gbs):
     """BASELINE config 5 inside the same run: RK4 ms/step (median), per stage, the tendency launch and
     the reference_compat Forward-Euler step on the 3 696 642-cell x 80-layer fp32-storage workload.  No CPU leg for it."""
@@ -447,7 +495,7 @@ def config5_leg(mk, backend, args, copy_gbs):
                         "frac_of_copy_this_run": b_step / (st["median"] * 1e-3) / 1e9 / copy_gbs if copy_gbs else None,
                         "formula": "contract: 18 state streams per step + 4 B_mesh, S = 4",
                         "per_stage": per_stage, "per_stage_steps": nst, "per_stage_sum_ms": ssum},
-           "placement": placement,
+           "placement": placement_summary(placement),
            "cpu_baseline": None, "cpu_baseline_note": "skipped for this leg: the CPU baseline belongs to the headline (config 4) line"}
     try:     # PMC traffic of this workload's stage launches, taken by tools/profile.sh in separate passes (as for the headline line)
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(name, {})
@@ -458,6 +506,8 @@ def config5_leg(mk, backend, args, copy_gbs):
     except Exception:
         pass
     out.update(single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, max(5, min(args.tend_iters, 10))))
+    out["under_load"] = {"rk4_steps": under_load(backend, step, 1.0, 5),
+                         "tendency_launches": under_load(backend, lambda: mk.computeTendency(Setup.mesh, Diag, Prog, Tend), 0.6, 10)}
     out["tendency"] = out["tendency_kernel"]
     backend.synchronize()
     Prog._state.close()
@@ -479,9 +529,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg of the default single-GPU run")
     ap.add_argument("--tend-iters", type=int, default=20)
-    ap.add_argument("--placement-tries", type=int, default=8,
-                    help="placements of the state's arrays tried at set-up, the fastest kept (mk.prognostic_vars_best_placement: where the "
-                         "allocator puts the arrays decides 5-14 %% of every launch; DESIGN section 5); 1 = take what comes")
+    ap.add_argument("--placement-tries", type=int, default=16,
+                    help="upper limit of the per-array re-allocations moka_state_optimize_placement tries at set-up (the library's own "
+                         "search, behind the C ABI: one array at a time gets a second allocation, the faster is kept; where the "
+                         "allocator puts the arrays decides 5-14 %% of every launch, DESIGN section 5); <= 1 = take what comes")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B measurement: moka_set_tuning(KEY, VALUE) before anything runs (include/moka_hip.h lists the keys); repeatable")
     ap.add_argument("--f32-wide-modes", type=int, default=None,
@@ -716,11 +767,17 @@ def main():
                       **({"halo_transport": args.transport, "halo_transport_trials_ms_per_step": transport_trials,
                           "rccl_usable": rccl_ok} if world > 1 else {})},
            "roofline": roofline, "calibration": calibration,
-           "placement": dict(placement, note="placements of the state's arrays tried at set-up (rank 0's; three dt = 0 steps each), the fastest kept: "
-                                             "where the allocator puts the arrays decides 5-14 % of every launch (DESIGN section 5)")}
+           "placement": placement_summary(placement)}
 
     if world == 1:
         out.update(single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, args.tend_iters))
+        # clock and power while the launches run (after every timed region of this workload)
+        out["under_load"] = {"rk4_steps": under_load(backend, step, 1.0, 10),
+                             "tendency_launches": under_load(backend, lambda: mk.computeTendency(Setup.mesh, Diag, Prog, Tend), 0.6, 20),
+                             "idle": device_sysfs(backend.pci_bus_id()),
+                             "note": "sysfs (pp_dpm_sclk, power1_average) sampled every 4 ms while the launches run back to back; the stage "
+                                     "launches run the package at its power limit (1400 W) and the shader clock drops below the 2.4 GHz it "
+                                     "shows when idle: the launches are bound by energy per step (profiles/r04_variants.txt section 4)"}
         if args.workload == "config4_1M_x60" and not args.no_config5:
             # free the headline workload's device objects, then time config 5 on the same device in the same run
             backend.synchronize()

@@ -220,6 +220,34 @@ void moka_state_destroy(moka_state *st);
 int  moka_state_upload(moka_state *st, int field, int time_level, const double *host);
 int  moka_state_download(moka_state *st, int field, int time_level, double *host);
 
+/* Selected rows of a field (caller's 0-based ids; any order, repeats allowed) into host (nVertLevels, nRows) -- (1, nRows) for
+ * ssh -- widened to double: what a row-sampled check of a full-size state needs without moving the whole field across PCIe.
+ * time_level 0 / 1 as moka_state_download; 2 / 3 = the two RK4 provisional states as the last stage launches left them
+ * (inspection only: prognostic fields; they exist after the first RK4 step). */
+int  moka_state_download_rows(moka_state *st, int field, int time_level, int64_t nRows, const int32_t *rows, double *host);
+
+/* Placement of the state's arrays in device memory.  Where the allocator puts the four buffer sets an RK4 step streams through
+ * (current level, previous level = New accumulator, two provisional states) decides 5-14 % of every stage launch (DESIGN.md
+ * section 5): a stable property of the memory behind an array, not visible in its address.  The reference's driver only ever
+ * calls ocn_init and the step (src/driver/mpas_ocean.jl:28-39), so the choice is made here, behind the boundary: the four
+ * launches of an RK4 step are timed with the library's own events (dt = 0), then up to max_tries times ONE array is given a
+ * second allocation while the first is still alive, the launches that array takes part in are timed again, and the faster
+ * allocation is kept (the loser is held back, within a quarter of the free memory, so that it is not handed out again; all
+ * are released on return).  Peak extra memory: the previous level (saved / restored) + one candidate + the held-back losers.
+ * The state's observable contents are unchanged (every array of Prog / Diag / Tend, both time levels, what is lazily
+ * pending); only the provisional RK states, which every RK4 step overwrites before reading, are clobbered.
+ * *ms_before / *ms_after (opt): sum of the four stage launches' median times before / with the kept layout.
+ * max_tries <= 0 measures only.  Stops early after 8 consecutive trials without a gain (every array tried once).
+ * MOKA_ERR_UNSUPPORTED once a halo or a tape of the state exists (they export / hold addresses): call it right after
+ * moka_state_create (+ uploads), which is what julia/MokaHIP.jl, moka_hip.shim and moka_hip.parallel do. */
+int  moka_state_optimize_placement(moka_state *st, int max_tries, double *ms_before, double *ms_after);
+/* What the last moka_state_optimize_placement tried: field = 2 * set + (0 normalVelocity, 1 layerThickness), set 0 = current
+ * level, 1 = previous level, 2 / 3 = RK provisional states; ms_old / ms_new = summed median times of the stage launches the
+ * array takes part in with the old / the candidate allocation; kept = 1 when the candidate replaced the old one.
+ * *n = number of trials; out receives min(*n, capacity) of them (may be NULL). */
+typedef struct { int32_t field; double ms_old, ms_new; int32_t kept; } moka_placement_trial;
+int  moka_state_placement_log(const moka_state *st, int32_t capacity, moka_placement_trial *out, int32_t *n);
+
 /* advanceTimeLevels!(Prog)                  src/forward/time_integration.jl:10-40 */
 int moka_advance_time_levels(moka_state *st, int flags);
 /* diagnostic_compute!(Mesh, Diag, Prog)     src/ocn/DiagnosticVars.jl:108-117 (flags: MOKA_FE_*) */

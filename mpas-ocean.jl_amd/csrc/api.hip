@@ -355,7 +355,7 @@ bool fe_stage_path(const moka_state *st, int flags)
 // level set, and -- with the reference's stale flux thickness -- that thickness to be derivable from the previous level.
 bool fe_lean(const moka_state *st, int flags)
 {
-    return moka::fe_lean_enabled() && !st->feForceEager && fe_stage_path(st, flags) && st->spare.ssh &&
+    return moka::fe_lean_enabled() && !st->feForceEager && !st->feNoLean && fe_stage_path(st, flags) && st->spare.ssh &&
            (!(flags & MOKA_FE_STALE_HEDGE) || (st->hEdgePrev && moka::fe_prev_mode()));
 }
 
@@ -1594,6 +1594,7 @@ struct moka_tape {
     bool seeded = false;
     moka::AdjMesh am{};
     std::vector<void *> allocs;
+    bool counted = false;                            // st->attached includes this tape
 };
 
 static int tape_alloc(moka_tape *t, void **out, size_t bytes)
@@ -1695,6 +1696,8 @@ int moka_tape_create(moka_state *st, int64_t capacity_steps, moka_tape **out)
     }
     if (rc != MOKA_OK) { moka_tape_destroy(t); return rc; }
     HIPCHK(st->ctx, hipStreamSynchronize(st->ctx->stream));
+    ++st->attached;
+    t->counted = true;
     *out = t;
     return MOKA_OK;
 }
@@ -1702,6 +1705,7 @@ int moka_tape_create(moka_state *st, int64_t capacity_steps, moka_tape **out)
 void moka_tape_destroy(moka_tape *t)
 {
     if (!t) return;
+    if (t->counted) --t->st->attached;
     (void)hipSetDevice(t->st->ctx->device);
     if (t->st->lazyOwner == t) {        // the stage-4 tendencies of the last taped step would be produced from a slot of this tape
         if (t->st->tendDirty) (void)flush_lazy(t->st, false, true);

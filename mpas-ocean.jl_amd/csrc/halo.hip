@@ -27,6 +27,12 @@
 //        therefore launched FIRST, ahead of the boundary launch and the push (moka_fe_dist_step; round 3: launched behind the
 //        interior patches it could still be reading when a neighbour that was a step ahead overwrote those rows).
 // A neighbour has waited for that flag before it computed what it now pushes.
+//   Lean Forward-Euler steps (moka_state.feLazy) are OFF for a state with a connected direct halo (moka_state.feNoLean): the
+//        arrays a lean step leaves pending are produced on first read from the level before the previous one -- the spare
+//        set, halo rows included -- and that is the set a neighbour's NEXT step pushes its new level into; the neighbour needs
+//        only this rank's flag of the current step for that, which is long sent when a caller reads diagnostics between
+//        steps.  Every step of such a state therefore stores all of its arrays inside the step, ahead of its own push
+//        (ADVICE r03).  The buffered transports keep lean steps: their unpack is ordered on this rank's own stream.
 //
 // Visibility of peer-written rows (the fields are ordinary, coarse-grained hipMalloc memory): a push kernel ends with
 // __threadfence_system() and its completion event precedes the flag store (release) the reader's host thread acquires
@@ -104,6 +110,7 @@ struct moka_halo {
     bool overlapB = false;                    // boundary patches on the comm stream, in flight together with the interior launch
     bool overlapNow = false;                  // ... as the running step was begun
     std::vector<void *> allocs;           // device allocations of this object
+    bool counted = false;                 // st->attached includes this object
 };
 
 namespace {
@@ -394,6 +401,8 @@ int moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCell
         moka_halo_destroy(h);
         return fail(st->ctx, MOKA_ERR_HIP, "hipEventCreate failed");
     }
+    ++st->attached;
+    h->counted = true;
     *out = h;
     return MOKA_OK;
 }
@@ -401,6 +410,7 @@ int moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCell
 void moka_halo_destroy(moka_halo *h)
 {
     if (!h) return;
+    if (h->counted) --h->st->attached;
     (void)hipSetDevice(h->st->ctx->device);
     (void)hipStreamSynchronize(h->st->ctx->stream);
     (void)hipStreamSynchronize(h->st->ctx->comm);
@@ -636,6 +646,7 @@ int moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer
     }
     h->peers[nbr] = pl;
     h->tabDirty = true;
+    st->feNoLean = true;          // peers may store into this state's level sets from now on: see the header (lean steps)
     return MOKA_OK;
 }
 
@@ -812,10 +823,10 @@ int moka_rk4_dist_step(moka_halo *h, double dt, moka_transport_fn transport, voi
     // selection were then never exercised)
     const bool direct = h->nNbr > 0 && !transport;
     if (direct && !all_connected(h)) return hfail(h, MOKA_ERR_ARG, "no transport callback and not every neighbour is connected");
-    if ((rc = moka_rk4_dist_begin(h, dt))) return rc;
     const bool nl = h->st->nonlinear;
-    if (nl && !moka_rk4_dist_parts_available(h))
+    if (nl && !moka_rk4_dist_parts_available(h))     // before the step is opened (rk4_begin supersedes what is lazily pending)
         return hfail(h, MOKA_ERR_UNSUPPORTED, "nonlinear terms: this kernel variant has whole-mesh stages only (moka_rk4_dist_stage part 2)");
+    if ((rc = moka_rk4_dist_begin(h, dt))) return rc;
     // nonlinear terms: the preparation pass of the interior patches of stage s + 1 is queued right behind the interior launch of
     // stage s (it reads owned rows only) and so overlaps exchange s as well; that of the boundary and halo patches follows the wait
     if (nl && (rc = moka_rk4_dist_stage(h, 1, 4))) return rc;

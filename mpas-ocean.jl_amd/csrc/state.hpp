@@ -83,6 +83,7 @@ struct moka_state {
     // supersedes them, exactly as an RK4 step supersedes its lazily produced diagnostics.
     bool feLazy = false, feLazyStale = false;
     bool feForceEager = false;        // a tape is recording: every step stores all of its arrays
+    bool feNoLean = false;            // a direct (peer-store) halo is connected: lean steps are off, see the halo.hip header
     double *scalar = nullptr;         // 1 double (sum_sq result)
     bool sshConsistent = false;       // lev[1].ssh == ksum(lev[1].h) - restingThicknessSum
     // moka_step_rk4 ends with diagnostic_compute! of the new state and leaves the stage-4 tendencies in
@@ -104,6 +105,10 @@ struct moka_state {
     double *nlZv = nullptr, *nlDiv = nullptr;   // Del2 mixing (moka_set_viscosity_del2)
     double viscDel2 = 0.0;
     std::vector<void *> allocs;
+    // objects that hold or have exported the addresses of this state's arrays (halos, tapes): while any exists the arrays stay
+    // where they are (moka_state_optimize_placement refuses)
+    int attached = 0;
+    std::vector<moka_placement_trial> placementLog;   // what the last moka_state_optimize_placement tried
 };
 
 namespace mk {

@@ -175,17 +175,43 @@ function destroy_mesh!(dm::DeviceMesh)
     dm.handle = C_NULL
     release!(dm.backend)
 end
-# reference Mesh object -> its device mesh.  The key is held WEAKLY: when the caller drops its Mesh the entry goes, the
-# DeviceMesh becomes collectable (states that use it hold it themselves), its finalizer runs moka_mesh_destroy and the
-# context's count can reach zero.  `Mesh` is an immutable struct in the reference (MPASMesh.jl:19); a WeakKeyDict needs
-# mutable keys, so the key is one of its arrays -- the MArray of areaCell -- which is mutable and lives exactly as long as
-# the Mesh holds it.
-const MESHES = WeakKeyDict{Any,DeviceMesh}()
-mesh_key(m::Mesh) = m.HorzMesh.PrimaryCells.areaCell
-"release the device copy of `m` now (otherwise: when `m` is collected)"
+# reference Mesh object -> its device mesh, by IDENTITY.  `Mesh` is an immutable struct in the reference (MPASMesh.jl:19), so
+# the identity used is that of two of the (mutable) MArrays it holds -- areaCell for the horizontal mesh,
+# restingThicknessSum for the vertical one -- together with the backend: two Mesh objects read from the same file, or one
+# HorzMesh under two VerticalMeshes (another nVertLevels / restingThickness), or the same Mesh on two backends, get a
+# DeviceMesh each.  (Round 3 keyed a WeakKeyDict by the areaCell array itself; AbstractArray keys hash and compare by
+# CONTENT, so equal-valued meshes shared one DeviceMesh with the wrong nVertLevels or context, and every lookup hashed
+# nCells elements: ADVICE r03.)  The arrays are referenced weakly: once the caller has dropped its Mesh the entry is pruned
+# at the next lookup, the DeviceMesh becomes collectable (states that use it hold it themselves), its finalizer runs
+# moka_mesh_destroy and the context's count can reach zero.
+struct MeshEntry
+    horz::WeakRef
+    vert::WeakRef
+    dm::DeviceMesh
+end
+const MESHES = Dict{NTuple{3,UInt},MeshEntry}()
+mesh_arrays(m::Mesh) = (m.HorzMesh.PrimaryCells.areaCell, m.VertMesh.restingThicknessSum)
+mesh_key(m::Mesh, b::Backend) = (objectid(mesh_arrays(m)[1]), objectid(mesh_arrays(m)[2]), objectid(b))
+function prune_meshes!()
+    for (k, e) in collect(MESHES)
+        (e.horz.value === nothing || e.vert.value === nothing) && delete!(MESHES, k)
+    end
+end
+function lookup_mesh(m::Mesh, b::Backend)
+    e = get(MESHES, mesh_key(m, b), nothing)
+    e === nothing && return nothing
+    h, v = mesh_arrays(m)
+    (e.horz.value === h && e.vert.value === v) ? e.dm : nothing      # (an objectid can be reused after its object is gone)
+end
+"release the device copies of `m` now (otherwise: when `m` is collected)"
 function close!(m::Mesh)
-    dm = pop!(MESHES, mesh_key(m), nothing)
-    dm === nothing || destroy_mesh!(dm)
+    h, v = mesh_arrays(m)
+    for (k, e) in collect(MESHES)
+        if e.horz.value === h && e.vert.value === v
+            delete!(MESHES, k)
+            destroy_mesh!(e.dm)
+        end
+    end
     nothing
 end
 
@@ -194,8 +220,9 @@ hostof(a::Array) = a
 
 "moka_mesh_create from the arrays the reference's Mesh holds (Adapt.adapt_structure(backend, ::Mesh), MPASMesh.jl:26)"
 function device_mesh(m::Mesh, b::Backend)
-    dm0 = get(MESHES, mesh_key(m), nothing)
+    dm0 = lookup_mesh(m, b)
     dm0 === nothing || return dm0
+    prune_meshes!()
     C, D, E, V = m.HorzMesh.PrimaryCells, m.HorzMesh.DualCells, m.HorzMesh.Edges, m.VertMesh
     rsum = vec(copy(hostof(V.restingThicknessSum)))               # (1,nC) or (nC): indexed linearly (SURVEY N5)
     arrs = map(hostof, (C.xᶜ, C.yᶜ, C.zᶜ, C.nEdgesOnCell, C.edgesOnCell, C.edgeSignOnCell, C.areaCell,
@@ -214,7 +241,7 @@ function device_mesh(m::Mesh, b::Backend)
         check(ccall((:moka_mesh_create, lib), Cint, (Ptr{Cvoid}, Ref{MeshDesc}, Ref{Ptr{Cvoid}}), b.ctx, d, ref), b.ctx)
         dm = DeviceMesh(ref[], retain!(b))
         finalizer(destroy_mesh!, dm)
-        MESHES[mesh_key(m)] = dm
+        MESHES[mesh_key(m, b)] = MeshEntry(WeakRef(mesh_arrays(m)[1]), WeakRef(mesh_arrays(m)[2]), dm)
         return dm
     end
 end
@@ -277,6 +304,8 @@ function curl_jvp!(d_curl::MArray{Float64,2}, d_V::MArray{Float64,2}, m::Mesh, b
 end
 
 # ---- binding Prog / Diag / Tend to one device state ---------------------------------------------------
+"upper limit of the per-array placement trials at binding (moka_state_optimize_placement); <= 1 switches the search off"
+const PLACEMENT_TRIES = Ref{Cint}(16)
 const MProg = PrognosticVars{<:Any,<:MArray}          # the reference's struct, parametrised by our array type
 const MDiag = DiagnosticVars{<:Any,<:MArray}
 const MTend = TendencyVars{<:Any,<:MArray}
@@ -310,6 +339,12 @@ function state_of(Prog::MProg, Diag, Tend, S::ModelSetup, b::Backend)
             bind!(Prog.normalVelocity[t], s, F_U, t - 1; upload = true)
             bind!(Prog.layerThickness[t], s, F_H, t - 1; upload = true)
         end
+        # The caller (src/driver/mpas_ocean.jl:28-39) only ever calls ocn_init and the step, so where the allocator put this
+        # state's arrays -- 5-14 % of every stage launch, DESIGN.md section 5 -- is settled here, by the library itself:
+        # up to PLACEMENT_TRIES per-array re-allocations, each kept only if the launches it takes part in got faster.  The
+        # state's contents are untouched.  Must come before any tape of the state exists (the library refuses afterwards).
+        PLACEMENT_TRIES[] > 1 && check(ccall((:moka_state_optimize_placement, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
+                                             s.handle, PLACEMENT_TRIES[], C_NULL, C_NULL), b.ctx)
     end
     if Diag !== nothing && Diag.layerThicknessEdge.state === nothing         # KA.zeros on the host == zero-initialised device fields
         for (a, f) in ((Diag.layerThicknessEdge, F_HEDGE), (Diag.thicknessFlux, F_FLUX), (Diag.velocityDivCell, F_DIV), (Diag.relativeVorticity, F_VORT))

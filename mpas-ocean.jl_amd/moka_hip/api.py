@@ -100,10 +100,20 @@ class MokaHIP:
         L.check(L.lib().moka_bw_probe_streams(self._h, int(iters), C.byref(s5)), self._h)
         rr, gb = C.c_double(), C.c_double()
         L.check(L.lib().moka_bw_probe_reread(self._h, 128 << 20, 16, int(iters), C.byref(rr)), self._h)
-        L.check(L.lib().moka_bw_probe_gather_big(self._h, 32 << 30, 3, C.byref(gb)), self._h)
+        # the state-sized gather: at most 32 GiB and at most a quarter of what is free now (ranks may share a device, a
+        # smaller GPU, placement candidates alive); a refused allocation is a missing figure, not an error of the run
+        big = None
+        try:
+            import torch
+            free_b = int(torch.cuda.mem_get_info(self.device)[0])
+        except Exception:
+            free_b = 32 << 30
+        want = min(32 << 30, free_b // 4) & ~((1 << 24) - 1)
+        if want >= (1 << 30) and L.lib().moka_bw_probe_gather_big(self._h, int(want), 3, C.byref(gb)) == L.OK:
+            big = float(gb.value)
         return {"copy_GBs": float(g[0]), "read_GBs": float(g[1]), "copy_GBs_mean": float(g[2]),
                 "gather_GBs": float(g[3]), "streams5_GBs": float(s5.value), "reread128_GBs": float(rr.value),
-                "gather32G_GBs": float(gb.value)}
+                "gather32G_GBs": big, "gather_big_bytes": int(want)}
 
     def pci_bus_id(self) -> str:
         buf = C.create_string_buffer(32)
@@ -327,6 +337,24 @@ class _State:
         _own(self, L.lib().moka_state_destroy, self._h, mesh, mesh.backend)
         self._dependents = []          # weak references to tapes on this state: they dereference it when they are destroyed
 
+    FIELD_NAMES = ("cur.normalVelocity", "cur.layerThickness", "prev.normalVelocity", "prev.layerThickness",
+                   "rk1.normalVelocity", "rk1.layerThickness", "rk2.normalVelocity", "rk2.layerThickness")
+
+    def optimize_placement(self, max_tries: int = 16) -> dict:
+        """moka_state_optimize_placement: re-allocate one array at a time where that makes the RK4 stage launches faster
+        (the state's contents are unchanged).  Returns {ms_before, ms_after, tries, kept, trials: [...]}; must come before
+        a halo or a tape is created on the state."""
+        b, a, n = C.c_double(), C.c_double(), C.c_int32()
+        ctx = self.mesh.backend._h
+        L.check(L.lib().moka_state_optimize_placement(self._h, int(max_tries), C.byref(b), C.byref(a)), ctx)
+        L.check(L.lib().moka_state_placement_log(self._h, 0, None, C.byref(n)), ctx)
+        buf = (L.PlacementTrial * max(n.value, 1))()
+        L.check(L.lib().moka_state_placement_log(self._h, n.value, buf, C.byref(n)), ctx)
+        trials = [{"field": self.FIELD_NAMES[t.field], "ms_old": float(t.ms_old), "ms_new": float(t.ms_new), "kept": bool(t.kept)}
+                  for t in buf[:n.value]]
+        return {"ms_before": float(b.value), "ms_after": float(a.value), "tries": int(n.value),
+                "kept": sum(t["kept"] for t in trials), "trials": trials}
+
     def close(self):
         if self._h:
             for ref in self._dependents:      # an explicit close() takes what lives on the state with it, in order
@@ -355,6 +383,16 @@ class DeviceField:
         if a.shape != self.shape:
             a = a.reshape(self.shape)
         L.check(L.lib().moka_state_upload(self._s._h, self.field, self.level, L.f64(a)), self._s.mesh.backend._h)
+
+    def rows(self, ids, level=None) -> np.ndarray:
+        """Selected rows (the caller's ids) of the field: (len(ids), K), or (len(ids),) for ssh (moka_state_download_rows).
+        level: 0 / 1 time levels (default: this field's), 2 / 3 the RK4 provisional states (inspection)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        K = self.shape[1] if len(self.shape) == 2 else 1
+        out = np.empty((ids.size, K), dtype=np.float64)
+        L.check(L.lib().moka_state_download_rows(self._s._h, self.field, self.level if level is None else int(level), ids.size,
+                                                 L.i32(ids), L.f64(out)), self._s.mesh.backend._h)
+        return out if len(self.shape) == 2 else out[:, 0]
 
     def __array__(self, dtype=None, copy=None):
         return self.get()
@@ -494,54 +532,16 @@ def ocn_run_loop(*args, backend=None, flags: int | None = None):
     return None
 
 
-def prognostic_vars_best_placement(ssh, normalVelocity, layerThickness, nTimeLevels, mesh: "Mesh", tries: int = 5, report: dict | None = None):
-    """PrognosticVars(...) with the state's arrays in the fastest of `tries` placements.
-
-    Why: where the allocator puts a state's arrays decides whether every stage launch runs at full speed or 5-14 % slower -- a stable
-    property of the memory (profiles/r03_variants.txt: six states alive together in one process: 6.74 6.84 6.75 7.19 6.87 6.77 ms per
-    RK4 step, each reproducible), invisible to copy / read / gather probes and not steerable through the addresses this side of the
-    allocator sees.  So: allocate a candidate, time three RK4 steps with dt = 0 on it (they leave the state as it is), keep it
-    alive, allocate the next elsewhere; keep the fastest, release the others.  Costs tries x (one upload + ~40 ms) at set-up."""
-    backend = mesh.backend
-    cands, times = [], []
-    tries = max(1, int(tries))
-    if tries > 1:       # all candidates are alive at once: keep them within 60 % of the device memory that is free now
-        try:
-            import torch
-            free_b = torch.cuda.mem_get_info(backend.device)[0]
-            d = mesh.HorzMesh.data
-            K = mesh.VertMesh.nVertLevels
-            # two time levels, two RK provisional states, DiagnosticVars (layerThicknessEdge x 2, thicknessFlux, velocityDivCell,
-            # relativeVorticity) and TendencyVars: what moka_state_create + the first RK4 step allocate
-            state_b = int(getattr(mesh, "state_bytes", 8)) * K * (8 * d.nEdges + 6 * d.nCells + d.nVertices)
-            tries = max(1, min(tries, int(0.6 * free_b // max(state_b, 1))))
-        except Exception:
-            pass
-    for _ in range(tries):
-        P = PrognosticVars(ssh, normalVelocity, layerThickness, nTimeLevels, mesh)
-        h = P._state._h
-        if tries > 1:
-            L.check(L.lib().moka_step_rk4(h, 0.0), backend._h)                  # allocates the RK buffers too; warm-up
-            backend.marks_reset(); backend.mark()
-            for _k in range(3):
-                L.check(L.lib().moka_step_rk4(h, 0.0), backend._h)
-                backend.mark()
-            ms = sorted(backend.marks_read())
-            times.append(ms[len(ms) // 2])
-        cands.append(P)
-        # stop early (after five at least: there are in-between kinds, 2 % slower than the best) only when the best two agree within
-        # 1 % AND a clearly slower one (3 % or more) has been seen: then the best are the fast kind.  (Two that merely agree can both be the slow kind: in some sessions most placements are.)
-        if len(times) >= 5 and sorted(times)[1] <= 1.01 * min(times) and max(times) >= 1.03 * min(times):
-            break
-    best = int(np.argmin(times)) if times else 0
-    for i, P in enumerate(cands):
-        if i != best:
-            P._state.close()
-    P = cands[best]
-    if tries > 1:      # dt = 0 steps leave normalVelocity / layerThickness as uploaded; ssh was recomputed from layerThickness: restore the caller's
-        P.ssh[-1].set(np.asarray(ssh, dtype=np.float64))
+def prognostic_vars_best_placement(ssh, normalVelocity, layerThickness, nTimeLevels, mesh: "Mesh", tries: int = 16, report: dict | None = None):
+    """PrognosticVars(...) followed by the library's own placement search (moka_state_optimize_placement, include/moka_hip.h):
+    where the allocator puts a state's arrays decides 5-14 % of every stage launch, so the library re-allocates
+    one array at a time -- at most `tries` times -- and keeps what makes the RK4 stage launches faster.  The state is, array for
+    array and flag for flag, what a fresh PrognosticVars(...) holds (round 3 did the search here, over whole candidate states, and
+    left the trial steps' traces in the kept one: ADVICE r03).  tries <= 1: no search."""
+    P = PrognosticVars(ssh, normalVelocity, layerThickness, nTimeLevels, mesh)
+    rep = P._state.optimize_placement(int(tries)) if int(tries) > 1 else {"tries": 0, "trials": [], "kept": 0}
     if report is not None:
-        report.update({"tries": len(cands), "ms_per_step_of_each": [float(t) for t in times], "chosen": best})
+        report.update(rep)
     return P
 
 

@@ -50,6 +50,10 @@ class MeshDesc(C.Structure):
     ]
 
 
+class PlacementTrial(C.Structure):     # moka_placement_trial
+    _fields_ = [("field", C.c_int32), ("ms_old", C.c_double), ("ms_new", C.c_double), ("kept", C.c_int32)]
+
+
 class MeshInfo(C.Structure):
     _fields_ = [
         ("nCells", C.c_int32), ("nEdges", C.c_int32), ("nVertices", C.c_int32), ("nVertLevels", C.c_int32),
@@ -87,6 +91,7 @@ EXPORTS = [
     "moka_mark", "moka_marks_reset", "moka_marks_read", "moka_bw_probe", "moka_bw_probe_streams", "moka_bw_probe_reread", "moka_bw_probe_gather_big", "moka_ctx_pci_bus_id", "moka_halo_set_acquire", "moka_set_tuning", "moka_get_tuning", "moka_rk4_dist_parts_available", "moka_adjoint_rk4_stage_part", "moka_adjoint_rk4_parts_available", "moka_adjoint_rk4_stage_out_fields",
     "moka_gradient_on_edge_vjp", "moka_gradient_on_edge_jvp", "moka_divergence_on_cell_vjp", "moka_divergence_on_cell_jvp",
     "moka_curl_on_vertex_vjp", "moka_curl_on_vertex_jvp", "moka_fe_lazy_pending",
+    "moka_state_optimize_placement", "moka_state_placement_log", "moka_state_download_rows",
 ]
 
 
@@ -149,6 +154,9 @@ def lib():
     L.moka_state_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.moka_state_destroy.argtypes = [vp]
     L.moka_state_destroy.restype = None
+    L.moka_state_optimize_placement.argtypes = [vp, C.c_int, _f64p, _f64p]
+    L.moka_state_placement_log.argtypes = [vp, C.c_int32, C.POINTER(PlacementTrial), _i32p]
+    L.moka_state_download_rows.argtypes = [vp, C.c_int, C.c_int, C.c_int64, _i32p, _f64p]
     L.moka_state_upload.argtypes = [vp, C.c_int, C.c_int, _f64p]
     L.moka_state_download.argtypes = [vp, C.c_int, C.c_int, _f64p]
     L.moka_advance_time_levels.argtypes = [vp, C.c_int]
@@ -244,6 +252,10 @@ def f64(a):
 
 def i32(a):
     return a.ctypes.data_as(_i32p)
+
+
+def i64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
 
 
 def make_desc(mesh, K, resting_thickness_sum=None, max_level_edge_top=None, ordering=ORDER_DEFAULT, patch_cells=0,

@@ -280,7 +280,7 @@ class DistributedModel:
 
     def __init__(self, mesh, ssh, u, h, rest, dt, backend, rank, world, ordering=0, patch_cells=0,
                  transport="nccl", part=None, group=None, state_bytes=8, exchange_lists=None, timeout_s=30.0, nonlinear=False,
-                 placement_tries=1,
+                 placement_tries=16,
                  visc_del2=0.0):
         """exchange_lists(wants: {rank: obj}) -> {rank: obj}: all-to-all of small Python objects between the ranks
         (default: torch.distributed.all_gather_object on `group`); LocalCluster passes None and calls finish() itself."""
@@ -311,8 +311,9 @@ class DistributedModel:
             desc.verticesOnEdge = None
         L.check(L.lib().moka_mesh_create(backend._h, C.byref(desc), C.byref(self.mesh._h)), backend._h)
         api._own(self.mesh, L.lib().moka_mesh_destroy, self.mesh._h, backend)
-        # placement_tries > 1: the rank's arrays in the fastest of a few placements (api.prognostic_vars_best_placement; before the
-        # halo exists: its peers address the buffers chosen here)
+        # placement_tries > 1 (default): the library's per-array placement search on this rank's state
+        # (moka_state_optimize_placement through api.prognostic_vars_best_placement) -- before the halo exists: its peers
+        # address the arrays chosen here, and the library refuses to move them afterwards
         self.placement = {}
         self.Prog = api.prognostic_vars_best_placement(np.asarray(ssh)[lm.cells_g], np.asarray(u).reshape(mesh.nEdges, K)[lm.edges_g],
                                                        np.asarray(h).reshape(mesh.nCells, K)[lm.cells_g], 2, self.mesh,
@@ -929,7 +930,7 @@ class LocalCluster:
     send and receive buffers, ordered by stream events only."""
 
     def __init__(self, mesh, ssh, u, h, rest, dt, world, device=0, ordering=0, patch_cells=0, state_bytes=8, direct=True,
-                 devices=None, overlap=-1, nonlinear=False, visc_del2=0.0, part=None):
+                 devices=None, overlap=-1, nonlinear=False, visc_del2=0.0, part=None, placement_tries=1):
         import torch
         self.torch, self.world = torch, world
         devs = list(devices) if devices is not None else [device] * world
@@ -937,7 +938,7 @@ class LocalCluster:
         part = partition_cells(mesh, world) if part is None else np.asarray(part, dtype=np.int32)
         self.models = [DistributedModel(mesh, ssh, u, h, rest, dt, self.backends[r], r, world, ordering=ordering,
                                         patch_cells=patch_cells, transport="local", part=part, state_bytes=state_bytes,
-                                        nonlinear=nonlinear, visc_del2=visc_del2)
+                                        nonlinear=nonlinear, visc_del2=visc_del2, placement_tries=placement_tries)
                        for r in range(world)]
         for r, m in enumerate(self.models):        # every rank learns the order its neighbours want their rows in
             m.finish({q: self.models[q]._wants[r] for q in m.lm.neighbors})

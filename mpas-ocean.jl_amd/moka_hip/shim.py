@@ -210,7 +210,9 @@ def ocn_setup_mesh(Config, backend: Backend) -> RefMesh:
 
 
 # ---- binding -----------------------------------------------------------------------------------------
-_MESHES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()      # const MESHES = WeakKeyDict{Any,DeviceMesh}() (+ close!)
+# const MESHES (MokaHIP.jl): by identity of the Mesh's arrays + backend, weakly.  Python objects hash by identity, so a
+# WeakKeyDictionary keyed by the RefMesh object is that (one device mesh per RefMesh object; a RefMesh names its backend)
+_MESHES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
 def _host(a):
@@ -258,6 +260,9 @@ def flush_host_writes(s: State):
         a.host_dirty, a.host_version = False, s.version
 
 
+PLACEMENT_TRIES = 16        # const PLACEMENT_TRIES = Ref{Cint}(16)
+
+
 def state_of(Prog: RefPrognosticVars, Diag, Tend, mesh: RefMesh, b: Backend) -> State:
     s = Prog.ssh[-1].state
     if s is None:
@@ -271,6 +276,9 @@ def state_of(Prog: RefPrognosticVars, Diag, Tend, mesh: RefMesh, b: Backend) -> 
             _bind(Prog.ssh[t], s, L.F_SSH, t, True)
             _bind(Prog.normalVelocity[t], s, L.F_NORMAL_VELOCITY, t, True)
             _bind(Prog.layerThickness[t], s, L.F_LAYER_THICKNESS, t, True)
+        # the library's own per-array placement search, at binding (MokaHIP.jl state_of: PLACEMENT_TRIES)
+        if PLACEMENT_TRIES > 1:
+            L.check(L.lib().moka_state_optimize_placement(h, PLACEMENT_TRIES, None, None), b._h)
     if Diag is not None and Diag.layerThicknessEdge.state is None:
         for a, f in ((Diag.layerThicknessEdge, L.F_LAYER_THICKNESS_EDGE), (Diag.thicknessFlux, L.F_THICKNESS_FLUX),
                      (Diag.velocityDivCell, L.F_VELOCITY_DIV_CELL), (Diag.relativeVorticity, L.F_RELATIVE_VORTICITY)):

@@ -409,3 +409,86 @@ class OracleNonlinear:
             st._nl_scratch = np.zeros(4 * K * m.nEdges + 2 * K * m.nVertices + 2 * K * m.nCells)
         lib().oracle_step_rk4_nonlinear_del2(self.om.ref, _p(self.voe), _p(self.cov), _p(self.kite), _p(self.fv),
                                              C.byref(st.c), float(dt), _p(st._work), _p(st._nl_scratch), self.visc_del2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Row-sampled oracle (test infrastructure): the tendencies / one RK stage at a few thousand SAMPLED cells and edges of a mesh too
+# large to run the whole oracle on, from the rows their stencils gather -- the same C loop nests (same slot order, same rounding
+# points) run on a SUB-MESH: the sampled entities plus everything their stencils name, renumbered, connectivity slot for slot.
+#   tendU[e] reads u of edgesOnEdge[:, e] and ssh (= column sum of h) of cellsOnEdge[:, e]      (K9 / K10)
+#   tendH[c] reads u of edgesOnCell[:, c] and h of both cells of each of those edges             (K5 / K7 / K8)
+# Entities of the closure that are not sampled keep whatever of their stencil lies inside it (anything else points at entity
+# 1): their results are garbage and are never looked at.
+# ---------------------------------------------------------------------------------------------------------------------
+class SubMesh:
+    """mesh: reference-convention arrays (1-based connectivity, 0 = none).  cells / edges: 0-based ids of the sampled entities."""
+
+    def __init__(self, mesh, cells, edges, K, resting_thickness_sum, max_level_edge_top=None):
+        import types
+        cells = np.unique(np.asarray(cells, dtype=np.int64))
+        edges = np.unique(np.asarray(edges, dtype=np.int64))
+        eoc = np.asarray(mesh.edgesOnCell)[cells].reshape(-1)
+        eoe = np.asarray(mesh.edgesOnEdge)[edges].reshape(-1)
+        E = np.unique(np.concatenate([edges, eoc[eoc > 0] - 1, eoe[eoe > 0] - 1]))          # closure, 0-based, sorted
+        ecell = eoc[eoc > 0] - 1
+        coe_s = np.asarray(mesh.cellsOnEdge)[edges].reshape(-1)
+        coe_c = np.asarray(mesh.cellsOnEdge)[ecell].reshape(-1)
+        Cc = np.unique(np.concatenate([cells, coe_s[coe_s > 0] - 1, coe_c[coe_c > 0] - 1]))
+        self.cells, self.edges = Cc, E                                   # closure ids (global, 0-based): rows to fetch
+        self.sample_cells = np.searchsorted(Cc, cells)                   # positions of the sampled entities inside the closure
+        self.sample_edges = np.searchsorted(E, edges)
+        self.sampled_cells_global, self.sampled_edges_global = cells, edges
+
+        def remap(conn, ids):              # 1-based global -> 1-based local; outside the closure -> 1 (results never read)
+            conn = np.asarray(conn, dtype=np.int64)
+            pos = np.searchsorted(ids, conn - 1)
+            pos = np.minimum(pos, ids.size - 1)
+            inside = (conn > 0) & (ids[pos] == conn - 1)
+            return np.where(conn > 0, np.where(inside, pos + 1, 1), 0).astype(np.int32)
+
+        m = types.SimpleNamespace()
+        m.nCells, m.nEdges, m.nVertices = int(Cc.size), int(E.size), 1
+        m.maxEdges, m.maxEdges2, m.vertexDegree = mesh.maxEdges, mesh.maxEdges2, mesh.vertexDegree
+        m.nEdgesOnCell = np.asarray(mesh.nEdgesOnCell)[Cc]
+        m.edgesOnCell = remap(np.asarray(mesh.edgesOnCell)[Cc], E)
+        m.edgeSignOnCell = np.asarray(mesh.edgeSignOnCell)[Cc]
+        m.areaCell = np.asarray(mesh.areaCell)[Cc]
+        m.cellsOnEdge = remap(np.asarray(mesh.cellsOnEdge)[E], Cc)
+        m.nEdgesOnEdge = np.asarray(mesh.nEdgesOnEdge)[E]
+        m.edgesOnEdge = remap(np.asarray(mesh.edgesOnEdge)[E], E)
+        # an edgesOnEdge slot that left the closure must not be skipped as "0 = none" would be, nor change the sampled sums: it
+        # only occurs on non-sampled edges (remap sends it to edge 1)
+        m.weightsOnEdge = np.asarray(mesh.weightsOnEdge)[E]
+        m.dvEdge, m.dcEdge, m.fEdge = (np.asarray(getattr(mesh, n))[E] for n in ("dvEdge", "dcEdge", "fEdge"))
+        m.edgesOnVertex = np.ones((1, mesh.vertexDegree), dtype=np.int32)
+        m.edgeSignOnVertex = np.ones((1, np.asarray(mesh.edgeSignOnVertex).shape[1]), dtype=np.int32)
+        m.areaTriangle = np.ones(1)
+        mlt = None if max_level_edge_top is None else (max_level_edge_top if np.isscalar(max_level_edge_top) else np.asarray(max_level_edge_top)[E])
+        self.K = int(K)
+        self.rsum = np.asarray(resting_thickness_sum, dtype=np.float64).reshape(-1)[Cc]
+        self.om = OracleMesh(m, K, resting_thickness_sum=self.rsum, max_level_edge_top=mlt)
+
+    def tendencies(self, u_rows, h_rows, mixed=False):
+        """u_rows (len(self.edges), K), h_rows (len(self.cells), K): the closure's rows of the provisional state.  Returns the
+        UNROUNDED fp64 tendencies at the sampled edges / cells (what a fused stage update consumes) and the stored ssh of the
+        sampled cells' columns."""
+        dt = np.float32 if mixed else np.float64
+        u, h = _c(_c(u_rows, dt), np.float64), _c(_c(h_rows, dt), np.float64)
+        tu, th = np.zeros_like(u), np.zeros_like(h)
+        ssh = np.zeros(self.cells.size)
+        s1, s2 = np.zeros_like(u), np.zeros_like(u)
+        fn = lib().oracle_tendencies_mixed if mixed else lib().oracle_tendencies_clean
+        fn(self.om.ref, _p(tu), _p(th), _p(u), _p(h), _p(ssh), _p(s1), _p(s2))
+        return tu[self.sample_edges], th[self.sample_cells], ssh[self.sample_cells]
+
+    def rk_stage(self, pu_rows, ph_rows, cur_u, cur_h, new_u, new_h, a, b, mixed=False):
+        """One fused RK4 stage (time_integration.jl:124-125,134-135) at the sampled entities: tendency of the provisional state
+        (closure rows pu_rows / ph_rows), Provis' = Curr + a * t, New' = New + b * t (cur_* / new_*: rows of the SAMPLED
+        entities), each rounded to storage when `mixed`; ssh' = column sum of the stored Provis' thickness - restingThicknessSum.
+        Returns (pu', ph', ssh', nu', nh')."""
+        tu, th, _ = self.tendencies(pu_rows, ph_rows, mixed)
+        rnd = (lambda x: x.astype(np.float32).astype(np.float64)) if mixed else (lambda x: x)
+        pu2, ph2 = rnd(cur_u + a * tu), rnd(cur_h + a * th)
+        nu2, nh2 = rnd(new_u + b * tu), rnd(new_h + b * th)
+        ssh2 = rnd(np.array([ksum(col) for col in ph2]) - self.rsum[self.sample_cells])
+        return pu2, ph2, ssh2, nu2, nh2

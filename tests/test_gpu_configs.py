@@ -11,6 +11,7 @@ C ABI, against the CPU oracle:
   stand-alone operators: tendU = -g grad(ssh) has the gradient norms, tendH = -div(u hEdge) the divergence norms
   (test/ocn/test_Operators.jl:52-53, 72-73).
 """
+import ctypes as C
 import datetime as dt
 import json
 import os
@@ -234,11 +235,67 @@ def test_config5_full_size_properties(backend):
     tot = (mesh.areaCell[:, None] * th).sum(0)
     scale = (mesh.areaCell[:, None] * np.abs(th)).sum(0)
     assert np.all(np.abs(tot) <= 6e-8 * scale)
-    # (b) a sample of whole columns against the storage-emulating oracle would need the full oracle run (minutes);
-    #     the same kernel is compared bit for bit at m = 32 / 64 above.  Here: the stored state widens exactly
+    # (b) the stored state widens exactly
     f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
     assert np.array_equal(Prog.layerThickness[-1].get(), f32(h))
     del th, tot, scale
+    # (b') BIT-LEVEL check at this size: the row-sampled oracle (oracle.SubMesh, cross-checked against the full
+    #     oracle in tests/test_oracle_operators.py) evaluates ~10 000 sampled cells and as many edges from the rows their
+    #     stencils gather -- the same C loop nests, the same rounding points -- for the tendency launch and for each of the
+    #     four stage launches of an RK4 step (kernel modes 0, 1, 2, 2, 3), every stage from the rows the GPU itself produced.
+    #     The sample: the first and the last patch of the library's order, the twelve pentagons and their edges, the finest
+    #     and the coarsest cells, edge rows beyond byte offset 2^31 of the 3.55 GB normalVelocity field, and random ones.
+    rng = np.random.default_rng(608)
+    lib, ctx, hS = L.lib(), backend._h, Prog._state._h
+    cperm = np.empty(mesh.nCells, dtype=np.int32); eperm = np.empty(mesh.nEdges, dtype=np.int32)
+    L.check(lib.moka_mesh_permutation(Setup.mesh._h, L.CELL, L.i32(cperm)), ctx)
+    L.check(lib.moka_mesh_permutation(Setup.mesh._h, L.EDGE, L.i32(eperm)), ctx)
+    pent = np.flatnonzero(mesh.nEdgesOnCell == 5)
+    by_area = np.argsort(mesh.areaCell)
+    far = np.arange(int(2**31 // (K * 4)) + 1, mesh.nEdges)          # library rows whose byte offset needs the 32nd bit
+    assert far.size > 10**6
+    s_cells = np.unique(np.concatenate([cperm[:48], cperm[-48:], pent, by_area[:300], by_area[-300:], rng.integers(0, mesh.nCells, 9000)]))
+    pe = mesh.edgesOnCell[pent].reshape(-1)
+    s_edges = np.unique(np.concatenate([eperm[:150], eperm[-150:], pe[pe > 0] - 1, eperm[rng.choice(far, 3000, replace=False)],
+                                        mesh.edgesOnCell[by_area[:100]].reshape(-1) - 1, rng.integers(0, mesh.nEdges, 6000)]))
+    sm = orc.SubMesh(mesh, s_cells, s_edges, K, rest.sum(1), max_level_edge_top=K)
+    sc, se, ccl, ecl = sm.sampled_cells_global, sm.sampled_edges_global, sm.cells, sm.edges
+    U, H, S = Prog.normalVelocity[-1], Prog.layerThickness[-1], Prog.ssh[-1]
+    # tendency launch (mode 0): accumulated in fp64, stored fp32
+    tu, th_s, _ = sm.tendencies(U.rows(ecl), H.rows(ccl), mixed=True)
+    assert np.array_equal(Tend.tendNormalVelocity.rows(se), f32(tu)), "tendNormalVelocity rows at 3.7 M x 80"
+    assert np.array_equal(Tend.tendLayerThickness.rows(sc), f32(th_s)), "tendLayerThickness rows at 3.7 M x 80"
+    # the four stage launches, one by one (the piecewise form of moka_step_rk4: a halo object without neighbours)
+    z64 = np.zeros(1, dtype=np.int64)
+    hh_ = C.c_void_p()
+    info = Setup.mesh.info()
+    L.check(lib.moka_halo_create(hS, 0, None, L.i64(z64), None, L.i64(z64), None, L.i64(z64), None, L.i64(z64), 0, info["nPatches"],
+                                 C.byref(hh_)), ctx)
+    a_s, b_s = (dts / 2., dts / 2., dts, 0.0), (dts / 6., dts / 3., dts / 3., dts / 6.)
+    L.check(lib.moka_rk4_dist_begin(hh_, dts), ctx)
+    cur_u, cur_h = U.rows(se), H.rows(sc)                         # Curr at the sampled entities (level 1 until the step ends)
+    new_u, new_h = cur_u.copy(), cur_h.copy()                     # the New accumulator starts from Curr (stage 1 aliases them)
+    pu_cl, ph_cl = U.rows(ecl), H.rows(ccl)                       # provisional state of stage 1 = Curr, on the closure
+    for s_ in range(1, 5):
+        L.check(lib.moka_rk4_dist_stage(hh_, s_, 2), ctx)
+        pu2, ph2, ssh2, nu2, nh2 = sm.rk_stage(pu_cl, ph_cl, cur_u, cur_h, new_u, new_h, a_s[s_ - 1], b_s[s_ - 1], mixed=True)
+        # New accumulator = the previous level's buffers (level 0) while the step is open
+        assert np.array_equal(Prog.normalVelocity[0].rows(se), nu2), f"New normalVelocity after stage {s_}"
+        assert np.array_equal(Prog.layerThickness[0].rows(sc), nh2), f"New layerThickness after stage {s_}"
+        new_u, new_h = nu2, nh2
+        if s_ < 4:
+            lvl = 3 if s_ == 2 else 2                             # stage 1, 3 -> provisional state R1 (level 2), stage 2 -> R2 (level 3)
+            assert np.array_equal(U.rows(se, level=lvl), pu2), f"provisional normalVelocity after stage {s_}"
+            assert np.array_equal(H.rows(sc, level=lvl), ph2), f"provisional layerThickness after stage {s_}"
+            assert np.array_equal(S.rows(sc, level=lvl), ssh2), f"provisional ssh after stage {s_}"
+            pu_cl, ph_cl = U.rows(ecl, level=lvl), H.rows(ccl, level=lvl)
+        else:                                                     # stage 4 leaves ssh of the new state
+            exp_ssh = f32(np.array([orc.ksum(col) for col in nh2]) - rest.sum(1)[sc])
+            assert np.array_equal(Prog.ssh[0].rows(sc), exp_ssh), "ssh of the new level"
+    L.check(lib.moka_rk4_dist_end(hh_), ctx)
+    lib.moka_halo_destroy(hh_)
+    assert np.array_equal(U.rows(se), new_u) and np.array_equal(H.rows(sc), new_h)     # the levels have swapped: New is current
+    del sm, pu_cl, ph_cl
     tu = Tend.tendNormalVelocity.get()
     assert np.all(np.isfinite(tu))
     del tu

@@ -1291,27 +1291,69 @@ def test_nonlinear_keeps_williamson_tc2_steady_on_the_gpu(backend):
     assert np.isfinite(drift[True]) and drift[True] < 0.25 * drift[False], drift
 
 
-def test_best_placement_leaves_the_state_as_uploaded(backend):
-    """mk.prognostic_vars_best_placement: several candidate placements of the state's arrays, three dt = 0 RK4 steps timed on each, the fastest
-    kept -- the state it returns holds exactly what was uploaded (an ssh that is NOT the column sum of layerThickness included), and steps from
-    it equal the oracle's bit for bit."""
+@pytest.mark.parametrize("sbytes,K", [(8, 60), (4, 80)])
+def test_optimize_placement_through_the_c_abi(backend, sbytes, K):
+    """moka_state_optimize_placement (include/moka_hip.h): arrays of the state are re-allocated one at a time where that makes the
+    RK4 stage launches faster.  Whatever it does, the state is the state: every array of Prog (BOTH time levels, an ssh that is not
+    the column sum of layerThickness included), Diag and Tend reads back bit for bit as before the call, in the middle of a
+    Forward-Euler run with lazily pending arrays too; the reference's stale-thickness steps (which carry layerThicknessEdge
+    and the previous level across steps) and RK4 steps that follow equal the oracle's; ms_after <= ms_before; and once a tape
+    or a halo holds the arrays' addresses the call refuses (round 3's search lived in Python, over whole candidate
+    states, and left the traces of its trial steps in the state it kept)."""
     mesh = get_mesh("ico16")
-    K = 60
-    ssh, u, h, rest = random_state(mesh, K, 5)
+    ssh, u, h, rest = random_state(mesh, K, 11)
     ssh = ssh + 0.125                                   # inconsistent with layerThickness on purpose: the caller's array must survive
-    hm = mk.HorzMesh(mesh)
-    vm = mk.VerticalMesh(hm, nVertLevels=K, restingThickness=rest, multilayer=True)
-    M = mk.Mesh(hm, vm, backend=backend)
-    rep = {}
-    Prog = mk.prognostic_vars_best_placement(ssh, u, h, 2, M, tries=4, report=rep)
-    assert rep["tries"] == 4 and len(rep["ms_per_step_of_each"]) == rep["tries"] and 0 <= rep["chosen"] < rep["tries"]
-    assert np.array_equal(Prog.ssh[-1].get(), ssh) and np.array_equal(Prog.normalVelocity[-1].get(), u)
-    assert np.array_equal(Prog.layerThickness[-1].get(), h)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True, state_bytes=sbytes)
+    rng = np.random.default_rng(5)
+    r32 = (lambda x: x.astype(np.float32).astype(np.float64)) if sbytes == 4 else (lambda x: x)
+    ssh0, u0, h0 = r32(ssh - 0.25), r32(u + 0.5 * rng.uniform(-1, 1, u.shape)), r32(h + 0.125)      # a previous level of its own
+    Prog.ssh[0].set(ssh0); Prog.normalVelocity[0].set(u0); Prog.layerThickness[0].set(h0)
+    he = r32(1000.0 / K + rng.uniform(-1, 1, (mesh.nEdges, K)))
+    Diag.layerThicknessEdge.set(he)
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
-    st = orc.OracleState(om, ssh, u, h)
-    mk.run_steps(Prog, mk.RungeKutta4, 20.0, 2)
+    st = orc.OracleState(om, ssh, u, h, mixed=sbytes == 4)
+    st.ssh[0][:] = ssh0; st.u[0][:] = u0; st.h[0][:] = h0; st.hEdge[:] = he
+    lib, hS = L.lib(), Prog._state._h
+
+    def prog_fields():
+        return {k: v for k, v in all_fields(Prog, Diag, Tend).items() if k in ("ssh0", "ssh1", "u0", "u1", "h0", "h1")}
+
+    before = all_fields(Prog, Diag, Tend)
+    rep = Prog._state.optimize_placement(6)
+    assert rep["tries"] <= 6 and rep["ms_after"] <= rep["ms_before"] and rep["ms_before"] > 0.0
+    assert all(t["field"] in mk.api._State.FIELD_NAMES and (t["ms_new"] < t["ms_old"]) >= t["kept"] for t in rep["trials"])
+    after = all_fields(Prog, Diag, Tend)
+    for k in before:
+        assert np.array_equal(before[k], after[k]), k
+    # the reference's live step, carrying layerThicknessEdge and the previous level across steps: three steps, then once more
+    # in the middle of the run (the arrays of the last lean step are pending when the call comes)
+    for _ in range(3):
+        L.check(lib.moka_step_fe(hS, 20.0, 3), backend._h)
+        st.step_fe(20.0, 3)
+    assert lib.moka_fe_lazy_pending(hS) == 1
+    rep2 = Prog._state.optimize_placement(4)
+    assert rep2["ms_after"] <= rep2["ms_before"]
     for _ in range(2):
-        st.step_rk4(20.0)
-    assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.layerThickness[-1].get(), st.h[1])
-    assert np.array_equal(Prog.ssh[-1].get(), st.ssh[1])
-    Prog._state.close(); M.close()
+        L.check(lib.moka_step_fe(hS, 20.0, 3), backend._h)
+        st.step_fe(20.0, 3)
+    got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    # RK4 steps from here, and a third call between them (the stage-4 tendencies of the step before are pending then)
+    mk.run_steps(Prog, mk.RungeKutta4, 20.0, 1); st.step_rk4(20.0)
+    Prog._state.optimize_placement(3)
+    mk.run_steps(Prog, mk.RungeKutta4, 20.0, 2); st.step_rk4(20.0); st.step_rk4(20.0)
+    got, exp = prog_fields(), oracle_fields(st)
+    for k in got:
+        assert np.array_equal(got[k], exp[k]), k
+    if sbytes == 8:
+        assert np.array_equal(Tend.tendNormalVelocity.get(), st.tendU) and np.array_equal(Tend.tendLayerThickness.get(), st.tendH)
+        tape = mk.AdjointTape(Prog, 2)                   # holds the arrays' addresses: the state stays where it is from now on
+        with pytest.raises(mk.MokaError) as ei:
+            Prog._state.optimize_placement(2)
+        assert ei.value.code == L.ERR_UNSUPPORTED
+        tape.close()
+        Prog._state.optimize_placement(1)               # ... and may move again once the tape is gone
+    Prog._state.close(); Setup.mesh.close()
+
+

@@ -200,3 +200,44 @@ def test_operator_transposes_satisfy_the_adjoint_identity():
     om.curl_on_vertex_vjp(d_v, d_c)
     assert np.array_equal(d_c, yv)
     assert rel(np.vdot(om.curl_on_vertex(xe), yv), np.vdot(xe, d_v)) < 1e-12
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_row_sampled_oracle_equals_the_full_oracle(mixed):
+    """oracle.SubMesh (the row-sampled oracle the full-size config-5 check uses): tendencies and one fused RK stage at sampled
+    cells / edges, evaluated on the sub-mesh of their stencils, equal the full oracle's rows bit for bit -- stretched sphere
+    (every cell shape, the twelve pentagons included), partial maxLevelEdgeTop, fp64 and fp32-storage forms."""
+    mesh = meshgen.icosahedral_mesh(20, stretch=4.47)
+    K = 8
+    rng = np.random.default_rng(41)
+    rest = np.full((mesh.nCells, K), 4000.0 / K)
+    u = 0.1 * rng.uniform(-1, 1, (mesh.nEdges, K))
+    h = rest + 0.3 * rng.uniform(-1, 1, (mesh.nCells, K))
+    mlt = rng.integers(1, K + 1, mesh.nEdges).astype(np.int32)
+    mlt[rng.random(mesh.nEdges) < 0.6] = K
+    rnd = (lambda x: x.astype(np.float32).astype(np.float64)) if mixed else (lambda x: x)
+    u, h = rnd(u), rnd(h)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=mlt)
+    pent = np.flatnonzero(mesh.nEdgesOnCell == 5)
+    cells = np.unique(np.concatenate([pent, rng.integers(0, mesh.nCells, 60), [0, mesh.nCells - 1]]))
+    edges = np.unique(np.concatenate([mesh.edgesOnCell[pent].reshape(-1)[mesh.edgesOnCell[pent].reshape(-1) > 0] - 1,
+                                      rng.integers(0, mesh.nEdges, 100), [0, mesh.nEdges - 1]]))
+    sm = orc.SubMesh(mesh, cells, edges, K, rest.sum(1), max_level_edge_top=mlt)
+    assert sm.cells.size < mesh.nCells // 2 and sm.edges.size < mesh.nEdges // 2          # a sub-mesh, not the mesh
+    # full oracle: unrounded tendencies of the whole mesh (the python wrapper rounds the mixed ones: call the C function)
+    tu, th = np.zeros_like(u), np.zeros_like(h)
+    ssh = np.zeros(mesh.nCells)
+    s1, s2 = np.zeros_like(u), np.zeros_like(u)
+    fn = orc.lib().oracle_tendencies_mixed if mixed else orc.lib().oracle_tendencies_clean
+    fn(om.ref, orc._p(tu), orc._p(th), orc._p(u), orc._p(h), orc._p(ssh), orc._p(s1), orc._p(s2))
+    stu, sth, sssh = sm.tendencies(u[sm.edges], h[sm.cells], mixed)
+    assert np.array_equal(stu, tu[edges]) and np.array_equal(sth, th[cells]) and np.array_equal(sssh, ssh[cells])
+    # one fused stage from those
+    a, b = 7.5, 2.5
+    cu, ch = rnd(u + 0.01), rnd(h - 0.02)
+    nu, nh = rnd(u - 0.03), rnd(h + 0.04)
+    pu2, ph2, ssh2, nu2, nh2 = sm.rk_stage(u[sm.edges], h[sm.cells], cu[edges], ch[cells], nu[edges], nh[cells], a, b, mixed)
+    assert np.array_equal(pu2, rnd(cu + a * tu)[edges]) and np.array_equal(ph2, rnd(ch + a * th)[cells])
+    assert np.array_equal(nu2, rnd(nu + b * tu)[edges]) and np.array_equal(nh2, rnd(nh + b * th)[cells])
+    full_ph2 = rnd(ch + a * th)
+    assert np.array_equal(ssh2, rnd(om.update_ssh(full_ph2))[cells])

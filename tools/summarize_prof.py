@@ -60,8 +60,10 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
     for leg_name, bl, pat in legs:
         stage = [(n, d) for _, n, d in seq if re.match(pat, n)]
         w, k = bl["warmup"], bl["steps"]
-        # in front of the warm-up: the placement trials of the set-up (one warm-up + three timed dt = 0 steps per candidate: 16 launches each)
-        skip = 16 * len(bl.get("placement", {}).get("ms_per_step_of_each", []))
+        # in front of the warm-up: the placement search of the set-up (moka_state_optimize_placement: one untimed + five timed dt = 0
+        # steps for the baseline and per trial: 24 launches each)
+        pl = bl.get("placement", {})
+        skip = 24 * (1 + pl.get("tries", 0)) if pl.get("ms_before") else 0
         timed = stage[skip + 4 * w:skip + 4 * (w + k)]
         print(f"== {leg_name} ==")
         if len(timed) == 4 * k:
