@@ -6,16 +6,34 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_set>
 #include <utility>
 #include <vector>
+
+#include <mutex>
+#include <unordered_set>
 
 #include "state.hpp"
 
 namespace moka { void fill_mesh_info(const Plan &p, moka_mesh_info *info); }
 
 namespace mk {
+
+static std::mutex g_liveMutex;
+static std::unordered_set<const moka_state *> g_liveStates;
+void state_attach(moka_state *st)
+{
+    std::lock_guard<std::mutex> lk(g_liveMutex);
+    if (g_liveStates.count(st)) ++st->attached;
+}
+void state_detach(moka_state *st)
+{
+    std::lock_guard<std::mutex> lk(g_liveMutex);
+    if (g_liveStates.count(st)) --st->attached;
+}
 
 int fail(moka_ctx *ctx, int code, const std::string &msg)
 {
@@ -1131,6 +1149,10 @@ int moka_state_create(moka_ctx *ctx, moka_mesh *mesh, moka_state **out)
     if (rc != MOKA_OK) { moka_state_destroy(st); return rc; }
     st->phys[0] = st->lev[0]; st->phys[1] = st->lev[1];
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        std::lock_guard<std::mutex> lk(g_liveMutex);
+        g_liveStates.insert(st);
+    }
     *out = st;
     return MOKA_OK;
 }
@@ -1138,6 +1160,10 @@ int moka_state_create(moka_ctx *ctx, moka_mesh *mesh, moka_state **out)
 void moka_state_destroy(moka_state *st)
 {
     if (!st) return;
+    {
+        std::lock_guard<std::mutex> lk(g_liveMutex);
+        g_liveStates.erase(st);
+    }
     (void)hipSetDevice(st->ctx->device);
     (void)hipStreamSynchronize(st->ctx->stream);
     for (void *q : st->allocs) (void)hipFree(q);
@@ -1696,7 +1722,7 @@ int moka_tape_create(moka_state *st, int64_t capacity_steps, moka_tape **out)
     }
     if (rc != MOKA_OK) { moka_tape_destroy(t); return rc; }
     HIPCHK(st->ctx, hipStreamSynchronize(st->ctx->stream));
-    ++st->attached;
+    state_attach(st);
     t->counted = true;
     *out = t;
     return MOKA_OK;
@@ -1705,7 +1731,7 @@ int moka_tape_create(moka_state *st, int64_t capacity_steps, moka_tape **out)
 void moka_tape_destroy(moka_tape *t)
 {
     if (!t) return;
-    if (t->counted) --t->st->attached;
+    if (t->counted) state_detach(t->st);
     (void)hipSetDevice(t->st->ctx->device);
     if (t->st->lazyOwner == t) {        // the stage-4 tendencies of the last taped step would be produced from a slot of this tape
         if (t->st->tendDirty) (void)flush_lazy(t->st, false, true);

@@ -401,7 +401,7 @@ int moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCell
         moka_halo_destroy(h);
         return fail(st->ctx, MOKA_ERR_HIP, "hipEventCreate failed");
     }
-    ++st->attached;
+    state_attach(st);
     h->counted = true;
     *out = h;
     return MOKA_OK;
@@ -410,7 +410,7 @@ int moka_halo_create(moka_state *st, int32_t nNeighbors, const int32_t *sendCell
 void moka_halo_destroy(moka_halo *h)
 {
     if (!h) return;
-    if (h->counted) --h->st->attached;
+    if (h->counted) state_detach(h->st);
     (void)hipSetDevice(h->st->ctx->device);
     (void)hipStreamSynchronize(h->st->ctx->stream);
     (void)hipStreamSynchronize(h->st->ctx->comm);

@@ -116,6 +116,10 @@ namespace mk {
 using namespace moka;
 
 int fail(moka_ctx *ctx, int code, const std::string &msg);
+// Halos and tapes count themselves in moka_state.attached while they hold the state's addresses.  Handles may be destroyed in
+// any order (garbage-collected callers: a state can go before its tape), so the count is only touched while the state is alive.
+void state_attach(moka_state *st);
+void state_detach(moka_state *st);
 
 #define HIPCHK(ctx, call)                                                                          \
     do {                                                                                           \

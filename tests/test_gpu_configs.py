@@ -256,8 +256,9 @@ def test_config5_full_size_properties(backend):
     assert far.size > 10**6
     s_cells = np.unique(np.concatenate([cperm[:48], cperm[-48:], pent, by_area[:300], by_area[-300:], rng.integers(0, mesh.nCells, 9000)]))
     pe = mesh.edgesOnCell[pent].reshape(-1)
+    fe_ = mesh.edgesOnCell[by_area[:100]].reshape(-1)
     s_edges = np.unique(np.concatenate([eperm[:150], eperm[-150:], pe[pe > 0] - 1, eperm[rng.choice(far, 3000, replace=False)],
-                                        mesh.edgesOnCell[by_area[:100]].reshape(-1) - 1, rng.integers(0, mesh.nEdges, 6000)]))
+                                        fe_[fe_ > 0] - 1, rng.integers(0, mesh.nEdges, 6000)]))
     sm = orc.SubMesh(mesh, s_cells, s_edges, K, rest.sum(1), max_level_edge_top=K)
     sc, se, ccl, ecl = sm.sampled_cells_global, sm.sampled_edges_global, sm.cells, sm.edges
     U, H, S = Prog.normalVelocity[-1], Prog.layerThickness[-1], Prog.ssh[-1]
