@@ -398,6 +398,36 @@ def stage_rooflines(backend, step, nrec, stream_bytes, b_mesh, modes=(1, 2, 2, 3
     return per_stage, nst, sum(ms4)
 
 
+def rk4_13_stream_entry(mk, backend, step, steps, warmup, nCK, stream_bytes, b_mesh, b_step):
+    """Second RK4 entry of the line: the opt-in 13-stream form (moka_set_tuning key 7; Float64 states on
+    whole meshes).  NOT the reference's round-off (tests bound it: <= 1e-12 relative per step), so it is reported beside the
+    headline, never as it: ms per step, the metric, `frac` on the contract bytes (the judge's formula) and on ITS OWN minimum
+    bytes (13 state streams: 2 / 3 / 3 / 5), per stage."""
+    from moka_hip import lib as _L
+    _L.check(_L.lib().moka_set_tuning(7, 1))
+    try:
+        wall, ms = timed_steps(backend, step, steps, warmup, backend.synchronize)
+        st = step_stats(ms)
+        backend.stage_timing(True)
+        for _ in range(min(steps, 10)):
+            step()
+        ms4, nst = backend.stage_timing_read()
+        backend.stage_timing(False)
+    finally:
+        _L.check(_L.lib().moka_set_tuning(7, 0))
+    step()                                   # (back in the reference's form: the buffer roles settle again)
+    streams = (2, 3, 3, 5)
+    own = sum(streams) * stream_bytes + 4 * b_mesh
+    t = st["median"] * 1e-3
+    return {"ms_per_step": st["median"], "step_ms": st, "value": nCK / t, "unit": "cell-updates/s",
+            "frac_contract_bytes": b_step / t / 1e9 / HBM_PEAK_GBS, "own_minimum_bytes": own, "frac_own_minimum_bytes": own / t / 1e9 / HBM_PEAK_GBS,
+            "per_stage": [{"stage": i + 1, "kernel_mode": (7, 8, 8, 9)[i], "ms": ms4[i], "state_streams": streams[i],
+                           "frac_own_bytes": (streams[i] * stream_bytes + b_mesh) / (ms4[i] * 1e-3) / 1e9 / HBM_PEAK_GBS} for i in range(4)],
+            "note": "moka_set_tuning(7, 1): stages 1-3 store only the provisional states, stage 4 forms New = C + ((P2 - C) + 2 (P3 - C) + "
+                    "(P4 - C)) / 3 + dt/6 k4 from own rows; same Runge-Kutta step, other round-off than the reference's running sum "
+                    "(time_integration.jl:134-135): opt-in, default off"}
+
+
 def single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, iters):
     """The pure tendency launch (north_star's 40 % target is quoted on it) and the reference's live integrator."""
     out = {}
@@ -771,6 +801,11 @@ def main():
 
     if world == 1:
         out.update(single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, args.tend_iters))
+        if sbytes == 8:
+            try:
+                out["rk4_13_streams"] = rk4_13_stream_entry(mk, backend, step, args.steps, args.warmup, mesh.nCells * K, stream_bytes, b_mesh, b_step)
+            except Exception as exc:             # noqa: BLE001
+                out["rk4_13_streams"] = {"error": f"{type(exc).__name__}: {exc}"}
         # clock and power while the launches run (after every timed region of this workload)
         out["under_load"] = {"rk4_steps": under_load(backend, step, 1.0, 10),
                              "tendency_launches": under_load(backend, lambda: mk.computeTendency(Setup.mesh, Diag, Prog, Tend), 0.6, 20),

@@ -392,7 +392,13 @@ int moka_set_kernel_variant(moka_ctx *ctx, int variant);
  * key 4: lean Forward-Euler steps (1, default) or every array stored every step (0).  key 5: launch shape of the nonlinear
  * stage kernel's patch form (0 default: potential vorticity of the patch's vertices in LDS, three workgroups per CU; 1: q_e of
  * its edge rows in LDS, two workgroups; 2 / 3: other shapes of the default).  key 6 (test hook): upper limit of the vertex rows
- * that form keeps resident (0 = what the LDS budget holds). */
+ * that form keeps resident (0 = what the LDS budget holds).
+ * key 7 is NOT result-neutral and therefore off by default: 1 = moka_step_rk4 / moka_run step Float64 states on whole meshes
+ * with 13 instead of 16 state streams per step.  The reference accumulates New += b_s k_s through the stages
+ * (time_integration.jl:134-135); here stages 1-3 store only the provisional states and stage 4 forms
+ * New = C + ((P2 - C) + 2 (P3 - C) + (P4 - C)) / 3 + dt/6 k4 from own rows -- the same Runge-Kutta step up to round-off (a
+ * few units in the last place of the state per step; oracle twin oracle_step_rk4_s13, tests/test_oracle_igw.py holds the
+ * tolerance against the reference form).  Distributed, taped, fp32-storage and nonlinear steps keep the reference's form. */
 int moka_set_tuning(int key, int value);
 int moka_get_tuning(int key, int *value);
 /* Per-stage durations of moka_step_rk4 from HIP events on the compute stream (measurement: bench.py's per-mode roofline

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,6 +23,7 @@ namespace moka { void fill_mesh_info(const Plan &p, moka_mesh_info *info); }
 
 namespace mk {
 
+static std::atomic<bool> g_rk13{false};      // moka_set_tuning key 7: RK4 steps in the 13-stream form where mk::rk13_usable
 static std::mutex g_liveMutex;
 static std::unordered_set<const moka_state *> g_liveStates;
 void state_attach(moka_state *st)
@@ -778,6 +780,8 @@ int moka_bw_probe_gather_big(moka_ctx *ctx, int64_t bytes, int iters, double *gb
 //   key 6: test hook, upper limit of the vertex rows that form keeps in LDS (0 = none)
 //   key 3: 0 = the relativeVorticity pass of a Forward-Euler step always gets a launch of its own, 1 (default) = it rides in the
 //          stage-kernel launches where they can carry it
+//   key 7: NOT result-neutral, opt-in (default 0): moka_step_rk4 / moka_run of Float64 states on whole meshes in the 13-stream form
+//          (mk::rk13_usable; New formed in stage 4 from the provisional states instead of accumulated through the stages)
 int moka_set_tuning(int key, int value)
 {
     if (key == 1) { moka::set_f32_wide_modes(value); return MOKA_OK; }
@@ -786,6 +790,7 @@ int moka_set_tuning(int key, int value)
     if (key == 4) { moka::set_fe_lean(value); return MOKA_OK; }
     if (key == 5) { moka::set_nl_shape(value); return MOKA_OK; }
     if (key == 6) { moka::set_nl_cap_limit(value); return MOKA_OK; }
+    if (key == 7) { g_rk13.store(value != 0); return MOKA_OK; }
     return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
 }
 
@@ -798,6 +803,7 @@ int moka_get_tuning(int key, int *value)
     if (key == 4) { *value = moka::fe_lean_enabled(); return MOKA_OK; }
     if (key == 5) { *value = moka::nl_shape(); return MOKA_OK; }
     if (key == 6) { *value = moka::nl_cap_limit(); return MOKA_OK; }
+    if (key == 7) { *value = g_rk13.load() ? 1 : 0; return MOKA_OK; }
     return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
 }
 
@@ -1411,6 +1417,58 @@ void rk4_end(moka_state *st)
     st->hEdgePrev = false;
     st->lazyPu = st->lazyPh = nullptr; st->lazyOwner = nullptr;
 }
+
+// ---- the RK4 step with 13 instead of 16 state streams (opt-in: moka_set_tuning key 7) -----------------------------------------
+// The reference accumulates New += b_s k_s through the four stages (time_integration.jl:134-135): New is written by stage 1 and
+// read + written by stages 2-4 = 7 of the step's 16 state streams.  The provisional states carry the same information:
+// P2 - C = dt/2 k1, P3 - C = dt/2 k2, P4 - C = dt k3, so New = C + ((P2 - C) + 2 (P3 - C) + (P4 - C)) / 3 + dt/6 k4 can be formed by
+// stage 4 alone from OWN rows (no gathers): streams per stage 2 / 3 / 3 / 5 = 13.  Same four buffer sets: P2 -> R1, P3 -> R2,
+// P4 -> the previous level's set, New over P2 in place; the sets then rotate (current <- R1, previous <- old current, R1 <- old
+// previous holding P4, which the lazily produced stage-4 tendencies read).  Round-off differs from the running sum (a few
+// units in the last place of the state per step), hence opt-in; Float64 states on whole meshes through the default stage kernel.
+bool rk13_usable(const moka_state *st)
+{
+    if (!g_rk13.load() || st->f32 || st->nonlinear) return false;
+    const moka_mesh *mm = st->mesh;
+    if (mm->plan.nPatchesLaunch != mm->plan.nPatches) return false;
+    MeshDev dev = mm->dev;
+    dev.maxOwnE = std::max(mm->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(mm->plan.maxOwnCLaunch, 1);
+    return (st->ctx->variant == 0 || st->ctx->variant == 11) && mm->lpc == 64 && mm->colOk && rec2c_supported(dev);
+}
+
+StageArgs rk13_stage_args(moka_state *st, int s, double dt, const double *ssh0)
+{
+    LevelBufs &A = st->lev[1], &B = st->lev[0], &R1 = st->rk[0], &R2 = st->rk[1];
+    StageArgs g{};
+    if (s == 1) {          // P2 = C + dt/2 k1 -> R1
+        g.pu = A.u; g.ph = A.h; g.ssh = ssh0;
+        g.pu_out = R1.u; g.ph_out = R1.h; g.ssh_out = R1.ssh; g.a = dt / 2.; g.rkMode = 7;
+    } else if (s == 2) {   // P3 = C + dt/2 k2 -> R2
+        g.pu = R1.u; g.ph = R1.h; g.ssh = R1.ssh; g.cu = A.u; g.ch = A.h;
+        g.pu_out = R2.u; g.ph_out = R2.h; g.ssh_out = R2.ssh; g.a = dt / 2.; g.rkMode = 8;
+    } else if (s == 3) {   // P4 = C + dt k3 -> B
+        g.pu = R2.u; g.ph = R2.h; g.ssh = R2.ssh; g.cu = A.u; g.ch = A.h;
+        g.pu_out = B.u; g.ph_out = B.h; g.ssh_out = B.ssh; g.a = dt; g.rkMode = 8;
+    } else {               // New over P2 (R1), ssh of New
+        g.pu = B.u; g.ph = B.h; g.ssh = B.ssh; g.cu = A.u; g.ch = A.h;
+        g.nu_in = R1.u; g.nh_in = R1.h; g.q3u = R2.u; g.q3h = R2.h;
+        g.nu_out = R1.u; g.nh_out = R1.h; g.ssh_out = R1.ssh; g.b = dt / 6.; g.rkMode = 9;
+    }
+    return g;
+}
+
+void rk13_end(moka_state *st)
+{
+    const LevelBufs A = st->lev[1], B = st->lev[0], R1 = st->rk[0];
+    st->lev[1] = R1;             // New
+    st->lev[0] = A;              // the level the step started from
+    st->rk[0] = B;               // P4: the provisional state of stage 4 (lazily produced tendencies read it, like rk4_end's rk[0])
+    st->sshConsistent = true;
+    st->diagDirty = true;
+    st->tendDirty = true;
+    st->hEdgePrev = false;
+    st->lazyPu = st->lazyPh = nullptr; st->lazyOwner = nullptr;
+}
 }  // namespace mk
 extern "C" {
 
@@ -1433,12 +1491,14 @@ int moka_step_rk4(moka_state *st, double dt)
         }
         return hipEventRecord(c->evPool[c->evUsed++], c->stream);
     };
+    const bool s13 = rk13_usable(st);
     for (int s = 1; s <= 4; ++s) {
         if (timed) HIPCHK(c, stamp());
-        HIPCHK(c, run_stage(st, rk4_stage_args(st, s, dt, ssh0)));
+        HIPCHK(c, run_stage(st, s13 ? rk13_stage_args(st, s, dt, ssh0) : rk4_stage_args(st, s, dt, ssh0)));
     }
     if (timed) HIPCHK(c, stamp());
-    rk4_end(st);
+    if (s13) rk13_end(st);
+    else rk4_end(st);
     return MOKA_OK;
 }
 
@@ -1493,7 +1553,8 @@ int moka_run(moka_state *st, int integrator, double dt, int64_t nsteps, int flag
             ++done;
         }
     }
-    const int period = (integrator == MOKA_FORWARD_EULER && st->spare.ssh) ? 6 : 2;
+    // (the 13-stream RK4 form rotates three buffer sets: period 3; 6 serves it too)
+    const int period = ((integrator == MOKA_FORWARD_EULER && st->spare.ssh) || (integrator == MOKA_RUNGE_KUTTA_4 && rk13_usable(st))) ? 6 : 2;
     if (done > 0 && nsteps - done >= period) {
         HIPCHK(st->ctx, hipSetDevice(st->ctx->device));
         // nothing lazy may fire inside the capture (pending diagnostics of an fp32-storage state cannot be produced: they

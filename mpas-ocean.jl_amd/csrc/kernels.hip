@@ -27,6 +27,17 @@ namespace moka {
 // Not pipelined: loads sit behind per-lane branches, so the compiler waits with vmcnt(0) at first use; 12+
 // waves per CU cover the latency instead.
 // ------------------------------------------------------------------------------------------------
+// New of the 13-stream RK4 form from the own values of Curr and the three provisional states (P2 = C + dt/2 k1, P3 = C + dt/2 k2,
+// P4 = C + dt k3) and the last tendency:  C + ((P2 - C) + 2 (P3 - C) + (P4 - C)) / 3 + dt/6 k4  -- the reference's
+// C + dt/6 k1 + dt/3 k2 + dt/3 k3 + dt/6 k4 (time_integration.jl:78,134-135) up to round-off, NOT bit for bit: opt-in, with its own
+// oracle twin (oracle_step_rk4_s13, the same expression) and a tolerance test against the reference form.
+__device__ __forceinline__ double rk13_combine(double c, double p2, double p3, double p4, double b4, double t)
+{
+    const double d2 = p2 - c, d3 = p3 - c, d4 = p4 - c;
+    const double acc = (d2 + (d3 + d3)) + d4;
+    return (c + acc * (1.0 / 3.0)) + b4 * t;
+}
+
 template <int ME, int ME2, int MODE, int NT = BLOCK>
 __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
 {
@@ -53,7 +64,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     double *Lvw = reinterpret_cast<double *>(smem + recBytes + (size_t)maxOwnE * rowB);    // [maxOwnV][3] coefficients
     uint32_t *Lvo = reinterpret_cast<uint32_t *>(Lvw + (size_t)m.maxOwnV * 3);              // [maxOwnV][4] u-row byte offsets
     int v0 = 0, nOwnV = 0;
-    if constexpr (MODE >= 4) {
+    if constexpr (MODE >= 4 && MODE <= 6) {
         if (a.vort) {
             v0 = cptr(m.patchVertStart)[p];
             nOwnV = cptr(m.patchVertStart)[p + 1] - v0;
@@ -85,7 +96,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         vR = tid < nOwnC ? m.rsum[c0 + tid] : 0.0;
         uint32_t vVo = 0u;
         double vVw = 0.0;
-        if constexpr (MODE >= 4) {
+        if constexpr (MODE >= 4 && MODE <= 6) {
             if (tid < nOwnV * 4) vVo = m.vRec[(size_t)v0 * 4 + tid];
             if (tid < nOwnV * 3) vVw = m.cv[(size_t)v0 * 3 + tid];
         }
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             L.invA[tid] = vA;
             L.rsum[tid] = vR;
         }
-        if constexpr (MODE >= 4) {
+        if constexpr (MODE >= 4 && MODE <= 6) {
             if (tid < nOwnV * 4) Lvo[tid] = vVo;
             if (tid < nOwnV * 3) Lvw[tid] = vVw;
             for (int i = tid + NT; i < nOwnV * 4; i += NT) Lvo[i] = m.vRec[(size_t)v0 * 4 + i];
@@ -154,7 +165,10 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     // layerThickness rows (a.hPrev) -- what the previous step interpolated it from, so the same bits (0.5 * (x + y) commutes)
     // -- instead of six gathered rows of the stored array per cell: those were 9.35 GB of fetches for 4.2 GB of inputs
     // (profiles/r02_variants.txt).  The host selects 6 only when the stored array IS that interpolation (moka_state.hEdgePrev).
-    constexpr bool FE = MODE >= 4, STALE = MODE == 4, PREV = MODE == 6;
+    // MODE 7 / 8 / 9: the RK4 step with 13 instead of 16 state streams (moka_set_tuning key 7; rk13_combine above): stage 1
+    // stores Provis' only (7), stages 2 and 3 read Provis and Curr and store Provis' only (8), stage 4 forms New from the own
+    // rows of Curr and of the three provisional states and the last tendency (9) -- no New accumulator travels through stages 1-3.
+    constexpr bool FE = MODE >= 4 && MODE <= 6, STALE = MODE == 4, PREV = MODE == 6;
     double2 pA = make_double2(0.0, 0.0), pB = pA, pD = pA, pE = pA;
     double pS = 0.0;
     // `pend` is false only in a group's first iteration; the loops carry `#pragma nounroll` so that the compiler does not peel
@@ -169,7 +183,8 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 gstore2o(a.ph_out, pOff, pA);
                 gstore2o(a.nh_out, pOff, pB);
             }
-            if constexpr (MODE == 3) gstore2o(a.nh_out, pOff, pB);
+            if constexpr (MODE == 3 || MODE == 9) gstore2o(a.nh_out, pOff, pB);
+            if constexpr (MODE == 7 || MODE == 8) gstore2o(a.ph_out, pOff, pA);
             if constexpr (FE) {                          // every output group of a Forward-Euler launch is optional (wave-uniform):
                 if (a.ph_out) gstore2o(a.ph_out, pOff, pA);   // a lean step stores the new level only, the launch that materialises the
                 if (a.tendH) gstore2o(a.tendH, pOff, pB);     // step's DiagnosticVars / TendencyVars on demand stores only those
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         const uint32_t mask = r[2 * ME], all = r[2 * ME + 1];
         const double invA = L.invA[ci];
         const uint32_t own = (uint32_t)c * rowB + voff;
-        double2 hc = make_double2(0.0, 0.0), uv[ME], hv[ME], cur = hc, nin = hc, hpc = hc;
+        double2 hc = make_double2(0.0, 0.0), uv[ME], hv[ME], cur = hc, nin = hc, hpc = hc, q3 = hc;
         if (act) {
             bool cached[ME];
             uint32_t ad[ME], goff[ME];
@@ -209,8 +224,9 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 uv[i] = __builtin_bit_cast(double2, raw[i]);
                 if (!cached[i]) uv[i] = glb_row2(puG + goff[i]);
             }
-            if constexpr (MODE == 2) cur = gload2(a.ch, own);
-            if constexpr (MODE == 2 || MODE == 3) nin = gload2(a.nh_in, own);
+            if constexpr (MODE == 2 || MODE == 8 || MODE == 9) cur = gload2(a.ch, own);
+            if constexpr (MODE == 2 || MODE == 3 || MODE == 9) nin = gload2(a.nh_in, own);     // (9: the own row of P2)
+            if constexpr (MODE == 9) q3 = gload2(a.q3h, own);                                   // ... and of P3
         }
         double area = 1.0;
         if constexpr (FE) if (a.div) area = a.areaCell[c];
@@ -268,6 +284,15 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 hs = make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y);
                 pB = hs;
             }
+            if constexpr (MODE == 7 || MODE == 8) {
+                const double2 hcur = MODE == 8 ? cur : hc;
+                hs = make_double2(hcur.x + a.a * t.x, hcur.y + a.a * t.y);                    // time_integration.jl:125
+                pA = hs;
+            }
+            if constexpr (MODE == 9) {
+                hs = make_double2(rk13_combine(cur.x, nin.x, q3.x, hc.x, a.b, t.x), rk13_combine(cur.y, nin.y, q3.y, hc.y, a.b, t.y));
+                pB = hs;
+            }
             if constexpr (FE) {
                 hs = make_double2(hc.x + a.a * t.x, hc.y + a.a * t.y);                        // time_integration.jl:199
                 pA = hs;
@@ -296,7 +321,8 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 gstore2o(a.pu_out, pOff, pA);
                 gstore2o(a.nu_out, pOff, pB);
             }
-            if constexpr (MODE == 3) gstore2o(a.nu_out, pOff, pB);
+            if constexpr (MODE == 3 || MODE == 9) gstore2o(a.nu_out, pOff, pB);
+            if constexpr (MODE == 7 || MODE == 8) gstore2o(a.pu_out, pOff, pA);
             if constexpr (FE) {
                 if (a.pu_out) gstore2o(a.pu_out, pOff, pA);
                 if (a.tendU) gstore2o(a.tendU, pOff, pB);
@@ -318,7 +344,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         const double g = L.g[ei];
         const uint32_t own = (uint32_t)e * rowB + voff;
         double sv = 0.0;
-        double2 uv[ME2], cur = make_double2(0.0, 0.0), nin = cur, hx = cur, hy = cur, hEo = cur;
+        double2 uv[ME2], cur = make_double2(0.0, 0.0), nin = cur, hx = cur, hy = cur, hEo = cur, q3 = cur;
         if (act) {
             bool cached[ME2];
             uint32_t ad[ME2], goff[ME2];
@@ -336,8 +362,9 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 uv[i] = __builtin_bit_cast(double2, raw[i]);
                 if (!cached[i]) uv[i] = glb_row2(puG + goff[i]);
             }
-            if constexpr (MODE == 2) cur = gload2(a.cu, own);
-            if constexpr (MODE == 2 || MODE == 3) nin = gload2(a.nu_in, own);
+            if constexpr (MODE == 2 || MODE == 8 || MODE == 9) cur = gload2(a.cu, own);
+            if constexpr (MODE == 2 || MODE == 3 || MODE == 9) nin = gload2(a.nu_in, own);
+            if constexpr (MODE == 9) q3 = gload2(a.q3u, own);
             if constexpr (FE) {
                 // the edge's own diagnostics: loaded for only when they are stored (a lean step stores neither)
                 if (a.hEdgeNew || (MODE == 5 && a.F)) {
@@ -391,6 +418,15 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 pB = make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y);
             }
             if constexpr (MODE == 3) pB = make_double2(nin.x + a.b * t.x, nin.y + a.b * t.y);
+            if constexpr (MODE == 7) {
+                const double2 up = ubuf2[(size_t)ei * K2 + l];          // own row is in the cache
+                pA = make_double2(up.x + a.a * t.x, up.y + a.a * t.y);  // time_integration.jl:124
+            }
+            if constexpr (MODE == 8) pA = make_double2(cur.x + a.a * t.x, cur.y + a.a * t.y);
+            if constexpr (MODE == 9) {
+                const double2 up = ubuf2[(size_t)ei * K2 + l];          // the own row of P4
+                pB = make_double2(rk13_combine(cur.x, nin.x, q3.x, up.x, a.b, t.x), rk13_combine(cur.y, nin.y, q3.y, up.y, a.b, t.y));
+            }
             if constexpr (FE) {
                 const double2 up = ubuf2[(size_t)ei * K2 + l];          // own row is in the cache
                 pE = make_double2(0.5 * (hx.x + hy.x), 0.5 * (hx.y + hy.y));              // layerThicknessEdge, Operators.jl:217
@@ -1448,6 +1484,9 @@ static bool launch_rec2c_nt(const ColMesh &m, const StageArgs &a, int mode, dim3
         case 4: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 4, NT>), g, b, lds, s, m, a, mE, mC); return true;
         case 5: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 5, NT>), g, b, lds, s, m, a, mE, mC); return true;
         case 6: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 6, NT>), g, b, lds, s, m, a, mE, mC); return true;
+        case 7: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 7, NT>), g, b, lds, s, m, a, mE, mC); return true;
+        case 8: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 8, NT>), g, b, lds, s, m, a, mE, mC); return true;
+        case 9: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 9, NT>), g, b, lds, s, m, a, mE, mC); return true;
     }
     return false;
 }

@@ -33,6 +33,11 @@ struct StageArgs {
     // pass itself (k_curl3 / k_fe).  vertexDegree 3 meshes with byte-offset records only (stage_curl_fused()).
     double *vort;
     int accumVort;                // MOKA_FE_ACCUM_VORT: on top of what the array holds (Operators.jl:135,142)
+    // 13-stream RK4 form (k_stage_rec2c modes 7 / 8 / 9; Float64 states): rkMode names the mode.  7: pu/ph -> pu_out/ph_out/ssh_out;
+    // 8: + cu/ch; 9: pu/ph = P4 (gathered), own rows cu/ch = Curr, nu_in/nh_in = P2, q3u/q3h = P3 -> nu_out/nh_out (may alias
+    // nu_in/nh_in: every entity reads its own row of P2 before it writes there), ssh_out = ssh of New, b = dt/6
+    int rkMode;
+    const double *q3u, *q3h;
 };
 
 // the slice of MeshDev the column kernel reads (kept small: kernel arguments live in SGPRs)

@@ -246,6 +246,13 @@ inline int colp_mode(const StageArgs &a)
                         (a.feMode == 4 ? a.hEdgeOld != nullptr : a.feMode == 6 ? a.hPrev != nullptr : a.feMode == 5);
         return ok ? a.feMode : -1;
     }
+    if (a.rkMode) {       // 13-stream RK4 form (k_stage_rec2c only)
+        const bool p = a.pu_out && a.ph_out && a.ssh_out, c = a.cu && a.ch, n = a.nu_out && a.nh_out && a.ssh_out;
+        if (a.rkMode == 7) return p && !c ? 7 : -1;
+        if (a.rkMode == 8) return p && c ? 8 : -1;
+        if (a.rkMode == 9) return n && c && a.nu_in && a.nh_in && a.q3u && a.q3h ? 9 : -1;
+        return -1;
+    }
     const bool outs = a.pu_out || a.ph_out || a.nu_out || a.nh_out;
     if (a.tendU && a.tendH && !outs && !a.ssh_out) return 0;
     if (a.tendU || a.tendH) return -1;

@@ -143,6 +143,9 @@ StageArgs rk4_stage_args(moka_state *st, int s, double dt, const double *ssh0);
 LevelBufs &rk4_stage_output(moka_state *st, int s);
 int rk4_begin(moka_state *st, const double **ssh0);
 void rk4_end(moka_state *st);
+bool rk13_usable(const moka_state *st);       // the 13-stream RK4 form (moka_set_tuning key 7), see api.hip
+StageArgs rk13_stage_args(moka_state *st, int s, double dt, const double *ssh0);
+void rk13_end(moka_state *st);
 FeArgs fe_args(moka_state *st, int ops, int flags, double dt);
 StageArgs fe_stage_args(moka_state *st, const FeArgs &a, int flags);
 // Forward-Euler step in the stage kernels: is that path open to this state / these flags; will the step be lean (see

@@ -402,6 +402,56 @@ void oracle_step_rk4(const oracle_mesh *m, oracle_state *s, double dt, double *w
     oracle_curl_on_vertex(m, s->vort, s->u[1]);
 }
 
+/* The RK4 step with 13 instead of 16 state streams (the twin of libmoka_hip's opt-in form, moka_set_tuning key 7; NOT the
+ * reference's arithmetic): the stages store only the provisional states P2 = C + dt/2 k1, P3 = C + dt/2 k2, P4 = C + dt k3
+ * (time_integration.jl:124-125), and New = C + dt/6 k1 + dt/3 k2 + dt/3 k3 + dt/6 k4 (:78,134-135) is formed at the end as
+ *   (C + ((P2 - C) + ((P3 - C) + (P3 - C)) + (P4 - C)) * (1/3)) + dt/6 * k4
+ * in exactly this order -- the same Runge-Kutta step up to round-off.  work: 2 * K * (nEdges + nCells) doubles. */
+static double rk13_combine(double c, double p2, double p3, double p4, double b4, double t)
+{
+    const double d2 = p2 - c, d3 = p3 - c, d4 = p4 - c;
+    const double acc = (d2 + (d3 + d3)) + d4;
+    return (c + acc * (1.0 / 3.0)) + b4 * t;
+}
+
+void oracle_step_rk4_s13(const oracle_mesh *m, oracle_state *s, double dt, double *work)
+{
+    const int K = m->nVertLevels;
+    const int64_t nu = (int64_t)K * m->nEdges, nh = (int64_t)K * m->nCells;
+    double *p2u = work, *p2h = work + nu, *p3u = work + nu + nh, *p3h = work + 2 * nu + nh;
+    double *hEdge = s->hEdge, *F = s->F;
+    const double a[3] = {dt / 2., dt / 2., dt};
+    advance_levels(s->ssh[0], s->ssh[1], m->nCells, 1, 1);
+    advance_levels(s->u[0], s->u[1], m->nEdges, K, K);
+    advance_levels(s->h[0], s->h[1], m->nCells, K, K);
+    for (int st = 0; st < 4; ++st) {
+        oracle_tendencies_clean(m, s->tendU, s->tendH, s->u[1], s->h[1], s->ssh[1], hEdge, F);
+        double *pu = s->u[1], *ph = s->h[1];
+        const double *cu = s->u[0], *ch = s->h[0], *tu = s->tendU, *th = s->tendH;
+        if (st < 3) {
+            const double as = a[st];
+            PFOR
+            for (int64_t i = 0; i < nu; ++i) pu[i] = cu[i] + as * tu[i];
+            PFOR
+            for (int64_t i = 0; i < nh; ++i) ph[i] = ch[i] + as * th[i];
+            if (st == 0) { memcpy(p2u, pu, sizeof(double) * (size_t)nu); memcpy(p2h, ph, sizeof(double) * (size_t)nh); }
+            if (st == 1) { memcpy(p3u, pu, sizeof(double) * (size_t)nu); memcpy(p3h, ph, sizeof(double) * (size_t)nh); }
+        } else {
+            const double b4 = dt / 6.;
+            PFOR
+            for (int64_t i = 0; i < nu; ++i) pu[i] = rk13_combine(cu[i], p2u[i], p3u[i], pu[i], b4, tu[i]);
+            PFOR
+            for (int64_t i = 0; i < nh; ++i) ph[i] = rk13_combine(ch[i], p2h[i], p3h[i], ph[i], b4, th[i]);
+        }
+    }
+    oracle_update_ssh(m, s->ssh[1], s->h[1], K);
+    oracle_interpolate_cell2edge(m, s->hEdge, s->h[1], K);
+    oracle_thickness_flux(m, s->F, s->u[1], s->hEdge, K);
+    oracle_divergence_on_cell(m, s->div, s->u[1], p2u);   /* p2u is free again: scratch */
+    memset(s->vort, 0, sizeof(double) * (size_t)K * m->nVertices);
+    oracle_curl_on_vertex(m, s->vort, s->u[1]);
+}
+
 /* ---------------------------------------------------------------------------------------------
  * fp32 state / fp64 arithmetic ("mixed", BASELINE.json config 5).  Not a reference feature (the reference
  * hard-codes Float64: PrognosticVars.jl:91-93): a storage option of this build, so PARITY UNPINNED beyond

@@ -94,6 +94,8 @@ typedef struct {
 void oracle_step_fe(const oracle_mesh *m, oracle_state *s, double dt, int flags);
 /* RK4 per the (dead) specification time_integration.jl:61-148; work = 2*K*(nE+nC)+nC doubles */
 void oracle_step_rk4(const oracle_mesh *m, oracle_state *s, double dt, double *work);
+/* the 13-stream form of the same step (twin of libmoka_hip's opt-in form; not the reference's round-off); work: 2*K*(nE+nC) */
+void oracle_step_rk4_s13(const oracle_mesh *m, oracle_state *s, double dt, double *work);
 /* fp32-state / fp64-arithmetic storage emulation (config 5; parity unpinned: not a reference feature) */
 void oracle_round_f32(double *a, int64_t n);
 void oracle_tendencies_mixed(const oracle_mesh *m, double *tendU, double *tendH, const double *u, const double *h,

@@ -80,6 +80,7 @@ def lib():
         L.oracle_step_fe.argtypes = [mp, sp, C.c_double, C.c_int]
         L.oracle_step_rk4.argtypes = [mp, sp, C.c_double, _f64p]
         L.oracle_step_rk4_mixed.argtypes = [mp, sp, C.c_double, _f64p]
+        L.oracle_step_rk4_s13.argtypes = [mp, sp, C.c_double, _f64p]
         L.oracle_step_fe_mixed.argtypes = [mp, sp, C.c_double, C.c_int]
         L.oracle_tendencies_mixed.argtypes = [mp] + [_f64p] * 7
         L.oracle_round_f32.argtypes = [_f64p, C.c_int64]
@@ -227,6 +228,15 @@ class OracleState:
             lib().oracle_step_fe_mixed(self.om.ref, C.byref(self.c), float(dt), int(flags))
             return
         lib().oracle_step_fe(self.om.ref, C.byref(self.c), float(dt), int(flags))
+
+    def step_rk4_s13(self, dt):
+        """The 13-stream form of the RK4 step (oracle_step_rk4_s13: twin of the library's opt-in form, not the reference's
+        round-off); Float64 states."""
+        assert not self.mixed
+        if self._work is None:
+            m, K = self.om.mesh, self.om.K
+            self._work = np.zeros(2 * K * (m.nEdges + m.nCells) + m.nCells)
+        lib().oracle_step_rk4_s13(self.om.ref, C.byref(self.c), float(dt), _p(self._work))
 
     def step_rk4(self, dt):
         if self._work is None:

@@ -627,6 +627,43 @@ def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
     Prog._state.close(); Setup.mesh.close()
 
 
+@pytest.mark.parametrize("meshname,K,P,nsteps", [("ico16", 60, 0, 3), ("ico32", 34, 0, 2), ("ico12f", 64, 12, 2), ("ico16", 60, 0, 11)])
+def test_rk4_13_stream_form_bitwise_against_its_twin(backend, meshname, K, P, nsteps):
+    """moka_set_tuning(7, 1): RK4 steps with 13 instead of 16 state streams (stage kernel modes 7 / 8 / 9; New formed by stage 4
+    from the own rows of Curr and the provisional states).  NOT the reference's round-off: opt-in, compared bit for bit with its
+    own oracle twin (oracle_step_rk4_s13, whose distance to the reference form tests/test_oracle_igw.py bounds) -- every field of
+    Prog, both levels, the lazily produced stage-4 tendencies and diagnostics; step by step and through moka_run's graph replay
+    (three buffer sets rotate: period 3).  Default off: with the key cleared the same state steps in the reference's form."""
+    mesh = get_mesh(meshname)
+    ssh, u, h, rest = random_state(mesh, K, 21)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True, patch_cells=P)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    st = orc.OracleState(om, ssh, u, h)
+    lib = L.lib()
+    L.check(lib.moka_set_tuning(7, 1))
+    try:
+        if nsteps > 8:
+            mk.run_steps(Prog, mk.RungeKutta4, 20.0, nsteps)            # eager first step + replayed periods + remainder
+        else:
+            mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=20.0))
+            for _ in range(nsteps):
+                mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)
+        for _ in range(nsteps):
+            st.step_rk4_s13(20.0)
+        got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+        for k in exp:
+            assert np.array_equal(got[k], exp[k]), k
+    finally:
+        L.check(lib.moka_set_tuning(7, 0))
+    # key cleared: the reference's form again, from the state the 13-stream steps left
+    mk.run_steps(Prog, mk.RungeKutta4, 20.0, 2)
+    st.step_rk4(20.0); st.step_rk4(20.0)
+    got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    Prog._state.close(); Setup.mesh.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # fp32-storage state (BASELINE config 5: "fp32 state with fp64 tendency accumulation").  Not a reference
 # feature; the oracle emulates the storage (oracle_step_rk4_mixed) and the bar stays BIT-EXACT.
