@@ -377,11 +377,9 @@ int  moka_fe_dist_step(moka_halo *h, double dt, int flags, moka_transport_fn tra
 
 /* kernel variant selection for measurement (all variants give identical results): 0 = auto [default: 11 when the mesh
  * allows it (even 34 <= nVertLevels <= 64), else 4 (nVertLevels >= 33), else 3]; 11 = record-staged, 16-byte lanes, two
- * entities per wave, own u rows cached in LDS; 4 = plain column kernel; 3 = generic index kernel.
- * The design points measured in round 1 (1 pipelined column, 5/6 16-byte-lane column, 7/8 record-staged without the row
- * cache, 2 LDS patch-tiled, 9 tiled two-burst prefetch, 10 persistent double-buffered tile) and of round 2 (12/13 every row
- * of a patch staged in LDS by LDS-DMA, 256 / 512 threads) are experiments: they are only
- * in a library built with `make VARIANTS=1`; moka_set_kernel_variant returns MOKA_ERR_UNSUPPORTED for them otherwise. */
+ * entities per wave, own u rows cached in LDS; 4 = plain column kernel; 3 = generic index kernel.  The other design points
+ * measured in rounds 1-3 (1, 2, 5-10, 12-14) lost and were removed in round 4 (their numbers: profiles/r0*_variants.txt);
+ * moka_set_kernel_variant returns MOKA_ERR_UNSUPPORTED for them. */
 int moka_kernel_variant_available(int variant);
 int moka_set_kernel_variant(moka_ctx *ctx, int variant);
 /* Process-wide launch-shape switches for A/B measurements (every setting gives identical results).  key 1: bit mask of the

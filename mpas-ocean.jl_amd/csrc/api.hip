@@ -246,7 +246,6 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
     MeshDev dev = m->dev;                 // the launch covers patches [pBegin, pBegin + pCount) (+ the patch `tail`)
     dev.tailPatch = -1;
     hipStream_t s = on ? on : st->ctx->stream;
-    if (tail >= 0 && st->ctx->variant >= 12) tail = -2;   // (no tail patches since round 2)
     if (tail >= 0) {
         // One extra, non-adjacent patch in the same launch: only the default kernels can carry it.  Anything else
         // (explicit variants, fallbacks for other K, the nonlinear path) gets a launch of its own for it.
@@ -310,51 +309,13 @@ hipError_t run_stage(moka_state *st, const StageArgs &g_in, int pBegin, int pCou
     }
     const int v = st->ctx->variant;
     // 0 = auto: rec2c (even 34 <= K <= 64, patches whose records + own rows fit the LDS), else the plain column kernel (K >= 33),
-    // else the generic index kernel.  11 rec2c, 4 column, 3 generic.  Built with VARIANTS=1 only (csrc/experiments):
-    // 8 rec2, 7 rec, 1 pipelined column, 5/6 16-byte-lane column, 2 LDS-tiled, 9 tile, 10 ptile, 12/13 tile3 (LDS-DMA).
-#ifdef MOKA_VARIANTS
-    if (v == 2 && m->ldsBytes > 0) return launch_stage_lds(dev, g, m->ldsBytes, s);
-    if (v == 10 && m->ptileOk) {           // persistent double-buffered tiled kernel (needs patch_cells <= ~14)
-        hipError_t e = launch_stage_ptile(dev, g, st->ctx->nCUs, s);
-        if (e != hipErrorNotSupported) return e;
-    }
-    if (v == 9 && m->tileOk) {             // tiled: u rows + records in LDS (needs patch_cells <= 16)
-        hipError_t e = launch_stage_tile(dev, g, s);
-        if (e != hipErrorNotSupported) return e;
-    }
-#endif
-#ifdef MOKA_VARIANTS
-    if (v == 14 && m->lpc == 64 && m->colOk) {               // persistent double-buffered LDS-DMA tile
-        hipError_t e = launch_stage_ptile2(dev, g, st->ctx->nCUs, s);
-        if (e != hipErrorNotSupported) return e;
-    }
-    if ((v == 12 || v == 13) && m->lpc == 64 && m->colOk) {  // every row of a patch staged in LDS by LDS-DMA (256 / 512 threads)
-        hipError_t e = launch_stage_tile3(dev, g, v == 13 ? 512 : 256, s);
-        if (e != hipErrorNotSupported) return e;
-    }
-#endif
+    // else the generic index kernel.  11 rec2c, 4 column, 3 generic.  (The other execution shapes measured in rounds 1-3 -- pipelined
+    // and 16-byte-lane column kernels, LDS-tiled and LDS-DMA forms, persistent double-buffered tiles -- lost and are gone; their
+    // numbers are in profiles/r01_variants.txt ... r03_variants.txt.)
     if ((v == 0 || v == 11) && m->lpc == 64 && m->colOk) {   // default: 16-byte lanes + own-edge u rows cached in LDS
         hipError_t e = launch_stage_rec2c(dev, g, s);
         if (e != hipErrorNotSupported) return e;
     }
-#ifdef MOKA_VARIANTS
-    if (v == 8 && m->lpc == 64 && m->colOk) {
-        hipError_t e = launch_stage_rec2(dev, g, s);
-        if (e != hipErrorNotSupported) return e;
-    }
-    if (v == 7 && m->lpc == 64 && m->colOk) {
-        hipError_t e = launch_stage_rec(dev, g, s);
-        if (e != hipErrorNotSupported) return e;
-    }
-    if ((v == 5 || v == 6) && m->lpc == 64 && m->colOk) {
-        hipError_t e = launch_stage_colx(dev, g, v == 6, s);
-        if (e != hipErrorNotSupported) return e;
-    }
-    if (v == 1 && m->lpc == 64 && m->colOk) {
-        hipError_t e = launch_stage_colp(dev, g, s);
-        if (e != hipErrorNotSupported) return e;
-    }
-#endif
     if (v != 3 && m->lpc == 64 && m->colOk) return launch_stage_col(dev, g, s);
     return launch_stage(dev, g, m->lpc, s);
 }
@@ -809,11 +770,7 @@ int moka_get_tuning(int key, int *value)
 
 int moka_kernel_variant_available(int variant)
 {
-#ifdef MOKA_VARIANTS
-    return variant >= 0 && variant <= 14;
-#else
     return variant == 0 || variant == 3 || variant == 4 || variant == 11;
-#endif
 }
 
 int moka_set_kernel_variant(moka_ctx *ctx, int variant)
@@ -821,7 +778,7 @@ int moka_set_kernel_variant(moka_ctx *ctx, int variant)
     if (!ctx) return fail(nullptr, MOKA_ERR_ARG, "ctx is NULL");
     if (variant < 0 || variant > 14) return fail(ctx, MOKA_ERR_ARG, "variant must be 0..14");
     if (!moka_kernel_variant_available(variant))
-        return fail(ctx, MOKA_ERR_UNSUPPORTED, "this kernel variant is an experiment: build the library with `make VARIANTS=1`");
+        return fail(ctx, MOKA_ERR_UNSUPPORTED, "this kernel variant was an experiment of rounds 1-3 and no longer exists (0, 3, 4, 11 do)");
     ctx->variant = variant;
     return MOKA_OK;
 }
@@ -877,35 +834,10 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     d.CI = p.CI; d.EI = p.EI;
     m->colOk = p.colOk;
     d.tileRecOk = 0;
-#ifdef MOKA_VARIANTS
-    if (!p.eRecT.empty()) {        // persistent tiled kernel: the loader keeps a bounded number of row indices per lane
-        const int rpp = 1024 / (p.K * 8);
-        int worst = 0;
-        for (int q = 0; q < p.nPatches; ++q) {
-            const int rows = p.rowStart[q + 1] - p.rowStart[q], own = p.patchEdgeStart[q + 1] - p.patchEdgeStart[q];
-            worst = std::max(worst, (rows + rpp - 1) / rpp - own / rpp);
-        }
-        d.tileRecOk = worst <= stage_ptile2_halo_piece_budget() ? 1 : 0;
-    }
-#endif
 
     d.maxRows = p.maxRows; d.maxOwnE = p.maxOwnE; d.maxOwnC = p.maxOwnC;
     d.maxOwnV = p.maxOwnV;
     if (p.vRec.empty()) d.vRec = nullptr;       // (upload_vec hands out a dummy allocation for an empty vector)
-#ifdef MOKA_VARIANTS
-    if (p.colOk && stage_tile_usable(d, p.ldsOk) && prepare_stage_tile(d) == hipSuccess) m->tileOk = true;
-    if (p.colOk && stage_ptile_usable(d, p.ldsOk) && prepare_stage_ptile(d) == hipSuccess) m->ptileOk = true;
-    if (p.ldsOk && p.K % 2 == 0 && p.K >= 8) {
-        const int64_t need = lds_stage_bytes(p.K, p.ME, p.ME2, p.maxRows, p.maxOwnE, p.maxOwnC);
-        if (need <= 160 * 1024) {
-            if (hipError_t e = prepare_stage_lds((size_t)need); e != hipSuccess) {
-                moka_mesh_destroy(m);
-                return fail(ctx, MOKA_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
-            }
-            m->ldsBytes = (size_t)need;
-        }
-    }
-#endif
     *out = m;
     return MOKA_OK;
 }

@@ -108,28 +108,6 @@ hipError_t launch_permute_rows_f32(void *dst, const void *src, const int32_t *n2
                                    hipStream_t s);
 hipError_t launch_halo_map_f32(float *buf, float *h, float *ssh, float *u, const uint32_t *map, int64_t n, int unpack,
                                hipStream_t s);
-#ifdef MOKA_VARIANTS
-// experiments (csrc/experiments/stage_variants.hip, `make VARIANTS=1`): the measured design points of round 1
-bool stage_ptile_usable(const MeshDev &md, bool ldsOk);
-hipError_t prepare_stage_ptile(const MeshDev &md);
-hipError_t launch_stage_ptile(const MeshDev &m, const StageArgs &a, int nCUs, hipStream_t s);
-bool stage_tile_usable(const MeshDev &md, bool ldsOk);
-hipError_t prepare_stage_tile(const MeshDev &md);
-hipError_t launch_stage_tile(const MeshDev &m, const StageArgs &a, hipStream_t s);
-hipError_t launch_stage_rec2(const MeshDev &m, const StageArgs &a, hipStream_t s);
-hipError_t launch_stage_rec(const MeshDev &m, const StageArgs &a, hipStream_t s);
-hipError_t launch_stage_colx(const MeshDev &m, const StageArgs &a, bool pipelined, hipStream_t s);
-hipError_t launch_stage_colp(const MeshDev &m, const StageArgs &a, hipStream_t s);
-hipError_t launch_stage_lds(const MeshDev &m, const StageArgs &a, size_t ldsBytes, hipStream_t s);
-hipError_t prepare_stage_lds(size_t ldsBytes);
-// every row of a patch staged in LDS by LDS-DMA (csrc/experiments/stage_tile.hip); threads = 256 or 512 per patch
-bool stage_tile3_usable(const MeshDev &m);
-hipError_t launch_stage_tile3(const MeshDev &m, const StageArgs &a, int threads, hipStream_t s);
-// persistent, double-buffered form of it (csrc/experiments/stage_ptile2.hip): one workgroup per CU, a loader wave + 8 compute waves
-int stage_ptile2_halo_piece_budget();
-bool stage_ptile2_usable(const MeshDev &m);
-hipError_t launch_stage_ptile2(const MeshDev &m, const StageArgs &a, int nCUs, hipStream_t s);
-#endif
 hipError_t launch_fe(const MeshDev &m, const FeArgs &a, int lpc, hipStream_t s);
 hipError_t launch_curl2(const MeshDev &m, const double *u, double *vort, bool accum, hipStream_t s);
 hipError_t launch_curl_f32(const MeshDev &m, const float *u, float *vort, bool accum, hipStream_t s);   // fp32-storage states

@@ -2,7 +2,7 @@
 // carries next to the default k_stage_rec2c / k_stage_rec2c_f32 (kernels.hip): the generic index kernel k_stage (any
 // nVertLevels: K <= 32, odd K, K > 128) and the plain column kernel k_stage_col (one wavefront per entity, lane = level:
 // even or odd K from 33 up, several sweeps beyond 64).  Same arithmetic and bit-identical results as the default kernel.
-// The other measured design points of round 1 (profiles/r01_variants.txt) live in csrc/experiments/ and are only built
+// The other measured design points of rounds 1-3 (profiles/r0*_variants.txt) lost and were removed in round 4; they were only built
 // with `make VARIANTS=1`.
 #include "kernels_common.hpp"
 

@@ -37,10 +37,7 @@ struct moka_mesh {
     moka::MeshDev dev{};
     std::vector<void *> allocs;
     int lpc = 1;
-    size_t ldsBytes = 0;      // > 0: the LDS-tiled stage kernel is usable for this mesh
     bool colOk = false;       // byte-offset records exist (every field < 4 GiB)
-    bool tileOk = false;      // the tiled stage kernel (u rows + records in LDS) fits this mesh
-    bool ptileOk = false;     // the persistent double-buffered tiled kernel fits this mesh
     double *opBuf[4] = {nullptr, nullptr, nullptr, nullptr};   // operator scratch [0], [1], [3] / transfer staging [2], lazily sized
     size_t opBufElems = 0;
     // transposed lists of the operator reverse mode (moka_*_vjp), built at first use

@@ -31,8 +31,7 @@ def backend():
 
 _MESH_CACHE = {}
 # kernel variants this build of the library carries: the product has 11 (default) / 4 (column) / 3 (generic); the round-1
-# experiments (csrc/experiments, `make VARIANTS=1`) add 1, 2, 5-10
-VARIANTS = [v for v in (14, 13, 12, 11, 10, 9, 8, 7, 1, 2, 3, 4, 5, 6) if L.lib().moka_kernel_variant_available(v)]
+VARIANTS = [v for v in (11, 3, 4) if L.lib().moka_kernel_variant_available(v)]
 
 
 def get_mesh(name):
@@ -241,7 +240,7 @@ def test_fused_tendency_bitwise(backend, meshname, K, ordering, P):
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     tu, th, ossh = om.tendencies_clean(u, h)
     info = Setup.mesh.info()
-    for variant in VARIANTS:   # 11 default, 4 plain column, 3 generic index (+ the experiments when built)
+    for variant in VARIANTS:   # 11 default, 4 plain column, 3 generic index 
         backend.set_kernel_variant(variant)
         Tend.tendNormalVelocity.set(np.full_like(tu, np.nan)); Tend.tendLayerThickness.set(np.full_like(th, np.nan))
         Prog.ssh[-1].set(ssh)
@@ -585,15 +584,10 @@ def test_reference_call_sequence_piecewise(backend):
 # ------------------------------------------------------------------------------------------------
 # RK4 stage loop
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("meshname,K,nsteps,variant", [("igw200", 1, 10, 0), ("ico16", 1, 5, 0), ("ico16", 60, 3, 1),
-                                                         ("ico16", 60, 3, 2), ("ico16", 80, 2, 2), ("ico32", 60, 2, 0), ("ico32", 60, 3, 9), ("ico32", 60, 3, 10), ("ico12f", 60, 3, 0), ("ico12f", 3, 3, 0), ("ico32", 60, 3, 11),
-                                                         ("ico16", 60, 3, 4), ("ico16", 80, 2, 4), ("ico16", 60, 3, 3), ("ico16", 33, 2, 0), ("ico16", 100, 2, 0),
-                                                         ("ico32", 60, 3, 12), ("ico32", 60, 3, 13), ("ico12f", 60, 3, 13), ("ico16", 34, 2, 12), ("ico32", 64, 2, 13),
-                                                         ("ico16", 40, 2, 13), ("ico32", 60, 3, 14), ("ico12f", 60, 3, 14), ("ico16", 34, 2, 14),
-                                                         ("ico32", 64, 2, 14)])
+@pytest.mark.parametrize("meshname,K,nsteps,variant", [("igw200", 1, 10, 0), ("ico16", 1, 5, 0), ("ico32", 60, 2, 0), ("ico12f", 60, 3, 0), ("ico12f", 3, 3, 0),
+                                                         ("ico32", 60, 3, 11), ("ico16", 60, 3, 4), ("ico16", 80, 2, 4), ("ico16", 60, 3, 3), ("ico16", 33, 2, 0),
+                                                         ("ico16", 100, 2, 0)])
 def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
-    if not L.lib().moka_kernel_variant_available(variant):
-        pytest.skip("experimental kernel variant: build the library with `make VARIANTS=1`")
     backend.set_kernel_variant(variant)
     mesh = get_mesh(meshname)
     if meshname == "igw200":
@@ -603,7 +597,7 @@ def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
         ssh, u, h, rest = random_state(mesh, K, 9)
         dtv = 20.0
     Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True,
-                                                       patch_cells=12 if variant in (2, 9, 11, 14) else 8 if variant == 10 else 0)
+                                                       patch_cells=12 if variant == 11 else 0)
     om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
     st = orc.OracleState(om, ssh, u, h)
     mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dtv))

@@ -25,7 +25,7 @@ def product_sources():
 
 def test_no_null_stream_copies_in_the_library():
     bad = []
-    for p in product_sources() + glob.glob(os.path.join(CSRC, "experiments", "*")):
+    for p in product_sources():
         for m in re.finditer(r"\bhipMem(cpy|set|cpyDtoH|cpyHtoD|cpyDtoD|cpyPeer)\s*\(", _code(p)):
             bad.append((os.path.basename(p), m.group(0)))
     assert not bad, bad
@@ -41,27 +41,10 @@ def test_no_debug_environment_hooks_and_no_oracle_in_the_product():
         assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), p
 
 
-def test_experiments_are_not_in_the_default_build():
-    mk = open(os.path.join(ROOT, "mpas-ocean.jl_amd", "Makefile")).read()
-    default_objs = mk.split("ifeq ($(VARIANTS),1)")[0]
-    assert "stage_variants" not in default_objs
-    assert os.path.exists(os.path.join(CSRC, "experiments", "stage_variants.hip"))
+def test_only_the_product_kernels_are_built():
+    """The execution shapes that were measured and lost in rounds 1-3 (csrc/experiments) are gone; their record is
+    profiles/r0*_variants.txt.  The library offers the default stage kernel (11), its two fallbacks (4, 3) and auto (0)."""
+    assert not os.path.exists(os.path.join(CSRC, "experiments"))
     from moka_hip import lib as L
-    avail = [v for v in range(12) if L.lib().moka_kernel_variant_available(v)]
-    assert set(avail) >= {0, 3, 4, 11}
-
-
-def test_experimental_kernels_still_compile():
-    """csrc/experiments/ (the measured-and-lost execution shapes, kept as a record) includes kernels_common.hpp and StageArgs,
-    which keep changing: `make VARIANTS=1` into a build directory of its own must still compile them (hipcc cross-compiles
-    gfx950 without a GPU), and the resulting library must offer the variants the default build refuses."""
-    import ctypes
-    import subprocess
-    pkg = os.path.join(ROOT, "mpas-ocean.jl_amd")
-    r = subprocess.run(["make", "-C", pkg, "--no-print-directory", "-j4", "VARIANTS=1", "BUILD=build_variants",
-                        "SONAME=libmoka_hip_variants.so"], capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lib = ctypes.CDLL(os.path.join(pkg, "libmoka_hip_variants.so"))
-    assert all(lib.moka_kernel_variant_available(v) for v in range(0, 15))
-    from moka_hip import lib as L
-    assert not L.lib().moka_kernel_variant_available(12)          # the product library stays without them
+    avail = [v for v in range(15) if L.lib().moka_kernel_variant_available(v)]
+    assert avail == [0, 3, 4, 11]
