@@ -479,6 +479,55 @@ def single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_te
     return out
 
 
+def exchange_report(mk, backend, model, step, sync_all, dist, group, rank, world, args, whole, ms_per_step):
+    """N > 1: WHERE a shortfall against N x comes from.  A second pass of the same steps with the library's
+    exchange statistics on (moka_halo_stats): per rank the host time inside moka_halo_push_wait, waiting for the own push kernel,
+    from that event to the flag stores, the host time of the whole step call, and the device time of the boundary and interior
+    launches; then rank 0 steps the WHOLE mesh on its device (t1) so that bound_from_share = t1 / (largest per-rank launch time per
+    step) says what the partition alone allows, before any exchange."""
+    n = max(3, min(args.steps, 10))
+    model.exchange_stats(True)
+    sync_all()
+    for _ in range(n):
+        step()
+    sync_all()
+    mine = model.exchange_stats()
+    model.exchange_stats(False)
+    every = [None] * world
+    dist.all_gather_object(every, mine, group=group)
+    t1 = None
+    if rank == 0:
+        try:
+            mesh, ssh, u, h, rest, cfg, sbytes = whole
+            S1, D1, T1, P1 = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, cfg, backend, multilayer=True, ordering=args.ordering,
+                                                     patch_cells=args.patch_cells, state_bytes=sbytes, placement_tries=1)
+            one = lambda: mk.ocn_timestep(P1, D1, T1, S1, mk.RungeKutta4)  # noqa: E731
+            _, ms1 = timed_steps(backend, one, 5, 3, backend.synchronize)
+            t1 = step_stats(ms1)["median"]
+            P1._state.close(); S1.mesh.close()
+        except Exception as exc:             # noqa: BLE001
+            log(f"[bench] single-device reference for the scaling bound failed: {exc!r}")
+    sync_all()
+    if rank != 0:
+        return None
+    share = [e["boundary_launch_ms_per_step"] + e["interior_launch_ms_per_step"] for e in every]
+    out = {"steps_recorded": n,
+           "host_wait_ms_per_step": [e["host_wait_ms_per_step"] for e in every],
+           "host_signal_wait_ms_per_step": [e["host_signal_wait_ms_per_step"] for e in every],
+           "push_to_flag_us": [e["push_to_flag_us"] for e in every],
+           "host_step_ms_per_step": [e["host_step_ms_per_step"] for e in every],
+           "boundary_launch_ms_per_step": [e["boundary_launch_ms_per_step"] for e in every],
+           "interior_launch_ms_per_step": [e["interior_launch_ms_per_step"] for e in every],
+           "rank_share_ms_per_step": share, "max_rank_share_ms": max(share),
+           "t1_whole_mesh_on_rank0_ms": t1, "bound_from_share": (t1 / max(share)) if t1 and max(share) > 0 else None,
+           "measured_speedup_vs_t1": (t1 / ms_per_step) if t1 else None,
+           "note": "per rank (list index = rank); *_launch_ms = device time of the four boundary / interior stage launches of a step "
+                   "(HIP events around each launch); host_wait = inside moka_halo_push_wait; host_signal_wait = waiting for the rank's own "
+                   "push kernel; push_to_flag = from that event to the last flag store; bound_from_share = what the partition allows with a "
+                   "free exchange; the direct transport only has the three host_* / push_* figures (buffered transports: zeros)"}
+    return out
+
+
 def placement_summary(rep):
     """What moka_state_optimize_placement did at set-up (rank 0's state): first_placement_ms = the four stage launches of an RK4
     step as moka_state_create placed the arrays (what a caller gets without the search), ms_after = with the kept layout, the
@@ -799,6 +848,9 @@ def main():
            "roofline": roofline, "calibration": calibration,
            "placement": placement_summary(placement)}
 
+    if world > 1:
+        out["exchange"] = exchange_report(mk, backend, model, step, sync_all, dist, gloo_group, rank, world, args,
+                                          (mesh, ssh, u, h, rest, cfg, sbytes), ms_per_step)
     if world == 1:
         out.update(single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, args.tend_iters))
         if sbytes == 8:

@@ -342,6 +342,22 @@ int  moka_halo_push_begin(moka_halo *h, int what);        /* queue the push behi
 int  moka_halo_push_signal(moka_halo *h);                 /* host: wait for the own push, then signal the neighbours */
 int  moka_halo_push_wait(moka_halo *h, double timeout_s); /* host: wait for every neighbour's signal (MOKA_ERR_COMM on timeout) */
 
+/* Measurement: where a distributed step spends its time on this rank.  moka_halo_stats_enable(h, 1) forgets earlier samples and
+ * starts recording, (h, 0) stops; moka_halo_stats_read synchronises the rank's two streams and returns the sums:
+ *   steps / host_step_ms              moka_rk4_dist_step calls and the host time spent inside them
+ *   exchanges                         direct exchanges signalled
+ *   host_signal_wait_ms               host time in moka_halo_push_signal waiting for the rank's own push kernel (its event)
+ *   host_flag_store_ms                ... and from that event to the last flag store (event -> flag)
+ *   host_wait_ms                      host time in moka_halo_push_wait polling the neighbours' flags
+ *   boundary_ / interior_launch_ms    device time of the boundary / interior stage launches (HIP events around each launch, on the
+ *   boundary_ / interior_launches     stream it was queued to; at most 2048 launches are recorded) and how many were recorded */
+typedef struct {
+    int64_t steps, exchanges, boundary_launches, interior_launches;
+    double host_step_ms, host_signal_wait_ms, host_flag_store_ms, host_wait_ms, boundary_launch_ms, interior_launch_ms;
+} moka_halo_stats;
+int  moka_halo_stats_enable(moka_halo *h, int on);
+int  moka_halo_stats_read(moka_halo *h, moka_halo_stats *out);
+
 /* distributed form of moka_step_rk4, piecewise: begin; for stage 1..4 { stage(s,0) boundary patches; pack(s) or
  * push_begin(s); stage(s,1) interior patches (overlaps the exchange); transport + unpack(s), or push_signal + push_wait };
  * end.  moka_rk4_dist_stage_launch(s) = stage(s,0) + push_begin(s) + stage(s,1).

@@ -111,6 +111,13 @@ struct moka_halo {
     bool overlapNow = false;                  // ... as the running step was begun
     std::vector<void *> allocs;           // device allocations of this object
     bool counted = false;                 // st->attached includes this object
+    // measurement (moka_halo_stats_enable / _read): where a distributed step spends its time on this rank
+    bool statsOn = false;
+    double stSignalWaitMs = 0.0, stFlagStoreMs = 0.0, stWaitMs = 0.0, stStepHostMs = 0.0;   // host clocks, summed
+    int64_t stExchanges = 0, stSteps = 0;
+    std::vector<hipEvent_t> stEv;         // timing events around the boundary / interior launches: 4 per recorded stage
+    size_t stEvUsed = 0;
+    std::vector<int> stEvPart;            // part (0 boundary, 1 interior) of every recorded pair
 };
 
 namespace {
@@ -281,6 +288,26 @@ int dist_stage_part(moka_halo *h, int stage, int part)
     const StageArgs g = rk4_stage_args(st, stage, h->dt, h->ssh0);
     const int p0 = part == 0 ? 0 : h->pFirst, cnt = part == 0 ? h->pFirst : h->pOwned - h->pFirst;
     moka_ctx *c = st->ctx;
+    // measurement: one event in front of and one behind the launch, on the stream it goes to (at most 2048 launches recorded)
+    hipStream_t on = (h->overlapNow && part == 0) ? c->comm : c->stream;
+    const bool rec = h->statsOn && cnt > 0 && h->stEvPart.size() < 2048;
+    auto stamp = [&]() -> hipError_t {
+        if (h->stEvUsed == h->stEv.size()) {
+            hipEvent_t e = nullptr;
+            if (hipError_t er = hipEventCreate(&e); er != hipSuccess) return er;
+            h->stEv.push_back(e);
+        }
+        return hipEventRecord(h->stEv[h->stEvUsed++], on);
+    };
+    struct Closer {                     // the closing event, whichever way the function returns
+        bool on; decltype(stamp) &f; moka_halo *h; int part;
+        ~Closer() { if (on && f() == hipSuccess) h->stEvPart.push_back(part); }
+    } closer{false, stamp, h, part};
+    if (rec) {
+        if (h->overlapNow && part == 0) HIPCHK(c, hipStreamWaitEvent(c->comm, c->evInterior, 0));   // (not counted as launch time)
+        HIPCHK(c, stamp());
+        closer.on = true;
+    }
     if (!h->overlapNow) {
         // boundary group first, interior right behind it on the same (compute) stream
         if (part == 0) if (int rc = launch_acquire(h, c->stream)) return rc;
@@ -411,6 +438,7 @@ void moka_halo_destroy(moka_halo *h)
 {
     if (!h) return;
     if (h->counted) state_detach(h->st);
+    for (hipEvent_t e : h->stEv) (void)hipEventDestroy(e);
     (void)hipSetDevice(h->st->ctx->device);
     (void)hipStreamSynchronize(h->st->ctx->stream);
     (void)hipStreamSynchronize(h->st->ctx->comm);
@@ -686,9 +714,16 @@ int moka_halo_push_signal(moka_halo *h)
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
     moka_ctx *c = h->st->ctx;
     HIPCHK(c, hipSetDevice(c->device));
+    const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipEventSynchronize(h->evPush));
+    const auto t1 = std::chrono::steady_clock::now();
     for (const PeerLink &pl : h->peers)
         __atomic_store_n(const_cast<uint64_t *>(pl.flags) + pl.slot, h->seq, __ATOMIC_RELEASE);
+    if (h->statsOn) {
+        h->stSignalWaitMs += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        h->stFlagStoreMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        ++h->stExchanges;
+    }
     return MOKA_OK;
 }
 
@@ -708,6 +743,48 @@ int moka_halo_push_wait(moka_halo *h, double timeout_s)
                 if (el > 0.002) std::this_thread::yield();
             }
         }
+    }
+    if (h->statsOn) h->stWaitMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MOKA_OK;
+}
+
+// Measurement: where does a distributed step spend its time on this rank?  enable(1) forgets earlier samples and starts
+// recording: host time inside moka_halo_push_signal (waiting for the own push kernel, then storing the flags) and inside
+// moka_halo_push_wait (polling the neighbours' flags), host time of whole moka_rk4_dist_step calls, and HIP events around every
+// boundary / interior launch (at most 2048 launches).  read synchronises both streams.
+int moka_halo_stats_enable(moka_halo *h, int on)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    moka_ctx *c = h->st->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->comm));
+    h->statsOn = on != 0;
+    if (on) {
+        h->stSignalWaitMs = h->stFlagStoreMs = h->stWaitMs = h->stStepHostMs = 0.0;
+        h->stExchanges = h->stSteps = 0;
+        h->stEvUsed = 0;
+        h->stEvPart.clear();
+    }
+    return MOKA_OK;
+}
+
+int moka_halo_stats_read(moka_halo *h, moka_halo_stats *out)
+{
+    if (!h || !out) return fail(h ? h->st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    moka_ctx *c = h->st->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->comm));
+    *out = moka_halo_stats{};
+    out->steps = h->stSteps; out->exchanges = h->stExchanges;
+    out->host_signal_wait_ms = h->stSignalWaitMs; out->host_flag_store_ms = h->stFlagStoreMs;
+    out->host_wait_ms = h->stWaitMs; out->host_step_ms = h->stStepHostMs;
+    for (size_t i = 0; i < h->stEvPart.size() && 2 * i + 1 < h->stEvUsed; ++i) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, h->stEv[2 * i], h->stEv[2 * i + 1]));
+        if (h->stEvPart[i] == 0) { out->boundary_launch_ms += ms; ++out->boundary_launches; }
+        else { out->interior_launch_ms += ms; ++out->interior_launches; }
     }
     return MOKA_OK;
 }
@@ -823,6 +900,10 @@ int moka_rk4_dist_step(moka_halo *h, double dt, moka_transport_fn transport, voi
     // selection were then never exercised)
     const bool direct = h->nNbr > 0 && !transport;
     if (direct && !all_connected(h)) return hfail(h, MOKA_ERR_ARG, "no transport callback and not every neighbour is connected");
+    struct StepClock {                  // measurement: host time of the whole call
+        moka_halo *h; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~StepClock() { if (h->statsOn) { h->stStepHostMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++h->stSteps; } }
+    } stepClock{h};
     const bool nl = h->st->nonlinear;
     if (nl && !moka_rk4_dist_parts_available(h))     // before the step is opened (rk4_begin supersedes what is lazily pending)
         return hfail(h, MOKA_ERR_UNSUPPORTED, "nonlinear terms: this kernel variant has whole-mesh stages only (moka_rk4_dist_stage part 2)");

@@ -50,6 +50,12 @@ class MeshDesc(C.Structure):
     ]
 
 
+class HaloStats(C.Structure):          # moka_halo_stats
+    _fields_ = [("steps", C.c_int64), ("exchanges", C.c_int64), ("boundary_launches", C.c_int64), ("interior_launches", C.c_int64),
+                ("host_step_ms", C.c_double), ("host_signal_wait_ms", C.c_double), ("host_flag_store_ms", C.c_double),
+                ("host_wait_ms", C.c_double), ("boundary_launch_ms", C.c_double), ("interior_launch_ms", C.c_double)]
+
+
 class PlacementTrial(C.Structure):     # moka_placement_trial
     _fields_ = [("field", C.c_int32), ("ms_old", C.c_double), ("ms_new", C.c_double), ("kept", C.c_int32)]
 
@@ -92,6 +98,7 @@ EXPORTS = [
     "moka_gradient_on_edge_vjp", "moka_gradient_on_edge_jvp", "moka_divergence_on_cell_vjp", "moka_divergence_on_cell_jvp",
     "moka_curl_on_vertex_vjp", "moka_curl_on_vertex_jvp", "moka_fe_lazy_pending",
     "moka_state_optimize_placement", "moka_state_placement_log", "moka_state_download_rows",
+    "moka_halo_stats_enable", "moka_halo_stats_read",
 ]
 
 
@@ -177,6 +184,8 @@ def lib():
     L.moka_halo_create.argtypes = [vp, C.c_int32, _i32p, i64p, _i32p, i64p, _i32p, i64p, _i32p, i64p,
                                    C.c_int32, C.c_int32, C.POINTER(vp)]
     L.moka_halo_destroy.argtypes = [vp]
+    L.moka_halo_stats_enable.argtypes = [vp, C.c_int]
+    L.moka_halo_stats_read.argtypes = [vp, C.POINTER(HaloStats)]
     L.moka_halo_destroy.restype = None
     L.moka_halo_buffer_elems.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.moka_halo_pack.argtypes = [vp, C.c_int, vp]

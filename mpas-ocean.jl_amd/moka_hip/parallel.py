@@ -610,6 +610,25 @@ class DistributedModel:
         self._check_cb(L.lib().moka_rk4_dist_step(self._halo, self.dt, cb, None, self.sendbuf.data_ptr(),
                                                   self.recvbuf.data_ptr(), self.timeout_s))
 
+    def exchange_stats(self, enable=None):
+        """moka_halo_stats: enable=True starts recording, enable=False stops; enable=None reads what was recorded, per RK4 step:
+        host time waiting for the own push kernel / storing the flags / polling the neighbours' flags, host time of the whole step
+        call, device time of the boundary and interior launches."""
+        if enable is not None:
+            L.check(L.lib().moka_halo_stats_enable(self._halo, 1 if enable else 0), self.backend._h)
+            return None
+        st = L.HaloStats()
+        L.check(L.lib().moka_halo_stats_read(self._halo, C.byref(st)), self.backend._h)
+        n = max(int(st.steps), 1)
+        return {"steps": int(st.steps), "exchanges": int(st.exchanges),
+                "host_step_ms_per_step": st.host_step_ms / n,
+                "host_wait_ms_per_step": st.host_wait_ms / n,                       # inside moka_halo_push_wait
+                "host_signal_wait_ms_per_step": st.host_signal_wait_ms / n,         # waiting for the own push kernel's event
+                "push_to_flag_us": 1e3 * st.host_flag_store_ms / max(int(st.exchanges), 1),   # event -> last flag store, per exchange
+                "boundary_launch_ms_per_step": 4.0 * st.boundary_launch_ms / max(int(st.boundary_launches), 1),
+                "interior_launch_ms_per_step": 4.0 * st.interior_launch_ms / max(int(st.interior_launches), 1),
+                "launches_recorded": int(st.boundary_launches + st.interior_launches)}
+
     def step_fe(self, flags=L.FE_REFERENCE_COMPAT & ~L.FE_LEVEL1_ONLY):
         """One distributed Forward-Euler step (the reference's live integrator) with the given compat flags."""
         cb = L.TRANSPORT_FN() if self._direct() or not self.lm.neighbors else self._cb

@@ -111,3 +111,13 @@ def test_bench_two_ranks_on_one_gpu_is_labelled_a_rehearsal():
     assert b["scaling"] == "strong" and b["config"]["halo_transport"] in ("ipc", "ipc-acq", "gloo", "nccl-a2a", "nccl-p2p")
     assert b["config"]["halo_transport"] in b["config"]["halo_transport_trials_ms_per_step"]
     assert b["value"] > 0 and "REHEARSAL" in b["config"]["parallelism"]
+    # the line says where the time of a distributed step goes: per rank, from the library's own statistics
+    ex = b["exchange"]
+    for k in ("host_wait_ms_per_step", "host_signal_wait_ms_per_step", "push_to_flag_us", "host_step_ms_per_step",
+              "boundary_launch_ms_per_step", "interior_launch_ms_per_step", "rank_share_ms_per_step"):
+        assert len(ex[k]) == 2 and all(v >= 0.0 for v in ex[k]), k
+    assert all(v > 0.0 for v in ex["interior_launch_ms_per_step"]) and ex["max_rank_share_ms"] == max(ex["rank_share_ms_per_step"])
+    # (two ranks on ONE device: each rank's launches wait for the other's, so the bound itself means nothing here -- it is there)
+    assert ex["t1_whole_mesh_on_rank0_ms"] > 0 and ex["bound_from_share"] > 0 and ex["measured_speedup_vs_t1"] > 0
+    if b["config"]["halo_transport"].startswith("ipc"):
+        assert all(v > 0.0 for v in ex["host_step_ms_per_step"])
