@@ -342,6 +342,13 @@ int  moka_halo_push_begin(moka_halo *h, int what);        /* queue the push behi
 int  moka_halo_push_signal(moka_halo *h);                 /* host: wait for the own push, then signal the neighbours */
 int  moka_halo_push_wait(moka_halo *h, double timeout_s); /* host: wait for every neighbour's signal (MOKA_ERR_COMM on timeout) */
 
+/* Experiment: the direct transport's handshake as stream memory operations (hipStreamWriteValue64 behind the push kernel,
+ * hipStreamWaitValue64 in front of the next boundary launch) instead of a host thread that waits for the push event, stores the
+ * flags and polls the neighbours': a distributed step becomes enqueue-only.  Call after every neighbour is connected.  A stream
+ * wait has no timeout (a dead neighbour blocks the queue until the process ends), so this is a transport CANDIDATE ("ipc-smo" in
+ * moka_hip.parallel), qualified like the others; MOKA_ERR_UNSUPPORTED where the device or the flag memory does not allow it. */
+int  moka_halo_set_stream_flags(moka_halo *h, int on);
+
 /* Measurement: where a distributed step spends its time on this rank.  moka_halo_stats_enable(h, 1) forgets earlier samples and
  * starts recording, (h, 0) stops; moka_halo_stats_read synchronises the rank's two streams and returns the sums:
  *   steps / host_step_ms              moka_rk4_dist_step calls and the host time spent inside them

@@ -72,6 +72,7 @@ struct PeerLink {
     bool connected = false, ipc = false;
     void *mapped[15] = {};                // peer field bases as this process sees them: [set][u, h, ssh]
     volatile uint64_t *flags = nullptr;   // the peer's flag block (host memory)
+    uint64_t *flagsDev = nullptr;         // ... as the device sees it (hipHostRegister), for stream memory operations
     size_t flagsBytes = 0;
     int32_t dstCell = 0, dstEdge = 0, slot = 0;
 };
@@ -101,6 +102,8 @@ struct moka_halo {
     PushDst *peerTab = nullptr;           // device: [5 sets][nNbr]
     bool tabDirty = true;
     volatile uint64_t *flags = nullptr;   // my flag block: slot i = last exchange neighbour i has completed towards me
+    uint64_t *flagsDev = nullptr;         // ... as the device sees it (stream memory operations)
+    bool streamFlags = false;             // moka_halo_set_stream_flags: the handshake is enqueued, the host neither waits nor polls
     size_t flagsBytes = 0;
     std::string shmName;                  // non-empty: the block is a POSIX shared-memory object (multi-process)
     uint64_t seq = 0;                     // exchanges started so far
@@ -442,6 +445,10 @@ void moka_halo_destroy(moka_halo *h)
     (void)hipSetDevice(h->st->ctx->device);
     (void)hipStreamSynchronize(h->st->ctx->stream);
     (void)hipStreamSynchronize(h->st->ctx->comm);
+    for (PeerLink &pl : h->peers)
+        if (pl.flagsDev && pl.ipc) (void)hipHostUnregister((void *)pl.flags);
+    if (h->flagsDev) (void)hipHostUnregister((void *)h->flags);
+    (void)hipGetLastError();
     for (PeerLink &pl : h->peers) {
         if (pl.connected && pl.ipc) {
             for (void *q : pl.mapped) if (q) (void)hipIpcCloseMemHandle(q);
@@ -658,6 +665,7 @@ int moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer
     } else {
         for (int i = 0; i < 3 * moka_state::NPHYS; ++i) pl.mapped[i] = (void *)(uintptr_t)peer->ptr[i];
         pl.flags = (volatile uint64_t *)(uintptr_t)peer->flagPtr;
+        pl.flagsBytes = sizeof(uint64_t) * (size_t)std::max(peer->nNeighbors, 1);
         if (peer->device != st->ctx->device) {        // one process driving several devices: map the peer's memory
             const hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
@@ -714,6 +722,12 @@ int moka_halo_push_signal(moka_halo *h)
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
     moka_ctx *c = h->st->ctx;
     HIPCHK(c, hipSetDevice(c->device));
+    if (h->streamFlags) {     // the flag words are written by the comm stream itself, behind the push kernel: nothing to wait for here
+        for (const PeerLink &pl : h->peers)
+            HIPCHK(c, hipStreamWriteValue64(c->comm, pl.flagsDev + pl.slot, h->seq, 0));
+        if (h->statsOn) ++h->stExchanges;
+        return MOKA_OK;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipEventSynchronize(h->evPush));
     const auto t1 = std::chrono::steady_clock::now();
@@ -731,6 +745,14 @@ int moka_halo_push_signal(moka_halo *h)
 int moka_halo_push_wait(moka_halo *h, double timeout_s)
 {
     if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    if (h->streamFlags) {     // the stream that takes the next boundary launch waits for the neighbours' flag words itself
+        moka_ctx *c = h->st->ctx;
+        HIPCHK(c, hipSetDevice(c->device));
+        hipStream_t next = h->overlapNow ? c->comm : c->stream;
+        for (int i = 0; i < h->nNbr; ++i)
+            HIPCHK(c, hipStreamWaitValue64(next, h->flagsDev + i, h->seq, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+        return MOKA_OK;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < h->nNbr; ++i) {
         unsigned spins = 0;
@@ -745,6 +767,49 @@ int moka_halo_push_wait(moka_halo *h, double timeout_s)
         }
     }
     if (h->statsOn) h->stWaitMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MOKA_OK;
+}
+
+// Experiment: the exchange handshake as stream memory operations.  on = 1: the flag blocks (this rank's and
+// every connected neighbour's) are registered with the device; from then on moka_halo_push_signal enqueues
+// hipStreamWriteValue64(comm stream, neighbour's slot, seq) behind the push kernel and moka_halo_push_wait enqueues
+// hipStreamWaitValue64(>= seq) for every neighbour on the stream that takes the next boundary launch: a distributed step is
+// enqueue-only, no host thread waits or polls.  A stream wait has no timeout: a neighbour that dies leaves the queue blocked
+// until the process ends -- which is why this is a candidate the transport selection has to qualify ("ipc-smo"), not the default.
+// MOKA_ERR_UNSUPPORTED when the device cannot wait on memory or the blocks cannot be registered.
+int moka_halo_set_stream_flags(moka_halo *h, int on)
+{
+    if (!h) return fail(nullptr, MOKA_ERR_ARG, "halo is NULL");
+    moka_ctx *c = h->st->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!on) { h->streamFlags = false; return MOKA_OK; }
+    if (!all_connected(h)) return hfail(h, MOKA_ERR_ARG, "stream flags: connect every neighbour first");
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess || !can) {
+        (void)hipGetLastError();
+        return hfail(h, MOKA_ERR_UNSUPPORTED, "this device cannot wait on memory from a stream (hipDeviceAttributeCanUseStreamWaitValue)");
+    }
+    auto reg = [&](volatile uint64_t *host, size_t bytes, uint64_t **dev) -> int {
+        if (*dev) return MOKA_OK;
+        void *q = const_cast<uint64_t *>(host), *d = nullptr;
+        hipError_t e = hipHostRegister(q, bytes, hipHostRegisterMapped);
+        if (e != hipSuccess && e != hipErrorHostMemoryAlreadyRegistered) {
+            (void)hipGetLastError();
+            return hfail(h, MOKA_ERR_UNSUPPORTED, std::string("hipHostRegister of a flag block: ") + hipGetErrorString(e));
+        }
+        (void)hipGetLastError();
+        if ((e = hipHostGetDevicePointer(&d, q, 0)) != hipSuccess) {
+            (void)hipGetLastError();
+            return hfail(h, MOKA_ERR_UNSUPPORTED, std::string("hipHostGetDevicePointer of a flag block: ") + hipGetErrorString(e));
+        }
+        *dev = static_cast<uint64_t *>(d);
+        return MOKA_OK;
+    };
+    if (h->nNbr > 0)
+        if (int rc = reg(h->flags, h->flagsBytes, &h->flagsDev)) return rc;
+    for (PeerLink &pl : h->peers)
+        if (int rc = reg(pl.flags, pl.flagsBytes, &pl.flagsDev)) return rc;
+    h->streamFlags = true;
     return MOKA_OK;
 }
 

@@ -98,7 +98,7 @@ EXPORTS = [
     "moka_gradient_on_edge_vjp", "moka_gradient_on_edge_jvp", "moka_divergence_on_cell_vjp", "moka_divergence_on_cell_jvp",
     "moka_curl_on_vertex_vjp", "moka_curl_on_vertex_jvp", "moka_fe_lazy_pending",
     "moka_state_optimize_placement", "moka_state_placement_log", "moka_state_download_rows",
-    "moka_halo_stats_enable", "moka_halo_stats_read",
+    "moka_halo_stats_enable", "moka_halo_stats_read", "moka_halo_set_stream_flags",
 ]
 
 
@@ -184,6 +184,7 @@ def lib():
     L.moka_halo_create.argtypes = [vp, C.c_int32, _i32p, i64p, _i32p, i64p, _i32p, i64p, _i32p, i64p,
                                    C.c_int32, C.c_int32, C.POINTER(vp)]
     L.moka_halo_destroy.argtypes = [vp]
+    L.moka_halo_set_stream_flags.argtypes = [vp, C.c_int]
     L.moka_halo_stats_enable.argtypes = [vp, C.c_int]
     L.moka_halo_stats_read.argtypes = [vp, C.POINTER(HaloStats)]
     L.moka_halo_destroy.restype = None

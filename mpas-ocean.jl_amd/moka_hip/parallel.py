@@ -449,10 +449,14 @@ class DistributedModel:
 
     def set_transport(self, name: str):
         """Select the halo transport of the steps that follow.  "ipc" = direct; "ipc-acq" = direct with an explicit
-        system-scope acquire in front of every launch that reads received rows (moka_halo_set_acquire)."""
+        system-scope acquire in front of every launch that reads received rows (moka_halo_set_acquire); "ipc-smo" = direct with
+        the flag handshake enqueued on the streams instead of done by the host thread (moka_halo_set_stream_flags)."""
         self.transport = name
         if getattr(self, "_halo", None):
             L.check(L.lib().moka_halo_set_acquire(self._halo, 1 if name == "ipc-acq" else 0), self.backend._h)
+            # "ipc-smo": the direct transport with its handshake enqueued as stream memory operations (experiment:
+            # moka_halo_set_stream_flags; raises MokaError where the device or the flag memory does not allow it)
+            L.check(L.lib().moka_halo_set_stream_flags(self._halo, 1 if name == "ipc-smo" else 0), self.backend._h)
 
     def snapshot(self):
         """The local prognostic state (current level, halo rows included) as host arrays."""
@@ -499,7 +503,7 @@ class DistributedModel:
                     [dist.P2POp(dist.isend, self.sendbuf[a:b], q) for q, a, b in self.send_slices if b > a]):
                 w.wait()
             torch.cuda.synchronize()
-        elif self.transport in ("local", "ipc", "ipc-acq"):
+        elif self.transport in ("local", "ipc", "ipc-acq", "ipc-smo"):
             raise RuntimeError(f"transport {self.transport!r} has no buffered form")
         elif self.transport != "gloo":
             raise ValueError(f"unknown halo transport {self.transport!r}")
@@ -517,7 +521,7 @@ class DistributedModel:
         """sendbuf -> the neighbours' recvbuf for the paths that exist in buffered form only (tape recording, the adjoint
         fields): the model's own transport, or host-staged gloo when that is the direct one."""
         t = self.transport
-        if t not in ("ipc", "ipc-acq"):
+        if t not in ("ipc", "ipc-acq", "ipc-smo"):
             return self._transport()
         self.transport = "gloo"
         try:
@@ -543,7 +547,7 @@ class DistributedModel:
         the same bytes on this rank (callers combine the ranks' answers)."""
         lib = L.lib()
         mine = self.transport
-        if mine in ("ipc", "ipc-acq"):
+        if mine in ("ipc", "ipc-acq", "ipc-smo"):
             lm = self.lm
             # wipe the halo rows, exchange directly, read them back
             hh, ssh, uu = self.Prog.layerThickness[-1].get(), self.Prog.ssh[-1].get(), self.Prog.normalVelocity[-1].get()
@@ -581,7 +585,7 @@ class DistributedModel:
         return bool(self.torch.equal(got, self.recvbuf))
 
     def _direct(self):
-        return self.transport in ("ipc", "ipc-acq") and self.connected
+        return self.transport in ("ipc", "ipc-acq", "ipc-smo") and self.connected
 
     def exchange_state(self):
         """Halo exchange of the current time level (e.g. after an upload).  Collective: every rank calls it."""
@@ -890,7 +894,7 @@ def choose_transport(model, candidates, fallbacks, control_group, log=lambda msg
 
     def works(cand):
         def setup():
-            if cand in ("ipc", "ipc-acq") and not model.connected:
+            if cand in ("ipc", "ipc-acq", "ipc-smo") and not model.connected:
                 # every rank must be able to go direct BEFORE anyone enters connect_ipc's collectives
                 if agree(1.0 if model.direct_available else 0.0, dist.ReduceOp.MIN) != 1.0:
                     return False
