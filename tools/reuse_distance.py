@@ -52,6 +52,51 @@ patch_of_cell = np.repeat(np.arange(nP), np.diff(cs))
 patch_of_edge = np.repeat(np.arange(nP), np.diff(es))
 rowB = K * sbytes
 chunk = (nP + 7) // 8
+# argv[5] = "hilbert": PREDICTION for another launch order -- inside every XCD chunk the patches are
+# visited along a Hilbert curve through their centroids (chunk projected onto its two principal axes) instead of in the
+# RCB order of the plan; everything below then measures index distances in that order.  Nothing on the GPU changes.
+order_name = "RCB (the plan's)"
+if len(sys.argv) > 5 and sys.argv[5] == "hilbert":
+    order_name = "Hilbert inside every XCD chunk"
+    cperm = plan.permutation(L.CELL) if hasattr(plan, "permutation") else None
+    if cperm is None:
+        raise SystemExit("this Plan binding has no permutation(): cannot place patches")
+    xyz = np.stack([mesh.xCell, mesh.yCell, mesh.zCell], 1)[cperm]          # library order
+    cen = np.add.reduceat(xyz, cs[:-1], axis=0) / np.diff(cs)[:, None]
+
+    def hilbert_index(ix, iy, bits):
+        """Hilbert curve index of integer grid points (vectorised xy2d)."""
+        d = np.zeros(ix.shape, dtype=np.int64)
+        x, y = ix.astype(np.int64).copy(), iy.astype(np.int64).copy()
+        sft = bits - 1
+        while sft >= 0:
+            s_ = 1 << sft
+            rx = (x & s_) > 0
+            ry = (y & s_) > 0
+            d += s_ * s_ * ((3 * rx.astype(np.int64)) ^ ry.astype(np.int64))
+            swap = ~ry
+            flip = swap & rx
+            x = np.where(flip, s_ - 1 - x, x); y = np.where(flip, s_ - 1 - y, y)      # (coordinates taken modulo the current cell)
+            x, y = np.where(swap, y, x), np.where(swap, x, y)
+            x &= s_ - 1; y &= s_ - 1
+            sft -= 1
+        return d
+
+    new_pos = np.empty(nP, dtype=np.int64)
+    for xcd in range(8):
+        a, b = xcd * chunk, min((xcd + 1) * chunk, nP)
+        if a >= b:
+            continue
+        pts = cen[a:b] - cen[a:b].mean(0)
+        _, _, vt = np.linalg.svd(pts, full_matrices=False)
+        uv = pts @ vt[:2].T
+        bits = 10
+        g = ((uv - uv.min(0)) / np.maximum(np.ptp(uv, axis=0), 1e-30) * ((1 << bits) - 1)).astype(np.int64)
+        hidx = hilbert_index(g[:, 0], g[:, 1], bits)
+        new_pos[a:b][np.argsort(hidx, kind="stable")] = np.arange(a, b)
+    relabel = new_pos            # old patch index -> position in the Hilbert launch order
+else:
+    relabel = np.arange(nP)
 
 
 def distinct_pairs(patch, row, valid):
@@ -74,7 +119,7 @@ halo_u = (patch_of_edge[ru] != pu).sum() / nP
 halo_h = (patch_of_cell[rh] != ph).sum() / nP
 per_patch = {"tendency": (2 * own_rows + halo_u + halo_h) * rowB + 14e3, "rk_stage": (5 * own_rows + halo_u + halo_h) * rowB + 14e3}
 L2, MALL = 4 << 20, 256 << 20
-print(f"mesh m={m}: {nC} cells, {nE} edges, K={K}, {rowB}-byte rows, P={info['patch_cells']}, {nP} patches, {chunk} per XCD")
+print(f"mesh m={m}: {nC} cells, {nE} edges, K={K}, {rowB}-byte rows, P={info['patch_cells']}, {nP} patches, {chunk} per XCD; launch order: {order_name}")
 print(f"per patch: {np.diff(es).mean():.1f} own u rows, {np.diff(cs).mean():.1f} own h rows, {halo_u:.1f} u rows and {halo_h:.1f} h rows "
       f"of other patches; it moves {per_patch['tendency'] / 1e3:.0f} KB (tendency launch) / {per_patch['rk_stage'] / 1e3:.0f} KB (RK stages 2-3)")
 for launch, bpp in per_patch.items():
@@ -84,7 +129,8 @@ for launch, bpp in per_patch.items():
     tot_bytes = 0.0
     acc = {"own": 0.0, "l2": 0.0, "mall": 0.0, "hbm": 0.0}
     for name, pp, rr, owner in (("normalVelocity", pu, ru, patch_of_edge), ("layerThickness", ph, rh, patch_of_cell)):
-        q = owner[rr]
+        q = relabel[owner[rr]]
+        pp = relabel[pp]
         d = np.abs(pp - q)
         same_xcd = (pp // chunk) == (q // chunk)
         own = d == 0
@@ -105,7 +151,8 @@ for launch, bpp in per_patch.items():
     tau = (L2 / (bpp * 128 / (T_us * 1e-6))) / (T_us * 1e-6)         # L2 bytes / (bytes per second through one XCD), in lifetimes
     est_l2 = 0.0
     for pp, rr, owner in ((pu, ru, patch_of_edge), (ph, rh, patch_of_cell)):
-        q = owner[rr]
+        q = relabel[owner[rr]]
+        pp = relabel[pp]
         other = (q != pp) & ((pp // chunk) == (q // chunk))
         lag = (q[other] - pp[other]) / 128.0                        # start of the owner relative to the gatherer, in lifetimes
         # P(|phase - lag| < tau), phase ~ U(0.1, 1)
