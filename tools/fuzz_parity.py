@@ -21,7 +21,8 @@ budget, seed = (float(sys.argv[1]) if len(sys.argv) > 1 else 150.0), (int(sys.ar
 rng = np.random.default_rng(seed)
 b = mk.MokaHIP(0)
 t0, n = time.time(), 0
-stats = {"f32": 0, "f32_fe": 0, "fe_tuned": 0, "fe_generic": 0, "masked": 0, "cells_max": 0, "adjoint": 0, "adjoint_rk4": 0, "nonlinear": 0}
+stats = {"f32": 0, "f32_fe": 0, "fe_tuned": 0, "fe_generic": 0, "masked": 0, "cells_max": 0, "adjoint": 0, "adjoint_rk4": 0, "nonlinear": 0,
+         "rk4_13_streams": 0, "placement": 0, "rows": 0}
 while time.time() - t0 < budget:
     kind = rng.integers(0, 3)
     if kind == 0:
@@ -135,6 +136,30 @@ while time.time() - t0 < budget:
                 tag + f" nonlinear visc {visc} form {form} shape {shape} cap {cap}"
             Prog3._state.close()
             stats["nonlinear"] += 1
+    # round 4: the per-array placement search leaves every array as it is (mid-run, whatever is lazily pending), sampled rows
+    # equal the whole-field download, and -- Float64 -- the opt-in 13-stream RK4 form equals its oracle twin
+    if n % 3 == 0:
+        before = {k: f.get() for k, f in (("u", Prog.normalVelocity[-1]), ("h", Prog.layerThickness[-1]), ("s", Prog.ssh[-1]),
+                                         ("u0", Prog.normalVelocity[0]), ("h0", Prog.layerThickness[0]), ("s0", Prog.ssh[0]))}
+        rep = Prog._state.optimize_placement(int(rng.integers(1, 6)))
+        assert rep["ms_after"] <= rep["ms_before"], tag + " placement"
+        for k, f in (("u", Prog.normalVelocity[-1]), ("h", Prog.layerThickness[-1]), ("s", Prog.ssh[-1]),
+                     ("u0", Prog.normalVelocity[0]), ("h0", Prog.layerThickness[0]), ("s0", Prog.ssh[0])):
+            assert np.array_equal(f.get(), before[k]), tag + f" placement changed {k}"
+        ids = r.integers(0, mesh.nEdges, 50)
+        assert np.array_equal(Prog.normalVelocity[-1].rows(ids), before["u"][ids]), tag + " rows"
+        stats["placement"] += 1; stats["rows"] += 1
+    if not f32 and n % 3 == 1:
+        L.check(L.lib().moka_set_tuning(7, 1))
+        try:
+            for _ in range(2):
+                L.check(L.lib().moka_step_rk4(Prog._state._h, dtv), b._h)
+                st.step_rk4_s13(dtv)
+        finally:
+            L.check(L.lib().moka_set_tuning(7, 0))
+        assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.layerThickness[-1].get(), st.h[1]) and \
+            np.array_equal(Prog.ssh[-1].get(), st.ssh[1]) and np.array_equal(Prog.normalVelocity[0].get(), st.u[0]), tag + " 13-stream rk4"
+        stats["rk4_13_streams"] += 1
     stats["f32"] += int(f32); stats["masked"] += int((mlt < K).any()); stats["cells_max"] = max(stats["cells_max"], mesh.nCells)
     Prog._state.close(); M.close()
     n += 1
