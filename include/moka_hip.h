@@ -414,6 +414,9 @@ int moka_set_kernel_variant(moka_ctx *ctx, int variant);
  * stage kernel's patch form (0 default: potential vorticity of the patch's vertices in LDS, three workgroups per CU; 1: q_e of
  * its edge rows in LDS, two workgroups; 2 / 3: other shapes of the default).  key 6 (test hook): upper limit of the vertex rows
  * that form keeps resident (0 = what the LDS budget holds).
+ * key 8: bit mask of the modes of the Float64 stage kernel whose large whole-range launches take two consecutive patches per
+ * 512-thread workgroup, one row cache over both (default: the tendency launch and RK stage 1, modes 0 / 1, and the
+ * 13-stream stage 1, mode 7; 0 = one patch per workgroup everywhere).
  * key 7 is NOT result-neutral and therefore off by default: 1 = moka_step_rk4 / moka_run step Float64 states on whole meshes
  * with 13 instead of 16 state streams per step.  The reference accumulates New += b_s k_s through the stages
  * (time_integration.jl:134-135); here stages 1-3 store only the provisional states and stage 4 forms

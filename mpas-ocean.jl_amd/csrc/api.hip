@@ -741,6 +741,8 @@ int moka_bw_probe_gather_big(moka_ctx *ctx, int64_t bytes, int iters, double *gb
 //   key 6: test hook, upper limit of the vertex rows that form keeps in LDS (0 = none)
 //   key 3: 0 = the relativeVorticity pass of a Forward-Euler step always gets a launch of its own, 1 (default) = it rides in the
 //          stage-kernel launches where they can carry it
+//   key 8: bit mask of the modes of the Float64 stage kernel whose large launches take TWO consecutive patches per 512-thread workgroup
+//          (default: 0, 1 and the 13-stream 7; kernels.hip, launch_stage_rec2c)
 //   key 7: NOT result-neutral, opt-in (default 0): moka_step_rk4 / moka_run of Float64 states on whole meshes in the 13-stream form
 //          (mk::rk13_usable; New formed in stage 4 from the provisional states instead of accumulated through the stages)
 int moka_set_tuning(int key, int value)
@@ -752,6 +754,7 @@ int moka_set_tuning(int key, int value)
     if (key == 5) { moka::set_nl_shape(value); return MOKA_OK; }
     if (key == 6) { moka::set_nl_cap_limit(value); return MOKA_OK; }
     if (key == 7) { g_rk13.store(value != 0); return MOKA_OK; }
+    if (key == 8) { moka::set_pair_modes(value); return MOKA_OK; }
     return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
 }
 
@@ -765,6 +768,7 @@ int moka_get_tuning(int key, int *value)
     if (key == 5) { *value = moka::nl_shape(); return MOKA_OK; }
     if (key == 6) { *value = moka::nl_cap_limit(); return MOKA_OK; }
     if (key == 7) { *value = g_rk13.load() ? 1 : 0; return MOKA_OK; }
+    if (key == 8) { *value = moka::pair_modes(); return MOKA_OK; }
     return fail(nullptr, MOKA_ERR_ARG, "unknown tuning key");
 }
 

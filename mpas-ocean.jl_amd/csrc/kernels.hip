@@ -44,7 +44,10 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     extern __shared__ __align__(16) unsigned char smem[];
     const int pl_ = patch_of_block(m.nPatches);
     if (pl_ >= m.nPatches) return;
-    const int p = (m.tailPlus1 && pl_ == m.nPatches - 1) ? m.tailPlus1 - 1 : pl_ + m.patchBegin;
+    // the unit a workgroup walks: one patch, or (m.pairEnd > 0) two consecutive patches as one -- their cell and edge ranges are
+    // consecutive too, so everything below sees one larger patch whose row cache covers both
+    const int p = m.pairEnd ? m.patchBegin + 2 * pl_ : (m.tailPlus1 && pl_ == m.nPatches - 1) ? m.tailPlus1 - 1 : pl_ + m.patchBegin;
+    const int pEnd = m.pairEnd ? (p + 2 < m.pairEnd ? p + 2 : m.pairEnd) : p + 1;
     constexpr int NG = NT / 32;
     const int tid = threadIdx.x;
     const int grp = tid >> 5, l = tid & 31;
@@ -56,8 +59,8 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                              ((size_t)maxOwnE * m.EI + (size_t)maxOwnC * m.CI) * 4 + 15) & ~(size_t)15;
     double2 *ubuf2 = reinterpret_cast<double2 *>(smem + recBytes);
     const unsigned char *ubytes = reinterpret_cast<const unsigned char *>(ubuf2) + voff;
-    const int c0 = cptr(m.patchCellStart)[p], c1 = cptr(m.patchCellStart)[p + 1];
-    const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[p + 1];
+    const int c0 = cptr(m.patchCellStart)[p], c1 = cptr(m.patchCellStart)[pEnd];
+    const int e0 = cptr(m.patchEdgeStart)[p], e1 = cptr(m.patchEdgeStart)[pEnd];
     const int nOwnC = c1 - c0, nOwnE = e1 - e0;
     const uint32_t e0B = (uint32_t)e0 * rowB, nOwnB = (uint32_t)nOwnE * rowB;
     // Forward-Euler modes with the vertex pass in the same launch (a.vort): the patch's vertex records sit behind the row cache
@@ -1501,6 +1504,33 @@ static bool launch_rec2c(const ColMesh &m, const StageArgs &a, int mode, dim3 g,
     return launch_rec2c_nt<ME, ME2, BLOCK>(m, a, mode, g, lds, mE, mC, s);
 }
 
+// the pair form (launch_stage_rec2c): 512-thread workgroups over two patches, whose records and rows need more than the default
+// 64 KB of dynamic LDS.  Default: the tendency launch (mode 0) and RK stage 1 (mode 1; 7 in the 13-stream form) -- measured on the
+// product mesh (P = 16, three interleaved rounds): tendency 1.188 -> 1.170 ms, stage 1 1.513 -> 1.479, stage 4 (mode 3) 1.443 ->
+// 1.461: mode 3 does not gain, stages 2 / 3 lose (profiles/r04_variants.txt section 8)
+static std::atomic<int> g_pairModes{(1 << 0) | (1 << 1) | (1 << 7)};
+void set_pair_modes(int mask) { g_pairModes.store(mask); }
+int pair_modes() { return g_pairModes.load(); }
+
+template <int ME, int ME2>
+static bool launch_rec2c_pair(const ColMesh &m, const StageArgs &a, int mode, dim3 g, size_t lds, int mE, int mC, hipStream_t s)
+{
+    const dim3 b(512);
+    // (once per device and mode, and never inside a stream capture: moka_run steps eagerly before it captures)
+    const bool raise = lds > 64 * 1024 && lds_attr_needed(22 + mode);
+#define PAIR_CASE(M)                                                                                                                      \
+    case M:                                                                                                                               \
+        if (raise)                                                                                                                        \
+            (void)hipFuncSetAttribute((const void *)k_stage_rec2c<ME, ME2, M, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, M, 512>), g, b, lds, s, m, a, mE, mC);                                                  \
+        return true;
+    switch (mode) {
+        PAIR_CASE(0) PAIR_CASE(1) PAIR_CASE(2) PAIR_CASE(3) PAIR_CASE(7) PAIR_CASE(8) PAIR_CASE(9)
+    }
+#undef PAIR_CASE
+    return false;
+}
+
 size_t rec2c_lds_bytes(const MeshDev &md)
 {
     return ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 8 + 16;
@@ -1532,7 +1562,7 @@ static inline ColMesh col_mesh(const MeshDev &md, int nLaunch)
 {
     return ColMesh{md.nC, md.nE, md.K, nLaunch, md.patchBegin, md.CI, md.EI, md.patchCellStart, md.patchEdgeStart,
                    md.cRec, md.eRec, md.mltc, md.sdv, md.invArea, md.rsum, md.woe, md.feoe, md.gInvDc, md.tailPatch >= 0 ? md.tailPatch + 1 : 0,
-                   md.patchVertStart, md.vRec, md.cv, md.maxOwnV};
+                   md.patchVertStart, md.vRec, md.cv, md.maxOwnV, 0};
 }
 
 // can launch_stage_rec2c serve whole-mesh launches of this mesh at all (even K <= 64, records + own rows within 64 KB of LDS)
@@ -1551,6 +1581,23 @@ hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t
     if (a.vort && (mode < 4 || !stage_curl_fused(md))) return hipErrorNotSupported;
     const size_t lds = rec2c_lds_bytes(md) + (a.vort ? vert_lds_bytes(md) : 0);
     if (mode < 0 || md.K > 64 || (md.K & 1) || lds > 64 * 1024 || md.maxOwnC < 1 || md.maxOwnE < 1) return hipErrorNotSupported;
+    // Two consecutive patches per 512-thread workgroup for the LIGHT modes (round 4; moka_set_tuning key 8).  Consecutive patches of
+    // the bisection order are neighbours, so one row cache over both serves 7-11 % of what they would otherwise fetch from each
+    // other through the L2 (FETCH_SIZE, profiles/r04_variants.txt section 8): the tendency launch and RK stage 1 gain 1.5-2 % on the
+    // product mesh (4-10 % on a mesh bisected down to 32-cell patches); stage 4 does not, stages 2 and 3 (five streams in flight per
+    // entity) lose: those keep one patch per 256-thread workgroup.  Same entities, same arithmetic, same bits.  Only launches large enough to fill the chip either way,
+    // without a tail patch, and when two such workgroups fit a CU's LDS (two per CU = the 16 waves of four small workgroups).
+    if (((pair_modes() >> mode) & 1) && md.tailPatch < 0 && md.nPatches >= 4096 && md.ME == 6 && md.ME2 == 10) {
+        MeshDev two = md;
+        two.maxOwnE = 2 * md.maxOwnE; two.maxOwnC = 2 * md.maxOwnC;
+        const size_t lds2 = rec2c_lds_bytes(two);
+        if (2 * lds2 + 2048 <= 160 * 1024) {
+            const int nPair = (md.nPatches + 1) / 2;
+            ColMesh mp = col_mesh(md, nPair);
+            mp.pairEnd = md.patchBegin + md.nPatches;
+            if (launch_rec2c_pair<6, 10>(mp, a, mode, dim3(8 * ((nPair + 7) / 8)), lds2, two.maxOwnE, two.maxOwnC, s)) return hipGetLastError();
+        }
+    }
     bool ok = false;
     if (md.ME == 6 && md.ME2 == 10) ok = launch_rec2c<6, 10>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);
     else if (md.ME == 8 && md.ME2 == 14) ok = launch_rec2c<8, 14>(m, a, mode, g, b, lds, md.maxOwnE, md.maxOwnC, s);

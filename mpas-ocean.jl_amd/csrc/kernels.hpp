@@ -53,6 +53,10 @@ struct ColMesh {
     const uint32_t *vRec;
     const double *cv;
     int32_t maxOwnV;
+    // > 0: every workgroup of this launch takes TWO consecutive patches (2 * block, 2 * block + 1 of the launched range, the last one
+    // alone when their number is odd) as one unit -- one staging phase, one row cache over both patches' own edges -- and pairEnd
+    // is the end of the launched patch range (absolute).  k_stage_rec2c, 512 threads; see launch_stage_rec2c.
+    int32_t pairEnd;
 };
 
 enum : int {
@@ -103,6 +107,8 @@ void set_fe_lean(int on);               // measurement: 0 = Forward-Euler steps 
 int fe_lean_enabled();
 void set_fe_prev_mode(int on);          // measurement: 0 = never form the stale layerThicknessEdge from the previous level (mode 6)
 int fe_prev_mode();
+void set_pair_modes(int mask);          // measurement: which modes of the Float64 stage kernel take two patches per 512-thread workgroup
+int pair_modes();
 hipError_t launch_update_ssh_f32(const MeshDev &m, const float *h, float *ssh, int nlev, int lpc, hipStream_t s);
 hipError_t launch_permute_rows_f32(void *dst, const void *src, const int32_t *n2o, int64_t n, int K, int to_device,
                                    hipStream_t s);
