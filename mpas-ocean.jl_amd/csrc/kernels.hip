@@ -1587,7 +1587,9 @@ hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t
     // product mesh (4-10 % on a mesh bisected down to 32-cell patches); stage 4 does not, stages 2 and 3 (five streams in flight per
     // entity) lose: those keep one patch per 256-thread workgroup.  Same entities, same arithmetic, same bits.  Only launches large enough to fill the chip either way,
     // without a tail patch, and when two such workgroups fit a CU's LDS (two per CU = the 16 waves of four small workgroups).
-    if (((pair_modes() >> mode) & 1) && md.tailPatch < 0 && md.nPatches >= 4096 && md.ME == 6 && md.ME2 == 10) {
+    // (bit 16 of the mask is a test hook: small launches too)
+    if (((pair_modes() >> mode) & 1) && md.tailPatch < 0 && (md.nPatches >= 4096 || ((pair_modes() >> 16) & 1)) && md.nPatches >= 2 &&
+        md.ME == 6 && md.ME2 == 10) {
         MeshDev two = md;
         two.maxOwnE = 2 * md.maxOwnE; two.maxOwnC = 2 * md.maxOwnC;
         const size_t lds2 = rec2c_lds_bytes(two);

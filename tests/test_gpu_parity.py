@@ -621,6 +621,54 @@ def test_rk4_bitwise(backend, meshname, K, nsteps, variant):
     Prog._state.close(); Setup.mesh.close()
 
 
+@pytest.mark.parametrize("meshname,K,P", [("ico32", 60, 0), ("ico16", 64, 0), ("ico12f", 34, 12), ("ico32", 60, 5)])
+def test_two_patches_per_workgroup_bitwise(backend, meshname, K, P):
+    """moka_set_tuning(8, mask): large launches of the Float64 stage kernel walk TWO consecutive patches per 512-thread workgroup
+    (one staging phase, one row cache over both patches' own edges).  Same entities, same arithmetic: the tendency launch, RK4 steps
+    in the reference's and in the 13-stream form, with every mode paired (bit 16 of the mask drops the size threshold for the test),
+    odd patch counts and partial level masks included, equal the oracle bit for bit -- and equal the unpaired launches."""
+    mesh = get_mesh(meshname)
+    ssh, u, h, rest = random_state(mesh, K, 31)
+    mlt = np.full(mesh.nEdges, K, dtype=np.int32)
+    if meshname == "ico12f":
+        r = np.random.default_rng(8)
+        sel = r.random(mesh.nEdges) < 0.3
+        mlt[sel] = r.integers(0, K + 1, int(sel.sum()))
+    hm = mk.HorzMesh(mesh)
+    vm = mk.VerticalMesh(hm, nVertLevels=K, restingThickness=rest, multilayer=True)
+    vm.maxLevelEdge.Top[:] = mlt
+    M = mk.Mesh(hm, vm, backend=backend, patch_cells=P)
+    Prog = mk.PrognosticVars(ssh, u, h, 2, M)
+    Diag, Tend = mk.DiagnosticVars(None, M, Prog._state), mk.TendencyVars(None, M, Prog._state)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=mlt)
+    st = orc.OracleState(om, ssh, u, h)
+    lib, hS = L.lib(), Prog._state._h
+    every = (1 << 16) | 0b1110001111                       # modes 0-3 and 7-9, no size threshold
+    try:
+        L.check(lib.moka_set_tuning(8, every))
+        mk.computeTendency(M, Diag, Prog, Tend)
+        tu, th, _ = om.tendencies_clean(u, h)
+        assert np.array_equal(Tend.tendNormalVelocity.get(), tu) and np.array_equal(Tend.tendLayerThickness.get(), th)
+        for _ in range(2):
+            L.check(lib.moka_step_rk4(hS, 20.0), backend._h)
+            st.step_rk4(20.0)
+        got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+        for k in exp:
+            assert np.array_equal(got[k], exp[k]), k
+        L.check(lib.moka_set_tuning(7, 1))
+        for _ in range(2):
+            L.check(lib.moka_step_rk4(hS, 20.0), backend._h)
+            st.step_rk4_s13(20.0)
+        L.check(lib.moka_set_tuning(7, 0))
+        got, exp = all_fields(Prog, Diag, Tend), oracle_fields(st)
+        for k in exp:
+            assert np.array_equal(got[k], exp[k]), k
+    finally:
+        L.check(lib.moka_set_tuning(7, 0))
+        L.check(lib.moka_set_tuning(8, 0b10000011))           # the default mask: modes 0, 1, 7
+    Prog._state.close(); M.close()
+
+
 @pytest.mark.parametrize("meshname,K,P,nsteps", [("ico16", 60, 0, 3), ("ico32", 34, 0, 2), ("ico12f", 64, 12, 2), ("ico16", 60, 0, 11)])
 def test_rk4_13_stream_form_bitwise_against_its_twin(backend, meshname, K, P, nsteps):
     """moka_set_tuning(7, 1): RK4 steps with 13 instead of 16 state streams (stage kernel modes 7 / 8 / 9; New formed by stage 4
