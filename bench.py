@@ -536,6 +536,17 @@ def placement_summary(rep):
     if rep.get("ms_before"):
         out["first_placement_ms"] = rep["ms_before"]
         out["kept_vs_first"] = rep["ms_after"] / rep["ms_before"]
+        # every trial as a whole-step figure (a trial reports the launches its array takes part in): the layout before the trial
+        # with those launches replaced by the trial's timing; the kept layout against the best of them
+        cur, totals = rep["ms_before"], []
+        for t in rep.get("trials", []):
+            tot = cur - (t["ms_old"] - t["ms_new"])
+            totals.append(tot)
+            if t["kept"]:
+                cur = tot
+        out["trial_totals_ms"] = totals
+        out["best_trial_ms"] = min(totals + [rep["ms_before"]])
+        out["kept_vs_best_trial"] = rep["ms_after"] / out["best_trial_ms"]
     out["note"] = ("moka_state_optimize_placement (C ABI; what julia/MokaHIP.jl calls at binding): dt = 0 stage launches timed with the "
                    "library's events, one array re-allocated per trial, kept when the launches it takes part in got faster; "
                    "ms_* = sum of the four stage launches' medians (DESIGN section 5)")
