@@ -619,7 +619,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg of the default single-GPU run")
     ap.add_argument("--tend-iters", type=int, default=20)
-    ap.add_argument("--placement-tries", type=int, default=16,
+    ap.add_argument("--placement-tries", type=int, default=24,
                     help="upper limit of the per-array re-allocations moka_state_optimize_placement tries at set-up (the library's own "
                          "search, behind the C ABI: one array at a time gets a second allocation, the faster is kept; where the "
                          "allocator puts the arrays decides 5-14 %% of every launch, DESIGN section 5); <= 1 = take what comes")

@@ -237,11 +237,12 @@ int  moka_state_download_rows(moka_state *st, int field, int time_level, int64_t
  * The state's observable contents are unchanged (every array of Prog / Diag / Tend, both time levels, what is lazily
  * pending); only the provisional RK states, which every RK4 step overwrites before reading, are clobbered.
  * *ms_before / *ms_after (opt): sum of the four stage launches' median times before / with the kept layout.
- * max_tries <= 0 measures only.  Stops early after 8 consecutive trials without a gain (every array tried once).
+ * max_tries <= 0 measures only.  Stops early after 12 consecutive trials without a gain (every array tried once: normalVelocity,
+ * layerThickness and ssh of the four buffer sets).
  * MOKA_ERR_UNSUPPORTED once a halo or a tape of the state exists (they export / hold addresses): call it right after
  * moka_state_create (+ uploads), which is what julia/MokaHIP.jl, moka_hip.shim and moka_hip.parallel do. */
 int  moka_state_optimize_placement(moka_state *st, int max_tries, double *ms_before, double *ms_after);
-/* What the last moka_state_optimize_placement tried: field = 2 * set + (0 normalVelocity, 1 layerThickness), set 0 = current
+/* What the last moka_state_optimize_placement tried: field = 3 * set + (0 normalVelocity, 1 layerThickness, 2 ssh), set 0 = current
  * level, 1 = previous level, 2 / 3 = RK provisional states; ms_old / ms_new = summed median times of the stage launches the
  * array takes part in with the old / the candidate allocation; kept = 1 when the candidate replaced the old one.
  * *n = number of trials; out receives min(*n, capacity) of them (may be NULL). */

@@ -18,14 +18,18 @@ using namespace mk;
 namespace {
 
 struct FieldSlot {
-    int id;              // moka_placement_trial.field: buffer set * 2 + (0 = normalVelocity, 1 = layerThickness)
+    int id;              // moka_placement_trial.field: buffer set * 3 + (0 = normalVelocity, 1 = layerThickness, 2 = ssh)
     int set;             // 0 current level (A), 1 previous level / New accumulator (B), 2 / 3 the RK provisional states R1 / R2
-    bool isH;
+    int which;           // 0 normalVelocity, 1 layerThickness, 2 ssh
     unsigned stages;     // bit s-1: the stage-s launch reads or writes the array (rk4_stage_args)
 };
 // A: gathered by stage 1, Curr of 2..4.  B: written by 1, read + written by 2..4.  R1: out of 1, in of 2, out of 3, in of 4.  R2: out of 2, in of 3.
-const FieldSlot kSlots[8] = {{4, 2, false, 0xF}, {6, 3, false, 0x6}, {2, 1, false, 0xF}, {0, 0, false, 0xF},
-                             {5, 2, true, 0xF},  {7, 3, true, 0x6},  {3, 1, true, 0xF},  {1, 0, true, 0xF}};
+// The ssh arrays are small (nCells reals) but every edge gathers two of their elements: they are candidates like the rows.
+// (A.ssh is read by stage 1 only, B.ssh written by stage 4 only.)
+const FieldSlot kSlots[12] = {{6, 2, 0, 0xF}, {9, 3, 0, 0x6}, {3, 1, 0, 0xF}, {0, 0, 0, 0xF},
+                              {7, 2, 1, 0xF}, {10, 3, 1, 0x6}, {4, 1, 1, 0xF}, {1, 0, 1, 0xF},
+                              {8, 2, 2, 0xF}, {11, 3, 2, 0x6}, {5, 1, 2, 0x8}, {2, 0, 2, 0x1}};
+constexpr int NSLOTS = 12;
 
 LevelBufs &set_of(moka_state *st, int set) { return set == 0 ? st->lev[1] : set == 1 ? st->lev[0] : st->rk[set - 2]; }
 
@@ -148,11 +152,11 @@ int moka_state_optimize_placement(moka_state *st, int max_tries, double *ms_befo
     if (ms_before) *ms_before = t0;
 
     int sinceGain = 0;
-    for (int tr = 0; tr < max_tries && sinceGain < 8; ++tr) {
-        const FieldSlot &f = kSlots[tr % 8];
+    for (int tr = 0; tr < max_tries && sinceGain < NSLOTS; ++tr) {
+        const FieldSlot &f = kSlots[tr % NSLOTS];
         LevelBufs &set = set_of(st, f.set);
-        double *oldp = f.isH ? set.h : set.u;
-        const size_t bytes = f.isH ? bytesH : bytesU;
+        double *oldp = f.which == 0 ? set.u : f.which == 1 ? set.h : set.ssh;
+        const size_t bytes = f.which == 0 ? bytesU : f.which == 1 ? bytesH : bytesS;
         // hold back at most a quarter of what is free now (and never less than room for this candidate)
         size_t freeB = 0, totalB = 0;
         (void)hipMemGetInfo(&freeB, &totalB);

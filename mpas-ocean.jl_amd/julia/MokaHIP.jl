@@ -305,7 +305,7 @@ end
 
 # ---- binding Prog / Diag / Tend to one device state ---------------------------------------------------
 "upper limit of the per-array placement trials at binding (moka_state_optimize_placement); <= 1 switches the search off"
-const PLACEMENT_TRIES = Ref{Cint}(16)
+const PLACEMENT_TRIES = Ref{Cint}(24)
 const MProg = PrognosticVars{<:Any,<:MArray}          # the reference's struct, parametrised by our array type
 const MDiag = DiagnosticVars{<:Any,<:MArray}
 const MTend = TendencyVars{<:Any,<:MArray}

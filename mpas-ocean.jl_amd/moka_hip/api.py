@@ -337,10 +337,10 @@ class _State:
         _own(self, L.lib().moka_state_destroy, self._h, mesh, mesh.backend)
         self._dependents = []          # weak references to tapes on this state: they dereference it when they are destroyed
 
-    FIELD_NAMES = ("cur.normalVelocity", "cur.layerThickness", "prev.normalVelocity", "prev.layerThickness",
-                   "rk1.normalVelocity", "rk1.layerThickness", "rk2.normalVelocity", "rk2.layerThickness")
+    FIELD_NAMES = ("cur.normalVelocity", "cur.layerThickness", "cur.ssh", "prev.normalVelocity", "prev.layerThickness", "prev.ssh",
+                   "rk1.normalVelocity", "rk1.layerThickness", "rk1.ssh", "rk2.normalVelocity", "rk2.layerThickness", "rk2.ssh")
 
-    def optimize_placement(self, max_tries: int = 16) -> dict:
+    def optimize_placement(self, max_tries: int = 24) -> dict:
         """moka_state_optimize_placement: re-allocate one array at a time where that makes the RK4 stage launches faster
         (the state's contents are unchanged).  Returns {ms_before, ms_after, tries, kept, trials: [...]}; must come before
         a halo or a tape is created on the state."""
@@ -532,7 +532,7 @@ def ocn_run_loop(*args, backend=None, flags: int | None = None):
     return None
 
 
-def prognostic_vars_best_placement(ssh, normalVelocity, layerThickness, nTimeLevels, mesh: "Mesh", tries: int = 16, report: dict | None = None):
+def prognostic_vars_best_placement(ssh, normalVelocity, layerThickness, nTimeLevels, mesh: "Mesh", tries: int = 24, report: dict | None = None):
     """PrognosticVars(...) followed by the library's own placement search (moka_state_optimize_placement, include/moka_hip.h):
     where the allocator puts a state's arrays decides 5-14 % of every stage launch, so the library re-allocates
     one array at a time -- at most `tries` times -- and keeps what makes the RK4 stage launches faster.  The state is, array for

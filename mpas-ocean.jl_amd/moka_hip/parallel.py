@@ -280,7 +280,7 @@ class DistributedModel:
 
     def __init__(self, mesh, ssh, u, h, rest, dt, backend, rank, world, ordering=0, patch_cells=0,
                  transport="nccl", part=None, group=None, state_bytes=8, exchange_lists=None, timeout_s=30.0, nonlinear=False,
-                 placement_tries=16,
+                 placement_tries=24,
                  visc_del2=0.0):
         """exchange_lists(wants: {rank: obj}) -> {rank: obj}: all-to-all of small Python objects between the ranks
         (default: torch.distributed.all_gather_object on `group`); LocalCluster passes None and calls finish() itself."""

@@ -260,7 +260,7 @@ def flush_host_writes(s: State):
         a.host_dirty, a.host_version = False, s.version
 
 
-PLACEMENT_TRIES = 16        # const PLACEMENT_TRIES = Ref{Cint}(16)
+PLACEMENT_TRIES = 24        # const PLACEMENT_TRIES = Ref{Cint}(24)
 
 
 def state_of(Prog: RefPrognosticVars, Diag, Tend, mesh: RefMesh, b: Backend) -> State:
