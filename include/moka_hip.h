@@ -226,6 +226,9 @@ int  moka_state_download(moka_state *st, int field, int time_level, double *host
  * (inspection only: prognostic fields; they exist after the first RK4 step). */
 int  moka_state_download_rows(moka_state *st, int field, int time_level, int64_t nRows, const int32_t *rows, double *host);
 
+/* Device address of a prognostic array (inspection; time_level as above, 0 when the array does not exist yet). */
+int  moka_state_array_address(moka_state *st, int field, int time_level, uint64_t *address);
+
 /* Placement of the state's arrays in device memory.  Where the allocator puts the four buffer sets an RK4 step streams through
  * (current level, previous level = New accumulator, two provisional states) decides 5-14 % of every stage launch (DESIGN.md
  * section 5): a stable property of the memory behind an array, not visible in its address.  The reference's driver only ever

@@ -94,3 +94,16 @@ extern "C" int moka_state_download_rows(moka_state *st, int field, int time_leve
     if (e != hipSuccess) return done(fail(c, MOKA_ERR_HIP, std::string("moka_state_download_rows: ") + hipGetErrorString(e)));
     return done(MOKA_OK);
 }
+
+// Device address of a prognostic array (inspection: tools/placement_addresses.py looks for what distinguishes the allocations the
+// placement search keeps from the ones it drops).  time_level as moka_state_download_rows.
+extern "C" int moka_state_array_address(moka_state *st, int field, int time_level, uint64_t *address)
+{
+    if (!st || !address) return fail(st ? st->ctx : nullptr, MOKA_ERR_ARG, "NULL argument");
+    if (time_level < 0 || time_level > 3 || field < MOKA_F_SSH || field > MOKA_F_LAYER_THICKNESS)
+        return fail(st->ctx, MOKA_ERR_ARG, "prognostic fields, time_level 0..3");
+    const LevelBufs &b = time_level < 2 ? st->lev[time_level] : st->rk[time_level - 2];
+    const double *q = field == MOKA_F_SSH ? b.ssh : field == MOKA_F_NORMAL_VELOCITY ? b.u : b.h;
+    *address = (uint64_t)(uintptr_t)q;
+    return MOKA_OK;
+}
