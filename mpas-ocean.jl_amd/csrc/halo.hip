@@ -748,9 +748,13 @@ int moka_halo_push_wait(moka_halo *h, double timeout_s)
     if (h->streamFlags) {     // the stream that takes the next boundary launch waits for the neighbours' flag words itself
         moka_ctx *c = h->st->ctx;
         HIPCHK(c, hipSetDevice(c->device));
-        hipStream_t next = h->overlapNow ? c->comm : c->stream;
-        for (int i = 0; i < h->nNbr; ++i)
-            HIPCHK(c, hipStreamWaitValue64(next, h->flagsDev + i, h->seq, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+        // on BOTH streams: which of them takes the next launch that reads received rows depends on what follows (an RK4 stage in
+        // either launch order, a Forward-Euler step, a pack, a download) and is not known here.  In the overlapped launch order
+        // this holds the next interior launch back until the exchange has arrived -- correctness before the last microseconds
+        // of an experimental transport.
+        for (hipStream_t q : {c->stream, c->comm})
+            for (int i = 0; i < h->nNbr; ++i)
+                HIPCHK(c, hipStreamWaitValue64(q, h->flagsDev + i, h->seq, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
         return MOKA_OK;
     }
     const auto t0 = std::chrono::steady_clock::now();
