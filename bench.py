@@ -708,6 +708,12 @@ def main():
     if rehearsal:
         log(f"[bench] rank {rank}: {world} ranks on {n_distinct} distinct device(s): this line is a REHEARSAL, not an {world}-GPU result")
 
+    # ---- same-run calibration, before: in front of the set-up (plan, upload, the library's placement search), which in turn sits
+    # right in front of the warm-up.  (Rounds 3 / 4a probed between set-up and warm-up: two seconds of a 600 W copy load let the
+    # package leave the state the stage launches run in -- 1400 W, shader clock 2.1-2.2 GHz -- and the first 100-200 ms of
+    # launches behind such a pause run 1-2 % slower than the steady state; W = 5 warm-up steps are 35 ms.  The probes measure the
+    # box, not the model: they lose nothing by coming first, and the timed region then starts from the state a running model is in.)
+    cal_before = calibrate(backend, "before")
     transport_trials = {}
     model = None
     if world > 1:
@@ -752,8 +758,6 @@ def main():
         if world > 1:
             dist.barrier(group=gloo_group)
 
-    # ---- same-run calibration, before: right in front of the warm-up ----
-    cal_before = calibrate(backend, "before")
     wall, step_ms = timed_steps(backend, step, args.steps, args.warmup, sync_all)
     # ---- ... and after: right behind the timed region ----
     cal_after = calibrate(backend, "after")
@@ -821,7 +825,7 @@ def main():
                    "reread128_GBs_before": cal_before.get("reread128_GBs"), "reread128_GBs_after": cal_after.get("reread128_GBs"),
                    "gather32G_GBs_before": cal_before.get("gather32G_GBs"), "gather32G_GBs_after": cal_after.get("gather32G_GBs"),
                    "probe": f"{PROBE_BYTES >> 30} GiB footprint (half source, half destination), 16 bytes per lane, best of 5 launches, "
-                            "HIP events on the compute stream; before = in front of the warm-up, after = behind the timed region; "
+                            "HIP events on the compute stream; before = in front of the set-up (plan, upload, placement search; the warm-up follows that directly), after = behind the timed region; "
                             "copy = one word per thread (bytes read + written), read = read-only sweep with nontemporal loads, "
                             "gather = 480-byte rows in a scattered order, a half-wave per row (the stage kernels' pattern), "
                             "streams5 = three streams read and two written at once (the mix of the RK stage launches), "
