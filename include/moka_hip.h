@@ -251,6 +251,8 @@ int  moka_state_optimize_placement(moka_state *st, int max_tries, double *ms_bef
  * *n = number of trials; out receives min(*n, capacity) of them (may be NULL). */
 typedef struct { int32_t field; double ms_old, ms_new; int32_t kept; } moka_placement_trial;
 int  moka_state_placement_log(const moka_state *st, int32_t capacity, moka_placement_trial *out, int32_t *n);
+/* stage launches the last search issued (bookkeeping for whoever lines a kernel trace up with a timed region) */
+int64_t moka_state_placement_launches(const moka_state *st);
 
 /* advanceTimeLevels!(Prog)                  src/forward/time_integration.jl:10-40 */
 int moka_advance_time_levels(moka_state *st, int flags);

@@ -63,6 +63,7 @@ int time_stages(moka_state *st, Timer &T, int reps, double ms[4])
         for (int s = 1; s <= 4; ++s) {
             if (r >= 0) HIPCHK(c, hipEventRecord(T.ev[s - 1], c->stream));
             HIPCHK(c, run_stage(st, rk4_stage_args(st, s, 0.0, st->lev[1].ssh)));
+            ++st->placementLaunches;
         }
         if (r < 0) continue;
         HIPCHK(c, hipEventRecord(T.ev[4], c->stream));
@@ -102,6 +103,7 @@ int moka_state_optimize_placement(moka_state *st, int max_tries, double *ms_befo
                                             "the arrays' addresses); call it before moka_halo_create / moka_tape_create");
     HIPCHK(c, hipSetDevice(c->device));
     st->placementLog.clear();
+    st->placementLaunches = 0;
     int rc = ensure_rk_bufs(st);
     if (rc) return rc;
     // what a finished RK4 or lean Forward-Euler step left pending is produced from arrays the measurement overwrites (the provisional
@@ -240,6 +242,8 @@ int moka_state_optimize_placement(moka_state *st, int max_tries, double *ms_befo
     if (ms_after) *ms_after = over(best, 0xF);
     return MOKA_OK;
 }
+
+int64_t moka_state_placement_launches(const moka_state *st) { return st ? st->placementLaunches : 0; }
 
 int moka_state_placement_log(const moka_state *st, int32_t capacity, moka_placement_trial *out, int32_t *n)
 {

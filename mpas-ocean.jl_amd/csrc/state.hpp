@@ -106,6 +106,7 @@ struct moka_state {
     // where they are (moka_state_optimize_placement refuses)
     int attached = 0;
     std::vector<moka_placement_trial> placementLog;   // what the last moka_state_optimize_placement tried
+    int64_t placementLaunches = 0;                    // ... and how many stage launches it issued (measurement bookkeeping)
 };
 
 namespace mk {

@@ -353,6 +353,7 @@ class _State:
         trials = [{"field": self.FIELD_NAMES[t.field], "ms_old": float(t.ms_old), "ms_new": float(t.ms_new), "kept": bool(t.kept)}
                   for t in buf[:n.value]]
         return {"ms_before": float(b.value), "ms_after": float(a.value), "tries": int(n.value),
+                "stage_launches": int(L.lib().moka_state_placement_launches(self._h)),
                 "kept": sum(t["kept"] for t in trials), "trials": trials}
 
     def close(self):

@@ -98,7 +98,7 @@ EXPORTS = [
     "moka_gradient_on_edge_vjp", "moka_gradient_on_edge_jvp", "moka_divergence_on_cell_vjp", "moka_divergence_on_cell_jvp",
     "moka_curl_on_vertex_vjp", "moka_curl_on_vertex_jvp", "moka_fe_lazy_pending",
     "moka_state_optimize_placement", "moka_state_placement_log", "moka_state_download_rows",
-    "moka_halo_stats_enable", "moka_halo_stats_read", "moka_halo_set_stream_flags", "moka_state_array_address",
+    "moka_halo_stats_enable", "moka_halo_stats_read", "moka_halo_set_stream_flags", "moka_state_array_address", "moka_state_placement_launches",
 ]
 
 
@@ -162,6 +162,8 @@ def lib():
     L.moka_state_destroy.argtypes = [vp]
     L.moka_state_destroy.restype = None
     L.moka_state_optimize_placement.argtypes = [vp, C.c_int, _f64p, _f64p]
+    L.moka_state_placement_launches.argtypes = [vp]
+    L.moka_state_placement_launches.restype = C.c_int64
     L.moka_state_placement_log.argtypes = [vp, C.c_int32, C.POINTER(PlacementTrial), _i32p]
     L.moka_state_array_address.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     L.moka_state_download_rows.argtypes = [vp, C.c_int, C.c_int, C.c_int64, _i32p, _f64p]

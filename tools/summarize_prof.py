@@ -63,7 +63,7 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
         # in front of the warm-up: the placement search of the set-up (moka_state_optimize_placement: one untimed + five timed dt = 0
         # steps for the baseline and per trial: 24 launches each)
         pl = bl.get("placement", {})
-        skip = 24 * (1 + pl.get("tries", 0)) if pl.get("ms_before") else 0
+        skip = pl.get("stage_launches", 24 * (1 + pl.get("tries", 0)) if pl.get("ms_before") else 0)
         timed = stage[skip + 4 * w:skip + 4 * (w + k)]
         print(f"== {leg_name} ==")
         if len(timed) == 4 * k:
