@@ -829,7 +829,7 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     UP(eoc) UP(coc) UP(mltc) UP(sdv) UP(invArea) UP(areaCell) UP(rsum)
     UP(ehdr) UP(eoe) UP(woe) UP(gInvDc) UP(dcEdge) UP(dvEdge) UP(fEdge)
     UP(eov) UP(cv) UP(cellN2O) UP(edgeN2O) UP(vertN2O)
-    UP(haloStart) UP(haloEdge) UP(leoc) UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(vRec) UP(lcOff) UP(leOff) UP(patchRegular) UP(rowStart) UP(rowEdge) UP(cRecT) UP(eRecT)
+    UP(leoe) UP(cRec) UP(eRec) UP(feoe) UP(vRec) UP(rowStart) UP(rowEdge)
     if (p.nlOk) { UP(voe) UP(cov) UP(kite) UP(invAreaTri) UP(fVertex) UP(keCoef) UP(invDc) UP(keoc) UP(rowVoe) }
     if (p.nl5Ok) { UP(pvStart) UP(pvList) UP(lvoe) }
 #undef UP
@@ -837,7 +837,6 @@ int moka_mesh_create(moka_ctx *ctx, const moka_mesh_desc *desc, moka_mesh **out)
     if (!p.nl5Ok) { d.pvStart = nullptr; d.pvList = nullptr; d.lvoe = nullptr; }
     d.CI = p.CI; d.EI = p.EI;
     m->colOk = p.colOk;
-    d.tileRecOk = 0;
 
     d.maxRows = p.maxRows; d.maxOwnE = p.maxOwnE; d.maxOwnC = p.maxOwnC;
     d.maxOwnV = p.maxOwnV;

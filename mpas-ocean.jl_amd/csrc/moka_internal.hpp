@@ -53,7 +53,6 @@ struct Plan {
     //   eRec[e][EI]: [0,ME2) u-row offsets of edgesOnEdge | c1 | c2 | valid-slot mask | maxLevelEdgeTop
     // invalid slots carry the entity's own (valid) offset.  feoe = fEdge[edgesOnEdge] per slot.
     std::vector<uint32_t> cRec, eRec;
-    std::vector<uint32_t> cRecT, eRecT;   // the same with patch-local LDS row-image offsets in the u-row slots (tiled kernels)
     std::vector<double>   feoe;       // nE*ME2
     // vRec[v][4] (vertexDegree 3 only): u-row byte offsets of the vertex's three edges | 0 -- the relativeVorticity pass of the
     // Forward-Euler modes of the stage kernels (weights: cv)
@@ -61,7 +60,7 @@ struct Plan {
     int32_t maxOwnV = 0;              // most vertices any patch owns
     int32_t CI = 0, EI = 0;
     bool colOk = false;               // K*stateBytes*nE < 4 GiB: offsets fit 32 bits
-    // patch-local view for the LDS-tiled kernel: the u-rows a patch needs are its own edges
+    // patch-local view (the nonlinear stage kernel's LDS q_e rows; host tests): the u-rows a patch needs are its own edges
     // [patchEdgeStart[p], patchEdgeStart[p+1]) followed by haloEdge[haloStart[p] .. haloStart[p+1]);
     // leoc / leoe hold, per cell slot / edgesOnEdge slot, the row index inside that list (0xFF = none).
     std::vector<int32_t> rowStart;    // nPatches + 1 : the full staged-row list (own edges then halo edges) ...
@@ -70,11 +69,6 @@ struct Plan {
     std::vector<int32_t> haloEdge;    // new edge ids
     std::vector<uint8_t> leoc;        // nC*8
     std::vector<uint8_t> leoe;        // nE*16
-    // the same as LDS BYTE offsets (local row * K*8; 0xFFFFFFFF = none) for the tiled kernel, and a per-patch
-    // flag "every slot valid and every level active" that selects its predicate-free fast path
-    std::vector<uint32_t> lcOff;      // nC*ME
-    std::vector<uint32_t> leOff;      // nE*ME2
-    std::vector<int32_t>  patchRegular;   // nPatches
     int32_t maxRows = 0, maxOwnE = 0, maxOwnC = 0;
     // the same maxima over the patches that are ever launched (those starting with a cell of class < 2: halo-only
     // patches of a partitioned mesh own up to 6 edges per cell and are never computed)
@@ -118,16 +112,13 @@ struct MeshDev {
     const int32_t *cellN2O, *edgeN2O, *vertN2O;
     // column kernel records
     const uint32_t *cRec, *eRec;
-    const uint32_t *cRecT, *eRecT;
     const double *feoe;
     const uint32_t *vRec;
     int32_t maxOwnV;
     int32_t CI, EI;
-    // LDS-tiled kernel
-    const int32_t *haloStart, *haloEdge, *rowStart, *rowEdge;
-    const uint8_t *leoc, *leoe;
-    const uint32_t *lcOff, *leOff;
-    const int32_t *patchRegular;
+    // patch row lists (the nonlinear stage kernel with q_e rows in LDS)
+    const int32_t *rowStart, *rowEdge;
+    const uint8_t *leoe;
     int32_t maxRows, maxOwnE, maxOwnC;
     // optional nonlinear terms (nullptr when the mesh did not bring them)
     const int32_t *voe, *cov;
@@ -136,7 +127,6 @@ struct MeshDev {
     const int32_t *pvStart, *pvList;   // k_stage_nl5 (nullptr when the plan could not build them)
     const uint16_t *lvoe;
     int32_t maxPV, pvCap;              // most vertices any patch lists; rows k_stage_nl5 keeps in LDS (set per launch)
-    int32_t tileRecOk;    // eRecT / cRecT exist and every patch fits the loader budget of the persistent tiled kernel
     int32_t tailPatch;    // >= 0: one extra, non-adjacent patch rides in this launch (default stage kernels only)
 };
 

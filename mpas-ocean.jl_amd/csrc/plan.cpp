@@ -646,48 +646,6 @@ int build_plan(const moka_mesh_desc *d, Plan &p)
     }
     p.pvList.push_back(0);
 
-    // records of the LDS-DMA tiled kernels: eRec / cRec with the u-row slots replaced by the byte offset of the row inside a
-    // patch's LDS row image (pieces of 1 KiB holding 1024 / rowBytes whole rows; csrc/experiments/stage_tile.hip)
-    p.eRecT.clear(); p.cRecT.clear();
-    if (p.ldsOk && p.colOk && !(p.K & 1) && (uint64_t)p.K * p.stateBytes <= 512 && p.stateBytes == 8) {
-        const uint32_t rowB = (uint32_t)p.K * 8u, rpp = 1024u / rowB;
-        auto toff = [&](uint32_t r) { return (r / rpp) * 1024u + (r % rpp) * rowB; };
-        p.eRecT = p.eRec; p.cRecT = p.cRec;
-        for (int e = 0; e < nE; ++e)
-            for (int i = 0; i < ME2; ++i) {
-                const uint8_t id = p.leoe[(size_t)e * 16 + i];
-                p.eRecT[(size_t)e * p.EI + i] = id == 0xFF ? 0u : toff(id);
-            }
-        for (int c = 0; c < nC; ++c)
-            for (int i = 0; i < ME; ++i) {
-                const uint8_t id = p.leoc[(size_t)c * 8 + i];
-                p.cRecT[(size_t)c * p.CI + i] = id == 0xFF ? 0u : toff(id);
-            }
-    }
-    p.lcOff.assign((size_t)nC * ME, 0xFFFFFFFFu);
-    p.leOff.assign((size_t)nE * ME2, 0xFFFFFFFFu);
-    p.patchRegular.assign(p.nPatches, 0);
-    if (p.ldsOk) {
-        const uint32_t rowB = (uint32_t)p.K * (uint32_t)p.stateBytes;
-        for (int c = 0; c < nC; ++c)
-            for (int i = 0; i < ME; ++i)
-                if (p.leoc[(size_t)c * 8 + i] != 0xFF) p.lcOff[IX(i, c, ME)] = p.leoc[(size_t)c * 8 + i] * rowB;
-        for (int e = 0; e < nE; ++e)
-            for (int i = 0; i < ME2; ++i)
-                if (p.leoe[(size_t)e * 16 + i] != 0xFF) p.leOff[IX(i, e, ME2)] = p.leoe[(size_t)e * 16 + i] * rowB;
-        for (int q = 0; q < p.nPatches; ++q) {
-            bool reg = true;
-            for (int c = p.patchCellStart[q]; c < p.patchCellStart[q + 1] && reg; ++c)
-                for (int i = 0; i < ME; ++i)
-                    if (p.eoc[IX(i, c, ME)] < 0 || p.mltc[IX(i, c, ME)] < p.K) { reg = false; break; }
-            for (int e = p.patchEdgeStart[q]; e < p.patchEdgeStart[q + 1] && reg; ++e) {
-                if (p.ehdr[4 * (size_t)e + 3] < p.K) { reg = false; break; }
-                for (int i = 0; i < ME2; ++i)
-                    if (p.eoe[IX(i, e, ME2)] < 0) { reg = false; break; }
-            }
-            p.patchRegular[q] = reg ? 1 : 0;
-        }
-    }
     return MOKA_OK;
 }
 
