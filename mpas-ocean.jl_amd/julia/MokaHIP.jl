@@ -343,8 +343,9 @@ function state_of(Prog::MProg, Diag, Tend, S::ModelSetup, b::Backend)
         # state's arrays -- 5-14 % of every stage launch, DESIGN.md section 5 -- is settled here, by the library itself:
         # up to PLACEMENT_TRIES per-array re-allocations, each kept only if the launches it takes part in got faster.  The
         # state's contents are untouched.  Must come before any tape of the state exists (the library refuses afterwards).
-        PLACEMENT_TRIES[] > 1 && check(ccall((:moka_state_optimize_placement, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
-                                             s.handle, PLACEMENT_TRIES[], C_NULL, C_NULL), b.ctx)
+        # (an optimisation: its failure -- e.g. no memory for a candidate -- leaves the state as it was and is not an error of the model)
+        PLACEMENT_TRIES[] > 1 && ccall((:moka_state_optimize_placement, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
+                                       s.handle, PLACEMENT_TRIES[], C_NULL, C_NULL)
     end
     if Diag !== nothing && Diag.layerThicknessEdge.state === nothing         # KA.zeros on the host == zero-initialised device fields
         for (a, f) in ((Diag.layerThicknessEdge, F_HEDGE), (Diag.thicknessFlux, F_FLUX), (Diag.velocityDivCell, F_DIV), (Diag.relativeVorticity, F_VORT))

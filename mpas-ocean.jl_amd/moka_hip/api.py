@@ -540,7 +540,14 @@ def prognostic_vars_best_placement(ssh, normalVelocity, layerThickness, nTimeLev
     array and flag for flag, what a fresh PrognosticVars(...) holds (round 3 did the search here, over whole candidate states, and
     left the trial steps' traces in the kept one: ADVICE r03).  tries <= 1: no search."""
     P = PrognosticVars(ssh, normalVelocity, layerThickness, nTimeLevels, mesh)
-    rep = P._state.optimize_placement(int(tries)) if int(tries) > 1 else {"tries": 0, "trials": [], "kept": 0}
+    rep = {"tries": 0, "trials": [], "kept": 0}
+    if int(tries) > 1:
+        try:
+            rep = P._state.optimize_placement(int(tries))
+        except MokaError as exc:               # an optimisation: no memory for a candidate etc. leaves the state as it was
+            if exc.code not in (L.ERR_ALLOC, L.ERR_HIP):
+                raise
+            rep["error"] = str(exc)
     if report is not None:
         report.update(rep)
     return P

@@ -278,7 +278,7 @@ def state_of(Prog: RefPrognosticVars, Diag, Tend, mesh: RefMesh, b: Backend) -> 
             _bind(Prog.layerThickness[t], s, L.F_LAYER_THICKNESS, t, True)
         # the library's own per-array placement search, at binding (MokaHIP.jl state_of: PLACEMENT_TRIES)
         if PLACEMENT_TRIES > 1:
-            L.check(L.lib().moka_state_optimize_placement(h, PLACEMENT_TRIES, None, None), b._h)
+            L.lib().moka_state_optimize_placement(h, PLACEMENT_TRIES, None, None)     # an optimisation: its failure is not the model's
     if Diag is not None and Diag.layerThicknessEdge.state is None:
         for a, f in ((Diag.layerThicknessEdge, L.F_LAYER_THICKNESS_EDGE), (Diag.thicknessFlux, L.F_THICKNESS_FLUX),
                      (Diag.velocityDivCell, L.F_VELOCITY_DIV_CELL), (Diag.relativeVorticity, L.F_RELATIVE_VORTICITY)):
