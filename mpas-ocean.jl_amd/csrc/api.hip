@@ -336,7 +336,7 @@ bool fe_stage_path(const moka_state *st, int flags)
 // level set, and -- with the reference's stale flux thickness -- that thickness to be derivable from the previous level.
 bool fe_lean(const moka_state *st, int flags)
 {
-    return moka::fe_lean_enabled() && !st->feForceEager && !st->feNoLean && fe_stage_path(st, flags) && st->spare.ssh &&
+    return moka::fe_lean_enabled() && !st->feForceEager && fe_stage_path(st, flags) && st->spare.ssh &&
            (!(flags & MOKA_FE_STALE_HEDGE) || (st->hEdgePrev && moka::fe_prev_mode()));
 }
 
@@ -361,6 +361,7 @@ void fe_end(moka_state *st, int flags, bool stageKernel, bool lean, bool prevMod
     if (!lean) std::swap(st->hEdge[0], st->hEdge[1]);          // a lean step has not written layerThicknessEdge
     st->feFast = stageKernel ? (prevMode ? 2 : 1) : 0;
     st->feLazy = lean;
+    st->feLazyCount = -1;              // (a distributed step with a direct halo narrows it: moka_fe_dist_end)
     st->feLazyStale = lean && (flags & MOKA_FE_STALE_HEDGE);
     // the stage kernel interpolated (or, lean, will interpolate) layerThicknessEdge of every computed edge from the level that is
     // the previous one now: the next step may form the reference's stale flux thickness from that level (mode 6)
@@ -412,9 +413,14 @@ static int materialize_fe(moka_state *st)
     MeshDev dev = mm->dev;
     dev.tailPatch = -1;
     dev.patchBegin = 0; dev.nPatches = mm->plan.nPatchesLaunch;
+    if (st->feLazyCount >= 0) {                                 // a distributed step with a direct halo: the interior patches only
+        dev.patchBegin = st->feLazyBegin; dev.nPatches = st->feLazyCount;
+    }
     dev.maxOwnE = std::max(mm->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(mm->plan.maxOwnCLaunch, 1);
-    HIPCHK(st->ctx, st->f32 ? launch_stage_rec2c_f32(dev, g, st->ctx->stream) : launch_stage_rec2c(dev, g, st->ctx->stream));
+    if (dev.nPatches > 0)
+        HIPCHK(st->ctx, st->f32 ? launch_stage_rec2c_f32(dev, g, st->ctx->stream) : launch_stage_rec2c(dev, g, st->ctx->stream));
     st->feLazy = false;
+    st->feLazyCount = -1;
     return MOKA_OK;
 }
 

@@ -27,12 +27,15 @@
 //        therefore launched FIRST, ahead of the boundary launch and the push (moka_fe_dist_step; round 3: launched behind the
 //        interior patches it could still be reading when a neighbour that was a step ahead overwrote those rows).
 // A neighbour has waited for that flag before it computed what it now pushes.
-//   Lean Forward-Euler steps (moka_state.feLazy) are OFF for a state with a connected direct halo (moka_state.feNoLean): the
-//        arrays a lean step leaves pending are produced on first read from the level before the previous one -- the spare
-//        set, halo rows included -- and that is the set a neighbour's NEXT step pushes its new level into; the neighbour needs
-//        only this rank's flag of the current step for that, which is long sent when a caller reads diagnostics between
-//        steps.  Every step of such a state therefore stores all of its arrays inside the step, ahead of its own push
-//        (ADVICE r03).  The buffered transports keep lean steps: their unpack is ordered on this rank's own stream.
+//   Lean Forward-Euler steps (moka_state.feLazy) with a connected direct halo (moka_state.feLeanInteriorOnly): the arrays a lean
+//        step leaves pending are produced on first read from the level before the previous one -- the spare set -- and the halo
+//        rows of that set are what a neighbour's NEXT step pushes its new level into (it needs only this rank's flag of the
+//        current step for that, long sent when a caller reads diagnostics between steps).  Only BOUNDARY patches read halo rows.
+//        So the boundary launch of such a step stores every array of its patches at once (in place: a lean step's launches read
+//        no stored layerThicknessEdge), ahead of this rank's own push, and only the INTERIOR patches' arrays stay pending
+//        (moka_state.feLazyBegin / feLazyCount): their stencils reach owned rows only -- a cell next to a halo cell is a boundary
+//        cell, and an edge between a boundary cell and a halo cell is owned by the boundary cell (round 4a had
+//        switched lean steps off altogether for such states: 2.85 instead of 1.65 ms per step at config 4).
 //
 // Visibility of peer-written rows (the fields are ordinary, coarse-grained hipMalloc memory): a push kernel ends with
 // __threadfence_system() and its completion event precedes the flag store (release) the reader's host thread acquires
@@ -682,7 +685,7 @@ int moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer
     }
     h->peers[nbr] = pl;
     h->tabDirty = true;
-    st->feNoLean = true;          // peers may store into this state's level sets from now on: see the header (lean steps)
+    st->feLeanInteriorOnly = true;   // peers may store into this state's level sets from now on: see the header (lean steps)
     return MOKA_OK;
 }
 
@@ -1088,6 +1091,11 @@ int moka_fe_dist_launch(moka_halo *h, double dt, int flags, int part)
     h->fePrev = g.hPrev != nullptr;
     const bool vortFused = fe_vort_fused(h);
     if (!vortFused) g.vort = nullptr;       // part 2 runs the vertex pass over every local vertex
+    if (part == 0 && st->feLeanInteriorOnly && fe_lean(st, flags)) {
+        // lean step, direct halo: the boundary patches store their DiagnosticVars / TendencyVars now (see the header), in place
+        g.tendU = a.tendU; g.tendH = a.tendH; g.F = a.F; g.div = a.div;
+        g.hEdgeNew = st->hEdge[0];
+    }
     if (st->f32) {                         // the Forward-Euler modes of the fp32-storage kernel: no generic form behind them
         HIPCHK(c, launch_stage_rec2c_f32(dev, g, c->stream));
         h->feStageKernel = true;
@@ -1111,6 +1119,10 @@ int moka_fe_dist_end(moka_halo *h)
     // (lean: decided by the same pure function the launches used; the stage kernel interpolates layerThicknessEdge of every edge
     //  with an owned cell from the level that becomes the previous one now)
     fe_end(st, h->feFlags, h->feStageKernel, h->feStageKernel && fe_lean(st, h->feFlags), h->fePrev);
+    if (st->feLazy && st->feLeanInteriorOnly) {      // the boundary patches have stored theirs: pending = the interior patches
+        st->feLazyBegin = h->pFirst;
+        st->feLazyCount = h->pOwned - h->pFirst;
+    }
     st->sshConsistent = true;
     return MOKA_OK;
 }

@@ -80,7 +80,9 @@ struct moka_state {
     // supersedes them, exactly as an RK4 step supersedes its lazily produced diagnostics.
     bool feLazy = false, feLazyStale = false;
     bool feForceEager = false;        // a tape is recording: every step stores all of its arrays
-    bool feNoLean = false;            // a direct (peer-store) halo is connected: lean steps are off, see the halo.hip header
+    bool feLeanInteriorOnly = false;  // a direct (peer-store) halo is connected: a lean distributed step stores every array of its
+                                      // BOUNDARY patches at once and leaves only the interior patches' pending (halo.hip header)
+    int feLazyBegin = 0, feLazyCount = -1;   // the patch range whose arrays are pending (-1: every launched patch)
     double *scalar = nullptr;         // 1 double (sum_sq result)
     bool sshConsistent = false;       // lev[1].ssh == ksum(lev[1].h) - restingThicknessSum
     // moka_step_rk4 ends with diagnostic_compute! of the new state and leaves the stage-4 tendencies in
