@@ -1370,6 +1370,42 @@ def test_nonlinear_keeps_williamson_tc2_steady_on_the_gpu(backend):
     assert np.isfinite(drift[True]) and drift[True] < 0.25 * drift[False], drift
 
 
+def test_round4_entry_points_arguments_and_edges(backend):
+    """moka_state_download_rows / moka_state_array_address / moka_state_optimize_placement(max_tries <= 0) /
+    moka_state_placement_launches: argument checks (nothing aborts: a negative status and a message) and the edge cases."""
+    mesh = get_mesh("ico16")
+    K = 60
+    ssh, u, h, rest = random_state(mesh, K, 3)
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    lib, hS, ctx = L.lib(), Prog._state._h, backend._h
+    U = Prog.normalVelocity[-1]
+    ids = np.array([0, mesh.nEdges - 1, 5, 5], dtype=np.int32)                 # any order, repeats allowed
+    assert np.array_equal(U.rows(ids), u[ids]) and np.array_equal(Prog.ssh[-1].rows([3, 1]), ssh[[3, 1]])
+    assert U.rows(np.zeros(0, dtype=np.int32)).shape == (0, K)
+    out = np.empty((1, K))
+    bad = np.array([mesh.nEdges], dtype=np.int32)
+    assert lib.moka_state_download_rows(hS, L.F_NORMAL_VELOCITY, 1, 1, L.i32(bad), L.f64(out)) == L.ERR_ARG
+    assert b"out of range" in lib.moka_last_error(ctx)
+    assert lib.moka_state_download_rows(hS, L.F_NORMAL_VELOCITY, 2, 1, L.i32(ids), L.f64(out)) == L.ERR_ARG     # no RK4 step yet
+    assert lib.moka_state_download_rows(hS, L.F_NORMAL_VELOCITY, 4, 1, L.i32(ids), L.f64(out)) == L.ERR_ARG
+    assert lib.moka_state_download_rows(hS, L.F_THICKNESS_FLUX, 3, 1, L.i32(ids), L.f64(out)) == L.ERR_ARG
+    assert lib.moka_state_download_rows(None, L.F_SSH, 1, 1, L.i32(ids), L.f64(out)) == L.ERR_ARG
+    a = C.c_uint64(1)
+    L.check(lib.moka_state_array_address(hS, L.F_NORMAL_VELOCITY, 2, C.byref(a)), ctx)
+    assert a.value == 0                                                           # the provisional states do not exist yet
+    L.check(lib.moka_state_array_address(hS, L.F_LAYER_THICKNESS, 1, C.byref(a)), ctx)
+    assert a.value != 0 and a.value % 16 == 0
+    assert lib.moka_state_array_address(hS, L.F_THICKNESS_FLUX, 1, C.byref(a)) == L.ERR_ARG
+    rep = Prog._state.optimize_placement(0)                                       # measures only
+    assert rep["tries"] == 0 and rep["ms_before"] == rep["ms_after"] > 0.0 and rep["stage_launches"] >= 48 and rep["stage_launches"] % 24 == 0
+    L.check(lib.moka_state_array_address(hS, L.F_NORMAL_VELOCITY, 2, C.byref(a)), ctx)
+    assert a.value != 0                                                           # (the measurement allocated them)
+    assert np.array_equal(U.get(), u)
+    mk.run_steps(Prog, mk.RungeKutta4, 20.0, 1)
+    assert U.rows(ids, level=2).shape == (4, K) and np.all(np.isfinite(U.rows(ids, level=3)))
+    Prog._state.close(); Setup.mesh.close()
+
+
 @pytest.mark.parametrize("sbytes,K", [(8, 60), (4, 80)])
 def test_optimize_placement_through_the_c_abi(backend, sbytes, K):
     """moka_state_optimize_placement (include/moka_hip.h): arrays of the state are re-allocated one at a time where that makes the
