@@ -428,9 +428,14 @@ int moka_set_kernel_variant(moka_ctx *ctx, int variant);
  * (time_integration.jl:134-135); here stages 1-3 store only the provisional states and stage 4 forms
  * New = C + ((P2 - C) + 2 (P3 - C) + (P4 - C)) / 3 + dt/6 k4 from own rows -- the same Runge-Kutta step up to round-off (a
  * few units in the last place of the state per step; oracle twin oracle_step_rk4_s13, tests/test_oracle_igw.py holds the
- * tolerance against the reference form).  Distributed, taped, fp32-storage and nonlinear steps keep the reference's form. */
+ * tolerance against the reference form).  With the nonlinear terms on: the same where the stage launch is the default patch
+ * kernel (even 34 <= nVertLevels <= 64; twin oracle_step_rk4_nonlinear_s13).  Distributed, taped and fp32-storage steps keep
+ * the reference's form.  moka_state_rk4_streams tells which form the next moka_step_rk4 of a state takes. */
 int moka_set_tuning(int key, int value);
 int moka_get_tuning(int key, int *value);
+/* 13 = the next moka_step_rk4 / moka_run of this state runs in the 13-stream form (key 7 set and the state qualifies), 16 = the
+ * reference's running sum (time_integration.jl:134-135); 0 for NULL. */
+int moka_state_rk4_streams(const moka_state *st);
 /* Per-stage durations of moka_step_rk4 from HIP events on the compute stream (measurement: bench.py's per-mode roofline
  * lines).  moka_stage_timing(ctx, 1) forgets earlier samples and records 5 events per step from now on; (ctx, 0) stops.
  * moka_stage_timing_read: ms[s-1] = mean duration of the stage-s launch over the *steps recorded steps. */

@@ -1366,12 +1366,15 @@ void rk4_end(moka_state *st)
 // stage 4 alone from OWN rows (no gathers): streams per stage 2 / 3 / 3 / 5 = 13.  Same four buffer sets: P2 -> R1, P3 -> R2,
 // P4 -> the previous level's set, New over P2 in place; the sets then rotate (current <- R1, previous <- old current, R1 <- old
 // previous holding P4, which the lazily produced stage-4 tendencies read).  Round-off differs from the running sum (a few
-// units in the last place of the state per step), hence opt-in; Float64 states on whole meshes through the default stage kernel.
+// units in the last place of the state per step), hence opt-in; Float64 states on whole meshes through the default stage kernel
+// (with the nonlinear terms: through k_stage_nl5, twin oracle_step_rk4_nonlinear_s13).
 bool rk13_usable(const moka_state *st)
 {
-    if (!g_rk13.load() || st->f32 || st->nonlinear) return false;
+    if (!g_rk13.load() || st->f32) return false;
     const moka_mesh *mm = st->mesh;
     if (mm->plan.nPatchesLaunch != mm->plan.nPatches) return false;
+    if (st->nonlinear)             // nonlinear terms: k_stage_nl5 carries the form (StageArgs.rkMode 9), the plainer kernels do not
+        return nl_stage_is_nl5(mm->dev, mm->lpc, st->ctx->variant == 4 ? 1 : st->ctx->variant == 3 ? 3 : 0);
     MeshDev dev = mm->dev;
     dev.maxOwnE = std::max(mm->plan.maxOwnELaunch, 1); dev.maxOwnC = std::max(mm->plan.maxOwnCLaunch, 1);
     return (st->ctx->variant == 0 || st->ctx->variant == 11) && mm->lpc == 64 && mm->colOk && rec2c_supported(dev);
@@ -1412,6 +1415,8 @@ void rk13_end(moka_state *st)
 }
 }  // namespace mk
 extern "C" {
+
+int moka_state_rk4_streams(const moka_state *st) { return !st ? 0 : rk13_usable(st) ? 13 : 16; }
 
 int moka_step_rk4(moka_state *st, double dt)
 {

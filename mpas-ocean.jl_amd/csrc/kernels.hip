@@ -27,16 +27,7 @@ namespace moka {
 // Not pipelined: loads sit behind per-lane branches, so the compiler waits with vmcnt(0) at first use; 12+
 // waves per CU cover the latency instead.
 // ------------------------------------------------------------------------------------------------
-// New of the 13-stream RK4 form from the own values of Curr and the three provisional states (P2 = C + dt/2 k1, P3 = C + dt/2 k2,
-// P4 = C + dt k3) and the last tendency:  C + ((P2 - C) + 2 (P3 - C) + (P4 - C)) / 3 + dt/6 k4  -- the reference's
-// C + dt/6 k1 + dt/3 k2 + dt/3 k3 + dt/6 k4 (time_integration.jl:78,134-135) up to round-off, NOT bit for bit: opt-in, with its own
-// oracle twin (oracle_step_rk4_s13, the same expression) and a tolerance test against the reference form.
-__device__ __forceinline__ double rk13_combine(double c, double p2, double p3, double p4, double b4, double t)
-{
-    const double d2 = p2 - c, d3 = p3 - c, d4 = p4 - c;
-    const double acc = (d2 + (d3 + d3)) + d4;
-    return (c + acc * (1.0 / 3.0)) + b4 * t;
-}
+// (MODE 7 / 8 / 9, the 13-stream RK4 form: rk13_combine in kernels_common.hpp -- the nonlinear stage kernel uses the same expression)
 
 template <int ME, int ME2, int MODE, int NT = BLOCK>
 __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)

@@ -148,6 +148,7 @@ struct NlArgs {
 // (prepare and stage must be called with the same form: forms 0 / 1 keep F alone in NlArgs.fq, forms 2 / 3 {F, q_e} pairs)
 void set_nl_shape(int v);
 int nl_shape();
+bool nl_stage_is_nl5(const MeshDev &m, int lpc, int form);  // the nonlinear stage launch of this mesh is k_stage_nl5 (knows StageArgs.rkMode 9)
 bool nl_patch_forms(const MeshDev &m, int lpc, int form);   // do the nonlinear launches of this mesh go through the per-patch kernels (which serve patch ranges)
 void set_nl_cap_limit(int v);
 int nl_cap_limit();

@@ -281,6 +281,18 @@ inline size_t rec_lds_bytes(const MeshDev &md)
 }
 
 
+// New of the 13-stream RK4 form from the own values of Curr and the three provisional states (P2 = C + dt/2 k1, P3 = C + dt/2 k2,
+// P4 = C + dt k3) and the last tendency:  C + ((P2 - C) + 2 (P3 - C) + (P4 - C)) / 3 + dt/6 k4  -- the reference's
+// C + dt/6 k1 + dt/3 k2 + dt/3 k3 + dt/6 k4 (time_integration.jl:78,134-135) up to round-off, NOT bit for bit: opt-in, with its own
+// oracle twins (oracle_step_rk4_s13, oracle_step_rk4_nonlinear_s13: the same expression) and a tolerance test against the
+// reference form.
+__device__ __forceinline__ double rk13_combine(double c, double p2, double p3, double p4, double b4, double t)
+{
+    const double d2 = p2 - c, d3 = p3 - c, d4 = p4 - c;
+    const double acc = (d2 + (d3 + d3)) + d4;
+    return (c + acc * (1.0 / 3.0)) + b4 * t;
+}
+
 // lanes-per-column dispatch of the generic column kernels (LPC = smallest power of two >= nVertLevels, capped at 64)
 #define DISPATCH_LPC(lpc, CALL)                 \
     switch (lpc) {                              \

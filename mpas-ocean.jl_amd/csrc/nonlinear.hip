@@ -1013,7 +1013,11 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
                 sto(a.ph_out, (unsigned)(c) * rowB + lo, hs);
             }
             if (a.nh_out) {
-                const double2 hn = make_double2(nb.x + a.b * t.x, nb.y + a.b * t.y);
+                double2 hn = make_double2(nb.x + a.b * t.x, nb.y + a.b * t.y);
+                if (a.rkMode == 9) {                                      // 13-stream form, stage 4: New from Curr, P2 (nb), P3, P4 (own rows)
+                    const double2 q3 = ldo(a.q3h, (unsigned)(c) * rowB + lo), p4 = ldo(a.ph, (unsigned)(c) * rowB + lo);
+                    hn = make_double2(rk13_combine(hcur.x, nb.x, q3.x, p4.x, a.b, t.x), rk13_combine(hcur.y, nb.y, q3.y, p4.y, a.b, t.y));
+                }
                 sto(a.nh_out, (unsigned)(c) * rowB + lo, hn);
                 if (!a.ph_out) hs = hn;
             }
@@ -1171,6 +1175,10 @@ __global__ __launch_bounds__(NT, MINW) void k_stage_nl5(const MeshDev m, const S
         pT = t;
         pA = make_double2(ucur.x + a.a * t.x, ucur.y + a.a * t.y);
         pB = make_double2(nbu.x + a.b * t.x, nbu.y + a.b * t.y);
+        if (a.rkMode == 9) {                                              // 13-stream form, stage 4 (own rows; no gathers)
+            const double2 q3 = ldo(a.q3u, pOff), p4 = ldo(a.pu, pOff);
+            pB = make_double2(rk13_combine(ucur.x, nbu.x, q3.x, p4.x, a.b, t.x), rk13_combine(ucur.y, nbu.y, q3.y, p4.y, a.b, t.y));
+        }
         pend = true;
     }
     if (pend) flush();
@@ -1248,6 +1256,17 @@ hipError_t launch_nl_prepare(const MeshDev &m, const double *u, const double *h,
 #define CALL(L) launch_nl_prepare_lpc<L>(m, u, h, nl, s)
     DISPATCH_LPC(lpc, CALL)
 #undef CALL
+}
+
+// the stage launch goes through k_stage_nl5 (the only nonlinear stage kernel that knows the 13-stream form: StageArgs.rkMode 9)
+bool nl_stage_is_nl5(const MeshDev &m, int lpc, int form)
+{
+    const int shape = g_nlShape.load();
+    if (!(lpc == 64 && nl3_ok(m) && form == 0 && shape != 1 && m.pvStart && m.maxPV > 0 &&
+          (uint64_t)std::max(m.nE, std::max(m.nV, m.nC)) * m.K * 8 < (1ull << 32)))
+        return false;
+    const bool cf = shape != 3 && nl5_cap(m, true) >= std::min(m.maxPV, 64);
+    return nl5_cap(m, cf) >= 16;
 }
 
 hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &nl, int lpc, bool rowsOk, int form, hipStream_t s)

@@ -99,6 +99,7 @@ EXPORTS = [
     "moka_curl_on_vertex_vjp", "moka_curl_on_vertex_jvp", "moka_fe_lazy_pending",
     "moka_state_optimize_placement", "moka_state_placement_log", "moka_state_download_rows",
     "moka_halo_stats_enable", "moka_halo_stats_read", "moka_halo_set_stream_flags", "moka_state_array_address", "moka_state_placement_launches",
+    "moka_state_rk4_streams",
 ]
 
 
@@ -163,6 +164,7 @@ def lib():
     L.moka_state_destroy.restype = None
     L.moka_state_optimize_placement.argtypes = [vp, C.c_int, _f64p, _f64p]
     L.moka_state_placement_launches.argtypes = [vp]
+    L.moka_state_rk4_streams.argtypes = [vp]
     L.moka_state_placement_launches.restype = C.c_int64
     L.moka_state_placement_log.argtypes = [vp, C.c_int32, C.POINTER(PlacementTrial), _i32p]
     L.moka_state_array_address.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint64)]

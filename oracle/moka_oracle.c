@@ -821,6 +821,47 @@ void oracle_step_rk4_nonlinear_del2(const oracle_mesh *m, const int32_t *vertice
     oracle_update_ssh(m, s->ssh[1], s->h[1], K);
 }
 
+/* The nonlinear RK4 step in the 13-stream form (twin of the library's opt-in form for nonlinear states: moka_set_tuning key 7):
+ * the stages of oracle_step_rk4_nonlinear_del2 with the update of oracle_step_rk4_s13 (rk13_combine above, same order).
+ * work: 2 * K * (nEdges + nCells) doubles. */
+void oracle_step_rk4_nonlinear_s13(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
+                                   const double *kiteAreasOnVertex, const double *fVertex, oracle_state *s, double dt,
+                                   double *work, double *scratch, double viscDel2)
+{
+    const int K = m->nVertLevels;
+    const int64_t nu = (int64_t)K * m->nEdges, nh = (int64_t)K * m->nCells;
+    double *p2u = work, *p2h = work + nu, *p3u = work + nu + nh, *p3h = work + 2 * nu + nh;
+    double *qe = scratch, *qv = scratch + nu, *ke = qv + (int64_t)K * m->nVertices;
+    double *zv = viscDel2 != 0.0 ? scratch + 4 * nu + (int64_t)K * m->nVertices + nh : NULL;
+    double *divc = zv ? zv + (int64_t)K * m->nVertices : NULL;
+    const double a[3] = {dt / 2., dt / 2., dt};
+    advance_levels(s->ssh[0], s->ssh[1], m->nCells, 1, 1);
+    advance_levels(s->u[0], s->u[1], m->nEdges, K, K);
+    advance_levels(s->h[0], s->h[1], m->nCells, K, K);
+    for (int st = 0; st < 4; ++st) {
+        oracle_tendencies_nonlinear_del2(m, verticesOnEdge, cellsOnVertex, kiteAreasOnVertex, fVertex, s->tendU, s->tendH,
+                                         s->u[1], s->h[1], s->ssh[1], s->hEdge, s->F, qv, qe, ke, viscDel2, zv, divc);
+        double *pu = s->u[1], *ph = s->h[1];
+        const double *cu = s->u[0], *ch = s->h[0], *tu = s->tendU, *th = s->tendH;
+        if (st < 3) {
+            const double as = a[st];
+            PFOR
+            for (int64_t i = 0; i < nu; ++i) pu[i] = cu[i] + as * tu[i];
+            PFOR
+            for (int64_t i = 0; i < nh; ++i) ph[i] = ch[i] + as * th[i];
+            if (st == 0) { memcpy(p2u, pu, sizeof(double) * (size_t)nu); memcpy(p2h, ph, sizeof(double) * (size_t)nh); }
+            if (st == 1) { memcpy(p3u, pu, sizeof(double) * (size_t)nu); memcpy(p3h, ph, sizeof(double) * (size_t)nh); }
+        } else {
+            const double b4 = dt / 6.;
+            PFOR
+            for (int64_t i = 0; i < nu; ++i) pu[i] = rk13_combine(cu[i], p2u[i], p3u[i], pu[i], b4, tu[i]);
+            PFOR
+            for (int64_t i = 0; i < nh; ++i) ph[i] = rk13_combine(ch[i], p2h[i], p3h[i], ph[i], b4, th[i]);
+        }
+    }
+    oracle_update_ssh(m, s->ssh[1], s->h[1], K);
+}
+
 /* K15 sumArray (serial, one work-item)                       src/forward/run_loop.jl:47-51
  *   sum = sum + a[j]*a[j] */
 double oracle_sum_sq(const double *a, int64_t n)

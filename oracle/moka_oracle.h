@@ -118,6 +118,10 @@ void oracle_tendencies_nonlinear_del2(const oracle_mesh *m, const int32_t *verti
 void oracle_step_rk4_nonlinear_del2(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
                                     const double *kiteAreasOnVertex, const double *fVertex, oracle_state *s, double dt,
                                     double *work, double *scratch, double viscDel2);
+/* 13-stream form of the nonlinear step (twin of moka_set_tuning key 7 on a nonlinear state); work: 2*K*(nEdges+nCells) */
+void oracle_step_rk4_nonlinear_s13(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
+                                   const double *kiteAreasOnVertex, const double *fVertex, oracle_state *s, double dt,
+                                   double *work, double *scratch, double viscDel2);
 void oracle_step_rk4_nonlinear(const oracle_mesh *m, const int32_t *verticesOnEdge, const int32_t *cellsOnVertex,
                                const double *kiteAreasOnVertex, const double *fVertex, oracle_state *s, double dt,
                                double *work, double *scratch);

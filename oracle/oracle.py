@@ -91,6 +91,7 @@ def lib():
         L.oracle_step_rk4_nonlinear.argtypes = [mp, _i32p, _i32p, _f64p, _f64p, sp, C.c_double, _f64p, _f64p]
         L.oracle_tendencies_nonlinear_del2.argtypes = [mp, _i32p, _i32p, _f64p, _f64p] + [_f64p] * 10 + [C.c_double, _f64p, _f64p]
         L.oracle_step_rk4_nonlinear_del2.argtypes = [mp, _i32p, _i32p, _f64p, _f64p, sp, C.c_double, _f64p, _f64p, C.c_double]
+        L.oracle_step_rk4_nonlinear_s13.argtypes = [mp, _i32p, _i32p, _f64p, _f64p, sp, C.c_double, _f64p, _f64p, C.c_double]
         L.oracle_sum_sq.restype = C.c_double
         _lib = L
     return _lib
@@ -411,14 +412,19 @@ class OracleNonlinear:
                                                self.visc_del2, _p(zv), _p(divc))
         return tu, th, ssh, {"pv_vertex": qv, "pv_edge": qe, "ke": ke, "relativeVorticity": zv, "velocityDivCell": divc}
 
-    def step_rk4(self, st: OracleState, dt):
+    def step_rk4(self, st: OracleState, dt, s13=False):
         m, K = self.om.mesh, self.om.K
         if st._work is None:
             st._work = np.zeros(2 * K * (m.nEdges + m.nCells) + m.nCells)
         if getattr(st, "_nl_scratch", None) is None:
             st._nl_scratch = np.zeros(4 * K * m.nEdges + 2 * K * m.nVertices + 2 * K * m.nCells)
-        lib().oracle_step_rk4_nonlinear_del2(self.om.ref, _p(self.voe), _p(self.cov), _p(self.kite), _p(self.fv),
-                                             C.byref(st.c), float(dt), _p(st._work), _p(st._nl_scratch), self.visc_del2)
+        fn = lib().oracle_step_rk4_nonlinear_s13 if s13 else lib().oracle_step_rk4_nonlinear_del2
+        fn(self.om.ref, _p(self.voe), _p(self.cov), _p(self.kite), _p(self.fv),
+           C.byref(st.c), float(dt), _p(st._work), _p(st._nl_scratch), self.visc_del2)
+
+    def step_rk4_s13(self, st: OracleState, dt):
+        """The 13-stream form (oracle_step_rk4_nonlinear_s13: twin of the library's opt-in form, its own round-off)."""
+        self.step_rk4(st, dt, s13=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

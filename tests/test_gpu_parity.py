@@ -1301,6 +1301,56 @@ def test_nonlinear_kernel_forms_with_partial_edge_masks(backend, meshname, K, vi
         L.check(L.lib().moka_set_tuning(6, 0))
 
 
+@pytest.mark.parametrize("meshname,K,visc,served", [("ico16", 60, 0.0, True), ("planar", 64, 1.0, True), ("ico32", 34, 0.0, True),
+                                                    ("ico12f", 40, 1.0, False), ("ico16", 70, 0.0, False), ("ico16", 3, 0.0, False)])
+def test_nonlinear_rk4_13_stream_form_bitwise_against_its_twin(backend, meshname, K, visc, served):
+    """moka_set_tuning(7, 1) on a state with the nonlinear terms: where the stage launch is k_stage_nl5 (even 34 <= K <= 64) the RK4
+    step runs in the 13-stream form (StageArgs.rkMode 9 in the last stage; not on ico12f, whose heptagons take the generic kernels) and equals its twin oracle_step_rk4_nonlinear_s13 bit for
+    bit -- both levels, the lazily produced stage-4 tendencies, graph replay; elsewhere the key changes nothing (the reference's
+    running sum).  Key cleared: the running sum again."""
+    mesh = get_mesh(meshname)
+    ssh, u, h, rest = random_state(mesh, K, 61 + K)
+    dtv = 2.0 if meshname == "planar" else 20.0
+    v = visc * 0.01 * float(mesh.dcEdge.min()) ** 2 / dtv
+    Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, CONFIG, backend, multilayer=True)
+    om = orc.OracleMesh(mesh, K, resting_thickness_sum=rest.sum(1), max_level_edge_top=K)
+    nl = orc.OracleNonlinear(om, visc_del2=v) if v else orc.OracleNonlinear(om)
+    mk.set_nonlinear(Prog, True, visc_del2=v)
+    st = orc.OracleState(om, ssh, u, h)
+    step = (lambda: nl.step_rk4_s13(st, dtv)) if served else (lambda: nl.step_rk4(st, dtv))
+    lib = L.lib()
+    assert lib.moka_state_rk4_streams(Prog._state._h) == 16 and lib.moka_state_rk4_streams(None) == 0
+    L.check(lib.moka_set_tuning(7, 1))
+    try:
+        assert lib.moka_state_rk4_streams(Prog._state._h) == (13 if served else 16)
+        mk.changeTimeStep(Setup.timeManager, dt.timedelta(seconds=dtv))
+        for _ in range(2):
+            mk.ocn_timestep(Prog, Diag, Tend, Setup, mk.RungeKutta4)
+            step()
+        for lev in (0, 1):
+            assert np.array_equal(Prog.normalVelocity[lev].get(), st.u[lev]), lev
+            assert np.array_equal(Prog.layerThickness[lev].get(), st.h[lev]), lev
+            assert np.array_equal(Prog.ssh[lev].get(), st.ssh[lev]), lev
+        assert np.array_equal(Tend.tendNormalVelocity.get(), st.tendU) and np.array_equal(Tend.tendLayerThickness.get(), st.tendH)
+        mk.run_steps(Prog, mk.RungeKutta4, dtv, 11)                     # eager first step + a replayed period + remainder
+        for _ in range(11):
+            step()
+        assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.layerThickness[-1].get(), st.h[1])
+        assert np.array_equal(Prog.ssh[-1].get(), st.ssh[1]) and np.array_equal(Prog.normalVelocity[0].get(), st.u[0])
+        if served:                                                      # and it is NOT the running sum's round-off
+            ref = orc.OracleState(om, ssh, u, h)
+            for _ in range(13):
+                nl.step_rk4(ref, dtv)
+            assert not np.array_equal(ref.u[1], st.u[1])
+            assert np.max(np.abs(ref.u[1] - st.u[1])) <= 1e-10 * np.max(np.abs(ref.u[1]))
+    finally:
+        L.check(lib.moka_set_tuning(7, 0))
+    mk.run_steps(Prog, mk.RungeKutta4, dtv, 2)
+    nl.step_rk4(st, dtv); nl.step_rk4(st, dtv)
+    assert np.array_equal(Prog.normalVelocity[-1].get(), st.u[1]) and np.array_equal(Prog.layerThickness[-1].get(), st.h[1])
+    Prog._state.close(); Setup.mesh.close()
+
+
 @pytest.mark.parametrize("meshname,K,nsteps", [("ico16", 1, 3), ("ico16", 60, 2), ("planar", 4, 3), ("ico12f", 5, 2), ("ico16", 70, 2),
                                                ("ico12f", 40, 2), ("planar", 34, 2)])
 def test_del2_mixing_bitwise(backend, meshname, K, nsteps):

@@ -106,6 +106,30 @@ def _del2_setup(mesh, K, seed=5):
     return om, u, h
 
 
+@pytest.mark.parametrize("visc", [0.0, 1.0])
+def test_rk4_nonlinear_13_stream_twin_against_the_running_sum(visc):
+    """oracle_step_rk4_nonlinear_s13 (twin of moka_set_tuning key 7 on a nonlinear state) is the same Runge-Kutta step as
+    oracle_step_rk4_nonlinear_del2 up to round-off: <= 1e-12 relative after one step, <= 1e-10 after 40, and not bit-identical
+    (so the GPU test of the form does compare against the twin, not against the running sum by accident)."""
+    mesh = mg.icosahedral_mesh(12)
+    K = 6
+    om, u, h = _del2_setup(mesh, K, seed=11)
+    rest = np.full((mesh.nCells, K), 400.0)
+    ssh = h.sum(1) - rest.sum(1)
+    dt = 0.2 * float(mesh.dcEdge.min()) / np.sqrt(G * 2400.0)
+    v = visc * 0.01 * float(mesh.dcEdge.min()) ** 2 / dt
+    nl = orc.OracleNonlinear(om, visc_del2=v)
+    a, b = orc.OracleState(om, ssh, u, h), orc.OracleState(om, ssh, u, h)
+    rel = lambda x, y: np.max(np.abs(x - y)) / np.max(np.abs(y))
+    nl.step_rk4(a, dt); nl.step_rk4_s13(b, dt)
+    assert rel(b.u[1], a.u[1]) <= 1e-12 and rel(b.h[1], a.h[1]) <= 1e-12 and rel(b.ssh[1], a.ssh[1]) <= 1e-10
+    assert np.array_equal(a.u[0], b.u[0]) and np.array_equal(a.h[0], b.h[0])          # the level the step started from
+    for _ in range(39):
+        nl.step_rk4(a, dt); nl.step_rk4_s13(b, dt)
+    assert rel(b.u[1], a.u[1]) <= 1e-10 and rel(b.h[1], a.h[1]) <= 1e-10
+    assert not np.array_equal(a.u[1], b.u[1])
+
+
 @pytest.mark.parametrize("mesh", [mg.icosahedral_mesh(6), mg.planar_hex_mesh(8, 6, 1000.0)], ids=["ico6", "planar"])
 def test_del2_term_is_built_from_the_reference_operators(mesh):
     """The extra tendency is exactly viscDel2 * (GradientOnEdge(DivergenceOnCell(u)) - d(CurlOnVertex(u))/dv): each

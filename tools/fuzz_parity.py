@@ -128,12 +128,19 @@ while time.time() - t0 < budget:
             mk.set_nonlinear(Prog3, True, visc_del2=visc)
             nl = orc.OracleNonlinear(om, visc_del2=visc)
             st3 = orc.OracleState(om, st.ssh[1], st.u[1], st.h[1])
+            # at random with moka_set_tuning key 7: the 13-stream form where the state qualifies (moka_state_rk4_streams tells: the
+            # default patch kernel on hexagon-dominated meshes, even 34 <= K <= 64)
+            s13 = bool(rng.integers(0, 2))
+            L.check(L.lib().moka_set_tuning(7, int(s13)))
+            streams = L.lib().moka_state_rk4_streams(Prog3._state._h)
+            assert streams == 16 or s13, tag
             L.check(L.lib().moka_step_rk4(Prog3._state._h, dtv), b._h)
             b.set_kernel_variant(0)
-            L.check(L.lib().moka_set_tuning(5, 0)); L.check(L.lib().moka_set_tuning(6, 0))
-            nl.step_rk4(st3, dtv)
+            L.check(L.lib().moka_set_tuning(5, 0)); L.check(L.lib().moka_set_tuning(6, 0)); L.check(L.lib().moka_set_tuning(7, 0))
+            (nl.step_rk4_s13 if streams == 13 else nl.step_rk4)(st3, dtv)
             assert np.array_equal(Prog3.normalVelocity[-1].get(), st3.u[1]) and np.array_equal(Prog3.layerThickness[-1].get(), st3.h[1]), \
-                tag + f" nonlinear visc {visc} form {form} shape {shape} cap {cap}"
+                tag + f" nonlinear visc {visc} form {form} shape {shape} cap {cap} streams {streams}"
+            stats["nonlinear_13"] = stats.get("nonlinear_13", 0) + int(streams == 13)
             Prog3._state.close()
             stats["nonlinear"] += 1
     # round 4: the per-array placement search leaves every array as it is (mid-run, whatever is lazily pending), sampled rows

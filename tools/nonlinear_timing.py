@@ -29,3 +29,11 @@ for nl, shape in [(False, 0)] + [(True, sh) for sh in shapes]:
     mk.run_steps(Prog, mk.RungeKutta4, dts, 10)
     b.synchronize(); t1 = time.perf_counter()
     print(f"{'nonlinear shape ' + str(shape) if nl else 'linear           '}: {mesh.nCells} cells x {K}: {1e3 * (t1 - t0) / 10:.2f} ms per RK4 step", flush=True)
+    if nl and shape in (0, 2, 3):          # the 13-stream form (moka_set_tuning key 7; k_stage_nl5 only), interleaved with the line above
+        L.check(L.lib().moka_set_tuning(7, 1))
+        mk.run_steps(Prog, mk.RungeKutta4, dts, 3)
+        b.synchronize(); t0 = time.perf_counter()
+        mk.run_steps(Prog, mk.RungeKutta4, dts, 12)
+        b.synchronize(); t1 = time.perf_counter()
+        L.check(L.lib().moka_set_tuning(7, 0))
+        print(f"nonlinear shape {shape}, 13 streams: {1e3 * (t1 - t0) / 12:.2f} ms per RK4 step", flush=True)
