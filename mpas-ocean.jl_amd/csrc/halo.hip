@@ -444,13 +444,15 @@ void moka_halo_destroy(moka_halo *h)
 {
     if (!h) return;
     if (h->counted) state_detach(h->st);
-    for (hipEvent_t e : h->stEv) (void)hipEventDestroy(e);
     (void)hipSetDevice(h->st->ctx->device);
     (void)hipStreamSynchronize(h->st->ctx->stream);
     (void)hipStreamSynchronize(h->st->ctx->comm);
+    for (hipEvent_t e : h->stEv) (void)hipEventDestroy(e);
     for (PeerLink &pl : h->peers)
         if (pl.flagsDev && pl.ipc) (void)hipHostUnregister((void *)pl.flags);
-    if (h->flagsDev) (void)hipHostUnregister((void *)h->flags);
+    // my own block: registered by moka_halo_set_stream_flags of this object -- or of a neighbour in the same process, which
+    // registers the very same memory; it is freed below, so the registration goes whoever made it (an error = none existed)
+    if (h->flags) (void)hipHostUnregister((void *)h->flags);
     (void)hipGetLastError();
     for (PeerLink &pl : h->peers) {
         if (pl.connected && pl.ipc) {
@@ -681,8 +683,10 @@ int moka_halo_connect(moka_halo *h, int32_t nbr, const moka_halo_peer_info *peer
     PeerLink &old = h->peers[nbr];
     if (old.connected && old.ipc) {                   // connected before: release the earlier mappings
         for (void *m : old.mapped) if (m) (void)hipIpcCloseMemHandle(m);
+        if (old.flagsDev) { (void)hipHostUnregister((void *)old.flags); (void)hipGetLastError(); }
         if (old.flags) munmap((void *)old.flags, old.flagsBytes);
     }
+    if (old.connected && h->streamFlags) h->streamFlags = false;   // the new link's flag block is not registered: host handshake until moka_halo_set_stream_flags is called again
     h->peers[nbr] = pl;
     h->tabDirty = true;
     st->feLeanInteriorOnly = true;   // peers may store into this state's level sets from now on: see the header (lean steps)
