@@ -412,7 +412,7 @@ int  moka_fe_dist_step(moka_halo *h, double dt, int flags, moka_transport_fn tra
 int moka_kernel_variant_available(int variant);
 int moka_set_kernel_variant(moka_ctx *ctx, int variant);
 /* Process-wide launch-shape switches for A/B measurements (every setting gives identical results).  key 1: bit mask of the
- * modes (0 tendency, 1..3 RK4 stages, 4..6 Forward Euler) of the fp32-storage stage kernel that run as 512-thread workgroups
+ * modes (0 tendency, 1..3 RK4 stages, 4..6 Forward Euler, 10 / 11 lean Forward Euler) of the fp32-storage stage kernel that run as 512-thread workgroups
  * bounded to 128 registers = 4 waves per SIMD instead of 3 (default: mode 0, the tendency launch).  key 2: 0 = Forward-Euler
  * steps always gather the stored layerThicknessEdge (mode 4); 1 (default) = formed from the previous level when valid (mode 6).
  * key 3: relativeVorticity of a Forward-Euler step inside the stage launches (1, default) or as a launch of its own (0).
@@ -423,6 +423,8 @@ int moka_set_kernel_variant(moka_ctx *ctx, int variant);
  * key 8: bit mask of the modes of the Float64 stage kernel whose large whole-range launches take two consecutive patches per
  * 512-thread workgroup, one row cache over both (default: the tendency launch and RK stage 1, modes 0 / 1, and the
  * 13-stream stage 1, mode 7; 0 = one patch per workgroup everywhere).
+ * key 9: lean Forward-Euler launches through their own kernel instances (1, default: stage-kernel modes 10 / 11, the optional
+ * DiagnosticVars / TendencyVars outputs compiled out) or through the general Forward-Euler instances (0; measurement).
  * key 7 is NOT result-neutral and therefore off by default: 1 = moka_step_rk4 / moka_run step Float64 states on whole meshes
  * with 13 instead of 16 state streams per step.  The reference accumulates New += b_s k_s through the stages
  * (time_integration.jl:134-135); here stages 1-3 store only the provisional states and stage 4 forms

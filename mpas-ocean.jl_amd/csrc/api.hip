@@ -749,12 +749,15 @@ int moka_bw_probe_gather_big(moka_ctx *ctx, int64_t bytes, int iters, double *gb
 //          stage-kernel launches where they can carry it
 //   key 8: bit mask of the modes of the Float64 stage kernel whose large launches take TWO consecutive patches per 512-thread workgroup
 //          (default: 0, 1 and the 13-stream 7; kernels.hip, launch_stage_rec2c)
+//   key 9: 1 (default) = lean Forward-Euler launches run the kernels' lean instances (modes 10 / 11: optional outputs compiled out),
+//          0 = the general Forward-Euler instances (outputs tested at run time)
 //   key 7: NOT result-neutral, opt-in (default 0): moka_step_rk4 / moka_run of Float64 states on whole meshes in the 13-stream form
 //          (mk::rk13_usable; New formed in stage 4 from the provisional states instead of accumulated through the stages)
 int moka_set_tuning(int key, int value)
 {
     if (key == 1) { moka::set_f32_wide_modes(value); return MOKA_OK; }
     if (key == 2) { moka::set_fe_prev_mode(value); return MOKA_OK; }
+    if (key == 9) { moka::set_fe_lean_instances(value); return MOKA_OK; }
     if (key == 3) { moka::set_curl_fused(value); return MOKA_OK; }
     if (key == 4) { moka::set_fe_lean(value); return MOKA_OK; }
     if (key == 5) { moka::set_nl_shape(value); return MOKA_OK; }
@@ -769,6 +772,7 @@ int moka_get_tuning(int key, int *value)
     if (!value) return fail(nullptr, MOKA_ERR_ARG, "value is NULL");
     if (key == 1) { *value = moka::f32_wide_modes(); return MOKA_OK; }
     if (key == 2) { *value = moka::fe_prev_mode(); return MOKA_OK; }
+    if (key == 9) { *value = moka::fe_lean_instances(); return MOKA_OK; }
     if (key == 3) { *value = moka::curl_fused(); return MOKA_OK; }
     if (key == 4) { *value = moka::fe_lean_enabled(); return MOKA_OK; }
     if (key == 5) { *value = moka::nl_shape(); return MOKA_OK; }

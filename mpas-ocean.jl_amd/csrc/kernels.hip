@@ -57,8 +57,14 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     // Forward-Euler modes with the vertex pass in the same launch (a.vort): the patch's vertex records sit behind the row cache
     double *Lvw = reinterpret_cast<double *>(smem + recBytes + (size_t)maxOwnE * rowB);    // [maxOwnV][3] coefficients
     uint32_t *Lvo = reinterpret_cast<uint32_t *>(Lvw + (size_t)m.maxOwnV * 3);              // [maxOwnV][4] u-row byte offsets
+    // MODE 10 / 11: the LEAN forms of modes 5 / 6 (a lean Forward-Euler step stores the new level and relativeVorticity only): the
+    // same loads and sums with every optional DiagnosticVars / TendencyVars output compiled out instead of tested at run time --
+    // no velocityDivCell sum, no layerThickness rows in the edge loop, fewer live registers
+    constexpr bool LEAN = MODE >= 10;
+    constexpr int BASE = LEAN ? MODE - 5 : MODE;
+    constexpr bool FE = BASE >= 4 && BASE <= 6, STALE = BASE == 4, PREV = BASE == 6;
     int v0 = 0, nOwnV = 0;
-    if constexpr (MODE >= 4 && MODE <= 6) {
+    if constexpr (FE) {
         if (a.vort) {
             v0 = cptr(m.patchVertStart)[p];
             nOwnV = cptr(m.patchVertStart)[p + 1] - v0;
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
         vR = tid < nOwnC ? m.rsum[c0 + tid] : 0.0;
         uint32_t vVo = 0u;
         double vVw = 0.0;
-        if constexpr (MODE >= 4 && MODE <= 6) {
+        if constexpr (FE) {
             if (tid < nOwnV * 4) vVo = m.vRec[(size_t)v0 * 4 + tid];
             if (tid < nOwnV * 3) vVw = m.cv[(size_t)v0 * 3 + tid];
         }
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             L.invA[tid] = vA;
             L.rsum[tid] = vR;
         }
-        if constexpr (MODE >= 4 && MODE <= 6) {
+        if constexpr (FE) {
             if (tid < nOwnV * 4) Lvo[tid] = vVo;
             if (tid < nOwnV * 3) Lvw[tid] = vVw;
             for (int i = tid + NT; i < nOwnV * 4; i += NT) Lvo[i] = m.vRec[(size_t)v0 * 4 + i];
@@ -162,7 +168,6 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
     // MODE 7 / 8 / 9: the RK4 step with 13 instead of 16 state streams (moka_set_tuning key 7; rk13_combine above): stage 1
     // stores Provis' only (7), stages 2 and 3 read Provis and Curr and store Provis' only (8), stage 4 forms New from the own
     // rows of Curr and of the three provisional states and the last tendency (9) -- no New accumulator travels through stages 1-3.
-    constexpr bool FE = MODE >= 4 && MODE <= 6, STALE = MODE == 4, PREV = MODE == 6;
     double2 pA = make_double2(0.0, 0.0), pB = pA, pD = pA, pE = pA;
     double pS = 0.0;
     // `pend` is false only in a group's first iteration; the loops carry `#pragma nounroll` so that the compiler does not peel
@@ -179,14 +184,15 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             }
             if constexpr (MODE == 3 || MODE == 9) gstore2o(a.nh_out, pOff, pB);
             if constexpr (MODE == 7 || MODE == 8) gstore2o(a.ph_out, pOff, pA);
-            if constexpr (FE) {                          // every output group of a Forward-Euler launch is optional (wave-uniform):
-                if (a.ph_out) gstore2o(a.ph_out, pOff, pA);   // a lean step stores the new level only, the launch that materialises the
-                if (a.tendH) gstore2o(a.tendH, pOff, pB);     // step's DiagnosticVars / TendencyVars on demand stores only those
-                if (a.div) gstore2o(a.div, pOff, pD);
+            if constexpr (LEAN) gstore2o(a.ph_out, pOff, pA);
+            if constexpr (FE && !LEAN) {                 // every output group of a Forward-Euler launch is optional (wave-uniform):
+                if (a.ph_out) gstore2o(a.ph_out, pOff, pA);   // a lean step stores the new level only (modes 10 / 11), the launch that
+                if (a.tendH) gstore2o(a.tendH, pOff, pB);     // materialises the step's DiagnosticVars / TendencyVars on demand stores
+                if (a.div) gstore2o(a.div, pOff, pD);         // only those
             }
         }
         if constexpr (MODE != 0)
-            if (l == 0 && (!FE || a.ssh_out)) a.ssh_out[pC] = pS;
+            if (l == 0 && (!FE || LEAN || a.ssh_out)) a.ssh_out[pC] = pS;
     };
     // ---------------- cells ----------------
 #pragma nounroll
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (MODE == 9) q3 = gload2(a.q3h, own);                                   // ... and of P3
         }
         double area = 1.0;
-        if constexpr (FE) if (a.div) area = a.areaCell[c];
+        if constexpr (FE && !LEAN) if (a.div) area = a.areaCell[c];
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this iteration's loads (needed next anyway) ...
         if (pend) flush_cell();                                        // ... so that the stores queue up behind them, not ahead
         double2 t = make_double2(0.0, 0.0);
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                     const double2 he = hE(i);
                     t.x += uv[i].x * he.x * rs[i] * invA;
                     t.y += uv[i].y * he.y * rs[i] * invA;
-                    if constexpr (FE) {
+                    if constexpr (FE && !LEAN) {
                         dv.x -= uv[i].x * rs[i];
                         dv.y -= uv[i].y * rs[i];
                     }
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 const double dy = uv[i].y * he.y * rs[i] * invA;   // horizontal_advection.jl:63
                 if (on && k0 < ml) t.x += dx;
                 if (on && k0 + 1 < ml) t.y += dy;
-                if constexpr (FE) {
+                if constexpr (FE && !LEAN) {
                     if (on) {
                         dv.x -= uv[i].x * rs[i];
                         dv.y -= uv[i].y * rs[i];
@@ -290,8 +296,10 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (FE) {
                 hs = make_double2(hc.x + a.a * t.x, hc.y + a.a * t.y);                        // time_integration.jl:199
                 pA = hs;
-                pB = t;
-                if (a.div) pD = make_double2(dv.x / area, dv.y / area);                       // Operators.jl:41
+                if constexpr (!LEAN) {
+                    pB = t;
+                    if (a.div) pD = make_double2(dv.x / area, dv.y / area);                   // Operators.jl:41
+                }
             }
         }
         if constexpr (MODE != 0) {
@@ -317,7 +325,8 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             }
             if constexpr (MODE == 3 || MODE == 9) gstore2o(a.nu_out, pOff, pB);
             if constexpr (MODE == 7 || MODE == 8) gstore2o(a.pu_out, pOff, pA);
-            if constexpr (FE) {
+            if constexpr (LEAN) gstore2o(a.pu_out, pOff, pA);
+            if constexpr (FE && !LEAN) {
                 if (a.pu_out) gstore2o(a.pu_out, pOff, pA);
                 if (a.tendU) gstore2o(a.tendU, pOff, pB);
                 if (a.F) gstore2o(a.F, pOff, pD);
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
             if constexpr (MODE == 2 || MODE == 8 || MODE == 9) cur = gload2(a.cu, own);
             if constexpr (MODE == 2 || MODE == 3 || MODE == 9) nin = gload2(a.nu_in, own);
             if constexpr (MODE == 9) q3 = gload2(a.q3u, own);
-            if constexpr (FE) {
+            if constexpr (FE && !LEAN) {
                 // the edge's own diagnostics: loaded for only when they are stored (a lean step stores neither)
                 if (a.hEdgeNew || (MODE == 5 && a.F)) {
                     hx = gload2(a.ph, r[ME2] * rowB + voff);           // layerThickness of cellsOnEdge[1], [2]
@@ -421,7 +430,11 @@ __global__ __launch_bounds__(NT) void k_stage_rec2c(const ColMesh m, const Stage
                 const double2 up = ubuf2[(size_t)ei * K2 + l];          // the own row of P4
                 pB = make_double2(rk13_combine(cur.x, nin.x, q3.x, up.x, a.b, t.x), rk13_combine(cur.y, nin.y, q3.y, up.y, a.b, t.y));
             }
-            if constexpr (FE) {
+            if constexpr (LEAN) {
+                const double2 up = ubuf2[(size_t)ei * K2 + l];          // own row is in the cache
+                pA = make_double2(up.x + a.a * t.x, up.y + a.a * t.y);                    // time_integration.jl:199
+            }
+            if constexpr (FE && !LEAN) {
                 const double2 up = ubuf2[(size_t)ei * K2 + l];          // own row is in the cache
                 pE = make_double2(0.5 * (hx.x + hy.x), 0.5 * (hx.y + hy.y));              // layerThicknessEdge, Operators.jl:217
                 const double2 hF = (STALE || PREV) ? hEo : pE;
@@ -545,8 +558,13 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
     // Forward-Euler modes with the vertex pass in the same launch (a.vort): vertex records behind the row cache (see k_stage_rec2c)
     double *Lvw = reinterpret_cast<double *>(smem + recBytes + (((size_t)maxOwnE * rowB + 15) & ~(size_t)15));
     uint32_t *Lvo = reinterpret_cast<uint32_t *>(Lvw + (size_t)m.maxOwnV * 3);
+    // MODE 10 / 11: the LEAN forms of modes 5 / 6 (a lean Forward-Euler step: new level and relativeVorticity only) -- the same
+    // loads and sums with every optional DiagnosticVars / TendencyVars output compiled out instead of tested at run time: fewer
+    // live registers (no spills at three waves per SIMD), no velocityDivCell sum, no layerThickness rows in the edge loop
+    constexpr bool LEAN = MODE >= 10;
+    constexpr int BASE = LEAN ? MODE - 5 : MODE;
     int v0 = 0, nOwnV = 0;
-    if constexpr (MODE >= 4) {
+    if constexpr (BASE >= 4) {
         if (a.vort) {
             v0 = cptr(m.patchVertStart)[p];
             nOwnV = cptr(m.patchVertStart)[p + 1] - v0;
@@ -594,7 +612,7 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
             L.invA[tid] = vA;
             L.rsum[tid] = vR;
         }
-        if constexpr (MODE >= 4) {
+        if constexpr (BASE >= 4) {
             for (int i = tid; i < nOwnV * 4; i += NT) Lvo[i] = m.vRec[(size_t)v0 * 4 + i];
             for (int i = tid; i < nOwnV * 3; i += NT) Lvw[i] = m.cv[(size_t)v0 * 3 + i];
         }
@@ -629,7 +647,7 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
     // k_stage_rec2c; layerThicknessEdge, thicknessFlux, velocityDivCell and the tendencies are float arrays like the state.
     // (6: the stored layerThicknessEdge is the fp32-rounded interpolation; formed again from the previous level it has to be
     // rounded the same way before it is used -- round4.)
-    constexpr bool FE = MODE >= 4, STALE = MODE == 4, PREV = MODE == 6;
+    constexpr bool FE = BASE >= 4, STALE = BASE == 4, PREV = BASE == 6;
 
     // ---------------- cells ----------------
     for (int ci = grp; ci < nOwnC; ci += NG) {
@@ -670,7 +688,7 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
             if constexpr (MODE == 2 || MODE == 3) ninf = gload4f(a.nh_in, own);
         }
         double area = 1.0;
-        if constexpr (FE) if (a.div) area = a.areaCell[c];
+        if constexpr (FE && !LEAN) if (a.div) area = a.areaCell[c];
         const d4 hc = widen4(hcf);
         d4 t = zero, dv = zero;                                         // dv: velocityDivCell (FE), Operators.jl:18,39
         // thickness at the edge: interpolated (Operators.jl:217) or, MODE 4, what the previous step stored
@@ -691,7 +709,7 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
                     t.y += uvi.y * he.y * rs[i] * invA;
                     t.z += uvi.z * he.z * rs[i] * invA;
                     t.w += uvi.w * he.w * rs[i] * invA;
-                    if constexpr (FE) {
+                    if constexpr (FE && !LEAN) {
                         dv.x -= uvi.x * rs[i]; dv.y -= uvi.y * rs[i]; dv.z -= uvi.z * rs[i]; dv.w -= uvi.w * rs[i];
                     }
                 }
@@ -710,7 +728,7 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
                 if (on && k0 + 1 < ml) t.y += dy;
                 if (on && k0 + 2 < ml) t.z += dz;
                 if (on && k0 + 3 < ml) t.w += dw;
-                if constexpr (FE) {
+                if constexpr (FE && !LEAN) {
                     if (on) { dv.x -= uvi.x * rs[i]; dv.y -= uvi.y * rs[i]; dv.z -= uvi.z * rs[i]; dv.w -= uvi.w * rs[i]; }
                 }
             }
@@ -731,9 +749,11 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
             }
             if constexpr (FE) {                          // every output group is optional (see k_stage_rec2c)
                 hs = round4(axpy4(hc, a.a, t));                                               // time_integration.jl:199
-                if (a.ph_out) gstore4(a.ph_out, own, hs);
-                if (a.tendH) gstore4(a.tendH, own, t);
-                if (a.div) gstore4(a.div, own, d4{dv.x / area, dv.y / area, dv.z / area, dv.w / area});  // Operators.jl:41
+                if (LEAN || a.ph_out) gstore4(a.ph_out, own, hs);
+                if constexpr (!LEAN) {
+                    if (a.tendH) gstore4(a.tendH, own, t);
+                    if (a.div) gstore4(a.div, own, d4{dv.x / area, dv.y / area, dv.z / area, dv.w / area});  // Operators.jl:41
+                }
             }
         }
         if constexpr (MODE != 0) {
@@ -741,7 +761,7 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
             for (int sft = 16; sft >= 1; sft >>= 1) {
                 hs = d4{hs.x + gxor(hs.x, sft), hs.y + gxor(hs.y, sft), hs.z + gxor(hs.z, sft), hs.w + gxor(hs.w, sft)};
             }
-            if (l == 0 && (!FE || a.ssh_out))                                                 // :209 (+N3), stored fp32
+            if (l == 0 && (!FE || LEAN || a.ssh_out))                                                 // :209 (+N3), stored fp32
                 reinterpret_cast<float *>(a.ssh_out)[c] = (float)(((hs.x + hs.z) + (hs.y + hs.w)) - L.rsum[ci]);
         }
     }
@@ -780,7 +800,7 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
             }
             if constexpr (MODE == 2) cur = gload4(a.cu, own);
             if constexpr (MODE == 2 || MODE == 3) nin = gload4(a.nu_in, own);
-            if constexpr (FE) {
+            if constexpr (FE && !LEAN) {
                 if (a.hEdgeNew || (MODE == 5 && a.F)) {
                     hxf = gload4f(a.ph, r[ME2] * rowB + voff);         // layerThickness of cellsOnEdge[1], [2]
                     hyf = gload4f(a.ph, r[ME2 + 1] * rowB + voff);
@@ -841,7 +861,11 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
                 gstore4(a.nu_out, own, axpy4(nin, a.b, t));
             }
             if constexpr (MODE == 3) gstore4(a.nu_out, own, axpy4(nin, a.b, t));
-            if constexpr (FE) {
+            if constexpr (LEAN) {
+                const d4 up = widen4(ubuf4[(size_t)ei * K4 + l]);       // own row is in the cache
+                gstore4(a.pu_out, own, axpy4(up, a.a, t));              // time_integration.jl:199
+            }
+            if constexpr (FE && !LEAN) {
                 const d4 up = widen4(ubuf4[(size_t)ei * K4 + l]);       // own row is in the cache
                 const d4 hx = widen4(hxf), hy = widen4(hyf);
                 const d4 pE{0.5 * (hx.x + hy.x), 0.5 * (hx.y + hy.y), 0.5 * (hx.z + hy.z), 0.5 * (hx.w + hy.w)};   // layerThicknessEdge, Operators.jl:217
@@ -1481,6 +1505,8 @@ static bool launch_rec2c_nt(const ColMesh &m, const StageArgs &a, int mode, dim3
         case 7: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 7, NT>), g, b, lds, s, m, a, mE, mC); return true;
         case 8: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 8, NT>), g, b, lds, s, m, a, mE, mC); return true;
         case 9: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 9, NT>), g, b, lds, s, m, a, mE, mC); return true;
+        case 10: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 10, NT>), g, b, lds, s, m, a, mE, mC); return true;
+        case 11: hipLaunchKernelGGL((k_stage_rec2c<ME, ME2, 11, NT>), g, b, lds, s, m, a, mE, mC); return true;
     }
     return false;
 }
@@ -1494,6 +1520,11 @@ static bool launch_rec2c(const ColMesh &m, const StageArgs &a, int mode, dim3 g,
     if (m.nPatches <= 512) return launch_rec2c_nt<ME, ME2, 512>(m, a, mode, g, lds, mE, mC, s);
     return launch_rec2c_nt<ME, ME2, BLOCK>(m, a, mode, g, lds, mE, mC, s);
 }
+
+// measurement: 0 = lean launches run the general Forward-Euler instances (outputs tested at run time) instead of modes 10 / 11
+static std::atomic<int> g_feLeanInst{1};
+void set_fe_lean_instances(int on) { g_feLeanInst.store(on); }
+int fe_lean_instances() { return g_feLeanInst.load(); }
 
 // the pair form (launch_stage_rec2c): 512-thread workgroups over two patches, whose records and rows need more than the default
 // 64 KB of dynamic LDS.  Default: the tendency launch (mode 0) and RK stage 1 (mode 1; 7 in the 13-stream form) -- measured on the
@@ -1568,8 +1599,9 @@ hipError_t launch_stage_rec2c(const MeshDev &md, const StageArgs &a, hipStream_t
     const int nLaunch = md.nPatches + (md.tailPatch >= 0 ? 1 : 0);
     const dim3 g(8 * ((nLaunch + 7) / 8)), b(BLOCK);
     const ColMesh m = col_mesh(md, nLaunch);
-    const int mode = colp_mode(a);
+    int mode = colp_mode(a);
     if (a.vort && (mode < 4 || !stage_curl_fused(md))) return hipErrorNotSupported;
+    if (fe_lean_instances() && colp_lean(a, mode)) mode += 5;        // a lean Forward-Euler launch: modes 10 / 11
     const size_t lds = rec2c_lds_bytes(md) + (a.vort ? vert_lds_bytes(md) : 0);
     if (mode < 0 || md.K > 64 || (md.K & 1) || lds > 64 * 1024 || md.maxOwnC < 1 || md.maxOwnE < 1) return hipErrorNotSupported;
     // Two consecutive patches per 512-thread workgroup for the LIGHT modes (round 4; moka_set_tuning key 8).  Consecutive patches of
@@ -1628,6 +1660,8 @@ static bool launch_rec2c_f32_nt(const ColMesh &m, const StageArgs &a, int mode, 
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 4, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 5, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 6, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 10, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_stage_rec2c_f32<ME, ME2, 11, NT, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     const dim3 b(NT);
     switch (mode) {
@@ -1638,6 +1672,8 @@ static bool launch_rec2c_f32_nt(const ColMesh &m, const StageArgs &a, int mode, 
         case 4: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 4, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
         case 5: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 5, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
         case 6: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 6, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
+        case 10: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 10, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
+        case 11: hipLaunchKernelGGL((k_stage_rec2c_f32<ME, ME2, 11, NT, WPE>), g, b, lds, s, m, a, mE, mC); return true;
     }
     return false;
 }
@@ -1666,9 +1702,10 @@ hipError_t launch_stage_rec2c_f32(const MeshDev &md, const StageArgs &a, hipStre
     const int nLaunch = md.nPatches + (md.tailPatch >= 0 ? 1 : 0);
     const dim3 g(8 * ((nLaunch + 7) / 8)), b(BLOCK);
     const ColMesh m = col_mesh(md, nLaunch);
-    const int mode = colp_mode(a);
+    int mode = colp_mode(a);
     if (mode < 0 || !stage_f32_supported(md)) return hipErrorNotSupported;
     if (a.vort && (mode < 4 || !stage_curl_fused(md))) return hipErrorNotSupported;
+    if (fe_lean_instances() && colp_lean(a, mode)) mode += 5;        // a lean Forward-Euler launch: modes 10 / 11
     const size_t lds = ((rec_lds_bytes(md) + 15) & ~(size_t)15) + (size_t)md.maxOwnE * md.K * 4 + 16 + (a.vort ? vert_lds_bytes(md) + 16 : 0);
     if (lds > 160 * 1024) return hipErrorNotSupported;
     bool ok = false;

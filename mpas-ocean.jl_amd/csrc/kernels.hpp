@@ -107,6 +107,8 @@ void set_fe_lean(int on);               // measurement: 0 = Forward-Euler steps 
 int fe_lean_enabled();
 void set_fe_prev_mode(int on);          // measurement: 0 = never form the stale layerThicknessEdge from the previous level (mode 6)
 int fe_prev_mode();
+void set_fe_lean_instances(int on);    // measurement: 0 = lean Forward-Euler launches through the general instances (modes 5 / 6) instead of 10 / 11
+int fe_lean_instances();
 void set_pair_modes(int mask);          // measurement: which modes of the Float64 stage kernel take two patches per 512-thread workgroup
 int pair_modes();
 hipError_t launch_update_ssh_f32(const MeshDev &m, const float *h, float *ssh, int nlev, int lpc, hipStream_t s);

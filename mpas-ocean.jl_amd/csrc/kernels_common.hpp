@@ -262,6 +262,13 @@ inline int colp_mode(const StageArgs &a)
     return -1;
 }
 
+// a Forward-Euler launch of mode 5 / 6 that stores the new level (and, separately selected, relativeVorticity) and none of the
+// optional DiagnosticVars / TendencyVars outputs: a LEAN step's launch, served by the kernels' modes 10 / 11
+inline bool colp_lean(const StageArgs &a, int mode)
+{
+    return (mode == 5 || mode == 6) && a.pu_out && a.ph_out && a.ssh_out && !a.tendU && !a.tendH && !a.F && !a.div && !a.hEdgeNew;
+}
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: remember per device (a process may
 // drive several, e.g. LocalCluster over a device list) whether `slot` (one bit per kernel family) has been raised there
 inline bool lds_attr_needed(int slot)

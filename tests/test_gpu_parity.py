@@ -500,6 +500,17 @@ def test_forward_euler_lean_steps_produce_every_array_on_demand(backend, sbytes,
         step(Prog, st, 3)
         check(Prog, Diag, Tend, st, "RK4 in between")
         Prog._state.close(); Setup.mesh.close()
+    # (d) lean launches run their own kernel instances (stage-kernel modes 10 / 11: the optional outputs compiled out); with
+    # moka_set_tuning(9, 0) they go through the general Forward-Euler instances (outputs tested at run time): the same bits
+    L.check(lib.moka_set_tuning(9, 0))
+    try:
+        Setup, Diag, Tend, Prog, st = fresh()
+        step(Prog, st, 4)
+        assert lib.moka_fe_lazy_pending(Prog._state._h) == 1
+        check(Prog, Diag, Tend, st, "lean steps through the general instances")
+        Prog._state.close(); Setup.mesh.close()
+    finally:
+        L.check(lib.moka_set_tuning(9, 1))
 
 
 def test_forward_euler_tuned_path_level_masks(backend):
