@@ -24,15 +24,15 @@ cfg = {"time_management": {"config_start_time": dt.datetime(1, 1, 1), "config_ru
 b = mk.MokaHIP(0)
 Setup, Diag, Tend, Prog = mk.ocn_init_from_arrays(mesh, ssh, u, h, rest, cfg, b, multilayer=True, state_bytes=sbytes)
 lib = L.lib()
-forms = [("general instances (key 9 = 0)", 0, 1), ("lean instances (key 9 = 1)", 1, 1)]
+forms = [("general instances (key 9 = 0)", 0, 1, 1), ("lean instances (key 9 = 1)", 1, 1, 1), ("lean instances, vertex pass as its own launch (key 3 = 0)", 1, 1, 0)]
 if sbytes == 4:
-    forms.append(("lean instances, 512 threads", 1, 1 | (1 << 10) | (1 << 11)))
+    forms.append(("lean instances, 512 threads", 1, 1 | (1 << 10) | (1 << 11), 1))
 for flags, what in ((3, "reference_compat (stale thickness, accumulating vorticity)"), (0, "flags 0")):
     print(f"{wl}: lean Forward-Euler step, {what}", flush=True)
     for r in range(rounds):
         line = []
-        for name, key9, mask in forms:
-            L.check(lib.moka_set_tuning(9, key9)); L.check(lib.moka_set_tuning(1, mask))
+        for name, key9, mask, key3 in forms:
+            L.check(lib.moka_set_tuning(9, key9)); L.check(lib.moka_set_tuning(1, mask)); L.check(lib.moka_set_tuning(3, key3))
             for _ in range(3):
                 mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=flags)
             b.synchronize(); b.marks_reset(); b.mark()
@@ -42,4 +42,4 @@ for flags, what in ((3, "reference_compat (stale thickness, accumulating vortici
             ms = sorted(b.marks_read())
             line.append(f"{name}: {ms[len(ms) // 2]:.3f} ms")
         print("   " + "   ".join(line), flush=True)
-L.check(lib.moka_set_tuning(9, 1)); L.check(lib.moka_set_tuning(1, 1))
+L.check(lib.moka_set_tuning(9, 1)); L.check(lib.moka_set_tuning(1, 1)); L.check(lib.moka_set_tuning(3, 1))
