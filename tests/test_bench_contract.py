@@ -99,6 +99,13 @@ def test_bench_line_on_one_gpu_small_workload():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert b["calibration"]["copy_GBs_before"] > 1000 and b["calibration"]["streams5_GBs_before"] > 1000
     assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["cores"] >= 1 and b["cpu_baseline"]["value"] > 0
+    # round 4: medians everywhere a single stray launch could move a mean, and the line says how many strays there were
+    assert b["step_ms"]["strays"] >= 0 and r["stray_steps"] == b["step_ms"]["strays"] and r["frac_at_median_step"] > 0
+    t = b["tendency_kernel"]
+    assert t["avg_launch_ms"] == t["launch_ms"]["median"] and t["launch_ms"]["n"] == 3 and t["launch_ms"]["min"] <= t["avg_launch_ms"] <= t["launch_ms"]["max"]
+    for k in ("under_load", "placement", "rk4_13_streams", "forward_euler_compat"):
+        assert k in b, k
+    assert b["forward_euler_compat"]["arrays_pending_after_a_step"] == 1 and b["rk4_13_streams"]["ms_per_step"] > 0
 
 
 @pytest.mark.gpu
