@@ -885,7 +885,7 @@ def main():
         # clock and power while the launches run (after every timed region of this workload)
         out["under_load"] = {"rk4_steps": under_load(backend, step, 1.0, 10),
                              "tendency_launches": under_load(backend, lambda: mk.computeTendency(Setup.mesh, Diag, Prog, Tend), 0.6, 20),
-                             "idle": device_sysfs(backend.pci_bus_id()),
+                             "right_after": device_sysfs(backend.pci_bus_id()),     # (the sensors still average over the launches)
                              "note": "sysfs (pp_dpm_sclk, power1_average) sampled every 4 ms while the launches run back to back; the stage "
                                      "launches run the package at its power limit (1400 W) and the shader clock drops below the 2.4 GHz it "
                                      "shows when idle: the launches are bound by energy per step (profiles/r04_variants.txt section 4)"}
