@@ -1296,6 +1296,7 @@ hipError_t launch_stage_nl(const MeshDev &m, const StageArgs &a, const NlArgs &n
             return hipGetLastError();
         }
     }
+    if (a.rkMode == 9) return hipErrorNotSupported;      // the 13-stream form's last stage exists in k_stage_nl5 only (mk::rk13_usable asks nl_stage_is_nl5 first)
     if (lpc == 64 && nl3_ok(m) && rowsOk && form == 0 && nl4_lds_bytes(m) <= 80 * 1024) {     // two 512-thread workgroups per CU
         const size_t lds = nl4_lds_bytes(m);
         if (lds_attr_needed(16)) {
