@@ -758,7 +758,6 @@ int moka_set_tuning(int key, int value)
     if (key == 1) { moka::set_f32_wide_modes(value); return MOKA_OK; }
     if (key == 2) { moka::set_fe_prev_mode(value); return MOKA_OK; }
     if (key == 9) { moka::set_fe_lean_instances(value); return MOKA_OK; }
-    if (key == 10) { moka::set_ssh_lds_reduce(value); return MOKA_OK; }
     if (key == 3) { moka::set_curl_fused(value); return MOKA_OK; }
     if (key == 4) { moka::set_fe_lean(value); return MOKA_OK; }
     if (key == 5) { moka::set_nl_shape(value); return MOKA_OK; }
@@ -774,7 +773,6 @@ int moka_get_tuning(int key, int *value)
     if (key == 1) { *value = moka::f32_wide_modes(); return MOKA_OK; }
     if (key == 2) { *value = moka::fe_prev_mode(); return MOKA_OK; }
     if (key == 9) { *value = moka::fe_lean_instances(); return MOKA_OK; }
-    if (key == 10) { *value = moka::ssh_lds_reduce(); return MOKA_OK; }
     if (key == 3) { *value = moka::curl_fused(); return MOKA_OK; }
     if (key == 4) { *value = moka::fe_lean_enabled(); return MOKA_OK; }
     if (key == 5) { *value = moka::nl_shape(); return MOKA_OK; }

@@ -526,9 +526,7 @@ __device__ __forceinline__ d4 round4(d4 v) { return widen4(narrow4(v)); }
 template <int ME, int ME2, int MODE, int NT = BLOCK, int WPE = 3>
 __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, const StageArgs a, int maxOwnE, int maxOwnC)
 {
-    extern __shared__ __align__(16) unsigned char smem_all[];
-    // m.redLds: the first 1.5 KB per wave are the scratch of the ssh column sum (see the cell loop); everything else sits behind it
-    unsigned char *smem = smem_all + (MODE != 0 && m.redLds ? (NT / 64) * 1536 : 0);
+    extern __shared__ __align__(16) unsigned char smem[];
     const int pl_ = patch_of_block(m.nPatches);
     if (pl_ >= m.nPatches) return;
     const int p = (m.tailPlus1 && pl_ == m.nPatches - 1) ? m.tailPlus1 - 1 : pl_ + m.patchBegin;
@@ -759,35 +757,9 @@ __global__ __launch_bounds__(NT, WPE) void k_stage_rec2c_f32(const ColMesh m, co
             }
         }
         if constexpr (MODE != 0) {
-            if (m.redLds) {
-                // Only lane 0 of a column stores ssh, so the butterfly of gxor can run as a reduction TREE: at the step with mask
-                // sft only lanes l < sft still matter, and each takes the sum of lane l + sft (0 beyond the column) -- exactly the
-                // value and the additions of the butterfly at those lanes.  The partner's four sums come through LDS: lanes
-                // [sft, 2 sft) write (two 16-byte stores), lanes [0, sft) read (two 16-byte loads); 19 lane transfers per column
-                // of K = 80 instead of 100 lanes x 8 permutes.  The lanes of a wave run in lockstep and its LDS operations
-                // complete in order: no barrier.  Slot of a writer: (its group, l - sft), m.redLds slots per group (the launcher
-                // made sure that all groups of a wave fit 48 slots of 16 bytes, twice).
-                double2 *red = reinterpret_cast<double2 *>(smem_all) + (tid >> 6) * 96;
-                const int slot0 = sub * m.redLds;
 #pragma unroll
-                for (int sft = 16; sft >= 1; sft >>= 1) {
-                    if (l >= sft && l < 2 * sft) {
-                        red[slot0 + l - sft] = make_double2(hs.x, hs.y);
-                        red[48 + slot0 + l - sft] = make_double2(hs.z, hs.w);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (l < sft) {
-                        double2 oa = make_double2(0.0, 0.0), ob = oa;
-                        if (l + sft < K4) { oa = red[slot0 + l]; ob = red[48 + slot0 + l]; }
-                        hs = d4{hs.x + oa.x, hs.y + oa.y, hs.z + ob.x, hs.w + ob.y};
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            } else {
-#pragma unroll
-                for (int sft = 16; sft >= 1; sft >>= 1) {
-                    hs = d4{hs.x + gxor(hs.x, sft), hs.y + gxor(hs.y, sft), hs.z + gxor(hs.z, sft), hs.w + gxor(hs.w, sft)};
-                }
+            for (int sft = 16; sft >= 1; sft >>= 1) {
+                hs = d4{hs.x + gxor(hs.x, sft), hs.y + gxor(hs.y, sft), hs.z + gxor(hs.z, sft), hs.w + gxor(hs.w, sft)};
             }
             if (l == 0 && (!FE || LEAN || a.ssh_out))                                                 // :209 (+N3), stored fp32
                 reinterpret_cast<float *>(a.ssh_out)[c] = (float)(((hs.x + hs.z) + (hs.y + hs.w)) - L.rsum[ci]);
@@ -1675,35 +1647,9 @@ static std::atomic<int> g_fePrevMode{1};
 void set_fe_prev_mode(int on) { g_fePrevMode.store(on); }
 int fe_prev_mode() { return g_fePrevMode.load(); }
 
-// measurement: 0 = the column sum behind ssh runs as a butterfly of lane permutes in every launch
-static std::atomic<int> g_sshLdsReduce{1};
-void set_ssh_lds_reduce(int on) { g_sshLdsReduce.store(on); }
-int ssh_lds_reduce() { return g_sshLdsReduce.load(); }
-
-// the scratch of the tree form of the ssh column sum (ColMesh.redLds): 1.5 KB per wave of the workgroup in front of the launch's other
-// dynamic LDS -- taken only where it cannot cost the CU a resident workgroup (`cap` = what the registers allow; 2 KB of slack per
-// workgroup for the allocation granule: round 4 saw launches drop from three workgroups per CU to two on a computed 157.5 of 160 KB)
-static inline size_t red_scratch(size_t lds, int mode, int nt, int cap)
-{
-    if (mode == 0 || !ssh_lds_reduce()) return 0;
-    const size_t red = (size_t)(nt / 64) * 1536, cu = 160 * 1024, slack = 2048;
-    if (lds + red + slack > cu) return 0;
-    return std::min<size_t>(cap, cu / (lds + red + slack)) == std::min<size_t>(cap, cu / lds) ? red : 0;
-}
-
 template <int ME, int ME2, int NT, int WPE>
-static bool launch_rec2c_f32_nt(const ColMesh &m_in, const StageArgs &a, int mode, dim3 g, size_t lds, int mE, int mC, hipStream_t s)
+static bool launch_rec2c_f32_nt(const ColMesh &m, const StageArgs &a, int mode, dim3 g, size_t lds, int mE, int mC, hipStream_t s)
 {
-    ColMesh m = m_in;
-    {   // WPE waves per SIMD = 4 * WPE waves per CU = that many / (NT / 64) workgroups
-        // slots per lane group = the most lanes of a group that write in one step; all groups of a wave must fit 48 slots
-        const int K4 = m.K / 4, epw = K4 > 0 ? 64 / K4 : 0;
-        int S = 1;
-        while (2 * S < K4) S *= 2;
-        const size_t red = (K4 >= 2 && K4 <= 32 && epw * S <= 48) ? red_scratch(lds, mode, NT, 4 * WPE / (NT / 64)) : 0;
-        m.redLds = red ? S : 0;
-        lds += red;
-    }
     // a launch that carries a halo-straddling patch of a partitioned mesh (up to 6 own edges per cell) may need more than
     // the default 64 KB of dynamic LDS; such launches are small (the boundary group), occupancy does not matter there
     if (lds > 64 * 1024 && lds_attr_needed((ME == 6 ? (ME2 == 10 ? 0 : 1) : 2) * 2 + (NT == 512 ? 1 : 0))) {

@@ -57,10 +57,6 @@ struct ColMesh {
     // alone when their number is odd) as one unit -- one staging phase, one row cache over both patches' own edges -- and pairEnd
     // is the end of the launched patch range (absolute).  k_stage_rec2c, 512 threads; see launch_stage_rec2c.
     int32_t pairEnd;
-    // != 0 (= slots per lane group): the launch's dynamic LDS begins with a scratch block of 1.5 KB per wave (k_stage_rec2c_f32): the column
-    // sum behind ssh hands its partial sums down through it as a reduction tree -- at every step only the lanes whose sums are
-    // still needed write and read -- instead of a butterfly of lane permutes over all lanes; the same pairs, the same order
-    int32_t redLds;
 };
 
 enum : int {
@@ -113,8 +109,6 @@ void set_fe_prev_mode(int on);          // measurement: 0 = never form the stale
 int fe_prev_mode();
 void set_fe_lean_instances(int on);    // measurement: 0 = lean Forward-Euler launches through the general instances (modes 5 / 6) instead of 10 / 11
 int fe_lean_instances();
-void set_ssh_lds_reduce(int on);      // measurement: 0 = the column sum behind ssh always as a butterfly of lane permutes (ColMesh.redLds = 0)
-int ssh_lds_reduce();
 void set_pair_modes(int mask);          // measurement: which modes of the Float64 stage kernel take two patches per 512-thread workgroup
 int pair_modes();
 hipError_t launch_update_ssh_f32(const MeshDev &m, const float *h, float *ssh, int nlev, int lpc, hipStream_t s);
