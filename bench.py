@@ -872,23 +872,34 @@ def main():
            "roofline": roofline, "calibration": calibration,
            "placement": placement_summary(placement)}
 
+    # Everything from here on is an appendix of the line assembled above: none of it may cost the line itself.  (Exception:
+    # exchange_report runs collectives -- a rank that failed alone would leave the others waiting, so it is not caught.)
+    def appendix(key, fn):
+        try:
+            return fn()
+        except Exception as exc:                 # noqa: BLE001
+            log(f"[bench] {key} failed: {exc!r}")
+            return {"error": f"{type(exc).__name__}: {exc}"}
+
     if world > 1:
         out["exchange"] = exchange_report(mk, backend, model, step, sync_all, dist, gloo_group, rank, world, args,
                                           (mesh, ssh, u, h, rest, cfg, sbytes), ms_per_step)
     if world == 1:
-        out.update(single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, args.tend_iters))
+        ex = appendix("tendency / Forward-Euler entries", lambda: single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, args.tend_iters))
+        out.update(ex if "error" not in ex else {"tendency_kernel": ex, "forward_euler_compat": ex})
         if sbytes == 8:
             try:
                 out["rk4_13_streams"] = rk4_13_stream_entry(mk, backend, step, args.steps, args.warmup, mesh.nCells * K, stream_bytes, b_mesh, b_step)
             except Exception as exc:             # noqa: BLE001
                 out["rk4_13_streams"] = {"error": f"{type(exc).__name__}: {exc}"}
         # clock and power while the launches run (after every timed region of this workload)
-        out["under_load"] = {"rk4_steps": under_load(backend, step, 1.0, 10),
-                             "tendency_launches": under_load(backend, lambda: mk.computeTendency(Setup.mesh, Diag, Prog, Tend), 0.6, 20),
-                             "right_after": device_sysfs(backend.pci_bus_id()),     # (the sensors still average over the launches)
-                             "note": "sysfs (pp_dpm_sclk, power1_average) sampled every 4 ms while the launches run back to back; the stage "
-                                     "launches run the package at its power limit (1400 W) and the shader clock drops below the 2.4 GHz it "
-                                     "shows when idle: the launches are bound by energy per step (profiles/r04_variants.txt section 4)"}
+        out["under_load"] = appendix("under_load", lambda: {
+            "rk4_steps": under_load(backend, step, 1.0, 10),
+            "tendency_launches": under_load(backend, lambda: mk.computeTendency(Setup.mesh, Diag, Prog, Tend), 0.6, 20),
+            "right_after": device_sysfs(backend.pci_bus_id()),     # (the sensors still average over the launches)
+            "note": "sysfs (pp_dpm_sclk, power1_average) sampled every 4 ms while the launches run back to back; the stage "
+                    "launches run the package at its power limit (1400 W) and the shader clock drops below the 2.4 GHz it "
+                    "shows when idle: the launches are bound by energy per step (profiles/r04_variants.txt section 4)"})
         if args.workload == "config4_1M_x60" and not args.no_config5:
             # free the headline workload's device objects, then time config 5 on the same device in the same run
             backend.synchronize()
@@ -908,12 +919,11 @@ def main():
         mixed = sbytes == 4
         if mesh.nCells * K > 1.5e8:        # bounded sample: the same workload family on a quarter of the cells
             cm = get_mesh(m // 2, stretch)
-            cssh, cu, ch, crest, cdts = mg.sphere_synthetic_state(cm, K)
-            out["cpu_baseline"] = cpu_baseline(cm, K, cssh, cu, ch, crest, cdts, mixed=mixed)
-            out["cpu_baseline_1t"] = cpu_baseline_1t(cm, K, cssh, cu, ch, crest, cdts, mixed=mixed)
+            cmesh = (cm, K) + tuple(mg.sphere_synthetic_state(cm, K))
         else:
-            out["cpu_baseline"] = cpu_baseline(mesh, K, ssh, u, h, rest, dts, mixed=mixed)
-            out["cpu_baseline_1t"] = cpu_baseline_1t(mesh, K, ssh, u, h, rest, dts, mixed=mixed)
+            cmesh = (mesh, K, ssh, u, h, rest, dts)
+        out["cpu_baseline"] = appendix("cpu_baseline", lambda: cpu_baseline(*cmesh, mixed=mixed))
+        out["cpu_baseline_1t"] = appendix("cpu_baseline_1t", lambda: cpu_baseline_1t(*cmesh, mixed=mixed))
         out["cpu_baseline"]["host"] = _cpu_model()
         log(f"[bench] cpu baseline legs: {time.time() - t0:.1f}s")
     if rank == 0:
