@@ -366,11 +366,12 @@ def timed_steps(backend, step, steps, warmup, sync_all):
     """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides, with one HIP event per step on
     the compute stream.  Returns (wall seconds, [ms per step])."""
     import gc
+    gc.collect()          # BEFORE the warm-up: a collection between warm-up and timed region is a host pause in which the device
+    gc.disable()          # idles, clocks up and then meets its power limit again inside the timed steps.  (Disabled: a 24 ms
+                          # host-side pause was seen once inside a 136 ms timed region; the collector is the one source of such
+                          # pauses this process controls.)
     for _ in range(warmup):
         step()
-    gc.collect()
-    gc.disable()          # a 24 ms host-side pause was seen once inside a 136 ms timed region: the collector is the one
-                          # source of such pauses this process controls
     backend.marks_reset()
     sync_all()
     t0 = time.perf_counter()
