@@ -387,6 +387,7 @@ def timed_steps(backend, step, steps, warmup, sync_all):
 
 def stage_rooflines(backend, step, nrec, stream_bytes, b_mesh, modes=(1, 2, 2, 3)):
     """Per-stage launch durations: a pass of the same steps with one HIP event between the launches."""
+    settle(backend, step, batch=2)           # (the figures are means over the recorded steps: no transient among them)
     backend.stage_timing(True)
     for _ in range(nrec):
         step()
@@ -432,13 +433,24 @@ def rk4_13_stream_entry(mk, backend, step, steps, warmup, nCK, stream_bytes, b_m
                     "(time_integration.jl:134-135): opt-in, default off"}
 
 
+def settle(backend, fn, seconds=0.05, batch=3):
+    """Untimed launches of `fn` for `seconds`: behind any host pause the device needs ~35 ms of launches to be back in its
+    steady state (power-limited clocks; tools/step_series.py: the first five RK4 steps behind a 50 ms pause run 13 ... 1 % slow).
+    The main timed region has the driver's warm-up steps for that; the shorter loops below get this."""
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(batch):
+            fn()
+        backend.synchronize()
+        if time.perf_counter() - t0 >= seconds:
+            return
+
+
 def single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_tend, iters):
     """The pure tendency launch (north_star's 40 % target is quoted on it) and the reference's live integrator."""
     out = {}
     mesh = Setup.mesh
-    for _ in range(3):
-        mk.computeTendency(mesh, Diag, Prog, Tend)
-    backend.synchronize()
+    settle(backend, lambda: mk.computeTendency(mesh, Diag, Prog, Tend))
     backend.marks_reset(); backend.mark()
     for _ in range(iters):
         mk.computeTendency(mesh, Diag, Prog, Tend)
@@ -463,9 +475,7 @@ def single_gpu_extras(mk, backend, Setup, Diag, Tend, Prog, K, sbytes, dts, b_te
         _L.check(_L.lib().moka_set_tuning(4, 1 if lean else 0))
         if sbytes == 4:     # an fp32-storage state has no DiagnosticVars to carry over right after RK4 steps
             mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=0)
-        for _ in range(3):
-            mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=fe_flags)
-        backend.synchronize()
+        settle(backend, lambda: mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=fe_flags))
         backend.marks_reset(); backend.mark()
         for _ in range(iters):
             mk.ocn_timestep(dts, Prog, Diag, Tend, Setup, mk.ForwardEuler, flags=fe_flags)
