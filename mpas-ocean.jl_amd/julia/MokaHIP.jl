@@ -445,6 +445,20 @@ function set_viscosity_del2!(Prog::MProg, viscDel2::Float64)
     check(ccall((:moka_set_viscosity_del2, lib), Cint, (Ptr{Cvoid}, Cdouble), s.handle, viscDel2), s.backend.ctx)
 end
 
+# The opt-in 13-stream form of the RK4 step (moka_set_tuning key 7; include/moka_hip.h): the same Runge-Kutta step with another
+# round-off than time_integration.jl:134-135's running sum (<= 1e-12 relative per step), 12 % fewer bytes.  Process-wide;
+# rk4_streams tells which form the next step of a bound model takes (13, or 16 = the reference's).
+function set_rk4_13_streams!(on::Bool = true)
+    rc = ccall((:moka_set_tuning, lib), Cint, (Cint, Cint), 7, on ? 1 : 0)
+    rc == 0 || error("MokaHIP: moka_set_tuning(7) failed")
+    nothing
+end
+function rk4_streams(Prog::MProg)
+    s = Prog.ssh[end].state
+    s === nothing && error("MokaHIP: the model is not on the device yet")
+    Int(ccall((:moka_state_rk4_streams, lib), Cint, (Ptr{Cvoid},), s.handle))
+end
+
 # reverse mode: the hand-written adjoint of the step loop (what Enzyme differentiates in the reference:
 # test/enzyme/test_Enzyme_end2end.jl).  MokaHIPEnzymeExt.jl registers it as the EnzymeRules rule of ocn_run_loop.
 mutable struct Tape
