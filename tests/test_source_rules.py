@@ -48,3 +48,19 @@ def test_only_the_product_kernels_are_built():
     from moka_hip import lib as L
     avail = [v for v in range(15) if L.lib().moka_kernel_variant_available(v)]
     assert avail == [0, 3, 4, 11]
+
+
+def test_every_symbol_the_julia_shim_calls_is_declared_in_the_header():
+    """julia/*.jl is never executed in this pipeline (no Julia in the image): at least every `ccall((:moka_..., lib)` names an
+    entry point include/moka_hip.h declares (and the library exports: tests/test_plan_host.py checks header == exports)."""
+    import glob
+    import re
+    header = open(os.path.join(ROOT, "include", "moka_hip.h")).read()
+    declared = set(re.findall(r"\b(moka_[a-z0-9_]+)\s*\(", header))
+    files = glob.glob(os.path.join(ROOT, "mpas-ocean.jl_amd", "julia", "*.jl"))
+    assert files
+    called = set()
+    for f in files:
+        called |= set(re.findall(r"ccall\(\(:(moka_[a-z0-9_]+)\s*,", open(f).read()))
+    assert len(called) >= 30 and not (called - declared), sorted(called - declared)
+
