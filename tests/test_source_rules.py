@@ -63,4 +63,32 @@ def test_every_symbol_the_julia_shim_calls_is_declared_in_the_header():
     for f in files:
         called |= set(re.findall(r"ccall\(\(:(moka_[a-z0-9_]+)\s*,", open(f).read()))
     assert len(called) >= 30 and not (called - declared), sorted(called - declared)
+    # ... with as many argument types in the ccall's tuple as the prototype has parameters
+    plain = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    nargs = {}
+    for m in re.finditer(r"\b(moka_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", plain, flags=re.S):
+        a = m.group(2).strip()
+        nargs[m.group(1)] = 0 if a in ("", "void") else len(a.split(","))
+    bad = []
+    for f in files:
+        t = open(f).read()
+        for m in re.finditer(r"ccall\(\(:(moka_[a-z0-9_]+)\s*,\s*lib\)\s*,\s*[A-Za-z{}\.]+\s*,\s*\(", t):
+            i, depth = m.end(), 1
+            j = i
+            while depth:
+                depth += {"(": 1, ")": -1}.get(t[j], 0)
+                j += 1
+            parts, d, cur = [], 0, ""
+            for c in t[i:j - 1]:
+                d += {"(": 1, "{": 1, "[": 1, ")": -1, "}": -1, "]": -1}.get(c, 0)
+                if c == "," and d == 0:
+                    parts.append(cur)
+                    cur = ""
+                else:
+                    cur += c
+            parts.append(cur)
+            n = len([q for q in parts if q.strip()])
+            if nargs.get(m.group(1)) != n:
+                bad.append((os.path.basename(f), m.group(1), n, nargs.get(m.group(1))))
+    assert not bad, bad
 
